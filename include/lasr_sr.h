@@ -1,0 +1,85 @@
+/*
+ * lasr_sr.h -- C ABI of the MI355X (gfx950) soft-rasteriser library, liblasr_hip.so.
+ *
+ * This is the drop-in boundary for the one native extension the LASR hot path
+ * needs: `soft_renderer.cuda.soft_rasterize`
+ *   /root/reference/third_party/softras/soft_renderer/cuda/soft_rasterize_cuda.cpp:59-76   forward_soft_rasterize
+ *   /root/reference/third_party/softras/soft_renderer/cuda/soft_rasterize_cuda.cpp:94-114  backward_soft_rasterize
+ *   /root/reference/third_party/softras/soft_renderer/cuda/soft_rasterize_cuda.cpp:135-138 pybind exports
+ * Every entry point takes plain device pointers, sizes and a hipStream_t passed
+ * as void*; no torch types cross this line.  INTEGRATION.md shows the binding a
+ * maintainer of the reference would write against it.
+ *
+ * Contract (same as the reference, see soft_rasterize.py:41-53,88-89 there):
+ *   - all buffers are caller-allocated, dense, fp32, resident on the current HIP device;
+ *   - soft_colors comes in pre-filled with the background colour (channels 0-2)
+ *     and 1 (channel 3) and is overwritten with the image;
+ *   - grad_faces / grad_textures are ACCUMULATED into (the caller zeroes them);
+ *   - kernels are enqueued on `stream` (the reference used the legacy default
+ *     stream); nothing synchronises the host;
+ *   - return value: 0 on success, a negative LASR_E_* code otherwise (the
+ *     reference only printf'd launch errors; this library never prints).
+ * Mode ids (soft_rasterize.py:22-25): dist {0 hard,1 barycentric,2 euclidean},
+ * rgb {0 hard,1 softmax}, alpha {0 hard,1 sum,2 prod}, texture {0 surface,1 vertex}.
+ * `dist_eps` is already the logit log(1/dist_eps - 1) (soft_rasterize.py:35).
+ */
+#ifndef LASR_SR_H_
+#define LASR_SR_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LASR_OK            0
+#define LASR_E_BADARG     (-1)   /* null pointer / negative size                     */
+#define LASR_E_BADMODE    (-2)   /* mode id out of range                             */
+#define LASR_E_WORKSPACE  (-3)   /* workspace missing or smaller than *_workspace_bytes */
+#define LASR_E_LAUNCH     (-4)   /* HIP reported an error at launch (see lasr_last_hip_error) */
+#define LASR_E_NODEVICE   (-5)   /* no gfx950 device / code object not loadable       */
+
+int         lasr_abi_version(void);
+const char* lasr_strerror(int code);
+int         lasr_last_hip_error(void);      /* hipError_t of the most recent LASR_E_LAUNCH on this thread */
+
+/* Scratch the caller must provide to forward/backward (per-face records + tile
+ * bounding boxes; replaces the reference's faces_info tensor, which becomes optional). */
+size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS);
+
+/*
+ * Replaces forward_soft_rasterize (soft_rasterize_cuda.cpp:59-76 -> kernel .cu:674-746).
+ *   faces       [N,F,3,3]  in    screen-space face vertices (x, y in NDC, z depth)
+ *   textures    [N,F,T,3]  in    T = 3 for vertex colours, R*R for surface texels
+ *   faces_info  [N,F,27]   out   OPTIONAL (may be NULL): reference-layout inv|sym|obt|0 record
+ *   aggrs_info  [N,2,IS,IS] out  softmax (sum,max) or hard (depth, face index)
+ *   soft_colors [N,4,IS,IS] in/out
+ */
+int lasr_sr_forward(const float* faces, const float* textures, float* faces_info,
+                    float* aggrs_info, float* soft_colors,
+                    void* workspace, size_t workspace_bytes,
+                    int N, int F, int T, int IS,
+                    float near, float far, float eps, float sigma_val,
+                    int func_id_dist, float dist_eps, float gamma_val,
+                    int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                    int double_side, void* hip_stream);
+
+/*
+ * Replaces backward_soft_rasterize (soft_rasterize_cuda.cpp:94-114 -> kernel .cu:749-813).
+ * faces_info is accepted for signature compatibility and ignored (records are
+ * rebuilt from `faces` into the workspace; that costs one 1-thread-per-face kernel).
+ */
+int lasr_sr_backward(const float* faces, const float* textures, const float* soft_colors,
+                     const float* faces_info, const float* aggrs_info,
+                     float* grad_faces, float* grad_textures, const float* grad_soft_colors,
+                     void* workspace, size_t workspace_bytes,
+                     int N, int F, int T, int IS,
+                     float near, float far, float eps, float sigma_val,
+                     int func_id_dist, float dist_eps, float gamma_val,
+                     int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                     int double_side, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASR_SR_H_ */

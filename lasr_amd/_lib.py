@@ -1,0 +1,55 @@
+"""ctypes binding of liblasr_hip.so (the C ABI declared in include/lasr_sr.h).
+
+There is deliberately NO fallback: if the library is missing or an entry point
+fails, the caller gets an exception.  The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'liblasr_hip.so')
+
+# every symbol include/lasr_sr.h and include/lasr_ops.h declare (checked by tests/test_abi.py)
+_f, _i, _p, _sz = ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+_RASTER_SCALARS = [_i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]
+SIGNATURES = {
+    'lasr_abi_version': (_i, []),
+    'lasr_strerror': (ctypes.c_char_p, [_i]),
+    'lasr_last_hip_error': (_i, []),
+    'lasr_sr_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'lasr_sr_forward': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
+    'lasr_sr_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
+}
+
+_lib = None
+
+
+class LasrNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LasrNativeError(
+                'liblasr_hip.so is not built (%s). Run `python -m lasr_amd.build` '
+                '(hipcc --offload-arch=gfx950); there is no CPU fallback.' % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)       # AttributeError here == ABI mismatch: let it propagate
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        h = lib()
+        msg = h.lasr_strerror(rc).decode()
+        if rc == -4:
+            msg += ' (hipError_t %d)' % h.lasr_last_hip_error()
+        raise LasrNativeError('%s failed: %s' % (what, msg))

@@ -1,0 +1,263 @@
+// sr_device.h -- gfx950 device-side arithmetic of the soft-rasteriser.
+//
+// Every expression keeps the operation order and the float/double promotions of
+// the reference kernel (/root/reference/third_party/softras/soft_renderer/cuda/
+// soft_rasterize_cuda_kernel.cu, "K.cu" below) so that, compiled with
+// -ffp-contract=off, the geometry (barycentrics, edge projections, depth) is
+// bit-identical to an un-contracted fp32 evaluation of the reference; only
+// exp() may differ by an ulp from a host libm.  What is NOT taken from the
+// reference is the execution shape: per-face constants live in a 36-float
+// record that a wave reads through the scalar cache (the face index is
+// wave-uniform), the bbox reject is precomputed, and runtime-indexed arrays are
+// replaced by compile-time edge indices so nothing spills to scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lasr {
+
+// ---- per-face record -------------------------------------------------------
+// [0..8]   x0 y0 z0 x1 y1 z1 x2 y2 z2
+// [9..17]  inv  : rows of adj([x y 1])/det                         (K.cu:274-286)
+// [18..26] e    : e[k][j] = sym[3k+j] - sym[3((k+1)%3)+j]           (K.cu:81-83,132-134, hoisted)
+// [27..29] den  : den[k]  = e[k][k] - e[k][(k+1)%3]                 (K.cu:85,136, hoisted)
+// [30]     flags: bit0..2 first obtuse corner (K.cu:296-304), bit3 front-facing (K.cu:41-44)
+// [31..35] pad to 144 B (16-B multiple so records start on a dwordx4 boundary)
+constexpr int REC = 36;
+constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30;
+
+struct Modes {
+    int dist, rgb, alpha, tex, double_side;
+};
+
+__device__ __forceinline__ float pix_center(int i, int is)
+{
+    // K.cu:345-346 -- evaluated in double, then narrowed
+    return (float)((2. * i + 1. - is) / is);
+}
+
+__device__ __forceinline__ void build_record(const float* __restrict__ f, float* __restrict__ rec,
+                                             float4* __restrict__ bbox, float margin, float* __restrict__ info27)
+{
+    const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+    float adj[9];
+    adj[0] = y1 - y2; adj[1] = x2 - x1; adj[2] = x1 * y2 - x2 * y1;
+    adj[3] = y2 - y0; adj[4] = x0 - x2; adj[5] = x2 * y0 - x0 * y2;
+    adj[6] = y0 - y1; adj[7] = x1 - x0; adj[8] = x0 * y1 - x1 * y0;
+    float det = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+    if (det > 0) { double d = (double)det; det = (float)(d > 1e-10 ? d : 1e-10); }
+    else         { double d = (double)det; det = (float)(d < -1e-10 ? d : -1e-10); }
+    float inv[9], sym[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) inv[k] = adj[k] / det;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) sym[3 * j + k] = f[3 * j] * f[3 * k] + f[3 * j + 1] * f[3 * k + 1] + 1;
+    int flags = 0;
+    {
+        const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int b = (k + 1) % 3, c = (k + 2) % 3;
+            const bool obt = (px[b] - px[k]) * (px[c] - px[k]) + (py[b] - py[k]) * (py[c] - py[k]) < 0;
+            if (obt && (flags & 7) == 0) flags |= 1 << k;
+        }
+    }
+    if ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) flags |= 8;
+#pragma unroll
+    for (int k = 0; k < 9; k++) rec[R_FACE + k] = f[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) rec[R_INV + k] = inv[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int b = (k + 1) % 3;
+        float e[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { e[j] = sym[3 * k + j] - sym[3 * b + j]; rec[R_E + 3 * k + j] = e[j]; }
+        rec[R_DEN + k] = e[k] - e[b];
+    }
+    rec[R_FLAGS] = __int_as_float(flags);
+#pragma unroll
+    for (int k = R_FLAGS + 1; k < REC; k++) rec[k] = 0.f;
+    // K.cu:33-38 with the max/min +- margin hoisted (same float ops, done once)
+    const float xmax = fmaxf(fmaxf(x0, x1), x2) + margin, xmin = fminf(fminf(x0, x1), x2) - margin;
+    const float ymax = fmaxf(fmaxf(y0, y1), y2) + margin, ymin = fminf(fminf(y0, y1), y2) - margin;
+    *bbox = make_float4(xmin, xmax, ymin, ymax);
+    if (info27) {   // reference layout, for callers that still want the tensor
+#pragma unroll
+        for (int k = 0; k < 9; k++) { info27[k] = inv[k]; info27[9 + k] = sym[k]; }
+        info27[18] = (flags & 1) ? 1.f : 0.f; info27[19] = (flags & 2) ? 1.f : 0.f; info27[20] = (flags & 4) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 21; k < 27; k++) info27[k] = 0.f;
+    }
+}
+
+__device__ __forceinline__ bool outside_bbox(float x, float y, const float4 b)
+{
+    return x > b.y || x < b.x || y > b.w || y < b.z;
+}
+
+__device__ __forceinline__ bool inside_closed(float w0, float w1, float w2)
+{
+    return w0 <= 1 && w0 >= 0 && w1 <= 1 && w1 >= 0 && w2 <= 1 && w2 >= 0;   // K.cu:47-50
+}
+
+// K.cu:53-58
+__device__ __forceinline__ void clip_normalise(float& w0, float& w1, float& w2)
+{
+    w0 = fmaxf(fminf(w0, 1.f), 0.f);     // == the reference's double-literal clamp (the bounds are exact)
+    w1 = fmaxf(fminf(w1, 1.f), 0.f);
+    w2 = fmaxf(fminf(w2, 1.f), 0.f);
+    const float s = fmaxf(w0 + w1 + w2, 1e-5f);   // (float)max((double)s, 1e-5) == fmaxf(s, 1e-5f) for every float s
+    w0 /= s; w1 /= s; w2 /= s;
+}
+
+// sigmoid through double exactly as K.cu:397,403 promotes it
+__device__ __forceinline__ float sigmoid_neg(float neg_arg)
+{
+    return (float)(1. / (1. + (double)expf(neg_arg)));
+}
+
+// One edge projection with compile-time edge K (a=K, b=K+1, c=K+2 mod 3): K.cu:85-95 / 136-148.
+// Returns u (already minus w) in (u0,u1,u2).  CLAMP selects the outside-branch variant.
+template <int K, bool CLAMP>
+__device__ __forceinline__ void edge_project(const float* __restrict__ rec, float w0, float w1, float w2,
+                                             float& u0, float& u1, float& u2)
+{
+    constexpr int B = (K + 1) % 3;
+    const float e0 = rec[R_E + 3 * K + 0], e1 = rec[R_E + 3 * K + 1], e2 = rec[R_E + 3 * K + 2];
+    const float eb = rec[R_E + 3 * K + B];
+    float ta = (w0 * e0 + w1 * e1 + w2 * e2 - eb) / rec[R_DEN + K];
+    float tb = 1 - ta;
+    float tc = 0;
+    if (CLAMP) {
+        ta = fminf(fmaxf(ta, 0.f), 1.f);
+        tb = fminf(fmaxf(tb, 0.f), 1.f);
+    }
+    float t[3];
+    t[K] = ta; t[B] = tb; t[(K + 2) % 3] = tc;
+    u0 = t[0] - w0; u1 = t[1] - w1; u2 = t[2] - w2;
+}
+
+struct Frag {
+    float D;            // fragment probability
+    float sign, dx, dy; // euclidean: signed displacement
+    float t0, t1, t2;   // euclidean/barycentric: saved for backward
+    float dis;
+};
+
+// Euclidean point-to-face distance: K.cu:61-151
+__device__ __forceinline__ void euclid(const float* __restrict__ rec, float xp, float yp,
+                                       float w0, float w1, float w2, Frag& fr)
+{
+    const float x0 = rec[0], y0 = rec[1], x1 = rec[3], y1 = rec[4], x2 = rec[6], y2 = rec[7];
+    if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
+        float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
+        float u0, u1, u2;
+#define LASR_TRY_EDGE(K)                                                          \
+        edge_project<K, false>(rec, w0, w1, w2, u0, u1, u2);                      \
+        {                                                                         \
+            const float px = u0 * x0 + u1 * x1 + u2 * x2;                         \
+            const float py = u0 * y0 + u1 * y1 + u2 * y2;                         \
+            const float d2 = px * px + py * py;                                   \
+            if (d2 < best) { best = d2; bx = px; by = py; b0 = u0; b1 = u1; b2 = u2; } \
+        }
+        LASR_TRY_EDGE(0) LASR_TRY_EDGE(1) LASR_TRY_EDGE(2)
+#undef LASR_TRY_EDGE
+        fr.dx = bx; fr.dy = by; fr.t0 = b0; fr.t1 = b1; fr.t2 = b2; fr.sign = 1.f;
+    } else {
+        const int flags = __float_as_int(rec[R_FLAGS]);
+        int a = -1;
+        if (w1 <= 0 && w2 <= 0) {
+            a = 0;
+            if ((flags & 1) && (xp - x0) * (x2 - x0) + (yp - y0) * (y2 - y0) > 0) a = 2;
+        } else if (w2 <= 0 && w0 <= 0) {
+            a = 1;
+            if ((flags & 2) && (xp - x1) * (x0 - x1) + (yp - y1) * (y0 - y1) > 0) a = 0;
+        } else if (w0 <= 0 && w1 <= 0) {
+            a = 2;
+            if ((flags & 4) && (xp - x2) * (x1 - x2) + (yp - y2) * (y1 - y2) > 0) a = 1;
+        } else if (w0 <= 0) a = 1;
+        else if (w1 <= 0) a = 2;
+        else if (w2 <= 0) a = 0;
+        if (a < 0) a = 0;   // reference indexes [-1] here (UB); pinned to edge 0 like the oracle
+        float u0, u1, u2;
+        if (a == 0) edge_project<0, true>(rec, w0, w1, w2, u0, u1, u2);
+        else if (a == 1) edge_project<1, true>(rec, w0, w1, w2, u0, u1, u2);
+        else edge_project<2, true>(rec, w0, w1, w2, u0, u1, u2);
+        fr.dx = u0 * x0 + u1 * x1 + u2 * x2;
+        fr.dy = u0 * y0 + u1 * y1 + u2 * y2;
+        fr.t0 = u0; fr.t1 = u1; fr.t2 = u2; fr.sign = -1.f;
+    }
+}
+
+// Fragment probability of the face in `rec` at (xp,yp): K.cu:387-404.  false = face skipped.
+__device__ __forceinline__ bool fragment(const float* __restrict__ rec, int dist, float thr, float sigma,
+                                         float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
+{
+    w0 = rec[R_INV + 0] * xp + rec[R_INV + 1] * yp + rec[R_INV + 2];   // K.cu:24-29
+    w1 = rec[R_INV + 3] * xp + rec[R_INV + 4] * yp + rec[R_INV + 5];
+    w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
+    if (dist == 0) {
+        if (!inside_closed(w0, w1, w2)) return false;
+        fr.D = 1.f;
+    } else if (dist == 1) {
+        float d = w0 > w1 ? (w1 > w2 ? w2 : w1) : (w0 > w2 ? w2 : w0);      // K.cu:155-158
+        d = d > 0 ? d * d : -(d * d);
+        fr.dis = d; fr.t0 = w0; fr.t1 = w1; fr.t2 = w2;
+        if (-d >= thr) return false;
+        fr.D = sigmoid_neg(-d / sigma);
+    } else {
+        euclid(rec, xp, yp, w0, w1, w2, fr);
+        fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
+        if (fr.sign < 0 && fr.dis >= thr) return false;
+        fr.D = sigmoid_neg(-fr.sign * fr.dis / sigma);
+    }
+    return true;
+}
+
+// K.cu:423 (1. / float-sum evaluated in double; narrowing a double quotient of
+// floats is the correctly rounded float quotient, so a float division is identical)
+__device__ __forceinline__ float depth_at(const float* __restrict__ rec, float c0, float c1, float c2)
+{
+    return 1.f / (c0 / rec[2] + c1 / rec[5] + c2 / rec[8]);
+}
+
+// K.cu:178-194
+__device__ __forceinline__ float sample_colour(const float* __restrict__ tex, float c0, float c1, float c2,
+                                               int res, int ch, int tex_type)
+{
+    if (tex_type == 0) {
+        const int ix = (int)(c0 * res), iy = (int)(c1 * res);
+        if ((c0 + c1) * res - ix - iy <= 1) return tex[(iy * res + ix) * 3 + ch];
+        return tex[((res - 1 - iy) * res + (res - 1 - ix)) * 3 + ch];
+    }
+    return c0 * tex[ch] + c1 * tex[3 + ch] + c2 * tex[6 + ch];
+}
+
+// texel index a surface sample lands in (K.cu:200-211)
+__device__ __forceinline__ int surface_texel(float c0, float c1, int res)
+{
+    const int ix = (int)(c0 * res), iy = (int)(c1 * res);
+    if ((c0 + c1) * res - ix - iy <= 1) return iy * res + ix;
+    return (res - 1 - iy) * res + (res - 1 - ix);
+}
+
+// ---- wave64 helpers ----------------------------------------------------------
+// Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic);
+// the total lands in lane 63.
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+#define LASR_DPP_ADD(ctrl, rmask, bmask)                                                              \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, bmask, false))
+    LASR_DPP_ADD(0x111, 0xf, 0xf);   // row_shr:1
+    LASR_DPP_ADD(0x112, 0xf, 0xf);   // row_shr:2
+    LASR_DPP_ADD(0x114, 0xf, 0xe);   // row_shr:4
+    LASR_DPP_ADD(0x118, 0xf, 0xc);   // row_shr:8
+    LASR_DPP_ADD(0x142, 0xa, 0xf);   // row_bcast:15
+    LASR_DPP_ADD(0x143, 0xc, 0xf);   // row_bcast:31
+#undef LASR_DPP_ADD
+    return v;
+}
+
+}  // namespace lasr

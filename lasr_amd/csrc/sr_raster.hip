@@ -1,0 +1,528 @@
+// sr_raster.hip -- soft-rasteriser forward/backward for MI355X (gfx950, wave64) + the C ABI.
+//
+// Replaces the three reference kernels (soft_rasterize_cuda_kernel.cu "K.cu":245-305,
+// 308-483, 486-668) with a different execution shape:
+//
+//   setup    1 thread / face      : 36-float record + margin-inflated bbox (sr_device.h)
+//   forward  1 workgroup / 16x16 px tile, 1 wave / 8x8 quadrant, 1 lane / pixel.
+//            The workgroup scans the image's face bboxes with coalesced float4
+//            loads and compacts, IN FACE-INDEX ORDER (wave ballots + prefix), the
+//            faces that can touch the tile into LDS.  Each wave then walks that
+//            list; the face index is wave-uniform, so the record is fetched
+//            through the scalar cache into SGPRs and only the per-pixel state
+//            lives in VGPRs.  Index order is preserved, so the alpha product, the
+//            online depth-softmax and the hard z-buffer tie-break see exactly the
+//            reference's sequence of faces.
+//   backward 1 wave / (image, face), FACE-major: lanes enumerate the pixels of the
+//            face's bbox, accumulate the 9+9 gradient components in registers,
+//            one DPP wave reduction per face, one plain read-modify-write per
+//            component.  The backward pass has no cross-face dependence (it only
+//            needs the finished per-pixel aggregates), so this removes every
+//            global atomic of the reference and makes the gradients deterministic.
+//            (Surface textures, T != 3 texels, scatter with atomics: cold path.)
+//
+// Brute force in the reference is N*P*F pair tests; here a pixel only ever sees
+// the faces binned to its tile (~40-100 instead of 1280-2560).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lasr_sr.h"
+#include "sr_device.h"
+
+namespace lasr {
+
+constexpr int TILE = 16;        // pixels per tile side (4 waves of 8x8)
+constexpr int LIST_CAP = 1024;  // faces scanned per round == LDS list capacity
+
+struct RasterArgs {
+    const float* __restrict__ recs;      // [N*F, REC]
+    const float4* __restrict__ bboxes;   // [N*F]
+    const float* __restrict__ textures;  // [N,F,T,3]
+    int N, F, T, res, IS;
+    float near, far, eps, sigma, gamma, thr;
+    Modes m;
+};
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__ faces, float* __restrict__ recs,
+                                                       float4* __restrict__ bboxes, float* __restrict__ info27,
+                                                       int total, float margin)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    build_record(faces + (size_t)i * 9, recs + (size_t)i * REC, bboxes + i, margin,
+                 info27 ? info27 + (size_t)i * 27 : nullptr);
+}
+
+// Block -> (image, tile) with all tiles of an image kept on one XCD (block b runs
+// on XCD b % 8; an image's records are then fetched into a single L2).
+__device__ __forceinline__ int xcd_remap(int b, int total)
+{
+    const int per = total >> 3;
+    if ((total & 7) == 0) return (b & 7) * per + (b >> 3);
+    return b;
+}
+
+// ---------------------------------------------------------------------------
+// Per-pixel forward state (K.cu:354-368)
+struct PixState {
+    float r, g, b, a;     // accumulators
+    float ssum, smax;     // softmax running (sum, max)  | hard: (zbest, -)
+    int fbest;
+};
+
+template <bool LASR_FAST>
+__device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, const float* __restrict__ rec,
+                                             const float* __restrict__ tex, int fn, float xp, float yp, PixState& s)
+{
+    float w0, w1, w2;
+    Frag fr;
+    if (!fragment(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) return;
+    const float D = fr.D;
+    // alpha first (K.cu:409-417), before the depth test
+    if (m.alpha == 0) { if ((double)D > 0.5) s.a = 1.f; }
+    else if (m.alpha == 1) s.a += D;
+    else s.a = (float)((double)s.a * (1. - (double)D));
+
+    float c0 = w0, c1 = w1, c2 = w2;
+    clip_normalise(c0, c1, c2);
+    const float zp = depth_at(rec, c0, c1, c2);
+    if (zp < A.near || zp > A.far) return;
+
+    const bool front = (__float_as_int(rec[R_FLAGS]) & 8) != 0;
+    if (m.rgb == 0) {
+        if (zp < s.ssum && inside_closed(w0, w1, w2) && (m.double_side || front)) {
+            s.ssum = zp; s.fbest = fn;
+            s.r = sample_colour(tex, c0, c1, c2, A.res, 0, m.tex);
+            s.g = sample_colour(tex, c0, c1, c2, A.res, 1, m.tex);
+            s.b = sample_colour(tex, c0, c1, c2, A.res, 2, m.tex);
+        }
+    } else {
+        if (front || m.double_side) {
+            const float zn = (A.far - zp) / (A.far - A.near);
+            float rescale = 1.f;
+            if (zn > s.smax) { rescale = expf((s.smax - zn) / A.gamma); s.smax = zn; }
+            const float ez = expf((zn - s.smax) / A.gamma);
+            s.ssum = rescale * s.ssum + ez * D;
+            s.r = rescale * s.r + ez * D * sample_colour(tex, c0, c1, c2, A.res, 0, m.tex);
+            s.g = rescale * s.g + ez * D * sample_colour(tex, c0, c1, c2, A.res, 1, m.tex);
+            s.b = rescale * s.b + ez * D * sample_colour(tex, c0, c1, c2, A.res, 2, m.tex);
+        }
+    }
+}
+
+template <bool LASR_FAST>
+__global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
+                                                         float* __restrict__ colors)
+{
+    __shared__ float4 s_bbox[LIST_CAP];
+    __shared__ int s_face[LIST_CAP];
+    __shared__ int s_wcnt[2][4];
+
+    // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
+    const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
+
+    const int IS = A.IS, P = IS * IS;
+    const int tiles_x = (IS + TILE - 1) / TILE;
+    const int tiles = tiles_x * tiles_x;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = blk / tiles;
+    const int tl = blk - bn * tiles;
+    const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool valid = px < IS && py < IS;
+    const int pn = py * IS + px;
+    const float xp = pix_center(px, IS);
+    const float yp = pix_center(IS - 1 - py, IS);
+
+    // NDC extent of the tile's pixel centres (same rounding as the per-pixel values)
+    const int tx1 = min(tx * TILE + TILE - 1, IS - 1), ty1 = min(ty * TILE + TILE - 1, IS - 1);
+    const float t_xlo = pix_center(tx * TILE, IS), t_xhi = pix_center(tx1, IS);
+    const float t_yhi = pix_center(IS - 1 - ty * TILE, IS), t_ylo = pix_center(IS - 1 - ty1, IS);
+
+    PixState s;
+    s.a = (m.alpha == 2) ? 1.f : 0.f;
+    s.fbest = -1;
+    float bg0 = 1.f, bg1 = 1.f, bg2 = 1.f;
+    if (valid) {
+        bg0 = colors[((size_t)bn * 4 + 0) * P + pn];
+        bg1 = colors[((size_t)bn * 4 + 1) * P + pn];
+        bg2 = colors[((size_t)bn * 4 + 2) * P + pn];
+    }
+    if (m.rgb == 0) { s.r = bg0; s.g = bg1; s.b = bg2; s.ssum = 10000000.f; s.smax = 0.f; }
+    else {
+        s.ssum = expf(A.eps / A.gamma);
+        s.smax = A.eps;
+        s.r = bg0 * s.ssum; s.g = bg1 * s.ssum; s.b = bg2 * s.ssum;
+    }
+
+    const float4* __restrict__ bb = A.bboxes + (size_t)bn * A.F;
+    const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
+    const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * 3;
+    const int texstride = A.T * 3;
+
+    for (int base = 0; base < A.F; base += LIST_CAP) {
+        const int end = min(base + LIST_CAP, A.F);
+        // ---- ordered compaction of faces [base,end) whose bbox touches this tile
+        int count = 0, flip = 0;
+        for (int c = base; c < end; c += 256, flip ^= 1) {
+            const int f = c + tid;
+            float4 b = make_float4(0, 0, 0, 0);
+            bool hit = false;
+            if (f < end) {
+                b = bb[f];
+                hit = !(t_xlo > b.y || t_xhi < b.x || t_ylo > b.w || t_yhi < b.z);
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (lane == 0) s_wcnt[flip][wave] = __popcll(mask);
+            __syncthreads();
+            const int c0 = s_wcnt[flip][0], c1 = s_wcnt[flip][1], c2 = s_wcnt[flip][2], c3 = s_wcnt[flip][3];
+            const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+            if (hit) {
+                const int pos = count + before + __popcll(mask & ((1ull << lane) - 1ull));
+                s_bbox[pos] = b;
+                s_face[pos] = f;
+            }
+            count += c0 + c1 + c2 + c3;
+        }
+        __syncthreads();
+        // ---- every wave walks the list for its 8x8 quadrant
+        for (int i = 0; i < count; i++) {
+            const float4 b = s_bbox[i];
+            const bool cand = valid && !outside_bbox(xp, yp, b);          // K.cu:375
+            if (__ballot(cand) == 0ull) continue;                         // wave-uniform skip
+            const int fn = __builtin_amdgcn_readfirstlane(s_face[i]);     // wave-uniform -> scalar loads
+            if (cand) {
+                forward_face<LASR_FAST>(A, m, recs + (size_t)fn * REC, texs + (size_t)fn * texstride, fn, xp, yp, s);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!valid) return;
+    // ---- finalise (K.cu:458-482)
+    float a_out;
+    if (m.alpha == 0) a_out = s.a;
+    else if (m.alpha == 1) a_out = s.a / A.F;
+    else a_out = (float)(1. - (double)s.a);
+    colors[((size_t)bn * 4 + 3) * P + pn] = a_out;
+    if (m.rgb == 0) {
+        if (s.fbest != -1) {
+            colors[((size_t)bn * 4 + 0) * P + pn] = s.r;
+            colors[((size_t)bn * 4 + 1) * P + pn] = s.g;
+            colors[((size_t)bn * 4 + 2) * P + pn] = s.b;
+        }
+        aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
+        aggrs[((size_t)bn * 2 + 1) * P + pn] = (float)s.fbest;
+    } else {
+        colors[((size_t)bn * 4 + 0) * P + pn] = s.r / s.ssum;
+        colors[((size_t)bn * 4 + 1) * P + pn] = s.g / s.ssum;
+        colors[((size_t)bn * 4 + 2) * P + pn] = s.b / s.ssum;
+        aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
+        aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Backward: one wave per (image, face); K.cu:486-668 evaluated face-major.
+template <bool LASR_FAST>
+__global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
+                                                          const float* __restrict__ aggrs,
+                                                          const float* __restrict__ gcolors,
+                                                          float* __restrict__ gfaces, float* __restrict__ gtex)
+{
+    const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (gw >= A.N * A.F) return;
+    const int bn = gw / A.F, fn = gw - bn * A.F;
+    const int IS = A.IS, P = IS * IS;
+    const float* __restrict__ rec = A.recs + (size_t)gw * REC;
+    const float* __restrict__ tex = A.textures + (size_t)gw * A.T * 3;
+    const float4 b = A.bboxes[gw];
+
+    // conservative pixel rectangle of the bbox; the exact test is repeated per pixel
+    // xp = (2 xi + 1 - IS)/IS  =>  xi = (xp IS + IS - 1)/2
+    const float half = 0.5f * (float)IS;
+    int x0 = (int)floorf(b.x * half + half - 0.5f) - 1, x1 = (int)ceilf(b.y * half + half - 0.5f) + 1;
+    int yi0 = (int)floorf(b.z * half + half - 0.5f) - 1, yi1 = (int)ceilf(b.w * half + half - 0.5f) + 1;
+    x0 = max(x0, 0); x1 = min(x1, IS - 1);
+    yi0 = max(yi0, 0); yi1 = min(yi1, IS - 1);
+    // NaN / inverted boxes give an empty range
+    const int bw = x1 - x0 + 1, bh = yi1 - yi0 + 1;
+    const bool empty = !(bw > 0 && bh > 0);
+    const int npx = empty ? 0 : bw * bh;
+
+    float gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2)
+    float gt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // vertex colours: [vertex j][channel k] at 3j+k
+    const bool front = (__float_as_int(rec[R_FLAGS]) & 8) != 0;
+    const bool vertex_tex = (m.tex == 1);
+
+    // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
+    int r = 0, c = 0;
+    const int dr = empty ? 0 : 64 / bw, dc = empty ? 0 : 64 - dr * bw;
+    if (!empty) { r = lane / bw; c = lane - r * bw; }
+
+    for (int i = lane; i < npx; i += 64) {
+        const int xi = x0 + c, yi = yi0 + r;
+        // advance for the next round
+        c += dc; r += dr;
+        if (c >= bw) { c -= bw; r += 1; }
+
+        const int pyy = IS - 1 - yi;
+        const int pn = pyy * IS + xi;
+        const float xp = pix_center(xi, IS), yp = pix_center(yi, IS);
+        if (outside_bbox(xp, yp, b)) continue;
+
+        float w0, w1, w2;
+        Frag fr;
+        if (!fragment(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+        const float D = fr.D;
+
+        // alpha path (K.cu:583-593)
+        float Ca = gcolors[((size_t)bn * 4 + 3) * P + pn];
+        if (m.alpha == 0) { /* no gradient; the reference still adds g_alpha into C (K.cu:583,593) */ }
+        else if (m.alpha == 1) Ca /= A.F;
+        else {
+            const float a_out = colors[((size_t)bn * 4 + 3) * P + pn];
+            const float omd = 1 - D;
+            const double den = (double)omd > 1e-6 ? (double)omd : 1e-6;
+            Ca = (float)((double)Ca * ((double)(1 - a_out) / den));
+        }
+        float C = Ca;
+
+        const float u0 = w0, u1 = w1, u2 = w2;       // unclipped barycentrics (w0 of K.cu:596)
+        clip_normalise(w0, w1, w2);
+        const float zp = depth_at(rec, w0, w1, w2);
+        if (zp < A.near || zp > A.far) continue;    // no gradient at all (K.cu:599)
+
+        float gz0 = 0, gz1 = 0, gz2 = 0;
+        if (m.rgb == 0) {
+            if ((float)fn == aggrs[((size_t)bn * 2 + 1) * P + pn]) {       // K.cu:603
+                const float g0 = gcolors[((size_t)bn * 4 + 0) * P + pn];
+                const float g1 = gcolors[((size_t)bn * 4 + 1) * P + pn];
+                const float g2 = gcolors[((size_t)bn * 4 + 2) * P + pn];
+                if (vertex_tex) {
+                    gt[0] += w0 * g0; gt[1] += w0 * g1; gt[2] += w0 * g2;
+                    gt[3] += w1 * g0; gt[4] += w1 * g1; gt[5] += w1 * g2;
+                    gt[6] += w2 * g0; gt[7] += w2 * g1; gt[8] += w2 * g2;
+                } else {
+                    const int j = surface_texel(w0, w1, A.res);
+                    float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
+                    atomicAdd(gtp + 0, g0); atomicAdd(gtp + 1, g1); atomicAdd(gtp + 2, g2);
+                }
+            }
+        } else if (front || m.double_side) {                                 // K.cu:611-640
+            const float ssum = aggrs[((size_t)bn * 2 + 0) * P + pn];
+            const float smax = aggrs[((size_t)bn * 2 + 1) * P + pn];
+            const float zn = (A.far - zp) / (A.far - A.near);
+            const float sm = D * expf((zn - smax) / A.gamma) / ssum;
+            const float g0 = gcolors[((size_t)bn * 4 + 0) * P + pn];
+            const float g1 = gcolors[((size_t)bn * 4 + 1) * P + pn];
+            const float g2 = gcolors[((size_t)bn * 4 + 2) * P + pn];
+            if (vertex_tex) {
+                gt[0] += sm * (w0 * g0); gt[1] += sm * (w0 * g1); gt[2] += sm * (w0 * g2);
+                gt[3] += sm * (w1 * g0); gt[4] += sm * (w1 * g1); gt[5] += sm * (w1 * g2);
+                gt[6] += sm * (w2 * g0); gt[7] += sm * (w2 * g1); gt[8] += sm * (w2 * g2);
+            } else {
+                const int j = surface_texel(w0, w1, A.res);
+                float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
+                atomicAdd(gtp + 0, sm * g0); atomicAdd(gtp + 1, sm * g1); atomicAdd(gtp + 2, sm * g2);
+            }
+            float Crgb = 0.f;
+            Crgb += g0 * (sample_colour(tex, w0, w1, w2, A.res, 0, m.tex) - colors[((size_t)bn * 4 + 0) * P + pn]);
+            Crgb += g1 * (sample_colour(tex, w0, w1, w2, A.res, 1, m.tex) - colors[((size_t)bn * 4 + 1) * P + pn]);
+            Crgb += g2 * (sample_colour(tex, w0, w1, w2, A.res, 2, m.tex) - colors[((size_t)bn * 4 + 2) * P + pn]);
+            Crgb *= sm;
+            C += Crgb / D;
+            const float Cz = Crgb / A.gamma / (A.near - A.far) * zp * zp;
+            gz0 = Cz * w0 / rec[2] / rec[2];
+            gz1 = Cz * w1 / rec[5] / rec[5];
+            gz2 = Cz * w2 / rec[8] / rec[8];
+        }
+
+        C *= D * (1 - D) / A.sigma;                                           // K.cu:644
+        float gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0, gx2 = 0, gy2 = 0;
+        if (m.dist == 1) {                                                    // K.cu:161-175
+            const float t0 = fr.t0, t1 = fr.t1, t2 = fr.t2;
+            const int p = t0 > t1 ? (t1 > t2 ? 2 : 1) : (t0 > t2 ? 2 : 0);
+            const float ipx = rec[R_INV + 3 * p + 0], ipy = rec[R_INV + 3 * p + 1];   // divergent gather: cold path
+            const float dis = fr.dis;
+            const double sc = dis > 0 ? 2. * (double)sqrtf(dis) : 2. * (double)sqrtf(-dis);
+            float gxy[3][2];
+#pragma unroll
+            for (int l = 0; l < 2; l++) {
+                const float ipl = l == 0 ? ipx : ipy;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float acc = 0.f;
+                    acc += -ipl * rec[R_INV + 3 * k + 0] * xp;
+                    acc += -ipl * rec[R_INV + 3 * k + 1] * yp;
+                    acc += -ipl * rec[R_INV + 3 * k + 2] * 1.f;
+                    const float g = acc * C;
+                    gxy[k][l] = (float)((double)g * sc);
+                }
+            }
+            gx0 = gxy[0][0]; gy0 = gxy[0][1]; gx1 = gxy[1][0]; gy1 = gxy[1][1]; gx2 = gxy[2][0]; gy2 = gxy[2][1];
+        } else if (m.dist == 2) {                                             // K.cu:649-655
+            const float k2 = 2 * fr.sign * C;
+            gx0 = k2 * (fr.t0 + u0) * fr.dx; gy0 = k2 * (fr.t0 + u0) * fr.dy;
+            gx1 = k2 * (fr.t1 + u1) * fr.dx; gy1 = k2 * (fr.t1 + u1) * fr.dy;
+            gx2 = k2 * (fr.t2 + u2) * fr.dx; gy2 = k2 * (fr.t2 + u2) * fr.dy;
+        }
+        gv[0] += gx0; gv[1] += gy0; gv[2] += gz0;
+        gv[3] += gx1; gv[4] += gy1; gv[5] += gz1;
+        gv[6] += gx2; gv[7] += gy2; gv[8] += gz2;
+    }
+
+    // one wave reduction per face, then a plain (non-atomic) accumulate: this wave owns the face
+#pragma unroll
+    for (int k = 0; k < 9; k++) gv[k] = wave_sum_to_lane63(gv[k]);
+    if (vertex_tex) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) gt[k] = wave_sum_to_lane63(gt[k]);
+    }
+    if (lane == 63) {
+        float* gf = gfaces + (size_t)gw * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) gf[k] += gv[k];
+        if (vertex_tex) {
+            float* gtp = gtex + (size_t)gw * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) gtp[k] += gt[k];
+        }
+    }
+}
+
+}  // namespace lasr
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+using namespace lasr;
+
+static thread_local int g_last_hip_error = 0;
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int lasr_abi_version(void) { return 1; }
+
+extern "C" int lasr_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" const char* lasr_strerror(int code)
+{
+    switch (code) {
+        case LASR_OK: return "ok";
+        case LASR_E_BADARG: return "bad argument (null pointer or negative size)";
+        case LASR_E_BADMODE: return "mode id out of range";
+        case LASR_E_WORKSPACE: return "workspace missing or too small";
+        case LASR_E_LAUNCH: return "HIP launch error";
+        case LASR_E_NODEVICE: return "no usable gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+extern "C" size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS)
+{
+    (void)T; (void)IS;
+    if (N < 0 || F < 0) return 0;
+    const size_t nf = (size_t)N * (size_t)F;
+    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(float4), 256) + 256;
+}
+
+static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alpha, int tex)
+{
+    if (N < 0 || F < 0 || T < 1 || IS < 0) return LASR_E_BADARG;
+    if (dist < 0 || dist > 2 || rgb < 0 || rgb > 1 || alpha < 0 || alpha > 2 || tex < 0 || tex > 1) return LASR_E_BADMODE;
+    if ((long long)N * F > 0x7fffffffLL / 64 || (long long)N * IS * IS > 0x7fffffffLL) return LASR_E_BADARG;
+    return LASR_OK;
+}
+
+static int launch_ok()
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return LASR_E_LAUNCH; }
+    return LASR_OK;
+}
+
+static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T, int IS, float near, float far,
+                            float eps, float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
+                            int tex, int double_side, float** recs, float4** bboxes)
+{
+    const size_t nf = (size_t)N * (size_t)F;
+    char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    *recs = (float*)p;
+    *bboxes = (float4*)(p + align_up(nf * REC * sizeof(float), 256));
+    RasterArgs A;
+    A.recs = *recs; A.bboxes = *bboxes; A.textures = textures;
+    A.N = N; A.F = F; A.T = T; A.res = (int)sqrt((double)T); A.IS = IS;   // K.cu:696
+    A.near = near; A.far = far; A.eps = eps; A.sigma = sigma; A.gamma = gamma;
+    A.thr = dist_eps * sigma;                                              // K.cu:352 (float product)
+    A.m = Modes{dist, rgb, alpha, tex, double_side ? 1 : 0};
+    return A;
+}
+
+static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
+
+extern "C" int lasr_sr_forward(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
+                               float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
+                               float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                               float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                               int double_side, void* hip_stream)
+{
+    int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
+    if (rc) return rc;
+    if (N == 0 || IS == 0) return LASR_OK;
+    if (!aggrs_info || !soft_colors || (F > 0 && (!faces || !textures))) return LASR_E_BADARG;
+    if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, IS)) return LASR_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    float* recs; float4* bboxes;
+    RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
+                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &bboxes);
+    const int total = N * F;
+    if (total > 0) {
+        hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, bboxes,
+                           faces_info, total, sqrtf(A.thr));
+        if ((rc = launch_ok())) return rc;
+    }
+    const int tiles_x = (IS + TILE - 1) / TILE;
+    const dim3 grid((unsigned)(N * tiles_x * tiles_x));
+    if (is_lasr_fast(A.m)) hipLaunchKernelGGL(sr_forward_kernel<true>, grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+    else hipLaunchKernelGGL(sr_forward_kernel<false>, grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+    return launch_ok();
+}
+
+extern "C" int lasr_sr_backward(const float* faces, const float* textures, const float* soft_colors,
+                                const float* faces_info, const float* aggrs_info, float* grad_faces,
+                                float* grad_textures, const float* grad_soft_colors, void* workspace,
+                                size_t workspace_bytes, int N, int F, int T, int IS, float near, float far, float eps,
+                                float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                                int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream)
+{
+    (void)faces_info;
+    int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
+    if (rc) return rc;
+    if (N == 0 || IS == 0 || F == 0) return LASR_OK;
+    if (!faces || !textures || !soft_colors || !aggrs_info || !grad_faces || !grad_textures || !grad_soft_colors)
+        return LASR_E_BADARG;
+    if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, IS)) return LASR_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    float* recs; float4* bboxes;
+    RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
+                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &bboxes);
+    const int total = N * F;
+    hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, bboxes,
+                       (float*)nullptr, total, sqrtf(A.thr));
+    if ((rc = launch_ok())) return rc;
+    const dim3 grid((unsigned)((total + 3) / 4));   // 4 waves (faces) per 256-thread workgroup
+    if (is_lasr_fast(A.m))
+        hipLaunchKernelGGL(sr_backward_kernel<true>, grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
+                           grad_soft_colors, grad_faces, grad_textures);
+    else
+        hipLaunchKernelGGL(sr_backward_kernel<false>, grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
+                           grad_soft_colors, grad_faces, grad_textures);
+    return launch_ok();
+}

@@ -1,0 +1,147 @@
+"""Soft rasterisation operator backed by the gfx950 HIP kernels.
+
+Mirror of the reference operator
+  /root/reference/third_party/softras/soft_renderer/functional/soft_rasterize.py:9-119
+(same positional/keyword arguments, same mode strings, same error for CPU
+tensors) with the native call going through the C ABI of include/lasr_sr.h
+instead of the `soft_renderer.cuda.soft_rasterize` pybind module.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from ... import _lib
+
+_DIST = {'hard': 0, 'barycentric': 1, 'euclidean': 2}
+_RGB = {'hard': 0, 'softmax': 1}
+_ALPHA = {'hard': 0, 'sum': 1, 'prod': 2}
+_TEX = {'surface': 0, 'vertex': 1}
+
+_workspaces = {}
+
+
+def _workspace(device, stream, nbytes):
+    key = (device.index, stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _as_float(v):
+    # LASR stores 0-dim device tensors in rasterizer.near/far (mesh_net.py:306-311)
+    return float(v.item()) if torch.is_tensor(v) else float(v)
+
+
+class SoftRasterizeFunction(Function):
+
+    @staticmethod
+    def forward(ctx, face_vertices, textures, image_size=256,
+                background_color=[0, 0, 0], near=1, far=100,
+                fill_back=True, eps=1e-3,
+                sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
+                gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod',
+                texture_type='surface'):
+        if face_vertices.dtype != torch.float32 or textures.dtype != torch.float32:
+            raise TypeError('lasr_amd soft_rasterize supports float32 tensors only')
+        dev = face_vertices.device
+        N, F = face_vertices.shape[:2]
+        fv = face_vertices.detach().reshape(N, F, 9).contiguous()
+        tx = textures.detach().reshape(N, F, -1, 3).contiguous()
+        T = tx.shape[2]
+        IS = int(image_size)
+
+        ctx.geom = (N, F, T, IS)
+        ctx.scalars = (_as_float(near), _as_float(far), float(eps), float(sigma_val), _DIST[dist_func],
+                       float(math.log(1. / dist_eps - 1.)), float(gamma_val), _RGB[aggr_func_rgb],
+                       _ALPHA[aggr_func_alpha], _TEX[texture_type], 1 if fill_back else 0)
+        ctx.in_shapes = (face_vertices.shape, textures.shape)
+
+        aggrs_info = torch.empty(N, 2, IS, IS, dtype=torch.float32, device=dev)
+        soft_colors = torch.empty(N, 4, IS, IS, dtype=torch.float32, device=dev)
+        soft_colors[:, 0] = float(background_color[0])
+        soft_colors[:, 1] = float(background_color[1])
+        soft_colors[:, 2] = float(background_color[2])
+        soft_colors[:, 3] = 1.0
+
+        h = _lib.lib()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            nbytes = h.lasr_sr_workspace_bytes(N, F, T, IS)
+            ws = _workspace(dev, stream, nbytes)
+            rc = h.lasr_sr_forward(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
+                                   soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   N, F, T, IS, *ctx.scalars, stream)
+        _lib.check(rc, 'lasr_sr_forward')
+        ctx.save_for_backward(fv, tx, soft_colors, aggrs_info)
+        ctx.mark_non_differentiable(aggrs_info)
+        return soft_colors
+
+    @staticmethod
+    def backward(ctx, grad_soft_colors):
+        fv, tx, soft_colors, aggrs_info = ctx.saved_tensors
+        N, F, T, IS = ctx.geom
+        dev = fv.device
+        grad_faces = torch.zeros(N, F, 9, dtype=torch.float32, device=dev)
+        grad_textures = torch.zeros(N, F, T, 3, dtype=torch.float32, device=dev)
+        g = grad_soft_colors.contiguous().float()
+        h = _lib.lib()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            nbytes = h.lasr_sr_workspace_bytes(N, F, T, IS)
+            ws = _workspace(dev, stream, nbytes)
+            rc = h.lasr_sr_backward(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
+                                    aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
+                                    g.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    N, F, T, IS, *ctx.scalars, stream)
+        _lib.check(rc, 'lasr_sr_backward')
+        fshape, tshape = ctx.in_shapes
+        return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+def soft_rasterize(face_vertices, textures, image_size=256,
+                   background_color=[0, 0, 0], near=1, far=100,
+                   fill_back=True, eps=1e-3,
+                   sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
+                   gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod',
+                   texture_type='surface'):
+    if face_vertices.device.type != 'cuda':
+        raise TypeError('Rasterize module supports only cuda Tensors')
+    return SoftRasterizeFunction.apply(face_vertices, textures, image_size,
+                                       background_color, near, far,
+                                       fill_back, eps,
+                                       sigma_val, dist_func, dist_eps,
+                                       gamma_val, aggr_func_rgb, aggr_func_alpha,
+                                       texture_type)
+
+
+def soft_rasterize_raw(face_vertices, textures, image_size, background_color, near, far, fill_back, eps,
+                       sigma_val, dist_func, dist_eps, gamma_val, aggr_func_rgb, aggr_func_alpha, texture_type,
+                       want_faces_info=False):
+    """Forward only, returning (soft_colors, aggrs_info[, faces_info]) like the raw extension call
+    (soft_rasterize_cuda.cpp:59-76); the autograd Function hides aggrs_info."""
+    dev = face_vertices.device
+    N, F = face_vertices.shape[:2]
+    fv = face_vertices.detach().reshape(N, F, 9).contiguous()
+    tx = textures.detach().reshape(N, F, -1, 3).contiguous()
+    T, IS = tx.shape[2], int(image_size)
+    aggrs_info = torch.empty(N, 2, IS, IS, dtype=torch.float32, device=dev)
+    soft_colors = torch.ones(N, 4, IS, IS, dtype=torch.float32, device=dev)
+    for k in range(3):
+        soft_colors[:, k] = float(background_color[k])
+    faces_info = torch.zeros(N, F, 27, dtype=torch.float32, device=dev) if want_faces_info else None
+    scalars = (_as_float(near), _as_float(far), float(eps), float(sigma_val), _DIST[dist_func],
+               float(math.log(1. / dist_eps - 1.)), float(gamma_val), _RGB[aggr_func_rgb],
+               _ALPHA[aggr_func_alpha], _TEX[texture_type], 1 if fill_back else 0)
+    h = _lib.lib()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
+        rc = h.lasr_sr_forward(fv.data_ptr(), tx.data_ptr(), faces_info.data_ptr() if want_faces_info else None,
+                               aggrs_info.data_ptr(), soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
+                               N, F, T, IS, *scalars, stream)
+    _lib.check(rc, 'lasr_sr_forward')
+    return (soft_colors, aggrs_info, faces_info) if want_faces_info else (soft_colors, aggrs_info)

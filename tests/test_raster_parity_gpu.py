@@ -1,0 +1,168 @@
+"""HIP soft-rasteriser vs the CPU oracle, through the C ABI (via the autograd Function).
+
+Bars (BASELINE.json north_star): rendered image max-abs <= 1e-4 against the fp32
+op-order-faithful oracle; hard-mode face-index map bit-exact; gradients within
+1e-3 of the largest gradient magnitude (the HIP backward sums in a different,
+but deterministic, order than the reference's atomics).
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from lasr_amd import synth
+from lasr_amd.soft_renderer import functional as srf
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+GRAD_REL = 1e-3
+
+
+def run_hip(dev, fv, ft, IS, g=None, **kw):
+    tfv = torch.from_numpy(fv).to(dev).requires_grad_(g is not None)
+    tft = torch.from_numpy(ft).to(dev).requires_grad_(g is not None)
+    if g is None:
+        img, aggr = srf.soft_rasterize_raw(tfv, tft, IS, kw['background_color'], kw['near'], kw['far'],
+                                           kw['fill_back'], kw['eps'], kw['sigma_val'], kw['dist_func'],
+                                           kw['dist_eps'], kw['gamma_val'], kw['aggr_func_rgb'],
+                                           kw['aggr_func_alpha'], kw['texture_type'])
+        return img.cpu().numpy(), aggr.cpu().numpy()
+    img = srf.soft_rasterize(tfv, tft, IS, **kw)
+    img.backward(torch.from_numpy(g).to(dev))
+    return img.detach().cpu().numpy(), tfv.grad.cpu().numpy(), tft.grad.cpu().numpy()
+
+
+def compare(oracle, dev, fv, ft, IS, kw, seed=2, check_grad=True):
+    ref = oracle.forward(fv, ft, IS, **kw)
+    img, aggr = run_hip(dev, fv, ft, IS, **kw)
+    err = np.abs(img - ref['soft_colors']).max()
+    assert err <= IMG_TOL, 'image max-abs %.3e' % err
+    if kw['aggr_func_rgb'] == 'hard':
+        assert np.array_equal(aggr[:, 1], ref['aggrs_info'][:, 1]), 'face-index map differs'
+        assert np.array_equal(aggr[:, 0], ref['aggrs_info'][:, 0]), 'z-buffer differs'
+    else:
+        assert np.abs(aggr[:, 1] - ref['aggrs_info'][:, 1]).max() <= 1e-6
+        np.testing.assert_allclose(aggr[:, 0], ref['aggrs_info'][:, 0], rtol=1e-4, atol=1e-30)
+    if not check_grad:
+        return err
+    g = synth.upstream_grad(fv.shape[0], IS, seed)
+    gf_ref, gt_ref = oracle.backward(ref, g, IS, **kw)
+    img2, gf, gt = run_hip(dev, fv, ft, IS, g=g, **kw)
+    assert np.abs(img2 - ref['soft_colors']).max() <= IMG_TOL
+    for name, a, b in (('grad_faces', gf, gf_ref), ('grad_textures', gt, gt_ref)):
+        assert np.isfinite(a).all() == np.isfinite(b).all()
+        scale = max(np.abs(b[np.isfinite(b)]).max() if np.isfinite(b).any() else 0.0, 1e-20)
+        d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).max()
+        assert d <= GRAD_REL * scale, '%s: max diff %.3e vs scale %.3e' % (name, d, scale)
+    return err
+
+
+def small_batch(nu, IS, n=2):
+    fv, ft, near, far = synth.raster_batch(nu, 3, count=n)
+    return fv, ft, near, far
+
+
+@pytest.mark.parametrize('dist,rgb,alpha', list(itertools.product(
+    ['hard', 'barycentric', 'euclidean'], ['hard', 'softmax'], ['hard', 'sum', 'prod'])))
+def test_all_mode_combinations_vertex(oracle, cuda, dist, rgb, alpha):
+    fv, ft, near, far = small_batch(4, 64)
+    kw = dict(synth.LASR_MODES, near=near, far=far, dist_func=dist, aggr_func_rgb=rgb, aggr_func_alpha=alpha)
+    compare(oracle, cuda, fv, ft, 64, kw)
+
+
+@pytest.mark.parametrize('res', [1, 2, 3])
+@pytest.mark.parametrize('rgb', ['hard', 'softmax'])
+def test_surface_textures(oracle, cuda, res, rgb):
+    fv, _, near, far = small_batch(4, 48)
+    rng = np.random.default_rng(5)
+    ft = rng.uniform(0, 1, (fv.shape[0], fv.shape[1], res * res, 3)).astype(np.float32)
+    kw = dict(synth.LASR_MODES, near=near, far=far, texture_type='surface', aggr_func_rgb=rgb)
+    compare(oracle, cuda, fv, ft, 48, kw)
+
+
+@pytest.mark.parametrize('IS', [1, 7, 16, 20, 33])
+def test_ragged_image_sizes(oracle, cuda, IS):
+    fv, ft, near, far = small_batch(2, IS)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    compare(oracle, cuda, fv, ft, IS, kw)
+
+
+def test_single_sided_and_sigma(oracle, cuda):
+    fv, ft, near, far = small_batch(4, 64)
+    for fill_back, sigma in ((False, 1e-4), (True, 1e-5), (False, 1e-5)):
+        kw = dict(synth.LASR_MODES, near=near, far=far, fill_back=fill_back, sigma_val=sigma)
+        compare(oracle, cuda, fv, ft, 64, kw)
+
+
+def test_depth_culling_keeps_alpha_but_not_gradient(oracle, cuda):
+    # near plane in the middle of the object: faces in front still count for alpha (K.cu:409-424)
+    fv, ft, near, far = small_batch(4, 64)
+    kw = dict(synth.LASR_MODES, near=10.0, far=far)
+    compare(oracle, cuda, fv, ft, 64, kw)
+
+
+def test_large_faces_and_more_than_one_list_round(oracle, cuda):
+    # two screen-filling triangles + 1500 small ones: exercises big bboxes in the face-major
+    # backward and a face count above the 1024-entry LDS list of the forward
+    rng = np.random.default_rng(7)
+    F = 1500
+    c = rng.uniform(-0.9, 0.9, (1, F, 1, 2))
+    tri = c + rng.uniform(-0.06, 0.06, (1, F, 3, 2))
+    z = rng.uniform(2, 4, (1, F, 3, 1))
+    fv = np.concatenate([tri, z], -1).astype(np.float32)
+    fv[0, 0] = [[-1.5, -1.2, 3], [1.4, -1.1, 3.5], [0.1, 1.6, 2.5]]
+    fv[0, 700] = [[-0.9, 0.8, 2.2], [0.95, 0.9, 3.9], [0.0, -0.97, 3.0]]
+    ft = rng.uniform(0, 1, fv.shape).astype(np.float32)
+    kw = dict(synth.LASR_MODES, near=1.0, far=5.0)
+    compare(oracle, cuda, fv, ft, 64, kw)
+    kw = dict(kw, aggr_func_rgb='hard', dist_func='hard', aggr_func_alpha='hard')
+    compare(oracle, cuda, fv, ft, 64, kw)
+
+
+def test_empty_and_degenerate_inputs(oracle, cuda):
+    kw = dict(synth.LASR_MODES, near=1.0, far=5.0)
+    # no faces at all: background image, alpha 0
+    fv = np.zeros((2, 0, 3, 3), np.float32)
+    img, _ = run_hip(cuda, fv, fv.copy(), 16, **kw)
+    assert np.array_equal(img[:, :3], np.ones_like(img[:, :3])) and np.array_equal(img[:, 3], np.zeros_like(img[:, 3]))
+    # zero-area and duplicated faces (det clamp path, K.cu:282)
+    fv = np.array([[[[0.1, 0.1, 2], [0.1, 0.1, 2], [0.1, 0.1, 2]],
+                    [[-0.5, -0.5, 3], [0.5, -0.5, 3], [0.0, 0.5, 3]],
+                    [[-0.5, -0.5, 3], [0.5, -0.5, 3], [0.0, 0.5, 3]],
+                    [[-0.5, 0.0, 2.5], [0.0, 0.0, 2.5], [0.5, 0.0, 2.5]]]], np.float32)
+    ft = np.random.default_rng(3).uniform(0, 1, fv.shape).astype(np.float32)
+    for modes in (dict(), dict(aggr_func_rgb='hard', dist_func='hard', aggr_func_alpha='hard')):
+        compare(oracle, cuda, fv, ft, 32, dict(kw, **modes), check_grad=False)
+
+
+def test_lasr_config_m1_256(oracle, cuda):
+    # spot3 stage-0 sized mesh at the full 256x256 (BASELINE configs[1])
+    fv, ft, near, far = synth.raster_batch(8, 3, count=2)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    err = compare(oracle, cuda, fv, ft, 256, kw)
+    print('M1 256x256 image max-abs err %.3e' % err)
+
+
+def test_lasr_config_m2_256(oracle, cuda):
+    # the ~1.2k vertex / 2.3k face mesh of the headline metric
+    fv, ft, near, far = synth.raster_batch(11, 3, count=1)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    err = compare(oracle, cuda, fv, ft, 256, kw)
+    print('M2 256x256 image max-abs err %.3e' % err)
+
+
+def test_backward_is_deterministic(cuda):
+    fv, ft, near, far = synth.raster_batch(8, 3, count=2)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    g = synth.upstream_grad(2, 128)
+    a = run_hip(cuda, fv, ft, 128, g=g, **kw)
+    b = run_hip(cuda, fv, ft, 128, g=g, **kw)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_cpu_tensor_is_rejected_like_the_reference():
+    t = torch.zeros(1, 1, 3, 3)
+    with pytest.raises(TypeError):
+        srf.soft_rasterize(t, t, 8)
