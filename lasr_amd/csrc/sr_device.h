@@ -223,24 +223,27 @@ __device__ __forceinline__ float depth_at(const float* __restrict__ rec, float c
     return 1.f / (c0 / rec[2] + c1 / rec[5] + c2 / rec[8]);
 }
 
-// K.cu:178-194
-__device__ __forceinline__ float sample_colour(const float* __restrict__ tex, float c0, float c1, float c2,
-                                               int res, int ch, int tex_type)
-{
-    if (tex_type == 0) {
-        const int ix = (int)(c0 * res), iy = (int)(c1 * res);
-        if ((c0 + c1) * res - ix - iy <= 1) return tex[(iy * res + ix) * 3 + ch];
-        return tex[((res - 1 - iy) * res + (res - 1 - ix)) * 3 + ch];
-    }
-    return c0 * tex[ch] + c1 * tex[3 + ch] + c2 * tex[6 + ch];
-}
-
-// texel index a surface sample lands in (K.cu:200-211)
+// texel index a surface sample lands in (K.cu:181-188 == 200-211).  A clipped barycentric
+// of exactly 1 yields ix (or iy) == res, i.e. an index >= T that runs into the next
+// face's texels: the reference reads it unchecked, and its backward (a loop over
+// j < T) then finds no texel to credit.  Both behaviours are kept; `lim` (texels
+// from this face to the end of the tensor) keeps the read inside the allocation.
 __device__ __forceinline__ int surface_texel(float c0, float c1, int res)
 {
     const int ix = (int)(c0 * res), iy = (int)(c1 * res);
     if ((c0 + c1) * res - ix - iy <= 1) return iy * res + ix;
     return (res - 1 - iy) * res + (res - 1 - ix);
+}
+
+// K.cu:178-194
+__device__ __forceinline__ float sample_colour(const float* __restrict__ tex, float c0, float c1, float c2,
+                                               int res, int ch, int tex_type, int lim)
+{
+    if (tex_type == 0) {
+        const int j = max(min(surface_texel(c0, c1, res), lim - 1), 0);
+        return tex[j * 3 + ch];
+    }
+    return c0 * tex[ch] + c1 * tex[3 + ch] + c2 * tex[6 + ch];
 }
 
 // ---- wave64 helpers ----------------------------------------------------------

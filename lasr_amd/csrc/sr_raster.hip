@@ -73,7 +73,7 @@ struct PixState {
 
 template <bool LASR_FAST>
 __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, const float* __restrict__ rec,
-                                             const float* __restrict__ tex, int fn, float xp, float yp, PixState& s)
+                                             const float* __restrict__ tex, int fn, int lim, float xp, float yp, PixState& s)
 {
     float w0, w1, w2;
     Frag fr;
@@ -93,9 +93,9 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
     if (m.rgb == 0) {
         if (zp < s.ssum && inside_closed(w0, w1, w2) && (m.double_side || front)) {
             s.ssum = zp; s.fbest = fn;
-            s.r = sample_colour(tex, c0, c1, c2, A.res, 0, m.tex);
-            s.g = sample_colour(tex, c0, c1, c2, A.res, 1, m.tex);
-            s.b = sample_colour(tex, c0, c1, c2, A.res, 2, m.tex);
+            s.r = sample_colour(tex, c0, c1, c2, A.res, 0, m.tex, lim);
+            s.g = sample_colour(tex, c0, c1, c2, A.res, 1, m.tex, lim);
+            s.b = sample_colour(tex, c0, c1, c2, A.res, 2, m.tex, lim);
         }
     } else {
         if (front || m.double_side) {
@@ -104,9 +104,9 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
             if (zn > s.smax) { rescale = expf((s.smax - zn) / A.gamma); s.smax = zn; }
             const float ez = expf((zn - s.smax) / A.gamma);
             s.ssum = rescale * s.ssum + ez * D;
-            s.r = rescale * s.r + ez * D * sample_colour(tex, c0, c1, c2, A.res, 0, m.tex);
-            s.g = rescale * s.g + ez * D * sample_colour(tex, c0, c1, c2, A.res, 1, m.tex);
-            s.b = rescale * s.b + ez * D * sample_colour(tex, c0, c1, c2, A.res, 2, m.tex);
+            s.r = rescale * s.r + ez * D * sample_colour(tex, c0, c1, c2, A.res, 0, m.tex, lim);
+            s.g = rescale * s.g + ez * D * sample_colour(tex, c0, c1, c2, A.res, 1, m.tex, lim);
+            s.b = rescale * s.b + ez * D * sample_colour(tex, c0, c1, c2, A.res, 2, m.tex, lim);
         }
     }
 }
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             if (__ballot(cand) == 0ull) continue;                         // wave-uniform skip
             const int fn = __builtin_amdgcn_readfirstlane(s_face[i]);     // wave-uniform -> scalar loads
             if (cand) {
-                forward_face<LASR_FAST>(A, m, recs + (size_t)fn * REC, texs + (size_t)fn * texstride, fn, xp, yp, s);
+                forward_face<LASR_FAST>(A, m, recs + (size_t)fn * REC, texs + (size_t)fn * texstride, fn,
+                                        (A.N * A.F - (bn * A.F + fn)) * A.T /* texels to the end of the tensor */, xp, yp, s);
             }
         }
         __syncthreads();
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     float gt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // vertex colours: [vertex j][channel k] at 3j+k
     const bool front = (__float_as_int(rec[R_FLAGS]) & 8) != 0;
     const bool vertex_tex = (m.tex == 1);
+    const int lim = (A.N * A.F - gw) * A.T;   // texels from this face to the end of the tensor
 
     // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
     int r = 0, c = 0;
@@ -311,8 +313,10 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
                     gt[6] += w2 * g0; gt[7] += w2 * g1; gt[8] += w2 * g2;
                 } else {
                     const int j = surface_texel(w0, w1, A.res);
-                    float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
-                    atomicAdd(gtp + 0, g0); atomicAdd(gtp + 1, g1); atomicAdd(gtp + 2, g2);
+                    if (j >= 0 && j < A.T) {   // the reference only credits texels j < T (K.cu:605)
+                        float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
+                        atomicAdd(gtp + 0, g0); atomicAdd(gtp + 1, g1); atomicAdd(gtp + 2, g2);
+                    }
                 }
             }
         } else if (front || m.double_side) {                                 // K.cu:611-640
@@ -329,13 +333,15 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
                 gt[6] += sm * (w2 * g0); gt[7] += sm * (w2 * g1); gt[8] += sm * (w2 * g2);
             } else {
                 const int j = surface_texel(w0, w1, A.res);
-                float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
-                atomicAdd(gtp + 0, sm * g0); atomicAdd(gtp + 1, sm * g1); atomicAdd(gtp + 2, sm * g2);
+                if (j >= 0 && j < A.T) {       // K.cu:620
+                    float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
+                    atomicAdd(gtp + 0, sm * g0); atomicAdd(gtp + 1, sm * g1); atomicAdd(gtp + 2, sm * g2);
+                }
             }
             float Crgb = 0.f;
-            Crgb += g0 * (sample_colour(tex, w0, w1, w2, A.res, 0, m.tex) - colors[((size_t)bn * 4 + 0) * P + pn]);
-            Crgb += g1 * (sample_colour(tex, w0, w1, w2, A.res, 1, m.tex) - colors[((size_t)bn * 4 + 1) * P + pn]);
-            Crgb += g2 * (sample_colour(tex, w0, w1, w2, A.res, 2, m.tex) - colors[((size_t)bn * 4 + 2) * P + pn]);
+            Crgb += g0 * (sample_colour(tex, w0, w1, w2, A.res, 0, m.tex, lim) - colors[((size_t)bn * 4 + 0) * P + pn]);
+            Crgb += g1 * (sample_colour(tex, w0, w1, w2, A.res, 1, m.tex, lim) - colors[((size_t)bn * 4 + 1) * P + pn]);
+            Crgb += g2 * (sample_colour(tex, w0, w1, w2, A.res, 2, m.tex, lim) - colors[((size_t)bn * 4 + 2) * P + pn]);
             Crgb *= sm;
             C += Crgb / D;
             const float Cz = Crgb / A.gamma / (A.near - A.far) * zp * zp;

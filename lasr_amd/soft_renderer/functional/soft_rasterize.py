@@ -21,6 +21,14 @@ _TEX = {'surface': 0, 'vertex': 1}
 _workspaces = {}
 
 
+def _texels(textures):
+    """T of a [N,F,T,3] (or flattened [N,F,T*3]) texture tensor; well defined for F == 0 too."""
+    n = 1
+    for d in textures.shape[2:]:
+        n *= int(d)
+    return max(n // 3, 1)
+
+
 def _workspace(device, stream, nbytes):
     key = (device.index, stream)
     ws = _workspaces.get(key)
@@ -49,8 +57,8 @@ class SoftRasterizeFunction(Function):
         dev = face_vertices.device
         N, F = face_vertices.shape[:2]
         fv = face_vertices.detach().reshape(N, F, 9).contiguous()
-        tx = textures.detach().reshape(N, F, -1, 3).contiguous()
-        T = tx.shape[2]
+        T = _texels(textures)
+        tx = textures.detach().reshape(N, F, T, 3).contiguous()
         IS = int(image_size)
 
         ctx.geom = (N, F, T, IS)
@@ -126,8 +134,8 @@ def soft_rasterize_raw(face_vertices, textures, image_size, background_color, ne
     dev = face_vertices.device
     N, F = face_vertices.shape[:2]
     fv = face_vertices.detach().reshape(N, F, 9).contiguous()
-    tx = textures.detach().reshape(N, F, -1, 3).contiguous()
-    T, IS = tx.shape[2], int(image_size)
+    T, IS = _texels(textures), int(image_size)
+    tx = textures.detach().reshape(N, F, T, 3).contiguous()
     aggrs_info = torch.empty(N, 2, IS, IS, dtype=torch.float32, device=dev)
     soft_colors = torch.ones(N, 4, IS, IS, dtype=torch.float32, device=dev)
     for k in range(3):
