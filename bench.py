@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- soft-rasteriser forward+backward throughput on MI355X (BASELINE.json metric #1).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE configs[1]): mesh M2 (geodesic nu=11, V=1212, F=2420,
+the "~1.2k vert / 2.3k face" mesh), 256x256, LASR's raster modes (euclidean / softmax /
+prod / vertex colours, sigma 1e-4, gamma 1e-2), B synthetic yaw-rotated frames per GPU per
+step, upstream gradient N(0,1)/P.  Inputs are resident in HBM before the timed region.
+
+One step = for the rank's B frames: fill soft_colors with the background, zero the gradient
+buffers, forward (setup + raster kernels), backward (setup + raster kernels) through the C ABI,
+scatter-add the face gradients to per-vertex mesh gradients; for N > 1 the [2,V,3] mesh
+gradient is then all-reduced over RCCL (frames are sharded data-parallel, weak scaling).
+Nothing inside the timed region touches the CPU oracle.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the
+library on the launch stream) and, at N=1, `cpu_baseline` (the oracle, OpenMP over host cores,
+on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from lasr_amd import _lib, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+IS = 256
+NU = 11                        # mesh M2
+N_FRAMES_CYCLE = 26            # yaw positions ("~26 frames" of BASELINE configs)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=64, help='frames per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+class RasterStep:
+    """Pre-allocated buffers + one fwd/bwd pass through the C ABI."""
+
+    def __init__(self, dev, B, first_frame):
+        self.dev, self.B = dev, B
+        v, f, tex = synth.blobby_mesh(NU)
+        self.V, self.F = v.shape[0], f.shape[0]
+        pv = synth.frame_vertices(v, N_FRAMES_CYCLE, first=first_frame, count=B)
+        self.near, self.far = synth.near_far(synth.frame_vertices(v, N_FRAMES_CYCLE)[:, :, 2])
+        self.faces_idx = torch.from_numpy(f).to(dev)
+        self.fv = torch.from_numpy(np.ascontiguousarray(pv[:, f])).to(dev).reshape(B, self.F, 9).contiguous()
+        self.ft = torch.from_numpy(np.ascontiguousarray(tex[f])).to(dev).reshape(1, self.F, 9).repeat(B, 1, 1).contiguous()
+        self.g = torch.from_numpy(synth.upstream_grad(B, IS)).to(dev)
+        self.colors = torch.empty(B, 4, IS, IS, device=dev)
+        self.aggrs = torch.empty(B, 2, IS, IS, device=dev)
+        self.gf = torch.empty(B, self.F, 9, device=dev)
+        self.gt = torch.empty(B, self.F, 9, device=dev)
+        self.mesh_grad = torch.zeros(2, self.V, 3, device=dev)    # d/d(vertex xyz), d/d(vertex colour), summed over frames
+        self.scatter_idx = self.faces_idx.reshape(-1)             # [F*3]
+        m = synth.LASR_MODES
+        self.h = _lib.lib()
+        self.ws = torch.empty(self.h.lasr_sr_workspace_bytes(B, self.F, 3, IS), dtype=torch.uint8, device=dev)
+        self.scalars = (float(self.near), float(self.far), float(m['eps']), float(m['sigma_val']), 2,
+                        float(math.log(1. / m['dist_eps'] - 1.)), float(m['gamma_val']), 1, 2, 1, 1)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(self):
+        B, F, h = self.B, self.F, self.h
+        self.colors.fill_(1.0)                       # background (1,1,1), alpha slot 1 (soft_rasterize.py:50-53)
+        self.gf.zero_()
+        self.gt.zero_()
+        rc = h.lasr_sr_forward(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
+                               self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                               B, F, 3, IS, *self.scalars, self.stream)
+        _lib.check(rc, 'lasr_sr_forward')
+        rc = h.lasr_sr_backward(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), None,
+                                self.aggrs.data_ptr(), self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(),
+                                self.ws.data_ptr(), self.ws.numel(), B, F, 3, IS, *self.scalars, self.stream)
+        _lib.check(rc, 'lasr_sr_backward')
+        # face -> vertex gradient scatter (autograd of face_vertices.py:4-22), summed over the rank's frames
+        self.mesh_grad.zero_()
+        self.mesh_grad[0].index_add_(0, self.scatter_idx, self.gf.sum(0).reshape(F * 3, 3))
+        self.mesh_grad[1].index_add_(0, self.scatter_idx, self.gt.sum(0).reshape(F * 3, 3))
+        return self.mesh_grad
+
+
+def collect_kernel_times(h):
+    out = {}
+    for k in range(h.lasr_prof_kernel_count()):
+        ms, n = ctypes.c_double(0), ctypes.c_longlong(0)
+        h.lasr_prof_collect(k, ctypes.byref(ms), ctypes.byref(n))
+        if n.value:
+            out[h.lasr_prof_kernel_name(k).decode()] = (ms.value / n.value, n.value)
+    return out
+
+
+def cpu_baseline(F):
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload."""
+    from oracle import sr_oracle
+    cores = os.cpu_count() or 1
+    n = max(2, min(cores, 32))                      # one frame per core; fwd is pixel-parallel, bwd image-parallel
+    fv, ft, near, far = synth.raster_batch(NU, N_FRAMES_CYCLE, count=n)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    g = synth.upstream_grad(n, IS)
+    sr_oracle.lib()
+    t0 = time.perf_counter()
+    ref = sr_oracle.forward(fv, ft, IS, **kw)
+    sr_oracle.backward(ref, g, IS, **kw)
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d frames fwd+bwd of the same M2 256x256 workload, OpenMP threads=%d, %.1f s wall'
+                      % (n, cores, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no HIP device visible); there is no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)   # 'nccl' == RCCL on ROCm
+
+    B = a.frames
+    job = RasterStep(dev, B, first_frame=rank * B)
+
+    def one_step():
+        mg = job.step()
+        if dist is not None:
+            dist.all_reduce(mg)                      # mesh-parameter gradient, [2,V,3] fp32 over xGMI
+        return mg
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline leg: per-kernel HIP-event timing inside the library (separate pass) ----
+    h = job.h
+    h.lasr_prof_enable(1)
+    for _ in range(min(a.steps, 10)):
+        job.step()
+    torch.cuda.synchronize()
+    h.lasr_prof_enable(0)
+    ktimes = collect_kernel_times(h)
+
+    if rank == 0:
+        F, P = job.F, IS * IS
+        alg = {'sr_forward_kernel': (72 * F + 24 * P) * B, 'sr_backward_kernel': (144 * F + 40 * P) * B,
+               'sr_setup_kernel': (36 + 160) * F * B}
+        dom = max((k for k in ktimes if k != 'sr_setup_kernel'), key=lambda k: ktimes[k][0])
+        achieved = alg[dom] / (ktimes[dom][0] * 1e-3) / 1e9
+        frames = world * B * a.steps
+        out = {
+            'metric': 'rasterizer fwd+bwd frames/sec at 256x256, 2.3k faces',
+            'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'soft-rasteriser fwd+bwd, mesh M2 (V=1212,F=2420), 256x256, LASR modes '
+                                   '(euclidean/softmax/prod/vertex, sigma=1e-4, gamma=1e-2)',
+                       'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
+                       'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ktimes[dom][0],
+                         'all_kernels_avg_ms': {k: v[0] for k, v in ktimes.items()}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(F)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

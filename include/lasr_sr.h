@@ -79,6 +79,18 @@ int lasr_sr_backward(const float* faces, const float* textures, const float* sof
                      int func_id_rgb, int func_id_alpha, int texture_sample_type,
                      int double_side, void* hip_stream);
 
+/*
+ * Optional per-kernel timing for benchmarks (no reference counterpart: the
+ * reference has no profiling hooks).  While enabled, every
+ * kernel launch of this library is bracketed by hipEvents on its stream;
+ * lasr_prof_collect blocks until those launches finished and returns their
+ * summed duration and count, then forgets them.
+ */
+int         lasr_prof_enable(int on);
+int         lasr_prof_kernel_count(void);
+const char* lasr_prof_kernel_name(int kernel_id);
+int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launches);
+
 #ifdef __cplusplus
 }
 #endif

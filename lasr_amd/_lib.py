@@ -20,6 +20,10 @@ SIGNATURES = {
     'lasr_sr_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'lasr_sr_forward': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
     'lasr_sr_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
+    'lasr_prof_enable': (_i, [_i]),
+    'lasr_prof_kernel_count': (_i, []),
+    'lasr_prof_kernel_name': (ctypes.c_char_p, [_i]),
+    'lasr_prof_collect': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
 }
 
 _lib = None
@@ -37,6 +41,10 @@ def lib():
             raise LasrNativeError(
                 'liblasr_hip.so is not built (%s). Run `python -m lasr_amd.build` '
                 '(hipcc --offload-arch=gfx950); there is no CPU fallback.' % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7; load it FIRST so that this library
+        # binds to the same HIP runtime instance (stream handles are only valid
+        # inside the runtime that created them).
+        import torch  # noqa: F401
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)       # AttributeError here == ABI mismatch: let it propagate
