@@ -1,0 +1,208 @@
+"""Pins for the CPU oracle (oracle/sr_oracle.c).
+
+The reference kernel cannot be built here (CUDA-only, no tests upstream), so the oracle is pinned by
+  (1) the known answers SURVEY.md App. A/B recorded from a run of the reference kernel,
+  (2) hand-computable analytic cases,
+  (3) finite differences of its own fp64 forward for the parts of the reference backward that are exact
+      derivatives (silhouette w.r.t. xy, depth-softmax w.r.t. z, colours w.r.t. textures).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from lasr_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+HARD = dict(background_color=(0, 0, 0), near=1, far=100, fill_back=True, eps=1e-3, sigma_val=1e-4, dist_func='hard',
+            dist_eps=1e-4, gamma_val=1e-4, aggr_func_rgb='hard', aggr_func_alpha='hard', texture_type='vertex')
+SOFT = dict(synth.LASR_MODES, near=1.0, far=100.0)
+
+
+def tri(*pts):
+    return np.asarray(pts, np.float32).reshape(1, -1, 3, 3)
+
+
+@pytest.mark.parametrize('which', ['reference_meshzoo', 'own_geodesic'])
+def test_survey_appendix_b_sanity_values(oracle, which):
+    # icosphere-3 x0.6, z+3, y-flipped, IS=64, modes (0,0,0,1), near 1, far 100:
+    # 1156 covered pixels, 514 distinct faces, identical index map in fp32 and fp64
+    if which == 'reference_meshzoo':
+        d = np.load(os.path.join(GOLD, 'meshzoo_icosphere.npz'))
+        v, f = d['v3'], d['f3']
+    else:
+        v, f = synth.geodesic_sphere(8)
+    v = (v * 0.6).astype(np.float32)
+    v[:, 2] += 3
+    v[:, 1] *= -1
+    fv = v[f][None]
+    r32 = oracle.forward(fv, np.ones_like(fv), 64, **HARD)
+    r64 = oracle.forward(fv, np.ones_like(fv), 64, dtype=np.float64, **HARD)
+    idx = r32['aggrs_info'][0, 1]
+    assert int((idx >= 0).sum()) == 1156
+    assert len(np.unique(idx[idx >= 0])) == 514
+    assert np.array_equal(idx, r64['aggrs_info'][0, 1].astype(np.float32))
+    assert r32['soft_colors'][0, 3].sum() == 1156
+
+
+def test_image_orientation_row0_is_top_col0_is_left(oracle):
+    # a triangle in x<0, y>0 lands only in the top-left quadrant
+    fv = tri([-0.8, 0.2, 2], [-0.2, 0.2, 2], [-0.5, 0.8, 2])
+    r = oracle.forward(fv, np.ones_like(fv), 16, **HARD)
+    a = r['soft_colors'][0, 3]
+    assert a[:8, :8].sum() > 0 and a[8:, :].sum() == 0 and a[:, 8:].sum() == 0
+
+
+def test_hard_coverage_equals_point_in_triangle(oracle):
+    IS = 32
+    p = np.array([[-0.63, -0.41], [0.71, -0.22], [0.05, 0.77]])
+    fv = tri(*[list(q) + [3.0] for q in p])
+    a = oracle.forward(fv, np.ones_like(fv), IS, **HARD)['soft_colors'][0, 3]
+    c = (2 * np.arange(IS) + 1 - IS) / IS
+    X, Y = np.meshgrid(c, c[::-1])
+
+    def side(a_, b_):
+        return (b_[0] - a_[0]) * (Y - a_[1]) - (b_[1] - a_[1]) * (X - a_[0])
+    s = [side(p[i], p[(i + 1) % 3]) for i in range(3)]
+    inside = ((s[0] > 0) & (s[1] > 0) & (s[2] > 0)) | ((s[0] < 0) & (s[1] < 0) & (s[2] < 0))
+    assert np.array_equal(a > 0.5, inside)
+
+
+def test_face_behind_near_plane_counts_for_alpha_only_and_gets_no_gradient(oracle):
+    # z=0.5 with near=1 still contributes alpha, leaves RGB at the background,
+    # and the backward pass returns exactly zero for it
+    fv = tri([-0.5, -0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.5, 0.5])
+    ft = np.full_like(fv, 0.25)
+    r = oracle.forward(fv, ft, 16, **SOFT)
+    img = r['soft_colors'][0]
+    assert img[3].sum() > 10 and np.array_equal(img[:3], np.ones_like(img[:3]))
+    g = synth.upstream_grad(1, 16)
+    gf, gt = oracle.backward(r, g, 16, **SOFT)
+    assert not gf.any() and not gt.any()
+
+
+def test_identical_faces_hard_mode_lowest_index_wins(oracle):
+    one = [[-0.6, -0.5, 2], [0.6, -0.5, 2], [0.0, 0.6, 2]]
+    fv = tri(*one, *one)
+    r = oracle.forward(fv, np.ones_like(fv), 16, **HARD)
+    idx = r['aggrs_info'][0, 1]
+    assert (idx >= 0).any() and set(np.unique(idx)) <= {-1.0, 0.0}
+
+
+def test_reversed_winding_single_sided_keeps_alpha_drops_rgb(oracle):
+    ccw = [[-0.6, -0.5, 2], [0.6, -0.5, 2], [0.0, 0.6, 2]]
+    kw = dict(SOFT, fill_back=False)
+    imgs = []
+    for pts in (ccw, ccw[::-1]):
+        fv = tri(*pts)
+        imgs.append(oracle.forward(fv, np.zeros_like(fv), 16, **kw)['soft_colors'][0])
+    a0, a1 = imgs[0][3], imgs[1][3]
+    np.testing.assert_allclose(a0, a1, atol=1e-6)
+    drew = [bool((im[:3] < 0.5).any()) for im in imgs]
+    assert drew.count(True) == 1                    # exactly one winding is front-facing
+    back = imgs[drew.index(False)]
+    assert np.array_equal(back[:3], np.ones_like(back[:3]))
+
+
+def test_background_vanishes_once_a_face_has_depth_weight(oracle):
+    # the eps-background term is rescaled by exp((eps-zn)/gamma) ~ e^-99
+    fv = tri([-0.9, -0.9, 2], [0.9, -0.9, 2], [0.0, 0.9, 2])
+    ft = np.full_like(fv, 0.3)
+    kw = dict(SOFT, near=1.0, far=100.0)
+    r = oracle.forward(fv, ft, 16, **kw)
+    c = r['soft_colors'][0, :, 8, 8]
+    assert abs(c[0] - 0.3) < 1e-6 and abs(c[3] - 1.0) < 1e-6
+    zn = (100.0 - 2.0) / 99.0
+    assert abs(r['aggrs_info'][0, 1, 8, 8] - zn) < 1e-6 and abs(r['aggrs_info'][0, 0, 8, 8] - 1.0) < 1e-5
+
+
+def test_euclidean_probability_outside_an_edge_is_sigmoid_of_squared_distance(oracle):
+    # big right triangle with a vertical edge at x = 0.25: pixels to its left, well inside the edge's span,
+    # are at distance (0.25 - xp); D = 1 / (1 + exp(d^2 / sigma))   (K.cu:403 with sign = -1)
+    IS, sigma = 64, 1e-3
+    fv = tri([0.25, -0.95, 2], [0.95, 0.0, 2], [0.25, 0.95, 2])
+    kw = dict(SOFT, sigma_val=sigma)
+    a = oracle.forward(fv, np.ones_like(fv), IS, dtype=np.float64, **kw)['soft_colors'][0, 3]
+    c = (2 * np.arange(IS) + 1 - IS) / IS
+    row = IS // 2
+    for col in range(IS):
+        d = 0.25 - c[col]
+        thr = np.log(1 / 1e-4 - 1) * sigma
+        if 0 < d and d * d < thr:
+            expect = 1 / (1 + np.exp(d * d / sigma))
+            assert abs(a[row, col] - expect) < 1e-7, (col, a[row, col], expect)
+
+
+def test_alpha_prod_of_two_faces(oracle):
+    A = [[-0.7, -0.6, 2], [0.5, -0.6, 2], [-0.1, 0.7, 2]]
+    B = [[-0.4, -0.7, 3], [0.8, -0.5, 3], [0.2, 0.6, 3]]
+    kw = dict(SOFT, sigma_val=1e-3)
+    a = [oracle.forward(tri(*p), np.ones((1, len(p) // 3, 3, 3), np.float32), 24, dtype=np.float64, **kw)['soft_colors'][0, 3]
+         for p in (A, B, A + B)]
+    np.testing.assert_allclose(a[2], 1 - (1 - a[0]) * (1 - a[1]), atol=1e-12)
+
+
+def test_fp32_tracks_fp64(oracle):
+    fv, ft, near, far = synth.raster_batch(4, 3, count=1)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    a = oracle.forward(fv, ft, 64, **kw)['soft_colors']
+    b = oracle.forward(fv, ft, 64, dtype=np.float64, **kw)['soft_colors']
+    d = np.abs(a - b)
+    assert d.mean() < 1e-5 and np.median(d) < 1e-6
+
+
+def test_backward_matches_finite_differences_where_the_reference_is_exact(oracle):
+    # fp64 oracle; loss = <g, image>.  Exact parts of K.cu:486-668: d alpha/d xy, d rgb/d z (w held fixed
+    # is automatic: z does not enter w), d rgb/d textures.  (d rgb/d xy is an approximation in the reference.)
+    rng = np.random.default_rng(11)
+    IS = 24
+    fv = np.array([[[[-0.62, -0.48, 2.0], [0.55, -0.57, 2.4], [-0.08, 0.66, 2.2]],
+                    [[-0.33, -0.71, 2.6], [0.74, -0.12, 2.1], [0.12, 0.58, 2.9]]]], np.float64)
+    ft = rng.uniform(0, 1, fv.shape)
+    kw = dict(SOFT, sigma_val=3e-3, gamma_val=5e-2, near=1.0, far=4.0)
+    g = rng.standard_normal((1, 4, IS, IS))
+
+    def loss(fv_, ft_, gg):
+        return float((oracle.forward(fv_, ft_, IS, dtype=np.float64, **kw)['soft_colors'] * gg).sum())
+
+    g_alpha = np.zeros_like(g)
+    g_alpha[:, 3] = g[:, 3]
+    r = oracle.forward(fv, ft, IS, dtype=np.float64, **kw)
+    gf_a, _ = oracle.backward(r, g_alpha, IS, dtype=np.float64, **kw)
+    gf, gt = oracle.backward(r, g, IS, dtype=np.float64, **kw)
+    h = 1e-6
+    for f in range(2):
+        for v in range(3):
+            for c in range(2):      # xy through the silhouette
+                p, m = fv.copy(), fv.copy()
+                p[0, f, v, c] += h
+                m[0, f, v, c] -= h
+                fd = (loss(p, ft, g_alpha) - loss(m, ft, g_alpha)) / (2 * h)
+                assert abs(fd - gf_a[0, f, v, c]) <= 2e-4 * max(1.0, abs(fd)), (f, v, c, fd, gf_a[0, f, v, c])
+            p, m = fv.copy(), fv.copy()   # z through the depth softmax
+            p[0, f, v, 2] += h
+            m[0, f, v, 2] -= h
+            fd = (loss(p, ft, g) - loss(m, ft, g)) / (2 * h)
+            assert abs(fd - gf[0, f, v, 2]) <= 2e-4 * max(1.0, abs(fd)), (f, v, 'z', fd, gf[0, f, v, 2])
+            for c in range(3):      # textures (linear)
+                p, m = ft.copy(), ft.copy()
+                p[0, f, v, c] += h
+                m[0, f, v, c] -= h
+                fd = (loss(fv, p, g) - loss(fv, m, g)) / (2 * h)
+                assert abs(fd - gt[0, f, v, c]) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_surface_texture_index_quirk_is_kept(oracle):
+    # clipped barycentric == 1 -> texel index res (>= T for res=1): read runs into the next face,
+    # backward credits nothing (K.cu:181-188 vs 605/620)
+    fv = tri([-0.5, -0.5, 2], [0.5, -0.5, 2], [0.0, 0.5, 2], [0.6, 0.6, 2], [0.9, 0.6, 2], [0.75, 0.9, 2])
+    ft = np.zeros((1, 2, 1, 3), np.float32)
+    ft[0, 0] = 0.2
+    ft[0, 1] = 0.9
+    kw = dict(SOFT, texture_type='surface', sigma_val=1e-3)
+    r = oracle.forward(fv, ft, 32, **kw)
+    img = r['soft_colors'][0]
+    assert img[0].min() >= 0.2 - 1e-6 and np.isfinite(img).all()
+    g = synth.upstream_grad(1, 32)
+    gf, gt = oracle.backward(r, g, 32, **kw)
+    assert np.isfinite(gf).all() and np.isfinite(gt).all()
