@@ -20,10 +20,19 @@ namespace lasr {
 // [9..17]  inv  : rows of adj([x y 1])/det                         (K.cu:274-286)
 // [18..26] e    : e[k][j] = sym[3k+j] - sym[3((k+1)%3)+j]           (K.cu:81-83,132-134, hoisted)
 // [27..29] den  : den[k]  = e[k][k] - e[k][(k+1)%3]                 (K.cu:85,136, hoisted)
-// [30]     flags: bit0..2 first obtuse corner (K.cu:296-304), bit3 front-facing (K.cu:41-44)
-// [31..35] pad to 144 B (16-B multiple so records start on a dwordx4 boundary)
-constexpr int REC = 36;
-constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30;
+// [30]     flags: bit0..2 first obtuse corner (K.cu:296-304), bit3 front-facing (K.cu:41-44),
+//                 bit4 well-conditioned (the cheap line-distance reject below may be used)
+// [31..33] hk2  : squared height of vertex k over its opposite edge (own addition: w_k * h_k is the
+//                 signed distance of a pixel to that edge's line, a lower bound of the true distance)
+// [34..39] pad to 160 B (16-B multiple so records start on a dwordx4 boundary)
+constexpr int REC = 40;
+constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30, R_HK2 = 31;
+
+// Read-only buffers written by an EARLIER kernel are viewed through the constant address
+// space: with a wave-uniform index the compiler then emits s_load (scalar cache -> SGPRs)
+// even after barriers, instead of 64 identical vector loads.
+typedef const float __attribute__((address_space(4)))* cptr_t;
+__device__ __forceinline__ cptr_t as_const(const float* p) { return (cptr_t)(unsigned long long)p; }
 
 struct Modes {
     int dist, rgb, alpha, tex, double_side;
@@ -31,8 +40,10 @@ struct Modes {
 
 __device__ __forceinline__ float pix_center(int i, int is)
 {
-    // K.cu:345-346 -- evaluated in double, then narrowed
-    return (float)((2. * i + 1. - is) / is);
+    // K.cu:345-346 evaluates (2.*i + 1. - is) / is in double and narrows.  The numerator is an exact
+    // integer and narrowing a double quotient of two floats is the correctly rounded float quotient
+    // (53 >= 2*24+2 bits), so one IEEE fp32 division gives the identical value.
+    return (float)(2 * i + 1 - is) / (float)is;
 }
 
 __device__ __forceinline__ void build_record(const float* __restrict__ f, float* __restrict__ rec,
@@ -76,9 +87,26 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
         for (int j = 0; j < 3; j++) { e[j] = sym[3 * k + j] - sym[3 * b + j]; rec[R_E + 3 * k + j] = e[j]; }
         rec[R_DEN + k] = e[k] - e[b];
     }
+    {
+        // heights^2 = det^2 / |opposite edge|^2 (unclamped det); a face is "well conditioned" when all
+        // three heights exceed 1e-3 NDC, so that the fp32 barycentrics carry a relative error << 1 %
+        const float det0 = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+        const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int b = (k + 1) % 3, c = (k + 2) % 3;
+            const float ex = px[c] - px[b], ey = py[c] - py[b];
+            const float l2 = ex * ex + ey * ey;
+            const float h2 = l2 > 0.f ? det0 * det0 / l2 : 0.f;
+            rec[R_HK2 + k] = h2;
+            ok = ok && (h2 > 1e-6f) && (h2 < 1e12f);
+        }
+        if (ok) flags |= 16;
+    }
     rec[R_FLAGS] = __int_as_float(flags);
 #pragma unroll
-    for (int k = R_FLAGS + 1; k < REC; k++) rec[k] = 0.f;
+    for (int k = R_HK2 + 3; k < REC; k++) rec[k] = 0.f;
     // K.cu:33-38 with the max/min +- margin hoisted (same float ops, done once)
     const float xmax = fmaxf(fmaxf(x0, x1), x2) + margin, xmin = fminf(fminf(x0, x1), x2) - margin;
     const float ymax = fmaxf(fmaxf(y0, y1), y2) + margin, ymin = fminf(fminf(y0, y1), y2) - margin;
@@ -103,13 +131,15 @@ __device__ __forceinline__ bool inside_closed(float w0, float w1, float w2)
 }
 
 // K.cu:53-58
+template <bool FM = false>
 __device__ __forceinline__ void clip_normalise(float& w0, float& w1, float& w2)
 {
     w0 = fmaxf(fminf(w0, 1.f), 0.f);     // == the reference's double-literal clamp (the bounds are exact)
     w1 = fmaxf(fminf(w1, 1.f), 0.f);
     w2 = fmaxf(fminf(w2, 1.f), 0.f);
     const float s = fmaxf(w0 + w1 + w2, 1e-5f);   // (float)max((double)s, 1e-5) == fmaxf(s, 1e-5f) for every float s
-    w0 /= s; w1 /= s; w2 /= s;
+    if (FM) { const float r = __builtin_amdgcn_rcpf(s); w0 *= r; w1 *= r; w2 *= r; }
+    else { w0 /= s; w1 /= s; w2 /= s; }
 }
 
 // sigmoid through double exactly as K.cu:397,403 promotes it
@@ -118,16 +148,40 @@ __device__ __forceinline__ float sigmoid_neg(float neg_arg)
     return (float)(1. / (1. + (double)expf(neg_arg)));
 }
 
+// ---- math flavours -----------------------------------------------------------------
+// FM = false : the reference's rounding sequence (forward pass: parity to ~1 ulp of expf)
+// FM = true  : v_rcp_f32 / v_exp_f32 based (backward pass only: the reference's own backward sums
+//              its terms with unordered float atomics, the gradient bar is relative 1e-3)
+template <bool FM> __device__ __forceinline__ float div_(float a, float b)
+{
+    return FM ? a * __builtin_amdgcn_rcpf(b) : a / b;
+}
+template <bool FM> __device__ __forceinline__ float exp_(float x) { return FM ? __expf(x) : expf(x); }
+template <bool FM> __device__ __forceinline__ float sigmoid_neg_(float neg_arg)
+{
+    if (FM) return __builtin_amdgcn_rcpf(1.f + __expf(neg_arg));
+    return (float)(1. / (1. + (double)expf(neg_arg)));   // K.cu:397,403 promote this to double
+}
+
+// Conservative reject for the compaction stages: true only if the pixel is certainly farther than
+// sqrt(thr) from the face (so the reference's `dis >= threshold` test would skip it as well).
+__device__ __forceinline__ bool certainly_far(cptr_t rec, float w0, float w1, float w2, float thr_pad)
+{
+    return (w0 < 0.f && w0 * w0 * rec[R_HK2 + 0] > thr_pad) ||
+           (w1 < 0.f && w1 * w1 * rec[R_HK2 + 1] > thr_pad) ||
+           (w2 < 0.f && w2 * w2 * rec[R_HK2 + 2] > thr_pad);
+}
+
 // One edge projection with compile-time edge K (a=K, b=K+1, c=K+2 mod 3): K.cu:85-95 / 136-148.
 // Returns u (already minus w) in (u0,u1,u2).  CLAMP selects the outside-branch variant.
-template <int K, bool CLAMP>
-__device__ __forceinline__ void edge_project(const float* __restrict__ rec, float w0, float w1, float w2,
+template <int K, bool CLAMP, bool FM = false>
+__device__ __forceinline__ void edge_project(cptr_t rec, float w0, float w1, float w2,
                                              float& u0, float& u1, float& u2)
 {
     constexpr int B = (K + 1) % 3;
     const float e0 = rec[R_E + 3 * K + 0], e1 = rec[R_E + 3 * K + 1], e2 = rec[R_E + 3 * K + 2];
     const float eb = rec[R_E + 3 * K + B];
-    float ta = (w0 * e0 + w1 * e1 + w2 * e2 - eb) / rec[R_DEN + K];
+    float ta = div_<FM>(w0 * e0 + w1 * e1 + w2 * e2 - eb, rec[R_DEN + K]);
     float tb = 1 - ta;
     float tc = 0;
     if (CLAMP) {
@@ -147,7 +201,8 @@ struct Frag {
 };
 
 // Euclidean point-to-face distance: K.cu:61-151
-__device__ __forceinline__ void euclid(const float* __restrict__ rec, float xp, float yp,
+template <bool FM = false>
+__device__ __forceinline__ void euclid(cptr_t rec, float xp, float yp,
                                        float w0, float w1, float w2, Frag& fr)
 {
     const float x0 = rec[0], y0 = rec[1], x1 = rec[3], y1 = rec[4], x2 = rec[6], y2 = rec[7];
@@ -155,7 +210,7 @@ __device__ __forceinline__ void euclid(const float* __restrict__ rec, float xp, 
         float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
         float u0, u1, u2;
 #define LASR_TRY_EDGE(K)                                                          \
-        edge_project<K, false>(rec, w0, w1, w2, u0, u1, u2);                      \
+        edge_project<K, false, FM>(rec, w0, w1, w2, u0, u1, u2);                      \
         {                                                                         \
             const float px = u0 * x0 + u1 * x1 + u2 * x2;                         \
             const float py = u0 * y0 + u1 * y1 + u2 * y2;                         \
@@ -182,9 +237,9 @@ __device__ __forceinline__ void euclid(const float* __restrict__ rec, float xp, 
         else if (w2 <= 0) a = 0;
         if (a < 0) a = 0;   // reference indexes [-1] here (UB); pinned to edge 0 like the oracle
         float u0, u1, u2;
-        if (a == 0) edge_project<0, true>(rec, w0, w1, w2, u0, u1, u2);
-        else if (a == 1) edge_project<1, true>(rec, w0, w1, w2, u0, u1, u2);
-        else edge_project<2, true>(rec, w0, w1, w2, u0, u1, u2);
+        if (a == 0) edge_project<0, true, FM>(rec, w0, w1, w2, u0, u1, u2);
+        else if (a == 1) edge_project<1, true, FM>(rec, w0, w1, w2, u0, u1, u2);
+        else edge_project<2, true, FM>(rec, w0, w1, w2, u0, u1, u2);
         fr.dx = u0 * x0 + u1 * x1 + u2 * x2;
         fr.dy = u0 * y0 + u1 * y1 + u2 * y2;
         fr.t0 = u0; fr.t1 = u1; fr.t2 = u2; fr.sign = -1.f;
@@ -192,12 +247,18 @@ __device__ __forceinline__ void euclid(const float* __restrict__ rec, float xp, 
 }
 
 // Fragment probability of the face in `rec` at (xp,yp): K.cu:387-404.  false = face skipped.
-__device__ __forceinline__ bool fragment(const float* __restrict__ rec, int dist, float thr, float sigma,
-                                         float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
+__device__ __forceinline__ void barycentric(cptr_t rec, float xp, float yp, float& w0, float& w1, float& w2)
 {
     w0 = rec[R_INV + 0] * xp + rec[R_INV + 1] * yp + rec[R_INV + 2];   // K.cu:24-29
     w1 = rec[R_INV + 3] * xp + rec[R_INV + 4] * yp + rec[R_INV + 5];
     w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
+}
+
+template <bool FM = false>
+__device__ __forceinline__ bool fragment(cptr_t rec, int dist, float thr, float sigma,
+                                         float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
+{
+    barycentric(rec, xp, yp, w0, w1, w2);
     if (dist == 0) {
         if (!inside_closed(w0, w1, w2)) return false;
         fr.D = 1.f;
@@ -206,21 +267,22 @@ __device__ __forceinline__ bool fragment(const float* __restrict__ rec, int dist
         d = d > 0 ? d * d : -(d * d);
         fr.dis = d; fr.t0 = w0; fr.t1 = w1; fr.t2 = w2;
         if (-d >= thr) return false;
-        fr.D = sigmoid_neg(-d / sigma);
+        fr.D = sigmoid_neg_<FM>(div_<FM>(-d, sigma));
     } else {
-        euclid(rec, xp, yp, w0, w1, w2, fr);
+        euclid<FM>(rec, xp, yp, w0, w1, w2, fr);
         fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
         if (fr.sign < 0 && fr.dis >= thr) return false;
-        fr.D = sigmoid_neg(-fr.sign * fr.dis / sigma);
+        fr.D = sigmoid_neg_<FM>(div_<FM>(-fr.sign * fr.dis, sigma));
     }
     return true;
 }
 
 // K.cu:423 (1. / float-sum evaluated in double; narrowing a double quotient of
 // floats is the correctly rounded float quotient, so a float division is identical)
-__device__ __forceinline__ float depth_at(const float* __restrict__ rec, float c0, float c1, float c2)
+template <bool FM = false>
+__device__ __forceinline__ float depth_at(cptr_t rec, float c0, float c1, float c2)
 {
-    return 1.f / (c0 / rec[2] + c1 / rec[5] + c2 / rec[8]);
+    return div_<FM>(1.f, div_<FM>(c0, rec[2]) + div_<FM>(c1, rec[5]) + div_<FM>(c2, rec[8]));
 }
 
 // texel index a surface sample lands in (K.cu:181-188 == 200-211).  A clipped barycentric
@@ -236,7 +298,7 @@ __device__ __forceinline__ int surface_texel(float c0, float c1, int res)
 }
 
 // K.cu:178-194
-__device__ __forceinline__ float sample_colour(const float* __restrict__ tex, float c0, float c1, float c2,
+__device__ __forceinline__ float sample_colour(cptr_t tex, float c0, float c1, float c2,
                                                int res, int ch, int tex_type, int lim)
 {
     if (tex_type == 0) {

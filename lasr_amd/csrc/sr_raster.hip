@@ -72,8 +72,8 @@ struct PixState {
 };
 
 template <bool LASR_FAST>
-__device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, const float* __restrict__ rec,
-                                             const float* __restrict__ tex, int fn, int lim, float xp, float yp, PixState& s)
+__device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, cptr_t rec,
+                                             cptr_t tex, int fn, int lim, float xp, float yp, PixState& s)
 {
     float w0, w1, w2;
     Frag fr;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             if (__ballot(cand) == 0ull) continue;                         // wave-uniform skip
             const int fn = __builtin_amdgcn_readfirstlane(s_face[i]);     // wave-uniform -> scalar loads
             if (cand) {
-                forward_face<LASR_FAST>(A, m, recs + (size_t)fn * REC, texs + (size_t)fn * texstride, fn,
+                forward_face<LASR_FAST>(A, m, as_const(recs + (size_t)fn * REC), as_const(texs + (size_t)fn * texstride), fn,
                                         (A.N * A.F - (bn * A.F + fn)) * A.T /* texels to the end of the tensor */, xp, yp, s);
             }
         }
@@ -228,22 +228,35 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
 }
 
 // ---------------------------------------------------------------------------
-// Backward: one wave per (image, face); K.cu:486-668 evaluated face-major.
+// Backward: one wave per (image, face); K.cu:486-668 evaluated face-major, in two stages.
+//   stage 1 (cheap, 64 bbox pixels per round): exact bbox test + barycentrics + the conservative
+//            line-distance reject; survivors are compacted (ballot + prefix) into a per-wave LDS ring.
+//   stage 2 (heavy, runs whenever 64 survivors are queued): full fragment + gradient math on dense lanes.
+// Roughly half of the bbox pixels of a face are farther than sqrt(threshold) from it; without the
+// compaction they would idle through the heavy code.  The heavy code uses v_rcp/v_exp based math
+// (FM = true): the reference backward is itself only defined up to float-atomic ordering.
+constexpr bool BWD_FM = true;
+constexpr int QCAP = 128;   // ring entries per wave (power of two, >= 2 * 64)
+
 template <bool LASR_FAST>
 __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
                                                           const float* __restrict__ aggrs,
                                                           const float* __restrict__ gcolors,
                                                           float* __restrict__ gfaces, float* __restrict__ gtex)
 {
+    __shared__ unsigned int s_ring[4][QCAP];
+    constexpr bool FM = BWD_FM;
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
     const int lane = threadIdx.x & 63;
+    unsigned int* ring = s_ring[threadIdx.x >> 6];
     const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (gw >= A.N * A.F) return;
     const int bn = gw / A.F, fn = gw - bn * A.F;
     const int IS = A.IS, P = IS * IS;
-    const float* __restrict__ rec = A.recs + (size_t)gw * REC;
-    const float* __restrict__ tex = A.textures + (size_t)gw * A.T * 3;
+    const cptr_t rec = as_const(A.recs + (size_t)gw * REC);
+    const cptr_t tex = as_const(A.textures + (size_t)gw * A.T * 3);
     const float4 b = A.bboxes[gw];
+    const int flags = __float_as_int(rec[R_FLAGS]);
 
     // conservative pixel rectangle of the bbox; the exact test is repeated per pixel
     // xp = (2 xi + 1 - IS)/IS  =>  xi = (xp IS + IS - 1)/2
@@ -252,53 +265,84 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     int yi0 = (int)floorf(b.z * half + half - 0.5f) - 1, yi1 = (int)ceilf(b.w * half + half - 0.5f) + 1;
     x0 = max(x0, 0); x1 = min(x1, IS - 1);
     yi0 = max(yi0, 0); yi1 = min(yi1, IS - 1);
-    // NaN / inverted boxes give an empty range
     const int bw = x1 - x0 + 1, bh = yi1 - yi0 + 1;
-    const bool empty = !(bw > 0 && bh > 0);
+    const bool empty = !(bw > 0 && bh > 0);      // also catches NaN / inverted boxes
     const int npx = empty ? 0 : bw * bh;
 
     float gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2)
     float gt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // vertex colours: [vertex j][channel k] at 3j+k
-    const bool front = (__float_as_int(rec[R_FLAGS]) & 8) != 0;
+    const bool front = (flags & 8) != 0;
     const bool vertex_tex = (m.tex == 1);
-    const int lim = (A.N * A.F - gw) * A.T;   // texels from this face to the end of the tensor
+    const int lim = (A.N * A.F - gw) * A.T;      // texels from this face to the end of the tensor
+    // cheap reject only for the soft distance modes and well-conditioned faces; 2 % slack on thr
+    const bool use_far = (m.dist == 2) && (flags & 16);
+    const float thr_pad = A.thr * 1.02f;
+    const float inv_is = 1.f / (float)IS;
 
     // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
     int r = 0, c = 0;
     const int dr = empty ? 0 : 64 / bw, dc = empty ? 0 : 64 - dr * bw;
     if (!empty) { r = lane / bw; c = lane - r * bw; }
 
-    for (int i = lane; i < npx; i += 64) {
-        const int xi = x0 + c, yi = yi0 + r;
-        // advance for the next round
-        c += dc; r += dr;
-        if (c >= bw) { c -= bw; r += 1; }
-
-        const int pyy = IS - 1 - yi;
-        const int pn = pyy * IS + xi;
+    int head = 0, tail = 0, base = 0;            // wave-uniform ring state
+    while (true) {
+        if (base < npx) {
+            // ---------------- stage 1
+            const int xi = x0 + c, yi = yi0 + r;
+            const bool in_range = base + lane < npx;
+            c += dc; r += dr;
+            if (c >= bw) { c -= bw; r += 1; }
+            base += 64;
+            bool keep = false;
+            if (in_range) {
+                const float xp = pix_center(xi, IS), yp = pix_center(yi, IS);
+                if (!outside_bbox(xp, yp, b)) {
+                    keep = true;
+                    if (use_far) {
+                        float w0, w1, w2;
+                        barycentric(rec, xp, yp, w0, w1, w2);
+                        keep = !certainly_far(rec, w0, w1, w2, thr_pad);
+                    }
+                }
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (keep) ring[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (unsigned)xi | ((unsigned)yi << 16);
+            tail += __popcll(mask);
+        }
+        const int avail = tail - head;
+        if (!(avail >= 64 || (base >= npx && avail > 0))) {
+            if (base >= npx) break;
+            continue;
+        }
+        // ---------------- stage 2 on up to 64 queued pixels
+        __builtin_amdgcn_wave_barrier();
+        const bool active = lane < avail;
+        const unsigned int packed = ring[(head + lane) & (QCAP - 1)];
+        head += min(avail, 64);
+        if (!active) continue;
+        const int xi = packed & 0xffff, yi = packed >> 16;
+        const int pn = (IS - 1 - yi) * IS + xi;
         const float xp = pix_center(xi, IS), yp = pix_center(yi, IS);
-        if (outside_bbox(xp, yp, b)) continue;
+        (void)inv_is;
 
         float w0, w1, w2;
         Frag fr;
-        if (!fragment(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+        if (!fragment<FM>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
         const float D = fr.D;
 
-        // alpha path (K.cu:583-593)
+        // alpha path (K.cu:583-593); hard alpha: the reference still adds g_alpha into C
         float Ca = gcolors[((size_t)bn * 4 + 3) * P + pn];
-        if (m.alpha == 0) { /* no gradient; the reference still adds g_alpha into C (K.cu:583,593) */ }
-        else if (m.alpha == 1) Ca /= A.F;
-        else {
+        if (m.alpha == 1) Ca = div_<FM>(Ca, (float)A.F);
+        else if (m.alpha == 2) {
             const float a_out = colors[((size_t)bn * 4 + 3) * P + pn];
-            const float omd = 1 - D;
-            const double den = (double)omd > 1e-6 ? (double)omd : 1e-6;
-            Ca = (float)((double)Ca * ((double)(1 - a_out) / den));
+            Ca *= div_<FM>(1 - a_out, fmaxf(1 - D, 1e-6f));
         }
         float C = Ca;
 
         const float u0 = w0, u1 = w1, u2 = w2;       // unclipped barycentrics (w0 of K.cu:596)
-        clip_normalise(w0, w1, w2);
-        const float zp = depth_at(rec, w0, w1, w2);
+        // surface sampling picks a texel from (int)(w * res): keep the exact division there
+        if (vertex_tex) clip_normalise<FM>(w0, w1, w2); else clip_normalise<false>(w0, w1, w2);
+        const float zp = depth_at<FM>(rec, w0, w1, w2);
         if (zp < A.near || zp > A.far) continue;    // no gradient at all (K.cu:599)
 
         float gz0 = 0, gz1 = 0, gz2 = 0;
@@ -322,8 +366,8 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
         } else if (front || m.double_side) {                                 // K.cu:611-640
             const float ssum = aggrs[((size_t)bn * 2 + 0) * P + pn];
             const float smax = aggrs[((size_t)bn * 2 + 1) * P + pn];
-            const float zn = (A.far - zp) / (A.far - A.near);
-            const float sm = D * expf((zn - smax) / A.gamma) / ssum;
+            const float zn = div_<FM>(A.far - zp, A.far - A.near);
+            const float sm = div_<FM>(D * exp_<FM>(div_<FM>(zn - smax, A.gamma)), ssum);
             const float g0 = gcolors[((size_t)bn * 4 + 0) * P + pn];
             const float g1 = gcolors[((size_t)bn * 4 + 1) * P + pn];
             const float g2 = gcolors[((size_t)bn * 4 + 2) * P + pn];
@@ -343,21 +387,22 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
             Crgb += g1 * (sample_colour(tex, w0, w1, w2, A.res, 1, m.tex, lim) - colors[((size_t)bn * 4 + 1) * P + pn]);
             Crgb += g2 * (sample_colour(tex, w0, w1, w2, A.res, 2, m.tex, lim) - colors[((size_t)bn * 4 + 2) * P + pn]);
             Crgb *= sm;
-            C += Crgb / D;
-            const float Cz = Crgb / A.gamma / (A.near - A.far) * zp * zp;
-            gz0 = Cz * w0 / rec[2] / rec[2];
-            gz1 = Cz * w1 / rec[5] / rec[5];
-            gz2 = Cz * w2 / rec[8] / rec[8];
+            C += div_<FM>(Crgb, D);
+            const float Cz = div_<FM>(div_<FM>(Crgb, A.gamma), A.near - A.far) * zp * zp;
+            const float iz0 = __builtin_amdgcn_rcpf(rec[2]), iz1 = __builtin_amdgcn_rcpf(rec[5]), iz2 = __builtin_amdgcn_rcpf(rec[8]);
+            gz0 = Cz * w0 * iz0 * iz0;
+            gz1 = Cz * w1 * iz1 * iz1;
+            gz2 = Cz * w2 * iz2 * iz2;
         }
 
-        C *= D * (1 - D) / A.sigma;                                           // K.cu:644
+        C *= div_<FM>(D * (1 - D), A.sigma);                                  // K.cu:644
         float gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0, gx2 = 0, gy2 = 0;
         if (m.dist == 1) {                                                    // K.cu:161-175
             const float t0 = fr.t0, t1 = fr.t1, t2 = fr.t2;
             const int p = t0 > t1 ? (t1 > t2 ? 2 : 1) : (t0 > t2 ? 2 : 0);
             const float ipx = rec[R_INV + 3 * p + 0], ipy = rec[R_INV + 3 * p + 1];   // divergent gather: cold path
             const float dis = fr.dis;
-            const double sc = dis > 0 ? 2. * (double)sqrtf(dis) : 2. * (double)sqrtf(-dis);
+            const float sc = 2.f * sqrtf(fabsf(dis));
             float gxy[3][2];
 #pragma unroll
             for (int l = 0; l < 2; l++) {
@@ -368,8 +413,7 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
                     acc += -ipl * rec[R_INV + 3 * k + 0] * xp;
                     acc += -ipl * rec[R_INV + 3 * k + 1] * yp;
                     acc += -ipl * rec[R_INV + 3 * k + 2] * 1.f;
-                    const float g = acc * C;
-                    gxy[k][l] = (float)((double)g * sc);
+                    gxy[k][l] = acc * C * sc;
                 }
             }
             gx0 = gxy[0][0]; gy0 = gxy[0][1]; gx1 = gxy[1][0]; gy1 = gxy[1][1]; gx2 = gxy[2][0]; gy2 = gxy[2][1];
