@@ -24,9 +24,10 @@ namespace lasr {
 //                 bit4 well-conditioned (the cheap line-distance reject below may be used)
 // [31..33] hk2  : squared height of vertex k over its opposite edge (own addition: w_k * h_k is the
 //                 signed distance of a pixel to that edge's line, a lower bound of the true distance)
-// [34..39] pad to 160 B (16-B multiple so records start on a dwordx4 boundary)
+// [34..37] bbox : xmin-m, xmax+m, ymin-m, ymax+m (m = sqrt(threshold)), K.cu:33-38 hoisted
+// [38..39] pad to 160 B (16-B multiple so records start on a dwordx4 boundary)
 constexpr int REC = 40;
-constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30, R_HK2 = 31;
+constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30, R_HK2 = 31, R_BB = 34;
 
 // Read-only buffers written by an EARLIER kernel are viewed through the constant address
 // space: with a wave-uniform index the compiler then emits s_load (scalar cache -> SGPRs)
@@ -89,7 +90,8 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
     }
     {
         // heights^2 = det^2 / |opposite edge|^2 (unclamped det); a face is "well conditioned" when all
-        // three heights exceed 1e-3 NDC, so that the fp32 barycentrics carry a relative error << 1 %
+        // three heights exceed 1e-2 NDC (about a pixel at 256x256) and no edge is longer than 4 NDC, so that
+        // the fp32 distance the reference computes for it is accurate to a small fraction of a percent
         const float det0 = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
         const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
         bool ok = true;
@@ -100,17 +102,17 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
             const float l2 = ex * ex + ey * ey;
             const float h2 = l2 > 0.f ? det0 * det0 / l2 : 0.f;
             rec[R_HK2 + k] = h2;
-            ok = ok && (h2 > 1e-6f) && (h2 < 1e12f);
+            ok = ok && (h2 > 1e-4f) && (h2 < 1e4f) && (l2 < 16.f);
         }
         if (ok) flags |= 16;
     }
     rec[R_FLAGS] = __int_as_float(flags);
-#pragma unroll
-    for (int k = R_HK2 + 3; k < REC; k++) rec[k] = 0.f;
+    rec[R_BB + 4] = 0.f; rec[R_BB + 5] = 0.f;
     // K.cu:33-38 with the max/min +- margin hoisted (same float ops, done once)
     const float xmax = fmaxf(fmaxf(x0, x1), x2) + margin, xmin = fminf(fminf(x0, x1), x2) - margin;
     const float ymax = fmaxf(fmaxf(y0, y1), y2) + margin, ymin = fminf(fminf(y0, y1), y2) - margin;
     *bbox = make_float4(xmin, xmax, ymin, ymax);
+    rec[R_BB + 0] = xmin; rec[R_BB + 1] = xmax; rec[R_BB + 2] = ymin; rec[R_BB + 3] = ymax;
     if (info27) {   // reference layout, for callers that still want the tensor
 #pragma unroll
         for (int k = 0; k < 9; k++) { info27[k] = inv[k]; info27[9 + k] = sym[k]; }
@@ -255,10 +257,21 @@ __device__ __forceinline__ void barycentric(cptr_t rec, float xp, float yp, floa
 }
 
 template <bool FM = false>
+__device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, float sigma,
+                                           float xp, float yp, float w0, float w1, float w2, Frag& fr);
+
+template <bool FM = false>
 __device__ __forceinline__ bool fragment(cptr_t rec, int dist, float thr, float sigma,
                                          float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
 {
     barycentric(rec, xp, yp, w0, w1, w2);
+    return fragment_w<FM>(rec, dist, thr, sigma, xp, yp, w0, w1, w2, fr);
+}
+
+template <bool FM>
+__device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, float sigma,
+                                           float xp, float yp, float w0, float w1, float w2, Frag& fr)
+{
     if (dist == 0) {
         if (!inside_closed(w0, w1, w2)) return false;
         fr.D = 1.f;

@@ -32,7 +32,7 @@
 namespace lasr {
 
 constexpr int TILE = 16;        // pixels per tile side (4 waves of 8x8)
-constexpr int LIST_CAP = 1024;  // faces scanned per round == LDS list capacity
+constexpr int LIST_CAP = 4096;  // faces scanned per round == LDS list capacity (u16 ids, 8 KB)
 
 struct RasterArgs {
     const float* __restrict__ recs;      // [N*F, REC]
@@ -73,11 +73,11 @@ struct PixState {
 
 template <bool LASR_FAST>
 __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, cptr_t rec,
-                                             cptr_t tex, int fn, int lim, float xp, float yp, PixState& s)
+                                             cptr_t tex, int fn, int lim, float xp, float yp,
+                                             float w0, float w1, float w2, PixState& s)
 {
-    float w0, w1, w2;
     Frag fr;
-    if (!fragment(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) return;
+    if (!fragment_w<false>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) return;
     const float D = fr.D;
     // alpha first (K.cu:409-417), before the depth test
     if (m.alpha == 0) { if ((double)D > 0.5) s.a = 1.f; }
@@ -115,8 +115,7 @@ template <bool LASR_FAST>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
 {
-    __shared__ float4 s_bbox[LIST_CAP];
-    __shared__ int s_face[LIST_CAP];
+    __shared__ unsigned short s_face[LIST_CAP];   // candidate face ids (relative to the round's base), index order
     __shared__ int s_wcnt[2][4];
 
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
@@ -163,17 +162,18 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * 3;
     const int texstride = A.T * 3;
+    const float thr_pad = A.thr * 1.05f;   // slack of the conservative "certainly far" reject
 
-    for (int base = 0; base < A.F; base += LIST_CAP) {
+    for (int base = 0; base < A.F; base += LIST_CAP) {      // one round unless F > LIST_CAP
         const int end = min(base + LIST_CAP, A.F);
-        // ---- ordered compaction of faces [base,end) whose bbox touches this tile
+        if (base > 0) __syncthreads();                      // the previous round's list is still being walked
+        // ---- ordered compaction of faces [base,end) whose bbox touches this 16x16 tile
         int count = 0, flip = 0;
         for (int c = base; c < end; c += 256, flip ^= 1) {
             const int f = c + tid;
-            float4 b = make_float4(0, 0, 0, 0);
             bool hit = false;
             if (f < end) {
-                b = bb[f];
+                const float4 b = bb[f];
                 hit = !(t_xlo > b.y || t_xhi < b.x || t_ylo > b.w || t_yhi < b.z);
             }
             const unsigned long long mask = __ballot(hit);
@@ -181,26 +181,35 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             __syncthreads();
             const int c0 = s_wcnt[flip][0], c1 = s_wcnt[flip][1], c2 = s_wcnt[flip][2], c3 = s_wcnt[flip][3];
             const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-            if (hit) {
-                const int pos = count + before + __popcll(mask & ((1ull << lane) - 1ull));
-                s_bbox[pos] = b;
-                s_face[pos] = f;
-            }
+            if (hit) s_face[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
             count += c0 + c1 + c2 + c3;
         }
         __syncthreads();
-        // ---- every wave walks the list for its 8x8 quadrant
-        for (int i = 0; i < count; i++) {
-            const float4 b = s_bbox[i];
-            const bool cand = valid && !outside_bbox(xp, yp, b);          // K.cu:375
-            if (__ballot(cand) == 0ull) continue;                         // wave-uniform skip
-            const int fn = __builtin_amdgcn_readfirstlane(s_face[i]);     // wave-uniform -> scalar loads
-            if (cand) {
-                forward_face<LASR_FAST>(A, m, as_const(recs + (size_t)fn * REC), as_const(texs + (size_t)fn * texstride), fn,
-                                        (A.N * A.F - (bn * A.F + fn)) * A.T /* texels to the end of the tensor */, xp, yp, s);
+        // ---- every wave walks the list for its own 8x8 quadrant; no barrier until the next round
+        for (int i0 = 0; i0 < count; i0 += 64) {
+            const int mine = (i0 + lane < count) ? (int)s_face[i0 + lane] : 0;
+            const int n = min(64, count - i0);
+            for (int j = 0; j < n; j++) {
+                const int fn = base + __builtin_amdgcn_readlane(mine, j);   // wave-uniform -> scalar loads
+                const cptr_t rec = as_const(recs + (size_t)fn * REC);
+                bool cand = valid && !(xp > rec[R_BB + 1] || xp < rec[R_BB + 0] ||
+                                       yp > rec[R_BB + 3] || yp < rec[R_BB + 2]);            // K.cu:375
+                if (__ballot(cand) == 0ull) continue;                                        // wave-uniform skip
+                float w0, w1, w2;
+                barycentric(rec, xp, yp, w0, w1, w2);
+                if (m.dist == 2 && (__float_as_int(rec[R_FLAGS]) & 16)) {
+                    // well-conditioned face: pixels certainly farther than sqrt(threshold) are the ones the
+                    // reference drops at K.cu:402; skip the distance code when that is the whole wave
+                    cand = cand && !certainly_far(rec, w0, w1, w2, thr_pad);
+                    if (__ballot(cand) == 0ull) continue;
+                }
+                if (cand) {
+                    forward_face<LASR_FAST>(A, m, rec, as_const(texs + (size_t)fn * texstride), fn,
+                                            (A.N * A.F - (bn * A.F + fn)) * A.T /* texels to the end of the tensor */,
+                                            xp, yp, w0, w1, w2, s);
+                }
             }
         }
-        __syncthreads();
     }
 
     if (!valid) return;
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     const int lim = (A.N * A.F - gw) * A.T;      // texels from this face to the end of the tensor
     // cheap reject only for the soft distance modes and well-conditioned faces; 2 % slack on thr
     const bool use_far = (m.dist == 2) && (flags & 16);
-    const float thr_pad = A.thr * 1.02f;
+    const float thr_pad = A.thr * 1.05f;
     const float inv_is = 1.f / (float)IS;
 
     // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
