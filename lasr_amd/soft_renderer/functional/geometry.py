@@ -1,0 +1,50 @@
+"""Per-face gathers and vertex normals.
+
+Reference behaviour: soft_renderer/functional/face_vertices.py:4-22 and vertex_normals.py:4-37
+(under /root/reference/third_party/softras/).  Same values, but the batch is flattened with one
+index_select / index_add_ instead of int32 offset arithmetic on the face tensor.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _flat_index(faces, num_vertices):
+    bs = faces.shape[0]
+    offs = torch.arange(bs, device=faces.device, dtype=torch.long) * num_vertices
+    return (faces.long() + offs[:, None, None]).reshape(-1)
+
+
+def face_vertices(vertices, faces):
+    """[B,V,C] per-vertex attributes + [B,F,3] indices -> [B,F,3,C] per-face attributes."""
+    if vertices.ndimension() != 3 or faces.ndimension() != 3:
+        raise AssertionError('vertices and faces must be 3-dimensional')
+    if vertices.shape[0] != faces.shape[0] or faces.shape[2] != 3:
+        raise AssertionError('batch sizes must agree and faces must be [B,F,3]')
+    bs, nv, ch = vertices.shape
+    nf = faces.shape[1]
+    flat = vertices.reshape(bs * nv, ch)
+    return flat.index_select(0, _flat_index(faces, nv)).reshape(bs, nf, 3, ch)
+
+
+def vertex_normals(vertices, faces):
+    """Area-weighted vertex normals, unit length (eps 1e-6), [B,V,3]."""
+    if vertices.shape[2] != 3:
+        raise AssertionError('vertices must be [B,V,3]')
+    bs, nv = vertices.shape[:2]
+    idx = _flat_index(faces, nv).reshape(-1, 3)                      # [B*F,3] into the flattened vertex list
+    tri = vertices.reshape(bs * nv, 3)[idx]                          # [B*F,3,3]
+    p0, p1, p2 = tri[:, 0], tri[:, 1], tri[:, 2]
+    acc = torch.zeros(bs * nv, 3, dtype=vertices.dtype, device=vertices.device)
+    # the reference accumulates corner 1, then 2, then 0 (vertex_normals.py:27-32); keep that order so
+    # the float sums match
+    acc.index_add_(0, idx[:, 1], torch.cross(p2 - p1, p0 - p1, dim=1))
+    acc.index_add_(0, idx[:, 2], torch.cross(p0 - p2, p1 - p2, dim=1))
+    acc.index_add_(0, idx[:, 0], torch.cross(p1 - p0, p2 - p0, dim=1))
+    return F.normalize(acc, eps=1e-6, dim=1).reshape(bs, nv, 3)
+
+
+def surface_normals(face_verts):
+    """Unit face normals from [B,F,3,3] (mesh.py:104-110 of the reference)."""
+    v10 = face_verts[:, :, 0] - face_verts[:, :, 1]
+    v12 = face_verts[:, :, 2] - face_verts[:, :, 1]
+    return F.normalize(torch.cross(v12, v10, dim=2), p=2, dim=2, eps=1e-6)
