@@ -1,0 +1,109 @@
+/*
+ * lasr_ops.h -- C ABI of the geometry / loss kernels that sit around the rasteriser on the LASR hot
+ * path (same library, liblasr_hip.so; same conventions as lasr_sr.h: device pointers, fp32, sizes,
+ * hipStream_t as void*, 0 / negative LASR_E_* return codes, nothing printed, nothing synchronised).
+ *
+ * The reference implements all of these as chains of eager PyTorch ops (no native interface to bind
+ * to); each entry point names the Python function it replaces.  Paths are relative to /root/reference/.
+ */
+#ifndef LASR_OPS_H_
+#define LASR_OPS_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Linear-blend skinning, nnutils/geom_utils.py:45-71 (obj_to_cam):
+ *   vs[n,v]  = sum_{k=1..K-1} skin[n,k-1,v] * (verts[n,v] @ R[n*K+k] + T[n*K+k])      (K > 1; else vs = verts)
+ *   out[n,v] = tocam ? vs[n,v] @ R[n*K] + T[n*K] : vs[n,v]
+ * verts [N,V,3], Rmat [N*K,3,3] (row-vector convention, bone-major inside a mesh), Tmat [N*K,3],
+ * skin [N,K-1,V] (may be NULL when K == 1), out [N,V,3].
+ * Forward: the blend contraction skin^T[V,K-1] x RT[K-1,12] runs on the matrix cores
+ * (v_mfma_f32_16x16x4_f32, exact fp32).  Backward overwrites (does not accumulate) all four gradients;
+ * it is deterministic (no atomics).  Any gradient pointer may be NULL to skip it.
+ */
+int lasr_lbs_forward(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out,
+                     int N, int V, int K, int tocam, void* hip_stream);
+int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
+                      const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
+                      float* grad_skin, int N, int V, int K, int tocam, void* hip_stream);
+
+/*
+ * Pinhole projection, nnutils/geom_utils.py:27-34 (pinhole_cam), with pp / fl already expanded per mesh:
+ *   out.x = pp[n,0] + x * fl[n] / z ;  out.y = pp[n,1] + y * fl[n] / z ;  out.z = z ; out.w = w
+ * verts/out [N,V,4], pp [N,2], fl [N].  Backward overwrites grad_verts [N,V,4], grad_pp [N,2], grad_fl [N].
+ */
+int lasr_pinhole_forward(const float* verts, const float* pp, const float* fl, float* out, int N, int V,
+                         void* hip_stream);
+int lasr_pinhole_backward(const float* verts, const float* pp, const float* fl, const float* grad_out,
+                          float* grad_verts, float* grad_pp, float* grad_fl, int N, int V, void* hip_stream);
+
+/*
+ * Silhouette loss table, nnutils/mesh_net.py:374-388:
+ *   loss[i,j] = 0.5 * mean_{p : occ[i,p] != 0} (mask_pred[i,j,p] - masks[i,p])^2
+ * mask_pred [I,H,P], masks [I,P], occ [I,P] -> loss [I,H].  (Empty selection -> NaN like torch's mean of
+ * an empty tensor.)  Backward: grad_pred [I,H,P] = grad_loss[i,j] * (pred - mask) / count on selected pixels.
+ */
+int lasr_mask_loss_forward(const float* mask_pred, const float* masks, const float* occ, float* loss,
+                           int I, int H, int P, void* hip_stream);
+int lasr_mask_loss_backward(const float* mask_pred, const float* masks, const float* occ, const float* grad_loss,
+                            float* grad_pred, int I, int H, int P, void* hip_stream);
+
+/*
+ * Optical-flow loss table, nnutils/mesh_net.py:393-413:
+ *   sel[i,j,p] = !bg[i,j,p] && occ[i,p] != 0 && masks[i,p] > 0
+ *   w[i,p]     = sigmoid(-occ[i,p]) / mean_{(j,p) in sel[i]} sigmoid(-occ[i,p])
+ *   loss[i,j]  = 0.5 * mean_{p in sel[i,j]} ||flow_rd[i,j,p,:] - flow_obs[i,:,p]||_2 * w[i,p]     (0 if sel[i,j] empty)
+ * flow_rd [I,H,P,2], flow_obs: channel planes of P floats, images obs_image_stride floats apart (the first two
+ * channels of the [I,3,P] observation), bg [I,H,P] uint8,
+ * occ/masks [I,P] -> loss [I,H], and the weighted error map flow_rd_map [I,H,P] the trainer logs.
+ * `scratch` holds 2*I floats.  Backward: gradient w.r.t. flow_rd only (the weights are data).
+ */
+int lasr_flow_loss_forward(const float* flow_rd, const float* flow_obs, const unsigned char* bg, const float* occ,
+                           const float* masks, float* loss, float* flow_rd_map, float* scratch,
+                           int I, int H, int P, int obs_image_stride, void* hip_stream);
+int lasr_flow_loss_backward(const float* flow_rd, const float* flow_obs, const unsigned char* bg, const float* occ,
+                            const float* masks, const float* scratch, const float* grad_loss, float* grad_flow_rd,
+                            int I, int H, int P, int obs_image_stride, void* hip_stream);
+
+/*
+ * L1 texture loss table, nnutils/mesh_net.py:425-441 (without the perceptual term):
+ *   loss[i,j] = 2*wt * ( mean_{occ[i]!=0} mean_c |img_obs[i,c,p] - rnd[i,j,c,p]*fg[i,j,p]|
+ *                      + mean_{occ[i]!=0} mean_c |img_white[i,c,p] - rnd[i,j,c,p]| )
+ * img_obs/img_white [I,3,P], rnd [I,H,3,P], fg [I,H,P], occ [I,P] -> loss [I,H].
+ * Backward: grad_rnd [I,H,3,P] and grad_fg [I,H,P] (overwritten).
+ */
+int lasr_tex_loss_forward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
+                          const float* occ, float* loss, float wt, int I, int H, int P, void* hip_stream);
+int lasr_tex_loss_backward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
+                           const float* occ, const float* grad_loss, float* grad_rnd, float* grad_fg, float wt,
+                           int I, int H, int P, void* hip_stream);
+
+/*
+ * Mesh regularisers on sparse adjacency instead of dense [V,V] operators.
+ *
+ * ARAP, nnutils/loss_utils.py:46-64:  loss[n] = mean over directed edges (v,u), u in nbr(v), of
+ *   | ||x[n,u]-x[n,v]||^2 - ||dx[n,u]-dx[n,v]||^2 |     (the reference builds six dense [N,V,V] tensors for this).
+ * Laplacian, third_party/ext_nnutils/loss_utils.py:34-65:  loss[n] = sum_v || x_v - mean_{u in nbr(v)} x_u ||^2 ;
+ *   vertices without neighbours contribute 0 (the reference leaves their row at zero, :50-51).
+ * Both take the mesh adjacency as CSR (row_ptr [V+1], col [nnz], unique neighbours, symmetric), x/dx [N,V,3]
+ * -> loss [N].  Backward entry points overwrite the gradients and are deterministic (vertex-centric gathers).
+ * (FlattenLoss, ext_nnutils/loss_utils.py:110-152, is already edge-based in the reference and stays a
+ * chain of torch ops in the host mirror.)
+ */
+int lasr_arap_forward(const float* dx, const float* x, const int* row_ptr, const int* col, float* loss,
+                      int N, int V, void* hip_stream);
+int lasr_arap_backward(const float* dx, const float* x, const int* row_ptr, const int* col, const float* grad_loss,
+                       float* grad_dx, float* grad_x, int N, int V, void* hip_stream);
+int lasr_laplacian_forward(const float* x, const int* row_ptr, const int* col, float* loss, int N, int V,
+                           void* hip_stream);
+int lasr_laplacian_backward(const float* x, const int* row_ptr, const int* col, const float* grad_loss,
+                            float* grad_x, float* scratch_lx /*[N,V,3]*/, int N, int V, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASR_OPS_H_ */

@@ -20,6 +20,21 @@ SIGNATURES = {
     'lasr_sr_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'lasr_sr_forward': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
     'lasr_sr_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
+    # include/lasr_ops.h
+    'lasr_lbs_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_lbs_backward': (_i, [_p] * 9 + [_i, _i, _i, _i, _p]),
+    'lasr_pinhole_forward': (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    'lasr_pinhole_backward': (_i, [_p] * 7 + [_i, _i, _p]),
+    'lasr_mask_loss_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_mask_loss_backward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_flow_loss_forward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),
+    'lasr_flow_loss_backward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),
+    'lasr_tex_loss_forward': (_i, [_p] * 6 + [_f, _i, _i, _i, _p]),
+    'lasr_tex_loss_backward': (_i, [_p] * 8 + [_f, _i, _i, _i, _p]),
+    'lasr_arap_forward': (_i, [_p] * 5 + [_i, _i, _p]),
+    'lasr_arap_backward': (_i, [_p] * 7 + [_i, _i, _p]),
+    'lasr_laplacian_forward': (_i, [_p] * 4 + [_i, _i, _p]),
+    'lasr_laplacian_backward': (_i, [_p] * 6 + [_i, _i, _p]),
     'lasr_prof_enable': (_i, [_i]),
     'lasr_prof_kernel_count': (_i, []),
     'lasr_prof_kernel_name': (ctypes.c_char_p, [_i]),
@@ -61,3 +76,15 @@ def check(rc, what):
         if rc == -4:
             msg += ' (hipError_t %d)' % h.lasr_last_hip_error()
         raise LasrNativeError('%s failed: %s' % (what, msg))
+
+
+def stream_of(t):
+    """(device-guard context, raw hipStream_t) for the tensor's device: kernels go on torch's current stream."""
+    import torch
+    return torch.cuda.device(t.device), torch.cuda.current_stream(t.device).cuda_stream
+
+
+def need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and t.device.type != 'cuda':
+            raise TypeError('lasr_amd kernels support only cuda (HIP) tensors; there is no CPU fallback')

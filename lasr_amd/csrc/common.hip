@@ -1,0 +1,81 @@
+// common.hip -- error reporting and the optional per-kernel timing of liblasr_hip.so (host code only).
+#include <mutex>
+#include <vector>
+
+#include "host_common.h"
+
+namespace {
+thread_local int g_last_hip_error = 0;
+struct ProfRec { int id; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+bool g_prof_on = false;
+const char* const kKernelNames[K_NUM_KERNELS] = {
+    "sr_setup_kernel", "sr_forward_kernel", "sr_backward_kernel",
+    "lbs_forward_kernel", "lbs_backward_kernel", "pinhole_forward_kernel", "pinhole_backward_kernel",
+    "mask_loss_forward_kernel", "mask_loss_backward_kernel", "flow_loss_stats_kernel", "flow_loss_forward_kernel",
+    "flow_loss_backward_kernel", "tex_loss_forward_kernel", "tex_loss_backward_kernel", "arap_forward_kernel",
+    "arap_backward_kernel", "laplacian_forward_kernel", "laplacian_backward_kernel"};
+}  // namespace
+
+int lasr_launch_ok()
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return LASR_E_LAUNCH; }
+    return LASR_OK;
+}
+
+bool lasr_prof_is_on() { return g_prof_on; }
+
+void lasr_prof_push(int id, hipEvent_t a, hipEvent_t b)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back(ProfRec{id, a, b});
+}
+
+extern "C" int lasr_abi_version(void) { return 1; }
+
+extern "C" int lasr_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" const char* lasr_strerror(int code)
+{
+    switch (code) {
+        case LASR_OK: return "ok";
+        case LASR_E_BADARG: return "bad argument (null pointer or negative size)";
+        case LASR_E_BADMODE: return "mode id out of range";
+        case LASR_E_WORKSPACE: return "workspace missing or too small";
+        case LASR_E_LAUNCH: return "HIP launch error";
+        case LASR_E_NODEVICE: return "no usable gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int lasr_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return LASR_OK;
+}
+
+extern "C" int lasr_prof_kernel_count(void) { return K_NUM_KERNELS; }
+
+extern "C" const char* lasr_prof_kernel_name(int id) { return id >= 0 && id < K_NUM_KERNELS ? kKernelNames[id] : ""; }
+
+// Sums (and clears) the recorded launches of kernel `id`; blocks until they finished.
+extern "C" int lasr_prof_collect(int id, double* total_ms, long long* launches)
+{
+    if (!total_ms || !launches) return LASR_E_BADARG;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tot = 0; long long n = 0;
+    std::vector<ProfRec> keep;
+    for (auto& r : g_prof_recs) {
+        if (r.id != id) { keep.push_back(r); continue; }
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; n++; }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof_recs.swap(keep);
+    *total_ms = tot; *launches = n;
+    return LASR_OK;
+}

@@ -1,0 +1,33 @@
+// host_common.h -- host-side helpers shared by the .hip translation units of liblasr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/lasr_sr.h"
+
+// kernel ids for lasr_prof_* (names in common.hip, same order)
+enum LasrKernelId {
+    K_SR_SETUP = 0, K_SR_FORWARD, K_SR_BACKWARD,
+    K_LBS_FORWARD, K_LBS_BACKWARD, K_PINHOLE_FORWARD, K_PINHOLE_BACKWARD,
+    K_MASK_LOSS_FORWARD, K_MASK_LOSS_BACKWARD, K_FLOW_LOSS_STATS, K_FLOW_LOSS_FORWARD, K_FLOW_LOSS_BACKWARD,
+    K_TEX_LOSS_FORWARD, K_TEX_LOSS_BACKWARD, K_ARAP_FORWARD, K_ARAP_BACKWARD, K_LAP_FORWARD, K_LAP_BACKWARD,
+    K_NUM_KERNELS
+};
+
+int lasr_launch_ok();                                   // hipGetLastError -> LASR_OK / LASR_E_LAUNCH (records the code)
+bool lasr_prof_is_on();
+void lasr_prof_push(int id, hipEvent_t a, hipEvent_t b);
+
+// Brackets one kernel launch with hipEvents on its stream when profiling is enabled.
+struct ProfScope {
+    hipStream_t st; int id; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(int id_, hipStream_t st_) : st(st_), id(id_), on(lasr_prof_is_on())
+    {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope()
+    {
+        if (on) { (void)hipEventRecord(b, st); lasr_prof_push(id, a, b); }
+    }
+};
+
+#define launch_ok lasr_launch_ok

@@ -1,0 +1,712 @@
+// ops.hip -- geometry and loss kernels around the rasteriser (include/lasr_ops.h), gfx950 / wave64.
+//
+// All of these replace chains of eager PyTorch ops in the reference (paths relative to /root/reference/):
+//   LBS        nnutils/geom_utils.py:45-71   K-1 separate bmm launches + a [N,K-1,V,3] temporary
+//   pinhole    nnutils/geom_utils.py:27-34   6 elementwise kernels + clones
+//   losses     nnutils/mesh_net.py:374-447   python loops over (image, hypothesis) with boolean-mask indexing
+//   ARAP       nnutils/loss_utils.py:46-64   six dense [N,V,V] tensors (O(N V^3) flops)
+//   Laplacian  third_party/ext_nnutils/loss_utils.py:57-65   dense [V,V] matmul
+// Every reduction here is deterministic (fixed tree inside a block, no float atomics).
+#include <hip/hip_runtime.h>
+
+#include "../../include/lasr_ops.h"
+#include "host_common.h"
+#include "sr_device.h"
+
+namespace lasr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dpp_f(float v, const int ctrl)
+{
+    // compile-time ctrl required by the builtin: dispatch on the few patterns used here
+    switch (ctrl) {
+        case 0x111: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+        case 0x112: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));
+        case 0x113: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x113, 0xf, 0xf, false));
+        case 0x116: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x116, 0xf, 0xf, false));
+        case 0x55: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55, 0xf, 0xf, false));
+        case 0xAA: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xAA, 0xf, 0xf, false));
+        default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFF, 0xf, 0xf, false));
+    }
+}
+
+// Sum over a 256-thread block; every thread gets the total.  `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+    v = wave_sum_to_lane63(v);
+    __syncthreads();                       // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ===========================================================================
+// Linear-blend skinning
+// ===========================================================================
+// One wave = 16 vertices.  C[16 vertices, 16 cols] = A[16, K-1] (skin^T) x B[K-1, 16] where the 12 live
+// columns of B are the bone's row-major R (9) and T (3): v_mfma_f32_16x16x4_f32, 4 bones per instruction.
+// Fragment maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C[row = (lane >> 4) * 4 + r][col = lane & 15].
+__global__ __launch_bounds__(256) void lbs_forward_kernel(const float* __restrict__ verts, const float* __restrict__ Rmat,
+                                                          const float* __restrict__ Tmat, const float* __restrict__ skin,
+                                                          float* __restrict__ out, int N, int V, int K, int tocam)
+{
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v0 = (blockIdx.x * 4 + wave) * 16;
+    if (v0 >= V) return;
+    const int col = lane & 15, kc = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nb = K - 1;
+    for (int kk = 0; kk < nb; kk += 4) {
+        const int k = kk + kc;
+        const int vi = v0 + col;
+        float a = 0.f, b = 0.f;
+        if (k < nb) {
+            if (vi < V) a = skin[((size_t)n * nb + k) * V + vi];
+            const size_t bone = (size_t)n * K + k + 1;
+            if (col < 9) b = Rmat[bone * 9 + col];
+            else if (col < 12) b = Tmat[bone * 3 + (col - 9)];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    const float* R0 = Rmat + (size_t)n * K * 9;
+    const float* T0 = Tmat + (size_t)n * K * 3;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int vert = v0 + kc * 4 + r;
+        const bool live = vert < V;
+        const float* p = verts + ((size_t)n * V + (live ? vert : 0)) * 3;
+        float x;
+        if (nb > 0) {
+            // lane `col` holds M[i][j] (col = 3i+j < 9) or t[j] (col = 9+j): form v_i*M[i][j] | t[j] and fold
+            // the four lanes {j, 3+j, 6+j, 9+j} of the 16-lane row into lane 9+j
+            x = col < 9 ? p[col / 3] * acc[r] : (col < 12 ? acc[r] : 0.f);
+            x += dpp_f(x, 0x113);          // row_shr:3
+            x += dpp_f(x, 0x116);          // row_shr:6
+        } else {
+            x = (col >= 9 && col < 12) ? p[col - 9] : 0.f;
+        }
+        if (tocam) {
+            // lanes 8..11 form a quad: broadcast vs_0..2 from its lanes 1..3
+            const float s0 = dpp_f(x, 0x55), s1 = dpp_f(x, 0xAA), s2 = dpp_f(x, 0xFF);
+            const int j = (col >= 9 && col < 12) ? col - 9 : 0;
+            x = s0 * R0[j] + s1 * R0[3 + j] + s2 * R0[6 + j] + T0[j];
+        }
+        if (live && col >= 9 && col < 12) out[((size_t)n * V + vert) * 3 + (col - 9)] = x;
+    }
+}
+
+// Backward: one block per mesh (tiny problem: V ~ 1e3, K ~ 30).  Phase A, thread per vertex: blend
+// matrix, g_verts, g_skin, and the 12 body-transform accumulators.  Phase B, thread per (bone, 1/8 of the
+// vertices): g_R / g_T of the part bones, folded across the 8 partial lanes with DPP.  No atomics.
+__global__ __launch_bounds__(256) void lbs_backward_kernel(const float* __restrict__ verts, const float* __restrict__ Rmat,
+                                                           const float* __restrict__ Tmat, const float* __restrict__ skin,
+                                                           const float* __restrict__ gout, float* __restrict__ gverts,
+                                                           float* __restrict__ gR, float* __restrict__ gT,
+                                                           float* __restrict__ gskin, int N, int V, int K, int tocam)
+{
+    extern __shared__ float lds[];          // [K*12] transforms, then 4 floats for block_sum
+    const int n = blockIdx.x, tid = threadIdx.x, nb = K - 1;
+    float* RT = lds;                        // RT[k*12 + c], k = 0 body
+    float* red = lds + K * 12;
+    for (int i = tid; i < K * 12; i += 256) {
+        const int k = i / 12, c = i - k * 12;
+        RT[i] = c < 9 ? Rmat[((size_t)n * K + k) * 9 + c] : Tmat[((size_t)n * K + k) * 3 + (c - 9)];
+    }
+    __syncthreads();
+    float accR0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, accT0[3] = {0, 0, 0};
+    for (int v = tid; v < V; v += 256) {
+        const size_t o = ((size_t)n * V + v) * 3;
+        const float px = verts[o], py = verts[o + 1], pz = verts[o + 2];
+        const float g0 = gout[o], g1 = gout[o + 1], g2 = gout[o + 2];
+        float h0 = g0, h1 = g1, h2 = g2;    // g_vs
+        if (tocam) {                         // g_vs = g_out @ R0^T
+            h0 = g0 * RT[0] + g1 * RT[1] + g2 * RT[2];
+            h1 = g0 * RT[3] + g1 * RT[4] + g2 * RT[5];
+            h2 = g0 * RT[6] + g1 * RT[7] + g2 * RT[8];
+        }
+        float M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        if (nb > 0) {
+#pragma unroll
+            for (int c = 0; c < 12; c++) M[c] = 0.f;
+            // G[c] = d out / d RT_blend[c] contracted with g_vs: (v_i * h_j | h_j)
+            const float G[12] = {px * h0, px * h1, px * h2, py * h0, py * h1, py * h2, pz * h0, pz * h1, pz * h2, h0, h1, h2};
+            for (int k = 0; k < nb; k++) {
+                const float s = skin[((size_t)n * nb + k) * V + v];
+                const float* b = RT + (k + 1) * 12;
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < 12; c++) { M[c] += s * b[c]; d += G[c] * b[c]; }
+                if (gskin) gskin[((size_t)n * nb + k) * V + v] = d;
+            }
+        }
+        if (gverts) {                        // g_v = g_vs @ M^T
+            gverts[o] = h0 * M[0] + h1 * M[1] + h2 * M[2];
+            gverts[o + 1] = h0 * M[3] + h1 * M[4] + h2 * M[5];
+            gverts[o + 2] = h0 * M[6] + h1 * M[7] + h2 * M[8];
+        }
+        if (tocam) {                         // body transform: g_R0 += vs^T g_out, g_T0 += g_out
+            const float s0 = px * M[0] + py * M[3] + pz * M[6] + M[9];
+            const float s1 = px * M[1] + py * M[4] + pz * M[7] + M[10];
+            const float s2 = px * M[2] + py * M[5] + pz * M[8] + M[11];
+            accR0[0] += s0 * g0; accR0[1] += s0 * g1; accR0[2] += s0 * g2;
+            accR0[3] += s1 * g0; accR0[4] += s1 * g1; accR0[5] += s1 * g2;
+            accR0[6] += s2 * g0; accR0[7] += s2 * g1; accR0[8] += s2 * g2;
+            accT0[0] += g0; accT0[1] += g1; accT0[2] += g2;
+        }
+    }
+    // body bone (k = 0)
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const float t = block_sum(accR0[c], red);
+        if (tid == 0 && gR) gR[((size_t)n * K) * 9 + c] = tocam ? t : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t = block_sum(accT0[c], red);
+        if (tid == 0 && gT) gT[((size_t)n * K) * 3 + c] = tocam ? t : 0.f;
+    }
+    // part bones: thread (k, part) with k = tid / 8, part = tid % 8; bones beyond 32 in further rounds
+    for (int kb = 0; kb < nb; kb += 32) {
+        const int k = kb + (tid >> 3), part = tid & 7;
+        float a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (k < nb) {
+            for (int v = part; v < V; v += 8) {
+                const size_t o = ((size_t)n * V + v) * 3;
+                const float px = verts[o], py = verts[o + 1], pz = verts[o + 2];
+                const float g0 = gout[o], g1 = gout[o + 1], g2 = gout[o + 2];
+                float h0 = g0, h1 = g1, h2 = g2;
+                if (tocam) {
+                    h0 = g0 * RT[0] + g1 * RT[1] + g2 * RT[2];
+                    h1 = g0 * RT[3] + g1 * RT[4] + g2 * RT[5];
+                    h2 = g0 * RT[6] + g1 * RT[7] + g2 * RT[8];
+                }
+                const float s = skin[((size_t)n * nb + k) * V + v];
+                a[0] += s * px * h0; a[1] += s * px * h1; a[2] += s * px * h2;
+                a[3] += s * py * h0; a[4] += s * py * h1; a[5] += s * py * h2;
+                a[6] += s * pz * h0; a[7] += s * pz * h1; a[8] += s * pz * h2;
+                a[9] += s * h0; a[10] += s * h1; a[11] += s * h2;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 12; c++) {       // fold the 8 partial lanes (aligned group of 8 inside a DPP row)
+            float x = a[c];
+            x += dpp_f(x, 0x111);            // row_shr:1
+            x += dpp_f(x, 0x112);            // row_shr:2
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, false));   // row_shr:4
+            a[c] = x;                        // lane part == 7 holds the sum of its group
+        }
+        if (k < nb && part == 7) {
+#pragma unroll
+            for (int c = 0; c < 9; c++) if (gR) gR[((size_t)n * K + k + 1) * 9 + c] = a[c];
+#pragma unroll
+            for (int c = 0; c < 3; c++) if (gT) gT[((size_t)n * K + k + 1) * 3 + c] = a[9 + c];
+        }
+    }
+}
+
+// ===========================================================================
+// Pinhole projection
+// ===========================================================================
+__global__ __launch_bounds__(256) void pinhole_forward_kernel(const float4* __restrict__ verts, const float* __restrict__ pp,
+                                                              const float* __restrict__ fl, float4* __restrict__ out,
+                                                              int N, int V)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * V) return;
+    const int n = i / V;
+    const float4 p = verts[i];
+    const float f = fl[n];
+    // same association as geom_utils.py:32-33: pp + (x * fl) / z
+    out[i] = make_float4(pp[2 * n] + p.x * f / p.z, pp[2 * n + 1] + p.y * f / p.z, p.z, p.w);
+}
+
+__global__ __launch_bounds__(256) void pinhole_backward_kernel(const float4* __restrict__ verts, const float* __restrict__ fl,
+                                                               const float4* __restrict__ gout, float4* __restrict__ gverts,
+                                                               float* __restrict__ gpp, float* __restrict__ gfl, int N, int V)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float f = fl[n];
+    float sx = 0.f, sy = 0.f, sf = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        const size_t i = (size_t)n * V + v;
+        const float4 p = verts[i], g = gout[i];
+        const float iz = 1.f / p.z;
+        const float xz = p.x * iz, yz = p.y * iz;
+        if (gverts) gverts[i] = make_float4(g.x * f * iz, g.y * f * iz, g.z - (g.x * xz + g.y * yz) * f * iz, g.w);
+        sx += g.x; sy += g.y; sf += g.x * xz + g.y * yz;
+    }
+    sx = block_sum(sx, red); sy = block_sum(sy, red); sf = block_sum(sf, red);
+    if (tid == 0) {
+        if (gpp) { gpp[2 * n] = sx; gpp[2 * n + 1] = sy; }
+        if (gfl) gfl[n] = sf;
+    }
+}
+
+// ===========================================================================
+// Image-loss tables: one block per (image i, hypothesis j)
+// ===========================================================================
+__global__ __launch_bounds__(256) void mask_loss_forward_kernel(const float* __restrict__ pred, const float* __restrict__ masks,
+                                                                const float* __restrict__ occ, float* __restrict__ loss,
+                                                                int H, int P)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / H;
+    const float* a = pred + (size_t)ij * P;
+    const float* m = masks + (size_t)i * P;
+    const float* oc = occ + (size_t)i * P;
+    float s = 0.f, c = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256)
+        if (oc[p] != 0.f) { const float d = a[p] - m[p]; s += d * d; c += 1.f; }
+    s = block_sum(s, red); c = block_sum(c, red);
+    if (threadIdx.x == 0) loss[ij] = 0.5f * (s / c);
+}
+
+__global__ __launch_bounds__(256) void mask_loss_backward_kernel(const float* __restrict__ pred, const float* __restrict__ masks,
+                                                                 const float* __restrict__ occ, const float* __restrict__ gloss,
+                                                                 float* __restrict__ gpred, int H, int P)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / H;
+    const float* a = pred + (size_t)ij * P;
+    const float* m = masks + (size_t)i * P;
+    const float* oc = occ + (size_t)i * P;
+    float c = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) c += oc[p] != 0.f ? 1.f : 0.f;
+    c = block_sum(c, red);
+    const float k = gloss[ij] / c;            // 0.5 * 2 * g / count
+    for (int p = threadIdx.x; p < P; p += 256) gpred[(size_t)ij * P + p] = oc[p] != 0.f ? k * (a[p] - m[p]) : 0.f;
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// per image: sum and count of sigmoid(-occ) over sel[i] (all hypotheses)  -> scratch[2i], scratch[2i+1]
+__global__ __launch_bounds__(256) void flow_loss_stats_kernel(const unsigned char* __restrict__ bg, const float* __restrict__ occ,
+                                                              const float* __restrict__ masks, float* __restrict__ scratch,
+                                                              int H, int P)
+{
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    const float* oc = occ + (size_t)i * P;
+    const float* m = masks + (size_t)i * P;
+    float s = 0.f, c = 0.f;
+    for (int j = 0; j < H; j++)
+        for (int p = threadIdx.x; p < P; p += 256)
+            if (!bg[((size_t)i * H + j) * P + p] && oc[p] != 0.f && m[p] > 0.f) { s += sigmoid_f(-oc[p]); c += 1.f; }
+    s = block_sum(s, red); c = block_sum(c, red);
+    if (threadIdx.x == 0) { scratch[2 * i] = s; scratch[2 * i + 1] = c; }
+}
+
+__global__ __launch_bounds__(256) void flow_loss_forward_kernel(const float2* __restrict__ flow_rd, const float* __restrict__ obs,
+                                                                const unsigned char* __restrict__ bg, const float* __restrict__ occ,
+                                                                const float* __restrict__ masks, const float* __restrict__ scratch,
+                                                                float* __restrict__ loss, float* __restrict__ fmap,
+                                                                int H, int P, int obs_stride)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / H;
+    const float* oc = occ + (size_t)i * P;
+    const float* m = masks + (size_t)i * P;
+    const float* ox = obs + (size_t)i * obs_stride;
+    const float* oy = ox + P;
+    const float wmean = scratch[2 * i] / scratch[2 * i + 1];
+    float s = 0.f, c = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const float2 f = flow_rd[(size_t)ij * P + p];
+        const float dx = f.x - ox[p], dy = f.y - oy[p];
+        const float e = sqrtf(dx * dx + dy * dy) * (sigmoid_f(-oc[p]) / wmean);
+        fmap[(size_t)ij * P + p] = e;
+        if (!bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f) { s += e; c += 1.f; }
+    }
+    s = block_sum(s, red); c = block_sum(c, red);
+    if (threadIdx.x == 0) loss[ij] = c > 0.f ? 0.5f * (s / c) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void flow_loss_backward_kernel(const float2* __restrict__ flow_rd, const float* __restrict__ obs,
+                                                                 const unsigned char* __restrict__ bg, const float* __restrict__ occ,
+                                                                 const float* __restrict__ masks, const float* __restrict__ scratch,
+                                                                 const float* __restrict__ gloss, float2* __restrict__ gflow,
+                                                                 int H, int P, int obs_stride)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / H;
+    const float* oc = occ + (size_t)i * P;
+    const float* m = masks + (size_t)i * P;
+    const float* ox = obs + (size_t)i * obs_stride;
+    const float* oy = ox + P;
+    const float wmean = scratch[2 * i] / scratch[2 * i + 1];
+    float c = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256)
+        c += (!bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f) ? 1.f : 0.f;
+    c = block_sum(c, red);
+    const float k = c > 0.f ? 0.5f * gloss[ij] / c : 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        // d loss / d map = k on selected pixels, 0 elsewhere; d map / d norm = w.  When image i has no selected
+        // pixel at all, w is NaN and 0 * NaN = NaN reaches every pixel -- exactly what autograd does with the
+        // reference code (its trainer then drops the step, nnutils/train_utils.py:289-290).  Kept on purpose.
+        const bool sel = !bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f;
+        const float gn = (sel ? k : 0.f) * (sigmoid_f(-oc[p]) / wmean);
+        const float2 f = flow_rd[(size_t)ij * P + p];
+        const float dx = f.x - ox[p], dy = f.y - oy[p];
+        const float nrm = sqrtf(dx * dx + dy * dy);
+        float2 g = make_float2(0.f, 0.f);
+        if (nrm > 0.f) g = make_float2(gn / nrm * dx, gn / nrm * dy);   // torch.norm's subgradient at 0 is 0
+        gflow[(size_t)ij * P + p] = g;
+    }
+}
+
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void tex_loss_forward_kernel(const float* __restrict__ img_obs, const float* __restrict__ img_white,
+                                                               const float* __restrict__ rnd, const float* __restrict__ fg,
+                                                               const float* __restrict__ occ, float* __restrict__ loss,
+                                                               float wt, int H, int P)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / H;
+    const float* oc = occ + (size_t)i * P;
+    float s1 = 0.f, s2 = 0.f, c = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        if (oc[p] == 0.f) continue;
+        const float a = fg[(size_t)ij * P + p];
+        float e1 = 0.f, e2 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float r = rnd[((size_t)ij * 3 + ch) * P + p];
+            e1 += fabsf(img_obs[((size_t)i * 3 + ch) * P + p] - r * a);
+            e2 += fabsf(img_white[((size_t)i * 3 + ch) * P + p] - r);
+        }
+        s1 += e1 / 3.f; s2 += e2 / 3.f; c += 1.f;
+    }
+    s1 = block_sum(s1, red); s2 = block_sum(s2, red); c = block_sum(c, red);
+    if (threadIdx.x == 0) loss[ij] = (s1 / c + s2 / c) * (2.f * wt);
+}
+
+__global__ __launch_bounds__(256) void tex_loss_backward_kernel(const float* __restrict__ img_obs, const float* __restrict__ img_white,
+                                                                const float* __restrict__ rnd, const float* __restrict__ fg,
+                                                                const float* __restrict__ occ, const float* __restrict__ gloss,
+                                                                float* __restrict__ grnd, float* __restrict__ gfg,
+                                                                float wt, int H, int P)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / H;
+    const float* oc = occ + (size_t)i * P;
+    float c = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) c += oc[p] != 0.f ? 1.f : 0.f;
+    c = block_sum(c, red);
+    const float k = gloss[ij] * (2.f * wt) / (3.f * c);
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const bool on = oc[p] != 0.f;
+        const float a = fg[(size_t)ij * P + p];
+        float ga = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const size_t q = ((size_t)ij * 3 + ch) * P + p;
+            float g = 0.f;
+            if (on) {
+                const float r = rnd[q];
+                const float s1 = sgn(img_obs[((size_t)i * 3 + ch) * P + p] - r * a);
+                const float s2 = sgn(img_white[((size_t)i * 3 + ch) * P + p] - r);
+                g = -k * (s1 * a + s2);
+                ga += -k * s1 * r;
+            }
+            grnd[q] = g;
+        }
+        gfg[(size_t)ij * P + p] = ga;
+    }
+}
+
+// ===========================================================================
+// Mesh regularisers on CSR adjacency: one block per mesh instance
+// ===========================================================================
+__global__ __launch_bounds__(256) void arap_forward_kernel(const float* __restrict__ dx, const float* __restrict__ x,
+                                                           const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                           float* __restrict__ loss, int V)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float* X = x + (size_t)n * V * 3;
+    const float* D = dx + (size_t)n * V * 3;
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float a0 = X[3 * v], a1 = X[3 * v + 1], a2 = X[3 * v + 2];
+        const float b0 = D[3 * v], b1 = D[3 * v + 1], b2 = D[3 * v + 2];
+        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
+            const int u = col[e];
+            const float p0 = X[3 * u] - a0, p1 = X[3 * u + 1] - a1, p2 = X[3 * u + 2] - a2;
+            const float q0 = D[3 * u] - b0, q1 = D[3 * u + 1] - b1, q2 = D[3 * u + 2] - b2;
+            s += fabsf((p0 * p0 + p1 * p1 + p2 * p2) - (q0 * q0 + q1 * q1 + q2 * q2));
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss[n] = s / (float)row_ptr[V];
+}
+
+__global__ __launch_bounds__(256) void arap_backward_kernel(const float* __restrict__ dx, const float* __restrict__ x,
+                                                            const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                            const float* __restrict__ gloss, float* __restrict__ gdx,
+                                                            float* __restrict__ gx, int V)
+{
+    const int n = blockIdx.x;
+    const float* X = x + (size_t)n * V * 3;
+    const float* D = dx + (size_t)n * V * 3;
+    // each undirected edge appears as (v,u) and (u,v) with the same value: 2 * d|e|/dx_v = 4 sign(e) (x_v - x_u)
+    const float k = 4.f * gloss[n] / (float)row_ptr[V];
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float a0 = X[3 * v], a1 = X[3 * v + 1], a2 = X[3 * v + 2];
+        const float b0 = D[3 * v], b1 = D[3 * v + 1], b2 = D[3 * v + 2];
+        float gx0 = 0, gx1 = 0, gx2 = 0, gd0 = 0, gd1 = 0, gd2 = 0;
+        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
+            const int u = col[e];
+            const float p0 = a0 - X[3 * u], p1 = a1 - X[3 * u + 1], p2 = a2 - X[3 * u + 2];
+            const float q0 = b0 - D[3 * u], q1 = b1 - D[3 * u + 1], q2 = b2 - D[3 * u + 2];
+            const float sg = sgn((p0 * p0 + p1 * p1 + p2 * p2) - (q0 * q0 + q1 * q1 + q2 * q2));
+            gx0 += sg * p0; gx1 += sg * p1; gx2 += sg * p2;
+            gd0 -= sg * q0; gd1 -= sg * q1; gd2 -= sg * q2;
+        }
+        const size_t o = ((size_t)n * V + v) * 3;
+        if (gx) { gx[o] = k * gx0; gx[o + 1] = k * gx1; gx[o + 2] = k * gx2; }
+        if (gdx) { gdx[o] = k * gd0; gdx[o + 1] = k * gd1; gdx[o + 2] = k * gd2; }
+    }
+}
+
+// lx[v] = x_v - mean_{u in nbr(v)} x_u  (0 for isolated vertices); loss = sum |lx|^2
+__global__ __launch_bounds__(256) void laplacian_forward_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr,
+                                                                const int* __restrict__ col, float* __restrict__ loss,
+                                                                float* __restrict__ lx_out, int V)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float* X = x + (size_t)n * V * 3;
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
+        float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+        if (e1 > e0) {
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+            for (int e = e0; e < e1; e++) { const int u = col[e]; m0 += X[3 * u]; m1 += X[3 * u + 1]; m2 += X[3 * u + 2]; }
+            const float inv = 1.f / (float)(e1 - e0);
+            l0 = X[3 * v] - m0 * inv; l1 = X[3 * v + 1] - m1 * inv; l2 = X[3 * v + 2] - m2 * inv;
+        }
+        if (lx_out) { const size_t o = ((size_t)n * V + v) * 3; lx_out[o] = l0; lx_out[o + 1] = l1; lx_out[o + 2] = l2; }
+        s += l0 * l0 + l1 * l1 + l2 * l2;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0 && loss) loss[n] = s;
+}
+
+// g_x = 2 g L^T (L x):  g_x[v] = 2 g (lx[v] - sum_{u in nbr(v)} lx[u] / deg(u))   (symmetric adjacency)
+__global__ __launch_bounds__(256) void laplacian_backward_kernel(const float* __restrict__ lx, const int* __restrict__ row_ptr,
+                                                                 const int* __restrict__ col, const float* __restrict__ gloss,
+                                                                 float* __restrict__ gx, int V)
+{
+    const int n = blockIdx.x;
+    const float* L = lx + (size_t)n * V * 3;
+    const float k = 2.f * gloss[n];
+    for (int v = threadIdx.x; v < V; v += 256) {
+        float a0 = L[3 * v], a1 = L[3 * v + 1], a2 = L[3 * v + 2];
+        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
+            const int u = col[e];
+            const float inv = 1.f / (float)(row_ptr[u + 1] - row_ptr[u]);
+            a0 -= L[3 * u] * inv; a1 -= L[3 * u + 1] * inv; a2 -= L[3 * u + 2] * inv;
+        }
+        const size_t o = ((size_t)n * V + v) * 3;
+        gx[o] = k * a0; gx[o + 1] = k * a1; gx[o + 2] = k * a2;
+    }
+}
+
+}  // namespace lasr
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+using namespace lasr;
+
+#define LASR_LAUNCH(ID, KERNEL, GRID, BLOCK, LDS, ...)                                   \
+    do {                                                                                 \
+        ProfScope ps_(ID, st);                                                           \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, st, __VA_ARGS__);                   \
+    } while (0)
+
+extern "C" int lasr_lbs_forward(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out,
+                                int N, int V, int K, int tocam, void* hip_stream)
+{
+    if (N < 0 || V < 0 || K < 1) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!verts || !Rmat || !Tmat || !out || (K > 1 && !skin)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_LBS_FORWARD, lbs_forward_kernel, dim3((V + 63) / 64, N), dim3(256), 0, verts, Rmat, Tmat, skin, out,
+                N, V, K, tocam);
+    return launch_ok();
+}
+
+extern "C" int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
+                                 const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
+                                 float* grad_skin, int N, int V, int K, int tocam, void* hip_stream)
+{
+    if (N < 0 || V < 0 || K < 1 || K > 1024) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!verts || !Rmat || !Tmat || !grad_out || (K > 1 && !skin)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_kernel, dim3(N), dim3(256), (K * 12 + 4) * sizeof(float), verts, Rmat, Tmat,
+                skin, grad_out, grad_verts, grad_Rmat, grad_Tmat, grad_skin, N, V, K, tocam);
+    return launch_ok();
+}
+
+extern "C" int lasr_pinhole_forward(const float* verts, const float* pp, const float* fl, float* out, int N, int V,
+                                    void* hip_stream)
+{
+    if (N < 0 || V < 0) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!verts || !pp || !fl || !out) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_PINHOLE_FORWARD, pinhole_forward_kernel, dim3((N * V + 255) / 256), dim3(256), 0, (const float4*)verts,
+                pp, fl, (float4*)out, N, V);
+    return launch_ok();
+}
+
+extern "C" int lasr_pinhole_backward(const float* verts, const float* pp, const float* fl, const float* grad_out,
+                                     float* grad_verts, float* grad_pp, float* grad_fl, int N, int V, void* hip_stream)
+{
+    (void)pp;
+    if (N < 0 || V < 0) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!verts || !fl || !grad_out) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_PINHOLE_BACKWARD, pinhole_backward_kernel, dim3(N), dim3(256), 0, (const float4*)verts, fl,
+                (const float4*)grad_out, (float4*)grad_verts, grad_pp, grad_fl, N, V);
+    return launch_ok();
+}
+
+static int check_ihp(int I, int H, int P) { return (I < 0 || H < 0 || P < 0) ? LASR_E_BADARG : LASR_OK; }
+
+extern "C" int lasr_mask_loss_forward(const float* mask_pred, const float* masks, const float* occ, float* loss,
+                                      int I, int H, int P, void* hip_stream)
+{
+    if (check_ihp(I, H, P)) return LASR_E_BADARG;
+    if (I * H == 0) return LASR_OK;
+    if (!mask_pred || !masks || !occ || !loss) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_MASK_LOSS_FORWARD, mask_loss_forward_kernel, dim3(I * H), dim3(256), 0, mask_pred, masks, occ, loss, H, P);
+    return launch_ok();
+}
+
+extern "C" int lasr_mask_loss_backward(const float* mask_pred, const float* masks, const float* occ,
+                                       const float* grad_loss, float* grad_pred, int I, int H, int P, void* hip_stream)
+{
+    if (check_ihp(I, H, P)) return LASR_E_BADARG;
+    if (I * H == 0) return LASR_OK;
+    if (!mask_pred || !masks || !occ || !grad_loss || !grad_pred) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_MASK_LOSS_BACKWARD, mask_loss_backward_kernel, dim3(I * H), dim3(256), 0, mask_pred, masks, occ,
+                grad_loss, grad_pred, H, P);
+    return launch_ok();
+}
+
+extern "C" int lasr_flow_loss_forward(const float* flow_rd, const float* flow_obs, const unsigned char* bg,
+                                      const float* occ, const float* masks, float* loss, float* flow_rd_map,
+                                      float* scratch, int I, int H, int P, int obs_image_stride, void* hip_stream)
+{
+    if (check_ihp(I, H, P)) return LASR_E_BADARG;
+    if (I * H == 0) return LASR_OK;
+    if (!flow_rd || !flow_obs || !bg || !occ || !masks || !loss || !flow_rd_map || !scratch) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_FLOW_LOSS_STATS, flow_loss_stats_kernel, dim3(I), dim3(256), 0, bg, occ, masks, scratch, H, P);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_FLOW_LOSS_FORWARD, flow_loss_forward_kernel, dim3(I * H), dim3(256), 0, (const float2*)flow_rd, flow_obs,
+                bg, occ, masks, scratch, loss, flow_rd_map, H, P, obs_image_stride);
+    return launch_ok();
+}
+
+extern "C" int lasr_flow_loss_backward(const float* flow_rd, const float* flow_obs, const unsigned char* bg,
+                                       const float* occ, const float* masks, const float* scratch,
+                                       const float* grad_loss, float* grad_flow_rd, int I, int H, int P,
+                                       int obs_image_stride, void* hip_stream)
+{
+    if (check_ihp(I, H, P)) return LASR_E_BADARG;
+    if (I * H == 0) return LASR_OK;
+    if (!flow_rd || !flow_obs || !bg || !occ || !masks || !scratch || !grad_loss || !grad_flow_rd) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_FLOW_LOSS_BACKWARD, flow_loss_backward_kernel, dim3(I * H), dim3(256), 0, (const float2*)flow_rd,
+                flow_obs, bg, occ, masks, scratch, grad_loss, (float2*)grad_flow_rd, H, P, obs_image_stride);
+    return launch_ok();
+}
+
+extern "C" int lasr_tex_loss_forward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
+                                     const float* occ, float* loss, float wt, int I, int H, int P, void* hip_stream)
+{
+    if (check_ihp(I, H, P)) return LASR_E_BADARG;
+    if (I * H == 0) return LASR_OK;
+    if (!img_obs || !img_white || !rnd || !fg || !occ || !loss) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_TEX_LOSS_FORWARD, tex_loss_forward_kernel, dim3(I * H), dim3(256), 0, img_obs, img_white, rnd, fg, occ,
+                loss, wt, H, P);
+    return launch_ok();
+}
+
+extern "C" int lasr_tex_loss_backward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
+                                      const float* occ, const float* grad_loss, float* grad_rnd, float* grad_fg,
+                                      float wt, int I, int H, int P, void* hip_stream)
+{
+    if (check_ihp(I, H, P)) return LASR_E_BADARG;
+    if (I * H == 0) return LASR_OK;
+    if (!img_obs || !img_white || !rnd || !fg || !occ || !grad_loss || !grad_rnd || !grad_fg) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_TEX_LOSS_BACKWARD, tex_loss_backward_kernel, dim3(I * H), dim3(256), 0, img_obs, img_white, rnd, fg,
+                occ, grad_loss, grad_rnd, grad_fg, wt, H, P);
+    return launch_ok();
+}
+
+extern "C" int lasr_arap_forward(const float* dx, const float* x, const int* row_ptr, const int* col, float* loss,
+                                 int N, int V, void* hip_stream)
+{
+    if (N < 0 || V < 0) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!dx || !x || !row_ptr || !col || !loss) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_ARAP_FORWARD, arap_forward_kernel, dim3(N), dim3(256), 0, dx, x, row_ptr, col, loss, V);
+    return launch_ok();
+}
+
+extern "C" int lasr_arap_backward(const float* dx, const float* x, const int* row_ptr, const int* col,
+                                  const float* grad_loss, float* grad_dx, float* grad_x, int N, int V, void* hip_stream)
+{
+    if (N < 0 || V < 0) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!dx || !x || !row_ptr || !col || !grad_loss) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_ARAP_BACKWARD, arap_backward_kernel, dim3(N), dim3(256), 0, dx, x, row_ptr, col, grad_loss, grad_dx,
+                grad_x, V);
+    return launch_ok();
+}
+
+extern "C" int lasr_laplacian_forward(const float* x, const int* row_ptr, const int* col, float* loss, int N, int V,
+                                      void* hip_stream)
+{
+    if (N < 0 || V < 0) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!x || !row_ptr || !col || !loss) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_LAP_FORWARD, laplacian_forward_kernel, dim3(N), dim3(256), 0, x, row_ptr, col, loss, (float*)nullptr, V);
+    return launch_ok();
+}
+
+extern "C" int lasr_laplacian_backward(const float* x, const int* row_ptr, const int* col, const float* grad_loss,
+                                       float* grad_x, float* scratch_lx, int N, int V, void* hip_stream)
+{
+    if (N < 0 || V < 0) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!x || !row_ptr || !col || !grad_loss || !grad_x || !scratch_lx) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_LAP_FORWARD, laplacian_forward_kernel, dim3(N), dim3(256), 0, x, row_ptr, col, (float*)nullptr,
+                scratch_lx, V);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_LAP_BACKWARD, laplacian_backward_kernel, dim3(N), dim3(256), 0, scratch_lx, row_ptr, col, grad_loss,
+                grad_x, V);
+    return launch_ok();
+}

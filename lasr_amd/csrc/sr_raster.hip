@@ -28,6 +28,7 @@
 
 #include "../../include/lasr_sr.h"
 #include "sr_device.h"
+#include "host_common.h"
 
 namespace lasr {
 
@@ -463,86 +464,9 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
 // ===========================================================================
 using namespace lasr;
 
-// ---- optional per-kernel timing (bench.py's roofline leg) --------------------
-// When enabled, every kernel launch is bracketed by hipEvents recorded on the
-// launch stream; lasr_prof_collect() synchronises them and returns totals.
-#include <mutex>
-#include <vector>
-namespace {
-struct ProfRec { int id; hipEvent_t a, b; };
-std::mutex g_prof_mu;
-std::vector<ProfRec> g_prof_recs;
-bool g_prof_on = false;
-const char* const kKernelNames[] = {"sr_setup_kernel", "sr_forward_kernel", "sr_backward_kernel"};
-constexpr int kNumKernels = 3;
-
-struct ProfScope {
-    hipStream_t st; int id; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(int id_, hipStream_t st_) : st(st_), id(id_), on(g_prof_on)
-    {
-        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-    }
-    ~ProfScope()
-    {
-        if (on) {
-            (void)hipEventRecord(b, st);
-            std::lock_guard<std::mutex> lk(g_prof_mu);
-            g_prof_recs.push_back(ProfRec{id, a, b});
-        }
-    }
-};
-}  // namespace
-
-extern "C" int lasr_prof_enable(int on)
-{
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
-    return LASR_OK;
-}
-
-extern "C" int lasr_prof_kernel_count(void) { return kNumKernels; }
-
-extern "C" const char* lasr_prof_kernel_name(int id) { return id >= 0 && id < kNumKernels ? kKernelNames[id] : ""; }
-
-// Sums (and clears) the recorded launches of kernel `id`; blocks until they finished.
-extern "C" int lasr_prof_collect(int id, double* total_ms, long long* launches)
-{
-    if (!total_ms || !launches) return LASR_E_BADARG;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    double tot = 0; long long n = 0;
-    std::vector<ProfRec> keep;
-    for (auto& r : g_prof_recs) {
-        if (r.id != id) { keep.push_back(r); continue; }
-        float ms = 0.f;
-        (void)hipEventSynchronize(r.b);
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; n++; }
-        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
-    }
-    g_prof_recs.swap(keep);
-    *total_ms = tot; *launches = n;
-    return LASR_OK;
-}
-
-static thread_local int g_last_hip_error = 0;
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-extern "C" int lasr_abi_version(void) { return 1; }
-
-extern "C" int lasr_last_hip_error(void) { return g_last_hip_error; }
-
-extern "C" const char* lasr_strerror(int code)
-{
-    switch (code) {
-        case LASR_OK: return "ok";
-        case LASR_E_BADARG: return "bad argument (null pointer or negative size)";
-        case LASR_E_BADMODE: return "mode id out of range";
-        case LASR_E_WORKSPACE: return "workspace missing or too small";
-        case LASR_E_LAUNCH: return "HIP launch error";
-        case LASR_E_NODEVICE: return "no usable gfx950 device";
-        default: return "unknown error";
-    }
-}
 
 extern "C" size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS)
 {
@@ -560,12 +484,6 @@ static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alph
     return LASR_OK;
 }
 
-static int launch_ok()
-{
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return LASR_E_LAUNCH; }
-    return LASR_OK;
-}
 
 static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T, int IS, float near, float far,
                             float eps, float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
@@ -604,7 +522,7 @@ extern "C" int lasr_sr_forward(const float* faces, const float* textures, float*
     const int total = N * F;
     if (total > 0) {
         {
-            ProfScope ps(0, st);
+            ProfScope ps(K_SR_SETUP, st);
             hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, bboxes,
                                faces_info, total, sqrtf(A.thr));
         }
@@ -613,7 +531,7 @@ extern "C" int lasr_sr_forward(const float* faces, const float* textures, float*
     const int tiles_x = (IS + TILE - 1) / TILE;
     const dim3 grid((unsigned)(N * tiles_x * tiles_x));
     {
-        ProfScope ps(1, st);
+        ProfScope ps(K_SR_FORWARD, st);
         if (is_lasr_fast(A.m)) hipLaunchKernelGGL(sr_forward_kernel<true>, grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else hipLaunchKernelGGL(sr_forward_kernel<false>, grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
     }
@@ -640,14 +558,14 @@ extern "C" int lasr_sr_backward(const float* faces, const float* textures, const
                              gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &bboxes);
     const int total = N * F;
     {
-        ProfScope ps(0, st);
+        ProfScope ps(K_SR_SETUP, st);
         hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, bboxes,
                            (float*)nullptr, total, sqrtf(A.thr));
     }
     if ((rc = launch_ok())) return rc;
     const dim3 grid((unsigned)((total + 3) / 4));   // 4 waves (faces) per 256-thread workgroup
     {
-        ProfScope ps(2, st);
+        ProfScope ps(K_SR_BACKWARD, st);
         if (is_lasr_fast(A.m))
             hipLaunchKernelGGL(sr_backward_kernel<true>, grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
                                grad_soft_colors, grad_faces, grad_textures);

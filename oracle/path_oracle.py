@@ -1,0 +1,108 @@
+"""CPU restatements (torch, eager) of the Python pieces of the LASR hot path -- TEST INFRASTRUCTURE ONLY.
+
+Each function follows the cited reference lines operation by operation (paths relative to /root/reference/)
+so torch autograd reproduces the reference gradients.  Pinned by tests/test_path_oracle.py against fixtures
+captured from the imported reference (obj_to_cam, pinhole_cam, Laplacian, Flatten, ARAP); the loss tables
+restate nnutils/mesh_net.py, which cannot be imported here (absl / kornia / pytorch3d are missing) and has no
+tests upstream: "parity unpinned" for those three, covered by hand-computable cases instead.
+"""
+import numpy as np
+import torch
+
+
+def obj_to_cam(verts, Rmat, Tmat, nmesh, n_hypo, skin, tocam=True):
+    """nnutils/geom_utils.py:45-71."""
+    verts = verts.reshape(-1, verts.shape[1], 3)
+    bodyR, bodyT = Rmat[::nmesh], Tmat[::nmesh]
+    if nmesh > 1:
+        vs = []
+        for k in range(nmesh - 1):
+            partR, partT = Rmat[k + 1::nmesh], Tmat[k + 1::nmesh]
+            vs.append((verts.matmul(partR) + partT)[:, None])
+        vs = (torch.cat(vs, 1) * skin).sum(1)
+    else:
+        vs = verts
+    return vs.matmul(bodyR) + bodyT if tocam else vs
+
+
+def pinhole_cam(verts, pp, fl):
+    """nnutils/geom_utils.py:27-34."""
+    n_hypo = verts.shape[0] // pp.shape[0]
+    pp = pp[:, None].repeat(1, n_hypo, 1).view(-1, 2)
+    fl = fl[:, None].reshape(-1, 1)
+    y = pp[:, 1:2] + verts[:, :, 1] * fl / verts[:, :, 2]
+    x = pp[:, 0:1] + verts[:, :, 0] * fl / verts[:, :, 2]
+    return torch.stack([x, y, verts[:, :, 2], verts[:, :, 3]], -1)
+
+
+def mask_loss_table(mask_pred, masks, occ):
+    """nnutils/mesh_net.py:374-388; mask_pred [I,H,S,S], masks/occ [I,S,S] -> [I,H]."""
+    sub = (mask_pred - masks[:, None]).pow(2)
+    out = torch.zeros(mask_pred.shape[0], mask_pred.shape[1], dtype=mask_pred.dtype)
+    for i in range(out.shape[0]):
+        for j in range(out.shape[1]):
+            out[i, j] = sub[i, j][occ[i] != 0].mean()
+    return 0.5 * out
+
+
+def flow_loss_table(flow_rd, flow_obs, bgmask, occ, masks):
+    """nnutils/mesh_net.py:393-413; flow_rd [I,H,S,S,2], flow_obs [I,>=2,S,S], bgmask [I,H,S,S] bool -> ([I,H], map)."""
+    I, H = flow_rd.shape[:2]
+    mask = (~bgmask) & ((occ != 0)[:, None] & (masks > 0)[:, None]).repeat(1, H, 1, 1)
+    fmap = torch.norm(flow_rd - flow_obs[:, None, :2].permute(0, 1, 3, 4, 2), 2, -1)
+    w = (-occ).sigmoid()[:, None].repeat(1, H, 1, 1)
+    w = torch.stack([w[i] / w[i][mask[i]].mean() for i in range(I)])
+    fmap = fmap * w
+    out = torch.zeros(I, H, dtype=flow_rd.dtype)
+    for i in range(I):
+        for j in range(H):
+            out[i, j] = fmap[i, j][mask[i, j]].mean() if mask[i, j].sum() > 0 else 0.
+    return 0.5 * out, fmap
+
+
+def tex_loss_table(img_obs, img_white, texture_render, fgmask, occ, l1tex_wt=1.0):
+    """nnutils/mesh_net.py:425-441 without the perceptual term; texture_render [I,H,3,S,S], fgmask [I,H,S,S]."""
+    I, H = texture_render.shape[:2]
+    img_rnd = texture_render * fgmask[:, :, None]
+    out = torch.zeros(I, H, dtype=texture_render.dtype)
+    for i in range(I):
+        for j in range(H):
+            a = (img_obs[i] - img_rnd[i, j]).abs().mean(0)[occ[i] != 0].mean()
+            b = (img_white[i] - texture_render[i, j]).abs().mean(0)[occ[i] != 0].mean()
+            out[i, j] = (a + b) * 2 * l1tex_wt
+    return out
+
+
+def _adjacency(nv, faces):
+    """0/1 dense adjacency as nnutils/loss_utils.py:36-43 builds it."""
+    A = np.zeros([nv, nv], np.float32)
+    f = np.asarray(faces)
+    for a, b in ((0, 1), (1, 0), (1, 2), (2, 1), (2, 0), (0, 2)):
+        A[f[:, a], f[:, b]] = 1
+    return A
+
+
+def arap(dx, x, faces):
+    """nnutils/loss_utils.py:46-64 (dense, for small V): [N]."""
+    lap = torch.from_numpy(_adjacency(x.shape[1], faces)).to(x.dtype)
+    diffx = torch.zeros(x.shape[0], x.shape[1], x.shape[1], dtype=x.dtype)
+    diffdx = torch.zeros_like(diffx)
+    for i in range(3):
+        dx_sub = lap.matmul(torch.diag_embed(dx[:, :, i]))
+        x_sub = lap.matmul(torch.diag_embed(x[:, :, i]))
+        diffdx = diffdx + (dx_sub - dx[:, :, i:i + 1]).pow(2)
+        diffx = diffx + (x_sub - x[:, :, i:i + 1]).pow(2)
+    diff = (diffx - diffdx).abs()
+    return torch.stack([diff[i][lap.bool()].mean() for i in range(x.shape[0])])
+
+
+def laplacian(x, faces):
+    """third_party/ext_nnutils/loss_utils.py:34-65 (dense): [N]."""
+    nv = x.shape[1]
+    L = -_adjacency(nv, faces)
+    L[np.arange(nv), np.arange(nv)] = -L.sum(1)
+    for i in range(nv):
+        if L[i, i] != 0:
+            L[i, :] /= L[i, i]
+    y = torch.matmul(torch.from_numpy(L).to(x.dtype), x)
+    return y.pow(2).sum((1, 2))

@@ -1,0 +1,193 @@
+"""HIP geometry / loss kernels (include/lasr_ops.h, called through lasr_amd.nnutils) vs the golden fixtures
+captured from the reference and vs the torch oracle on random shapes.  Tolerances are fp32 round-off:
+the kernels reassociate sums (MFMA blend, tree reductions) but use the same formulas."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lasr_amd.nnutils import geom_utils, image_losses, loss_utils
+from lasr_amd import synth
+from oracle import path_oracle as po
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GEO = np.load(os.path.join(G, 'geom_utils.npz'))
+ML = np.load(os.path.join(G, 'mesh_losses.npz'))
+
+
+def dev_t(a, dev, grad=False):
+    return torch.from_numpy(np.asarray(a)).to(dev).requires_grad_(grad)
+
+
+def close(a, b, tol, what=''):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else b
+    assert np.array_equal(np.isnan(a), np.isnan(b)), '%s: NaN pattern differs' % what
+    a, b = np.nan_to_num(a), np.nan_to_num(b)
+    scale = max(float(np.abs(b).max()), 1e-12)
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, '%s: max err %.3e vs scale %.3e' % (what, err, scale)
+
+
+def test_obj_to_cam_vs_reference_fixture(cuda):
+    K, H = int(GEO['o2c_K']), int(GEO['o2c_H'])
+    for tag, tocam in (('cam', True), ('obj', False)):
+        v, R, T, s = (dev_t(GEO['o2c_' + n], cuda, True) for n in ('verts', 'Rmat', 'Tmat', 'skin'))
+        out = geom_utils.obj_to_cam(v, R, T, K, H, s, tocam=tocam)
+        close(out, GEO['o2c_%s_out' % tag], 1e-6, 'obj_to_cam ' + tag)
+        (out * dev_t(GEO['o2c_up'], cuda)).sum().backward()
+        for name, x in zip(('verts', 'Rmat', 'Tmat', 'skin'), (v, R, T, s)):
+            close(x.grad, GEO['o2c_%s_g_%s' % (tag, name)], 1e-5, 'grad ' + name)
+    N = GEO['o2c_verts'].shape[0]
+    out1 = geom_utils.obj_to_cam(dev_t(GEO['o2c_verts'], cuda), dev_t(GEO['o2c_Rmat'], cuda)[:N],
+                                 dev_t(GEO['o2c_Tmat'], cuda)[:N], 1, H, None)
+    close(out1, GEO['o2c_k1_out'], 1e-6, 'obj_to_cam K=1')
+
+
+@pytest.mark.parametrize('N,V,K', [(16, 642, 21), (2, 802, 26), (4, 1212, 36), (3, 17, 2), (1, 1, 5), (2, 70, 1)])
+def test_obj_to_cam_vs_oracle_at_lasr_sizes(cuda, N, V, K):
+    rng = np.random.default_rng(N * 1000 + V + K)
+    v = rng.standard_normal((N, V, 3)).astype(np.float32)
+    R = rng.standard_normal((N * K, 3, 3)).astype(np.float32)
+    T = rng.standard_normal((N * K, 1, 3)).astype(np.float32)
+    s = torch.softmax(torch.from_numpy(rng.standard_normal((N, max(K - 1, 1), V, 1)).astype(np.float32)), 1).numpy()
+    up = rng.standard_normal((N, V, 3)).astype(np.float32)
+    for tocam in (True, False):
+        ref_in = [torch.from_numpy(a).requires_grad_(True) for a in (v, R, T, s)]
+        ref = po.obj_to_cam(ref_in[0], ref_in[1], ref_in[2], K, 1, ref_in[3] if K > 1 else None, tocam=tocam)
+        (ref * torch.from_numpy(up)).sum().backward()
+        hip_in = [dev_t(a, cuda, True) for a in (v, R, T, s)]
+        out = geom_utils.obj_to_cam(hip_in[0], hip_in[1], hip_in[2], K, 1, hip_in[3] if K > 1 else None, tocam=tocam)
+        close(out, ref, 2e-6, 'out')
+        (out * dev_t(up, cuda)).sum().backward()
+        for name, a, b in zip(('verts', 'Rmat', 'Tmat', 'skin'), hip_in, ref_in):
+            if b.grad is None:
+                assert a.grad is None or float(a.grad.abs().max()) == 0.0
+                continue
+            close(a.grad, b.grad, 2e-5, 'grad %s tocam=%s' % (name, tocam))
+
+
+def test_joint_projection_call_pattern_with_broadcast_identity_skin(cuda):
+    # mesh_net.py:285: obj_to_cam(rest_ts[:,:,:,0], Rmat, Tmat[:,None], n_bones, n_hypo, eye(K-1)[None,:,:,None])
+    rng = np.random.default_rng(5)
+    N, K = 4, 6
+    joints = rng.standard_normal((N, K - 1, 3)).astype(np.float32)
+    R = rng.standard_normal((N * K, 3, 3)).astype(np.float32)
+    T = rng.standard_normal((N * K, 1, 3)).astype(np.float32)
+    eye = torch.eye(K - 1)[None, :, :, None]
+    ref = po.obj_to_cam(torch.from_numpy(joints), torch.from_numpy(R), torch.from_numpy(T), K, 1, eye)
+    out = geom_utils.obj_to_cam(dev_t(joints, cuda), dev_t(R, cuda), dev_t(T, cuda), K, 1, eye.to(cuda))
+    close(out, ref, 2e-6)
+
+
+def test_pinhole_vs_reference_fixture(cuda):
+    v, pp, fl = dev_t(GEO['pin_verts'], cuda, True), dev_t(GEO['pin_pp'], cuda, True), dev_t(GEO['pin_fl'], cuda, True)
+    out = geom_utils.pinhole_cam(v, pp, fl)
+    close(out, GEO['pin_out'], 1e-6, 'pinhole')
+    (out * dev_t(GEO['pin_up'], cuda)).sum().backward()
+    close(v.grad, GEO['pin_g_verts'], 1e-5)
+    close(pp.grad, GEO['pin_g_pp'], 1e-5)
+    close(fl.grad, GEO['pin_g_fl'], 1e-5)
+
+
+def test_mesh_regularisers_vs_reference_fixture(cuda):
+    faces = torch.from_numpy(ML['faces'])
+    base = torch.from_numpy(ML['base'])
+    w = dev_t(ML['w'], cuda)
+    x = dev_t(ML['x'], cuda, True)
+    lap = loss_utils.LaplacianLoss(base, faces).to(cuda)(x)
+    close(lap, ML['lap_out'], 1e-5, 'laplacian')
+    (lap * w).sum().backward()
+    close(x.grad, ML['lap_g0'], 1e-5, 'laplacian grad')
+    x, dx = dev_t(ML['x'], cuda, True), dev_t(ML['dx'], cuda, True)
+    ar = loss_utils.ARAPLoss(base, faces).to(cuda)(dx, x)
+    close(ar, ML['arap_out'], 1e-5, 'arap')
+    (ar * w).sum().backward()
+    close(dx.grad, ML['arap_g0'], 1e-5, 'arap grad dx')
+    close(x.grad, ML['arap_g1'], 1e-5, 'arap grad x')
+    x = dev_t(ML['x'], cuda, True)
+    fl = loss_utils.FlattenLoss(faces).to(cuda)(x)
+    close(fl, ML['flat_out'], 1e-5, 'flatten')
+    (fl * w).sum().backward()
+    close(x.grad, ML['flat_g0'], 1e-5, 'flatten grad')
+
+
+def test_arap_at_full_mesh_size_is_cheap_and_finite(cuda):
+    v, f, _ = synth.blobby_mesh(11)                       # V=1212: the reference builds 6 x [N,1212,1212] here
+    base, faces = torch.from_numpy(v), torch.from_numpy(f)
+    x = torch.from_numpy(v)[None].repeat(4, 1, 1).to(cuda)
+    dx = (x + 0.01 * torch.randn_like(x)).requires_grad_(True)
+    out = loss_utils.ARAPLoss(base, faces).to(cuda)(dx, x)
+    out.sum().backward()
+    assert out.shape == (4,) and torch.isfinite(out).all() and torch.isfinite(dx.grad).all()
+
+
+def _loss_inputs(rng, I, H, S):
+    pred = rng.uniform(0, 1, (I, H, S, S)).astype(np.float32)
+    masks = (rng.uniform(0, 1, (I, S, S)) > 0.4).astype(np.float32)
+    occ = rng.standard_normal((I, S, S)).astype(np.float32)
+    occ[rng.uniform(0, 1, occ.shape) < 0.2] = 0.0
+    return pred, masks, occ
+
+
+@pytest.mark.parametrize('I,H,S', [(2, 8, 32), (4, 1, 17), (2, 3, 256)])
+def test_mask_loss_table(cuda, I, H, S):
+    rng = np.random.default_rng(I + H + S)
+    pred, masks, occ = _loss_inputs(rng, I, H, S)
+    w = rng.uniform(0.5, 1.5, (I, H)).astype(np.float32)
+    a = torch.from_numpy(pred).requires_grad_(True)
+    ref = po.mask_loss_table(a, torch.from_numpy(masks), torch.from_numpy(occ))
+    (ref * torch.from_numpy(w)).sum().backward()
+    b = dev_t(pred, cuda, True)
+    out = image_losses.mask_loss_table(b, dev_t(masks, cuda), dev_t(occ, cuda))
+    close(out, ref, 1e-5, 'mask loss')
+    (out * dev_t(w, cuda)).sum().backward()
+    close(b.grad, a.grad, 1e-5, 'mask loss grad')
+
+
+@pytest.mark.parametrize('I,H,S', [(2, 8, 32), (4, 1, 17), (2, 2, 256)])
+def test_flow_loss_table(cuda, I, H, S):
+    rng = np.random.default_rng(10 + I + H + S)
+    _, masks, occ = _loss_inputs(rng, I, H, S)
+    flow_rd = rng.standard_normal((I, H, S, S, 2)).astype(np.float32)
+    obs = rng.standard_normal((I, 3, S, S)).astype(np.float32)
+    bg = rng.uniform(0, 1, (I, H, S, S)) < 0.5
+    bg[0, 0] = True                                        # one (image, hypothesis) with nothing selected
+    w = rng.uniform(0.5, 1.5, (I, H)).astype(np.float32)
+    a = torch.from_numpy(flow_rd).requires_grad_(True)
+    ref, ref_map = po.flow_loss_table(a, torch.from_numpy(obs), torch.from_numpy(bg), torch.from_numpy(occ),
+                                      torch.from_numpy(masks))
+    (ref * torch.from_numpy(w)).sum().backward()
+    b = dev_t(flow_rd, cuda, True)
+    out, fmap = image_losses.flow_loss_table(b, dev_t(obs, cuda), dev_t(bg, cuda), dev_t(occ, cuda), dev_t(masks, cuda))
+    close(out, ref, 1e-5, 'flow loss')
+    close(fmap, ref_map, 1e-5, 'flow map')
+    (out * dev_t(w, cuda)).sum().backward()
+    close(b.grad, a.grad, 1e-5, 'flow loss grad')
+
+
+@pytest.mark.parametrize('I,H,S', [(2, 8, 32), (4, 1, 17), (2, 2, 256)])
+def test_tex_loss_table(cuda, I, H, S):
+    rng = np.random.default_rng(20 + I + H + S)
+    _, _, occ = _loss_inputs(rng, I, H, S)
+    obs = rng.uniform(0, 1, (I, 3, S, S)).astype(np.float32)
+    white = rng.uniform(0, 1, (I, 3, S, S)).astype(np.float32)
+    rnd = rng.uniform(0, 1, (I, H, 3, S, S)).astype(np.float32)
+    fg = rng.uniform(0, 1, (I, H, S, S)).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, (I, H)).astype(np.float32)
+    a, af = torch.from_numpy(rnd).requires_grad_(True), torch.from_numpy(fg).requires_grad_(True)
+    ref = po.tex_loss_table(torch.from_numpy(obs), torch.from_numpy(white), a, af, torch.from_numpy(occ), 0.7)
+    (ref * torch.from_numpy(w)).sum().backward()
+    b, bf = dev_t(rnd, cuda, True), dev_t(fg, cuda, True)
+    out = image_losses.tex_loss_table(dev_t(obs, cuda), dev_t(white, cuda), b, bf, dev_t(occ, cuda), 0.7)
+    close(out, ref, 1e-5, 'tex loss')
+    (out * dev_t(w, cuda)).sum().backward()
+    close(b.grad, a.grad, 1e-5, 'tex grad rnd')
+    close(bf.grad, af.grad, 1e-5, 'tex grad fg')
+
+
+def test_cpu_tensors_are_rejected():
+    with pytest.raises(TypeError):
+        geom_utils.pinhole_cam(torch.zeros(1, 2, 4), torch.zeros(1, 2), torch.zeros(1, 1))

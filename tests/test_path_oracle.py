@@ -1,0 +1,89 @@
+"""oracle/path_oracle.py (torch restatements of the Python path pieces) against fixtures captured from the
+imported reference, plus hand-computable cases for the loss tables that cannot be captured."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import path_oracle as po
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GEO = np.load(os.path.join(G, 'geom_utils.npz'))
+ML = np.load(os.path.join(G, 'mesh_losses.npz'))
+
+
+def t(a, grad=False):
+    return torch.from_numpy(np.asarray(a)).clone().requires_grad_(grad)
+
+
+def test_obj_to_cam_matches_reference_outputs_and_gradients():
+    K, H = int(GEO['o2c_K']), int(GEO['o2c_H'])
+    for tag, tocam in (('cam', True), ('obj', False)):
+        v, R, T, s = (t(GEO['o2c_' + n], True) for n in ('verts', 'Rmat', 'Tmat', 'skin'))
+        out = po.obj_to_cam(v, R, T, K, H, s, tocam=tocam)
+        np.testing.assert_allclose(out.detach().numpy(), GEO['o2c_%s_out' % tag], atol=1e-6)
+        grads = torch.autograd.grad((out * t(GEO['o2c_up'])).sum(), [v, R, T, s], allow_unused=True)
+        for name, g in zip(('verts', 'Rmat', 'Tmat', 'skin'), grads):
+            ref = GEO['o2c_%s_g_%s' % (tag, name)]
+            np.testing.assert_allclose(np.zeros_like(ref) if g is None else g.numpy(), ref, atol=2e-5)
+    N = GEO['o2c_verts'].shape[0]
+    out1 = po.obj_to_cam(t(GEO['o2c_verts']), t(GEO['o2c_Rmat'])[:N], t(GEO['o2c_Tmat'])[:N], 1, H, None)
+    np.testing.assert_allclose(out1.numpy(), GEO['o2c_k1_out'], atol=1e-6)
+
+
+def test_pinhole_cam_matches_reference():
+    v, pp, fl = t(GEO['pin_verts'], True), t(GEO['pin_pp'], True), t(GEO['pin_fl'], True)
+    out = po.pinhole_cam(v, pp, fl)
+    np.testing.assert_allclose(out.detach().numpy(), GEO['pin_out'], atol=1e-6)
+    g = torch.autograd.grad((out * t(GEO['pin_up'])).sum(), [v, pp, fl])
+    for a, name in zip(g, ('verts', 'pp', 'fl')):
+        np.testing.assert_allclose(a.numpy(), GEO['pin_g_' + name], rtol=1e-5, atol=1e-5)
+
+
+def test_mesh_regularisers_match_reference():
+    x, dx = t(ML['x'], True), t(ML['dx'], True)
+    w = t(ML['w'])
+    lap = po.laplacian(x, ML['faces'])
+    np.testing.assert_allclose(lap.detach().numpy(), ML['lap_out'], rtol=1e-5)
+    np.testing.assert_allclose(torch.autograd.grad((lap * w).sum(), x)[0].numpy(), ML['lap_g0'], atol=1e-5)
+    ar = po.arap(dx, x, ML['faces'])
+    np.testing.assert_allclose(ar.detach().numpy(), ML['arap_out'], rtol=1e-5)
+    g = torch.autograd.grad((ar * w).sum(), [dx, x])
+    np.testing.assert_allclose(g[0].numpy(), ML['arap_g0'], atol=1e-6)
+    np.testing.assert_allclose(g[1].numpy(), ML['arap_g1'], atol=1e-6)
+
+
+def test_mask_loss_hand_case():
+    pred = torch.tensor([[[[0.5, 1.0], [0.0, 0.25]]]])            # I=1,H=1,2x2
+    masks = torch.tensor([[[1.0, 1.0], [0.0, 1.0]]])
+    occ = torch.tensor([[[1.0, 0.0], [2.0, -1.0]]])               # pixel (0,1) is invalid
+    # selected squared errors: .25, 0, .5625 -> mean .27083.. -> x0.5
+    assert abs(po.mask_loss_table(pred, masks, occ).item() - 0.5 * (0.25 + 0 + 0.5625) / 3) < 1e-7
+
+
+def test_flow_loss_hand_case():
+    flow_rd = torch.zeros(1, 2, 1, 2, 2)
+    flow_rd[0, 0, 0, 0] = torch.tensor([3.0, 4.0])                # error norm 5 at pixel 0, hypothesis 0
+    flow_rd[0, 1, 0, 1] = torch.tensor([0.0, 2.0])                # error norm 2 at pixel 1, hypothesis 1
+    obs = torch.zeros(1, 3, 1, 2)
+    bg = torch.zeros(1, 2, 1, 2, dtype=torch.bool)
+    bg[0, 1, 0, 0] = True                                         # hypothesis 1 does not cover pixel 0
+    occ = torch.tensor([[[1.0, 2.0]]])
+    masks = torch.ones(1, 1, 2)
+    s = lambda v: 1 / (1 + np.exp(v))                             # sigmoid(-v)
+    wmean = (s(1) + s(2) + s(2)) / 3                              # selected (j,p): (0,0),(0,1),(1,1)
+    loss, fmap = po.flow_loss_table(flow_rd, obs, bg, occ, masks)
+    assert abs(loss[0, 0].item() - 0.5 * (5 * s(1) / wmean + 0) / 2) < 1e-6
+    assert abs(loss[0, 1].item() - 0.5 * (2 * s(2) / wmean)) < 1e-6
+    bg[:] = True                                                  # nothing selected -> 0, not NaN (mesh_net.py:412)
+    assert po.flow_loss_table(flow_rd, obs, bg, occ, masks)[0].abs().sum().item() == 0
+
+
+def test_tex_loss_hand_case():
+    obs = torch.full((1, 3, 1, 2), 0.5)
+    white = torch.ones(1, 3, 1, 2)
+    rnd = torch.full((1, 1, 3, 1, 2), 0.25)
+    fg = torch.tensor([[[[1.0, 0.0]]]])
+    occ = torch.tensor([[[1.0, 1.0]]])
+    # |0.5-0.25| and |0.5-0| -> mean .375 ; |1-.25| -> .75 ; (0.375+0.75)*2
+    assert abs(po.tex_loss_table(obs, white, rnd, fg, occ).item() - 2.25) < 1e-6
