@@ -1,0 +1,634 @@
+"""LASR model: analysis-by-synthesis forward pass on the MI355X kernels.
+
+Mirror of the reference model API (/root/reference/nnutils/mesh_net.py:115-556 `LASR`, and the mesh container of
+/root/reference/third_party/ext_nnutils/mesh_net.py:60-185 `MeshNet`): `LASR(input_shape, opts, nz_feat)`,
+`forward(batch_input) -> (total_loss, aux_output)`, the same batch keys (trailing blanks included), the same
+parameter names (`mean_v`, `tex`, `ctl_rs`, `rest_ts`, `ctl_ts`, `log_ctl`, `encoder.*`, `code_predictor.*`) so the
+trainer's optimiser groups and checkpoints line up.  What changes is how the rendering + loss section runs:
+
+  reference                                              here
+  K-1 bmm launches + [N,K-1,V,3] temporary per LBS       one MFMA kernel (lasr_lbs_forward)
+  6 elementwise kernels per pinhole_cam                  one kernel
+  brute-force CUDA rasteriser with float atomics         tile-binned / face-major HIP kernels (lasr_sr_*)
+  python loops over (image, hypothesis) + mask indexing  fused loss-table kernels, no host sync
+  dense [V,V] Laplacian matmul, six dense [N,V,V] ARAP   CSR gathers
+  dead LBS + projection for `verts_mask` (:341-345)      dropped (never rendered in the reference)
+
+The ResNet-18 encoder and the AlexNet perceptual term are dense convolutions that stay on PyTorch/MIOpen
+(SURVEY.md section 2, rows marked OUT); without network access they are randomly initialised.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import soft_renderer as sr
+from .. import synth
+from . import image_losses
+from .geom_utils import obj_to_cam, pinhole_cam
+
+
+# ----------------------------------------------------------------------------------------------
+# small math helpers standing in for kornia / ext_utils (absent here; formulas are the standard ones)
+# ----------------------------------------------------------------------------------------------
+def quaternion_to_rotation_matrix(q):
+    """(x, y, z, w) quaternion -> 3x3, normalising first (kornia 0.5.3 semantics, call sites mesh_net.py:232,250,265)."""
+    q = F.normalize(q, p=2, dim=-1, eps=1e-12)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    m = torch.stack([1 - (ty * y + tz * z), tx * y - tz * w, tx * z + ty * w,
+                     tx * y + tz * w, 1 - (tx * x + tz * z), ty * z - tx * w,
+                     tx * z - ty * w, ty * z + tx * w, 1 - (tx * x + ty * y)], -1)
+    return m.reshape(q.shape[:-1] + (3, 3))
+
+
+def geodesic_distance(m1, m2):
+    """Rotation angle between two batches of 3x3 matrices (ext_utils/util_rot.py:27-37)."""
+    m = torch.bmm(m1, m2.transpose(1, 2))
+    cos = (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1) / 2
+    return torch.acos(cos.clamp(-1, 1))
+
+
+def reg_decay(curr_steps, max_steps, min_wt, max_wt):
+    """Exponential decay of a regulariser weight from max_wt to min_wt (mesh_net.py:106-113)."""
+    if curr_steps > max_steps:
+        return min_wt
+    return float(np.exp(curr_steps / float(max_steps) * (np.log(min_wt) - np.log(max_wt))) * max_wt)
+
+
+def chamfer_distance(a, b):
+    """Symmetric squared Chamfer distance averaged over the batch (pytorch3d.loss.chamfer_distance()[0] as used
+    at mesh_net.py:503); brute force, the point sets here are the <= 35 control points."""
+    d = (a[:, :, None] - b[:, None]).pow(2).sum(-1)
+    return (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
+
+
+def nearest_index(a, b):
+    """For each point of a [1,V,3] the index of the nearest point of b [1,V,3] (idx1 of chamfer3D, mesh_net.py:477)."""
+    return (a[:, :, None] - b[:, None]).pow(2).sum(-1).argmin(2)
+
+
+def point_mesh_face_distance(verts, faces, points):
+    """mean_p min_f d^2(p, f) + mean_f min_p d^2(p, f), averaged over the batch
+    (pytorch3d.loss.point_mesh_face_distance as used at mesh_net.py:470-471).  Brute force over V x F pairs."""
+    tri = verts[:, faces]                                                # [B,F,3,3]
+    a, b, c = tri[:, None, :, 0], tri[:, None, :, 1], tri[:, None, :, 2]  # [B,1,F,3]
+    p = points[:, :, None]                                                # [B,P,1,3]
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p - b
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p - c
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    va, vb, vc = d3 * d6 - d5 * d4, d5 * d2 - d1 * d6, d1 * d4 - d3 * d2
+    eps = 1e-12
+    # closest point by Voronoi region (Ericson, Real-Time Collision Detection 5.1.5), branch-free
+    denom = (va + vb + vc).clamp_min(eps)
+    v, w = vb / denom, vc / denom
+    inside = a + ab * v[..., None] + ac * w[..., None]
+    t_ab = (d1 / (d1 - d3).clamp_min(eps)).clamp(0, 1)
+    t_ac = (d2 / (d2 - d6).clamp_min(eps)).clamp(0, 1)
+    t_bc = ((d4 - d3) / ((d4 - d3) + (d5 - d6)).clamp_min(eps)).clamp(0, 1)
+    cands = torch.stack([inside, a + ab * t_ab[..., None], a + ac * t_ac[..., None],
+                         b + (c - b) * t_bc[..., None], a.expand_as(inside), b.expand_as(inside), c.expand_as(inside)], 0)
+    ok_inside = (va >= 0) & (vb >= 0) & (vc >= 0)
+    d = (cands - p).pow(2).sum(-1)                                        # [7,B,P,F]
+    d_in = torch.where(ok_inside, d[0], torch.full_like(d[0], float('inf')))
+    dist = torch.minimum(d_in, d[1:].min(0)[0])                           # [B,P,F]
+    return (dist.min(2)[0].mean(1) + dist.min(1)[0].mean(1)).mean()
+
+
+# ----------------------------------------------------------------------------------------------
+# camera / pose regressor (dense convolutions: PyTorch/MIOpen, random init; SURVEY.md section 2 "OUT")
+# ----------------------------------------------------------------------------------------------
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class ResNetConv(nn.Module):
+    """ResNet-18 trunk without the classifier (net_blocks.py:291-313 wraps torchvision's; same layer shapes)."""
+
+    def __init__(self, n_blocks=4):
+        super().__init__()
+        self.n_blocks = n_blocks
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layers = nn.ModuleList()
+        cin = 64
+        for i, cout in enumerate((64, 128, 256, 512)):
+            self.layers.append(nn.Sequential(_BasicBlock(cin, cout, 1 if i == 0 else 2), _BasicBlock(cout, cout, 1)))
+            cin = cout
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+        for layer in self.layers[:self.n_blocks]:
+            x = layer(x)
+        return x
+
+
+def _fc_stack(nc_in, nc_out, n):
+    mods = []
+    for _ in range(n):
+        mods += [nn.Linear(nc_in, nc_out), nn.BatchNorm1d(nc_out), nn.LeakyReLU(0.2, inplace=True)]
+        nc_in = nc_out
+    return nn.Sequential(*mods)
+
+
+class Encoder(nn.Module):
+    """trunk -> conv(512->256, k4, s2) -> 2 FC layers -> nz_feat (net_blocks.py:316-339)."""
+
+    def __init__(self, input_shape, n_blocks=4, nz_feat=100):
+        super().__init__()
+        self.resnet_conv = ResNetConv(n_blocks=4)
+        self.enc_conv1 = nn.Sequential(nn.Conv2d(512, 256, 4, 2, 1, bias=True), nn.BatchNorm2d(256),
+                                       nn.LeakyReLU(0.2, inplace=True))
+        self.enc_fc = _fc_stack(256 * (input_shape[0] // 64) * (input_shape[1] // 64), nz_feat, 2)
+        for m in self.enc_conv1.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, 0.02)
+                m.bias.data.zero_()
+
+    def forward(self, img):
+        f = self.enc_conv1(self.resnet_conv(img))
+        return self.enc_fc(f.view(img.size(0), -1))
+
+
+class _Linear(nn.Module):
+    def __init__(self, nz, nout):
+        super().__init__()
+        self.pred_layer = nn.Linear(nz, nout)
+
+
+class QuatPredictor(_Linear):
+    def __init__(self, nz_feat, n_bones, n_hypo):
+        super().__init__(nz_feat, 4 * n_bones * n_hypo)
+        self.nmesh, self.nhypo = n_bones, n_hypo
+
+    def forward(self, feat):
+        quat = self.pred_layer(feat).view(-1, self.nhypo, self.nmesh, 4)
+        bias = torch.zeros_like(quat)
+        bias[:, :, 1:, 3] = 10                       # part bones start near identity (net_blocks.py:353)
+        quat = F.normalize((quat + bias).view(-1, 4))
+        return quaternion_to_rotation_matrix(quat).reshape(-1, 9)
+
+
+class DepthPredictor(_Linear):
+    def __init__(self, nz, n_bones, offset=10):
+        super().__init__(nz, n_bones)
+        self.offset = offset
+
+    def forward(self, feat):
+        return F.relu(self.pred_layer(feat) + self.offset) + 1e-12
+
+
+class TransPredictor(_Linear):
+    def __init__(self, nz, n_bones):
+        super().__init__(nz, 2 * n_bones)
+
+    def forward(self, feat):
+        return self.pred_layer(feat).view(-1, 2)
+
+
+class PPointPredictor(_Linear):
+    def __init__(self, nz):
+        super().__init__(nz, 2)
+
+    def forward(self, feat):
+        return self.pred_layer(feat)
+
+
+class CodePredictor(nn.Module):
+    """feat -> (scale [2B,H], trans [2B*K,2], rot [2B*H*K,9], depth [2B,K], ppoint [2B,2]) (net_blocks.py:424-450)."""
+
+    def __init__(self, nz_feat=100, num_verts=1000, n_bones=None, n_hypo=None):
+        super().__init__()
+        self.offset = 20
+        torch.manual_seed(0)
+        self.quat_predictor = QuatPredictor(nz_feat, n_bones, n_hypo)
+        self.scale_predictor = DepthPredictor(nz_feat, n_hypo, self.offset)
+        self.trans_predictor = TransPredictor(nz_feat, n_bones)
+        self.depth_predictor = DepthPredictor(nz_feat, n_bones, self.offset)
+        self.ppoint_predictor = PPointPredictor(nz_feat)
+        self.nmesh, self.nhypo = n_bones, n_hypo
+
+    def forward(self, feat):
+        scale = self.scale_predictor(feat)
+        quat = self.quat_predictor(feat)
+        trans = self.trans_predictor(feat) / 10.
+        depth = self.depth_predictor(feat).view(-1, 1, self.nmesh)
+        depth = torch.cat([depth[:, :, :1], (depth[:, :, 1:] - self.offset) / 10.], 2).view(feat.shape[0], -1)
+        ppoint = self.ppoint_predictor(feat) / 10.
+        return scale, trans, quat, depth, ppoint
+
+
+class PerceptualDistance(nn.Module):
+    """AlexNet-feature cosine distance (third_party/PerceptualSimilarity, models/networks_basic.py:42-64, called at
+    mesh_net.py:442).  The pretrained weights cannot be downloaded here: random init, frozen."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        cfg = [(3, 64, 11, 4, 2), (64, 192, 5, 1, 2), (192, 384, 3, 1, 1), (384, 256, 3, 1, 1), (256, 256, 3, 1, 1)]
+        self.convs = nn.ModuleList([nn.Conv2d(a, b, k, s, p) for a, b, k, s, p in cfg])
+        for c in self.convs:
+            c.weight.data = torch.randn(c.weight.shape, generator=g) * math.sqrt(2.0 / (c.weight[0].numel()))
+            c.bias.data.zero_()
+        for p_ in self.parameters():
+            p_.requires_grad_(False)
+        self.register_buffer('shift', torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1))
+        self.register_buffer('scale', torch.tensor([.458, .448, .450]).view(1, 3, 1, 1))
+
+    def _feats(self, x):
+        x = (x - self.shift) / self.scale
+        out = []
+        for i, c in enumerate(self.convs):
+            if i in (1, 2):
+                x = F.max_pool2d(x, 3, 2)
+            x = F.relu(c(x))
+            out.append(x)
+        return out
+
+    def forward_pair(self, a, b):
+        d = 0
+        for fa, fb in zip(self._feats(a), self._feats(b)):
+            d = d + (1. - F.cosine_similarity(fa, fb, dim=1, eps=1e-10).mean((1, 2)))
+        return d
+
+
+# ----------------------------------------------------------------------------------------------
+# mesh container
+# ----------------------------------------------------------------------------------------------
+def make_symmetric(verts, faces, idx=0):
+    """Reorder a mirror-symmetric mesh as [on-plane, positive side, mirrored negatives] (the layout of
+    ext_utils/mesh.py:44-87).  Returns verts, faces, num_indept, num_sym (faces keep their order: textures are
+    per-vertex on this path, so the reference's face re-sorting is not needed)."""
+    v = np.asarray(verts, np.float64)
+    tol = 1e-6
+    center = np.where(np.abs(v[:, idx]) <= tol)[0]
+    right = np.where(v[:, idx] > tol)[0]
+    left = np.where(v[:, idx] < -tol)[0]
+    assert len(left) == len(right), 'mesh is not mirror symmetric'
+    flip = np.ones(3)
+    flip[idx] = -1
+    d = ((v[right] * flip)[:, None] - v[left][None]).__pow__(2).sum(-1)
+    match = left[d.argmin(1)]
+    assert len(set(match.tolist())) == len(right) and d.min(1).max() < 1e-8, 'mesh is not mirror symmetric'
+    order = np.concatenate([center, right, match])
+    inv = np.empty(len(order), np.int64)
+    inv[order] = np.arange(len(order))
+    nv = v[order]
+    nv[:len(center), idx] = 0
+    nv[len(center) + len(right):] = nv[len(center):len(center) + len(right)] * flip     # exact mirror images
+    return nv.astype(np.float32), inv[np.asarray(faces)], len(center), len(right)
+
+
+class MeshNet(nn.Module):
+    def __init__(self, input_shape, opts, nz_feat=100):
+        super().__init__()
+        self.opts = opts
+        self.symmetric = opts.symmetric
+        self.symmetric_texture = opts.symmetric_texture
+        verts, faces = synth.geodesic_sphere(2 ** opts.subdivide)          # 3 -> 642 verts, 1280 faces
+        num_verts = verts.shape[0]
+        self.texture_type = 'vertex'
+        if self.symmetric:
+            verts, faces, num_indept, num_sym = make_symmetric(verts, faces, opts.symidx)
+            num_sym_output = num_indept + num_sym
+            self.num_output = num_verts if opts.only_mean_sym else num_sym_output
+            self.num_sym, self.num_indept = num_sym, num_indept
+            mean_v = torch.from_numpy(verts[:num_sym_output])
+            tex = torch.normal(torch.zeros(num_sym_output, 3), 1)
+            flip = torch.ones(1, 3)
+            flip[0, opts.symidx] = -1
+            self.register_buffer('flip', flip)
+        else:
+            self.num_output = num_verts
+            mean_v = torch.from_numpy(verts)
+            tex = torch.normal(torch.zeros(num_verts, 3), 1)
+        self.mean_v = nn.Parameter(mean_v[None].repeat(opts.n_hypo, 1, 1))
+        tex = tex[None].repeat(opts.n_hypo, 1, 1)
+        if opts.opt_tex == 'yes':
+            self.tex = nn.Parameter(tex)
+        else:
+            self.register_buffer('tex', tex)
+        self.register_buffer('faces', torch.from_numpy(np.asarray(faces, np.int64)))
+        self.encoder = Encoder(input_shape, n_blocks=4, nz_feat=nz_feat)
+        self.code_predictor = CodePredictor(nz_feat=nz_feat, num_verts=self.num_output, n_bones=opts.n_bones,
+                                            n_hypo=opts.n_hypo)
+
+    def symmetrize(self, V):
+        """[num_indept+num_sym,3] -> full mesh (ext_nnutils/mesh_net.py:128-149); identity if not symmetric."""
+        if not self.symmetric:
+            return V
+        left = self.flip * V[-self.num_sym:]
+        out = torch.cat([V, left], 0)
+        mask = torch.ones_like(out)
+        mask[:self.num_indept, self.opts.symidx] = 0
+        return out * mask
+
+    def symmetrize_color(self, V):
+        return torch.cat([V, V[-self.num_sym:]], 0) if self.symmetric else V
+
+    def get_mean_shape(self, local_batch_size):
+        """-> mean_v [2B*H,V,3], tex [2B*H,V,3] (sigmoid), faces [2B,F,3] (ext_nnutils/mesh_net.py:171-185)."""
+        mean_v = torch.stack([self.symmetrize(v) for v in self.mean_v], 0)
+        tex = torch.stack([self.symmetrize_color(t) for t in self.tex], 0)
+        n2 = 2 * local_batch_size
+        faces = self.faces[None].repeat(n2, 1, 1)
+        mean_v = mean_v[None].repeat(n2, 1, 1, 1).view(n2 * mean_v.shape[0], -1, 3)
+        tex = tex[None].repeat(n2, 1, 1, 1).sigmoid().view(n2 * tex.shape[0], -1, 3)
+        return mean_v, tex, faces
+
+
+# ----------------------------------------------------------------------------------------------
+def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0, pp1, proj_cam0, proj_cam1):
+    """Render the camera-space positions of frame t and t' as vertex colours on frame-t geometry and reproject both
+    (mesh_net.py:75-104).  Returns flow [B*H,IS,IS,2], bgmask (bool), fgmask."""
+    n_hypo = verts.shape[0] // faces.shape[0]
+    faces = faces[:, None].repeat(1, n_hypo, 1, 1).view(-1, faces.shape[1], 3)
+    eye = torch.tensor(renderer_soft.transform.transformer._eye, dtype=verts.dtype, device=verts.device)[None, None]
+    verts_pre = verts[:, :, :3] + eye
+    verts_pre = verts_pre * verts_pre.new_tensor([1, -1, 1])
+    nb = verts.shape[0]
+    px = renderer_soft.render_mesh(sr.Mesh(torch.cat([verts_pre, verts_pre], 0), torch.cat([faces, faces], 0),
+                                           textures=torch.cat([verts_pos0[:, :, :3], verts_pos1[:, :, :3]], 0),
+                                           texture_type='vertex'))
+    fgmask = px[:nb, -1]
+    px = px[:, :3]
+    p0 = px[:nb].permute(0, 2, 3, 1)
+    p1 = px[nb:].permute(0, 2, 3, 1)
+    bgmask = (p0[:, :, :, 2] < 1e-9) | (p1[:, :, :, 2] < 1e-9)
+    ten = p0.new_tensor(10.)
+    p0 = torch.where(bgmask[..., None], ten, p0)
+    p1 = torch.where(bgmask[..., None], ten, p1)
+
+    def reproject(p, pp, fl):
+        x = pp[:, 0:1, None] + p[:, :, :, 0] * fl[:, :1, None] / p[:, :, :, 2]
+        y = pp[:, 1:2, None] + p[:, :, :, 1] * fl[:, :1, None] / p[:, :, :, 2]
+        return torch.stack([x, y], -1)
+    flow = reproject(p1, pp1, proj_cam1) - reproject(p0, pp0, proj_cam0).detach()
+    flow = torch.where(bgmask[..., None], flow.detach(), flow)
+    return flow, bgmask, fgmask
+
+
+class LASR(MeshNet):
+    def __init__(self, input_shape, opts, nz_feat=100):
+        super().__init__(input_shape, opts, nz_feat)
+        nbm1, H = opts.n_bones - 1, opts.n_hypo
+        ident = torch.tensor([[0., 0., 0., 1.]])
+        self.register_buffer('rest_rs', ident.repeat(nbm1, 1))
+        self.register_buffer('transg', torch.zeros(nbm1, 3))
+        tensors = dict(ctl_rs=ident.repeat(H * nbm1, 1), rest_ts=torch.zeros(H * nbm1, 3),
+                       ctl_ts=torch.zeros(H * nbm1, 3), log_ctl=torch.zeros(H * nbm1, 3))
+        for name, t in tensors.items():
+            if opts.n_bones > 1:
+                setattr(self, name, nn.Parameter(t))
+            else:
+                self.register_buffer(name, t)
+        common = dict(image_size=opts.img_size, sigma_val=1e-4, camera_mode='look_at', perspective=False,
+                      light_mode='vertex', light_intensity_ambient=1., light_intensity_directionals=0.)
+        # the five renderers of mesh_net.py:132-149 (renderer_soft is constructed there but never rendered)
+        self.renderer_soft = sr.SoftRenderer(aggr_func_rgb='hard', **common)
+        self.renderer_softflf = sr.SoftRenderer(gamma_val=1e-2, aggr_func_rgb='softmax', **common)
+        self.renderer_softflb = sr.SoftRenderer(gamma_val=1e-2, aggr_func_rgb='softmax', **common)
+        self.renderer_softtex = sr.SoftRenderer(gamma_val=1e-2, aggr_func_rgb='softmax', **common)
+        self.renderer_softpart = sr.SoftRenderer(gamma_val=1e-4, aggr_func_rgb='softmax', **common)
+        self.epoch, self.iters, self.total_steps = 0, 0, 0
+        self.optim_idx = 0
+        # criteria attached by the trainer in the reference (train_utils.py:113-123); None until then
+        self.triangle_loss_fn_sr = self.arap_loss_fn = self.flatten_loss = self.ptex_loss = None
+
+    def _skinning(self, pred_v, n2):
+        """GMM skinning weights (mesh_net.py:264-271): softmax_k(-10 * sum_d exp(log_ctl) * ((ctl_ts - v) R(ctl_rs))_d^2)."""
+        opts = self.opts
+        H = opts.n_hypo
+        v0 = pred_v.view(n2, H, -1, 3)[0, :, None].detach()                       # H,1,V,3
+        dis = self.ctl_ts.view(H, -1, 1, 3) - v0                                  # H,J,V,3
+        dis = dis.matmul(quaternion_to_rotation_matrix(self.ctl_rs).view(H, -1, 3, 3))
+        dis = self.log_ctl.exp().view(H, -1, 1, 3) * dis.pow(2)
+        return (-10 * dis.sum(3)).softmax(1)[:, :, :, None]                        # H,J,V,1
+
+    def forward(self, batch_input):
+        opts = self.opts
+        if not self.training:
+            feat = self.encoder(batch_input)
+            return self.code_predictor(feat)
+        B = batch_input['input_imgs  '].shape[0] // 2
+        n2, H, K, IS = 2 * B, opts.n_hypo, opts.n_bones, opts.img_size
+        bi = {k: v.view(B, 2, -1).permute(1, 0, 2).reshape(v.shape) for k, v in batch_input.items()}   # :155-156
+        self.input_imgs, self.imgs, self.masks = bi['input_imgs  '], bi['imgs        '], bi['masks       ']
+        self.cams, self.depth_gt, self.flow = bi['cams        '], bi['depth_gt    '], bi['flow        ']
+        self.ddts_barrier, self.pp, self.occ = bi['ddts_barrier'], bi['pp          '], bi['occ         ']
+        self.oriimg_shape, self.frameid, self.dataid = bi['oriimg_shape'], bi['frameid'], bi['dataid']
+
+        pred_v, tex, faces = self.get_mean_shape(B)                              # [N,V,3], [N,V,3], [2B,F,3]
+        for m in self.modules():                                                 # BN always in eval mode (:190-195)
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                m.eval()
+        scale, trans, quat, depth, ppoint = self.code_predictor(self.encoder(self.input_imgs))
+
+        # intrinsics bookkeeping (:204-217)
+        scale = self.cams[:, :1] * scale
+        depth = torch.cat([self.cams[:, :1] * depth[:, :1], depth[:, 1:]], 1).reshape(-1, 1)
+        ppb1 = self.cams[:B, :1] * self.pp[:B] / (IS / 2.)
+        ppb2 = self.cams[B:, :1] * self.pp[B:] / (IS / 2.)
+        ppa1 = ppoint[:B] + ppb1 + 1
+        ppa2 = ppa1 * (self.cams[B:, :1] / self.cams[:B, :1])
+        ppoint = torch.cat([ppoint[:B], ppa2 - ppb2 - 1], 0)
+
+        quat = quat.view(-1, 9)
+        if opts.noise and self.epoch > 0 and 1 < self.iters < 100:               # pose / scale noise (:220-235)
+            decay = 0.2 * (1e-4) ** (self.iters / 100)
+            axis = F.normalize(torch.randn(quat.shape[0], 3, device=quat.device), dim=1)
+            ang = torch.rand(quat.shape[0], 1, device=quat.device) * math.pi * decay
+            noise = torch.cat([axis * torch.sin(ang / 2), torch.cos(ang / 2)], 1)
+            quat = quat.view(-1, 3, 3).matmul(quaternion_to_rotation_matrix(noise)).view(-1, 9)
+            scale = scale * (decay * torch.randn_like(scale) * opts.rscale).exp()
+        depth = depth.view(n2, 1, K, 1).repeat(1, H, 1, 1).view(-1, 1)
+        trans = trans.view(n2, 1, K, 2).repeat(1, H, 1, 1).view(-1, 2)
+
+        if opts.use_gtpose:                                                      # (:240-253)
+            quat_pred, scale_pred, trans_pred = quat.clone(), scale.clone(), trans.clone()
+            ppoint_pred, depth_pred = ppoint.clone(), depth.clone()
+            scale = 10 * self.cams[:, :1]
+            trans = self.cams[:, 1:3]
+            quat = quaternion_to_rotation_matrix(torch.cat((self.cams[:, 4:], self.cams[:, 3:4]), -1)).view(-1, 9)
+            depth = self.depth_gt[:]
+            halforisize = 0.5 * IS / self.cams[:, :1]
+            ppoint = (0.5 * self.oriimg_shape - self.pp[:]) / halforisize - 1
+
+        # ---- rigid + articulated transforms (:259-289)
+        Rmat = quat.view(-1, 3, 3).permute(0, 2, 1)
+        Tmat = torch.cat([trans, depth], 1)
+        skin = None
+        if K > 1:
+            skin_h = self._skinning(pred_v, n2)
+            skin = skin_h.repeat(n2, 1, 1, 1)
+            rest_ts = self.rest_ts[:, None, :, None].repeat(n2, 1, 1, 1).view(-1, K - 1, 3, 1)
+            ctl_ts = self.ctl_ts[:, None, :, None].repeat(n2, 1, 1, 1).view(-1, K - 1, 3, 1)
+            Rm = Rmat.reshape(-1, K, 3, 3)
+            Tm = Tmat.view(-1, K, 3, 1)
+            Tm = torch.cat([Tm[:, :1], -Rm[:, 1:].matmul(rest_ts) + Tm[:, 1:] + rest_ts], 1)   # rotate about the joint
+            Rm = torch.cat([Rm[:, :1], Rm[:, 1:].permute(0, 1, 3, 2)], 1)
+            Rmat, Tmat = Rm.reshape(-1, 3, 3), Tm.reshape(-1, 3)
+            eye = torch.eye(K - 1, device=Rmat.device)[None, :, :, None]
+            # joints / control points through the same transforms; only rest_ts / ctl_ts receive gradient (:285-288)
+            jp = obj_to_cam(rest_ts[:, :, :, 0], Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
+            self.joints_proj = pinhole_cam(torch.cat([jp, torch.ones_like(jp[:, :, :1])], -1), ppoint.detach(), scale.detach())
+            cp = obj_to_cam(ctl_ts[:, :, :, 0], Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
+            self.ctl_proj = pinhole_cam(torch.cat([cp, torch.ones_like(cp[:, :, :1])], -1), ppoint.detach(), scale.detach())
+        self.deform_v = obj_to_cam(pred_v, Rmat.reshape(-1, 3, 3), Tmat[:, None, :], K, H, skin, tocam=False)
+
+        # ---- 1) flow rendering (:298-335)
+        verts_cam = obj_to_cam(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
+        verts_fl = torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1)
+        vp = verts_fl.view(n2, H, -1, 4)
+        verts_pos0 = vp[:B].reshape(B * H, -1, 4)
+        verts_pos1 = vp[B:].reshape(B * H, -1, 4)
+        verts_fl = pinhole_cam(verts_fl, ppoint, scale)
+        with torch.no_grad():                                                    # near/far stay on the device (:304-311)
+            dmax, dmin = verts_fl[:, :, 2].max(), verts_fl[:, :, 2].min()
+            near, far = dmin - (dmax - dmin) / 2, dmax + (dmax - dmin) / 2
+        for r in (self.renderer_softflf, self.renderer_softflb, self.renderer_softtex):
+            r.rasterizer.near, r.rasterizer.far = near, far
+            if opts.sigval != 1e-4:
+                r.rasterizer.sigma_val = opts.sigval
+        if opts.sigval != 1e-4:
+            self.renderer_soft.rasterizer.sigma_val = opts.sigval
+        vf = verts_fl.view(n2, H, -1, 4)
+        pp_rep = ppoint[:, None].repeat(1, H, 1)
+        self.flow_fw, self.bgmask_fw, self.fgmask_flowf = render_flow_soft_2(
+            self.renderer_softflf, vf[:B].reshape(B * H, -1, 4), faces[:B], verts_pos0, verts_pos1,
+            pp_rep[:B].reshape(-1, 2), pp_rep[B:].reshape(-1, 2), scale[:B].reshape(-1, 1), scale[B:].reshape(-1, 1))
+        self.flow_bw, self.bgmask_bw, self.fgmask_flowb = render_flow_soft_2(
+            self.renderer_softflb, vf[B:].reshape(B * H, -1, 4), faces[B:], verts_pos1, verts_pos0,
+            pp_rep[B:].reshape(-1, 2), pp_rep[:B].reshape(-1, 2), scale[B:].reshape(-1, 1), scale[:B].reshape(-1, 1))
+        self.bgmask = torch.cat([self.bgmask_fw, self.bgmask_bw], 0)
+        self.flow_rd = torch.cat([self.flow_fw, self.flow_bw], 0)
+
+        # ---- 3) texture + silhouette rendering (:348-363).  The reference recomputes LBS + projection here from
+        # a clone of the same Rmat (verts_tex == verts_fl) and once more for a never-rendered verts_mask: reused.
+        eye3 = torch.tensor(self.renderer_softtex.transform.transformer._eye, device=verts_fl.device)[None, None]
+        verts_pre = (verts_fl[:, :, :3] + eye3) * verts_fl.new_tensor([1, -1, 1])
+        self.renderer_softtex.rasterizer.background_color = [1, 1, 1]
+        faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
+        tex_img = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=tex, texture_type='vertex'))
+        self.mask_pred = tex_img[:, -1]
+        self.texture_render = tex_img[:, :3]
+        fg_obs = (self.masks > 0).float()[:, None]
+        img_obs = self.imgs * fg_obs
+        img_white = 1 - fg_obs + img_obs
+        if K > 1 and self.iters == 0:                                            # part rendering, logging only (:368-370)
+            with torch.no_grad():
+                cmap = torch.tensor(synth.label_palette(K - 1), dtype=torch.float32, device=tex.device)
+                skin_colors = (skin_h[self.optim_idx] * cmap[:, None]).sum(0) / 256.
+                self.part_render = self.renderer_softpart.render_mesh(
+                    sr.Mesh(verts_pre.view(n2, H, -1, 3)[:1, self.optim_idx].detach(), faces[:1],
+                            textures=skin_colors[None], texture_type='vertex'))[:, :3]
+
+        # ---- losses.  1) silhouette (:374-390)
+        self.mask_loss_sub = image_losses.mask_loss_table(self.mask_pred.view(n2, H, IS, IS), self.masks, self.occ)
+        self.mask_loss = self.mask_loss_sub.mean()
+        total = self.mask_loss.clone()
+        # 2) flow (:393-416)
+        self.flow_rd_loss_sub, self.flow_rd_map = image_losses.flow_loss_table(
+            self.flow_rd.view(n2, H, IS, IS, 2), self.flow, self.bgmask.view(n2, H, IS, IS), self.occ, self.masks)
+        self.vis_mask = (~self.bgmask).view(n2, H, IS, IS) & ((self.occ != 0) & (self.masks > 0))[:, None]
+        self.flow_rd_loss = self.flow_rd_loss_sub.mean()
+        total = total + self.flow_rd_loss
+        # 3) texture (:419-447)
+        tr = self.texture_render.view(n2, H, 3, IS, IS)
+        tmp = image_losses.tex_loss_table(img_obs, img_white, tr, self.mask_pred.view(n2, H, IS, IS), self.occ,
+                                          opts.l1tex_wt)
+        if self.ptex_loss is not None:
+            img_rnd = self.texture_render * self.mask_pred[:, None]
+            obspair = torch.cat([img_obs[:, None].repeat(1, H, 1, 1, 1).view(-1, 3, IS, IS),
+                                 img_white[:, None].repeat(1, H, 1, 1, 1).view(-1, 3, IS, IS)], 0)
+            rndpair = torch.cat([img_rnd, self.texture_render], 0)
+            percept = self.ptex_loss.forward_pair(2 * obspair - 1, 2 * rndpair - 1)
+            tmp = tmp + 0.005 * percept.view(2, -1).sum(0).view(n2, H)
+        self.texture_loss_sub = 0.25 * tmp
+        self.texture_loss = self.texture_loss_sub.mean()
+        total = total + self.texture_loss
+
+        # 4) shape smoothness (:449-459)
+        factor = 1 if H > 1 else reg_decay(self.epoch, opts.num_epochs, 0.05, 0.5)
+        tri = factor * 0.005 * self.triangle_loss_fn_sr(pred_v) * (4 ** opts.subdivide) / 64.
+        tri = tri + factor * 5e-4 * self.flatten_loss(pred_v) * (2 ** opts.subdivide / 8.0)
+        self.triangle_loss_sub = tri.view(n2, H)
+        self.triangle_loss = self.triangle_loss_sub.mean()
+        total = total + self.triangle_loss
+        if (not opts.symmetric) and opts.symmetric_loss:                          # symmetry (:461-478)
+            pa = pred_v.view(n2, H, -1, 3)[0]
+            pb = pa * pa.new_tensor([-1, 1, 1])
+            total = total + point_mesh_face_distance(pa, self.faces, pb) + point_mesh_face_distance(pb, self.faces, pa)
+            if opts.opt_tex == 'yes':
+                p1 = pred_v[:1].detach()
+                idx1 = nearest_index(p1, p1 * p1.new_tensor([-1, 1, 1]))
+                total = total + (self.tex[0][idx1[0]].detach() - self.tex[0]).abs().mean() * 1e-3
+        # 5) deformation (:481-497)
+        if K > 1:
+            self.lmotion_loss_sub = factor * (self.deform_v - pred_v).norm(2, -1).mean(-1).view(n2, H)
+            self.lmotion_loss = self.lmotion_loss_sub.mean()
+            total = total + self.lmotion_loss
+            self.arap_loss = self.arap_loss_fn(self.deform_v[:B * H], self.deform_v[B * H:]).mean() * (4 ** opts.subdivide) / 64.
+            total = total + self.arap_loss
+            if opts.symmetric_loss:                                              # bone symmetry (:500-503)
+                ca = self.ctl_ts.view(H, -1, 3)
+                total = total + 0.1 * chamfer_distance(ca, ca * ca.new_tensor([-1, 1, 1]))
+        # 7) camera (:506-522)
+        if opts.use_gtpose:
+            cam = geodesic_distance(quat.view(-1, 3, 3), quat_pred.view(-1, 3, 3)).mean()
+            cam = cam + (scale_pred - scale).abs().mean() + (trans_pred - trans).abs().mean()
+            cam = cam + (depth_pred - depth).abs().mean() + (ppoint_pred - ppoint).abs().mean()
+            self.cam_loss = 0.2 * cam
+        else:
+            q = quat.view(-1, H, K, 9)
+            self.cam_loss = 0.001 * geodesic_distance(q[:B].reshape(-1, 3, 3), q[B:].reshape(-1, 3, 3)).mean()
+            if K > 1:
+                t4, d4 = trans.view(-1, H, K, 2), depth.view(-1, H, K, 1)
+                self.cam_loss = self.cam_loss + 0.01 * (t4[:B, :, 1:] - t4[B:, :, 1:]).abs().mean()
+                self.cam_loss = self.cam_loss + 0.01 * (d4[:B, :, 1:] - d4[B:, :, 1:]).abs().mean()
+        total = total + self.cam_loss
+        # 8) aux (:524-530)
+        total = total + 0.02 * F.relu(2 - Tmat.view(-1, 1, K, 3)[:, :, :1, -1]).mean()
+        if K > 1:
+            barrier = self.ddts_barrier.repeat(1, H, 1, 1).view(-1, 1, IS, IS)
+            bl = F.grid_sample(barrier, self.joints_proj[:, :, :2].reshape(-1, K - 1, 1, 2), padding_mode='border',
+                               align_corners=False).mean()
+            cl = F.grid_sample(barrier, self.ctl_proj[:, :, :2].reshape(-1, K - 1, 1, 2), padding_mode='border',
+                               align_corners=False).mean()
+            total = total + 100 * (0.1 * bl + 0.1 * cl)
+        self.total_loss = total
+
+        aux = dict(flow_rd_map=self.flow_rd_map, flow_rd=self.flow_rd, vis_mask=self.vis_mask, mask_pred=self.mask_pred,
+                   total_loss=self.total_loss, mask_loss=self.mask_loss, texture_loss=self.texture_loss,
+                   flow_rd_loss=self.flow_rd_loss, triangle_loss=self.triangle_loss)
+        if K > 1:
+            aux['lmotion_loss'] = self.lmotion_loss
+            aux['ctl_proj'] = self.ctl_proj
+        aux['current_nscore'] = self.texture_loss_sub.mean(0) + self.flow_rd_loss_sub.mean(0) + self.mask_loss_sub.mean(0)
+        if H > 1:
+            for h in range(H):
+                aux['mask_hypo_%d' % h] = self.mask_loss_sub[:, h].mean()
+                aux['flow_hypo_%d' % h] = self.flow_rd_loss_sub[:, h].mean()
+                aux['tex_hypo_%d' % h] = self.texture_loss_sub[:, h].mean()
+        aux['texture_render'] = self.texture_render
+        if hasattr(self, 'part_render'):
+            aux['part_render'] = self.part_render
+        return self.total_loss, aux

@@ -1,0 +1,199 @@
+"""Trainer for the per-video optimisation (reference API: /root/reference/nnutils/train_utils.py:87-487
+`LASRTrainer`, base class third_party/ext_nnutils/train_utils.py:63-136): define_model / define_criterion_ddp /
+init_training / train / save_network / load_network, one process per GPU, DDP over RCCL (backend 'nccl').
+
+Differences, all behind the same calls:
+  * data comes from an in-memory synthetic sequence already resident on the device (no dataset here);
+  * the NaN-gradient guard of :282-291 costs one host sync per step instead of one per parameter tensor;
+  * k-means bone initialisation (:243-251, kmeans_pytorch) is a small Lloyd iteration with farthest-point seeding.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import loss_utils, mesh_net
+from .. import synth_data
+
+
+def kmeans(x, k, iters=20):
+    """Deterministic Lloyd k-means (farthest-point seeding).  x [n,3] -> (assignment [n], centres [k,3])."""
+    c = [x[0]]
+    d = (x - c[0]).pow(2).sum(1)
+    for _ in range(k - 1):
+        c.append(x[d.argmax()])
+        d = torch.minimum(d, (x - c[-1]).pow(2).sum(1))
+    c = torch.stack(c)
+    for _ in range(iters):
+        a = (x[:, None] - c[None]).pow(2).sum(-1).argmin(1)
+        for j in range(k):
+            if (a == j).any():
+                c[j] = x[a == j].mean(0)
+    return a, c
+
+
+class LASRTrainer:
+    def __init__(self, opts):
+        self.opts = opts
+        self.save_dir = os.path.join(opts.checkpoint_dir, opts.name)
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.device = torch.device('cuda', opts.local_rank) if torch.cuda.is_available() else torch.device('cpu')
+        if self.rank == 0 and opts.checkpoint_dir:
+            os.makedirs(self.save_dir, exist_ok=True)
+            with open(os.path.join(self.save_dir, 'opts.log'), 'w') as f:
+                for k in sorted(vars(opts)):
+                    f.write('%s: %s\n' % (k, getattr(opts, k)))
+
+    # ---- model ------------------------------------------------------------------------------
+    def define_model(self):
+        opts = self.opts
+        self.model = mesh_net.LASR((opts.img_size, opts.img_size), opts, nz_feat=opts.nz_feat)
+        if opts.model_path != '':
+            self.load_network(self.model, model_path=opts.model_path)
+        self.model = nn.SyncBatchNorm.convert_sync_batchnorm(self.model).to(self.device)
+        if self.distributed:
+            kw = dict(device_ids=[opts.local_rank], output_device=opts.local_rank) if self.device.type == 'cuda' else {}
+            self.model = nn.parallel.DistributedDataParallel(self.model, find_unused_parameters=True, **kw)
+        self.define_criterion_ddp()
+
+    @property
+    def module(self):
+        return self.model.module if hasattr(self.model, 'module') else self.model
+
+    def define_criterion_ddp(self):
+        m = self.module
+        mean_v, _, faces = m.get_mean_shape(1)
+        m.triangle_loss_fn_sr = loss_utils.LaplacianLoss(mean_v[0].cpu(), faces[0].cpu()).to(self.device)
+        m.arap_loss_fn = loss_utils.ARAPLoss(mean_v[0].cpu(), faces[0].cpu()).to(self.device)
+        m.flatten_loss = loss_utils.FlattenLoss(faces[0].cpu()).to(self.device)
+        m.ptex_loss = mesh_net.PerceptualDistance().to(self.device) if self.opts.perceptual else None
+
+    # ---- data -------------------------------------------------------------------------------
+    def init_dataset(self):
+        opts = self.opts
+        self.sequence = synth_data.SyntheticSequence(self.device, opts.img_size, n_frames=opts.n_frames)
+        npairs = len(self.sequence.pairs())
+        # an epoch is padded to ~200 iterations per rank (dataloader/vid.py:78-80); pairs are dealt round-robin
+        # over ranks like DistributedSampler does (dataloader/vid.py:126-131)
+        per_epoch = opts.iters_per_epoch
+        order = torch.randperm(max(npairs, per_epoch * opts.batch_size * self.world),
+                               generator=torch.Generator().manual_seed(0)) % npairs
+        mine = order[self.rank::self.world]
+        self.dataloader = [mine[i * opts.batch_size:(i + 1) * opts.batch_size].tolist() for i in range(per_epoch)]
+
+    def set_input(self, pair_ids):
+        return self.sequence.batch(pair_ids)
+
+    # ---- optimisation -----------------------------------------------------------------------
+    def init_training(self):
+        opts = self.opts
+        self.init_dataset()
+        self.define_model()
+        m = self.module
+        special = ('mean_v', 'tex', 'ctl_rs', 'rest_ts', 'ctl_ts', 'log_ctl')
+        rest = [p for n, p in m.named_parameters() if n not in special]
+        groups = [{'params': rest}]
+        for n in special:                                   # 50x learning rate for the mesh / bone parameters (:205-214)
+            p = getattr(m, n)
+            if isinstance(p, nn.Parameter):
+                groups.append({'params': [p], 'lr': 50 * opts.learning_rate})
+        self.optimizer = torch.optim.AdamW(groups, lr=opts.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4)
+        max_lr = [opts.learning_rate] + [50 * opts.learning_rate] * (len(groups) - 1)
+        self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
+            self.optimizer, max_lr, 200 * len(self.dataloader), pct_start=0.01, cycle_momentum=False,
+            anneal_strategy='linear', final_div_factor=1. / 25)
+        return self
+
+    def train_step(self, batch):
+        """forward, backward (DDP all-reduces the gradients), clipping + NaN guard, AdamW, OneCycleLR (:274-296)."""
+        m = self.module
+        self.optimizer.zero_grad()
+        total_loss, aux = self.model(batch)
+        total_loss.mean().backward()
+        cam_grad, finite = [], []
+        for name, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            if name == 'mean_v':
+                self.grad_meanv_norm = torch.nn.utils.clip_grad_norm_(p, 1.)
+            elif 'code_predictor' in name or 'encoder' in name:
+                cam_grad.append(p)
+            finite.append(p.grad.sum())
+        self.grad_cam_norm = torch.nn.utils.clip_grad_norm_(cam_grad, 10.) if cam_grad else None
+        if finite and not bool(torch.isfinite(torch.stack(finite).sum())):     # one sync (the reference: ~70)
+            self.optimizer.zero_grad()
+        self.optimizer.step()
+        self.scheduler.step()
+        return total_loss.detach(), aux
+
+    def reinit_bones(self):
+        """Epoch-0 bone placement by k-means on the mean shape, rank 0 then broadcast (:243-256)."""
+        opts, m = self.opts, self.module
+        if opts.n_bones <= 1:
+            return
+        nb = opts.n_bones - 1
+        if self.rank == 0:
+            with torch.no_grad():
+                for h in range(opts.n_hypo):
+                    _, centres = kmeans(m.symmetrize(m.mean_v[h]).detach(), nb)
+                    m.rest_ts.data[h * nb:(h + 1) * nb] = centres
+                    m.ctl_ts.data[h * nb:(h + 1) * nb] = centres
+                m.ctl_rs.data[:] = torch.tensor([0., 0., 0., 1.], device=m.ctl_rs.device)
+                m.log_ctl.data[:] = 1.
+        if self.distributed:
+            dist.barrier()
+            for t in (m.ctl_ts, m.rest_ts, m.ctl_rs, m.log_ctl):
+                dist.broadcast(t.data, 0)
+
+    def train(self):
+        opts, m = self.opts, self.module
+        total_steps = 0
+        torch.manual_seed(8)
+        self.epoch_nscore = torch.zeros(opts.n_hypo, device=self.device)
+        self.model.train()
+        for epoch in range(opts.num_epochs):
+            m.epoch = epoch
+            if epoch == 0:
+                self.reinit_bones()
+            m.optim_idx = int((-self.epoch_nscore).argmax())
+            self.epoch_nscore[:] = 0
+            for i, pair_ids in enumerate(self.dataloader):
+                m.iters, m.total_steps = i, total_steps
+                loss, aux = self.train_step(self.set_input(pair_ids))
+                self.epoch_nscore += aux['current_nscore'].detach()
+                total_steps += 1
+            if self.distributed:                              # keep hypothesis selection identical on all ranks
+                dist.all_reduce(self.epoch_nscore)
+            if self.rank == 0 and opts.checkpoint_dir:
+                self.save('latest')
+                self.save(epoch + 1)
+        return total_steps
+
+    # ---- checkpoints (:363-378) ---------------------------------------------------------------
+    def save(self, label):
+        m = self.module
+        states = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        states['faces'] = m.faces.cpu()
+        states['full_shape'] = [m.symmetrize(v).detach().cpu() for v in m.mean_v]
+        states['full_tex'] = [m.symmetrize_color(t).detach().cpu() for t in m.tex]
+        states['epoch_nscore'] = self.epoch_nscore.cpu() if hasattr(self, 'epoch_nscore') else None
+        torch.save(states, os.path.join(self.save_dir, 'pred_net_%s.pth' % label))
+
+    def load_network(self, network, model_path):
+        """Warm start from the previous stage (:381-487): parameters whose shapes still match are copied; the best
+        hypothesis' shape/texture seed the new mesh when the vertex count is unchanged.  (Re-meshing through the
+        external Manifold binaries, :419-428, is not available offline.)"""
+        states = torch.load(model_path, map_location='cpu')
+        best = int((-states['epoch_nscore']).argmax()) if states.get('epoch_nscore') is not None else 0
+        own = network.state_dict()
+        for k, v in states.items():
+            if k in own and torch.is_tensor(v) and own[k].shape == v.shape:
+                own[k].copy_(v)
+        full = states.get('full_shape')
+        if full is not None and not network.symmetric and full[best].shape == own['mean_v'].shape[1:]:
+            own['mean_v'].copy_(full[best][None].expand_as(own['mean_v']))
+            own['tex'].copy_(states['full_tex'][best][None].expand_as(own['tex']))
+        network.load_state_dict(own)

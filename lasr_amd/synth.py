@@ -110,3 +110,17 @@ def upstream_grad(n, image_size, seed=2):
 LASR_MODES = dict(background_color=(1, 1, 1), fill_back=True, eps=1e-3, sigma_val=1e-4, dist_func='euclidean',
                   dist_eps=1e-4, gamma_val=1e-2, aggr_func_rgb='softmax', aggr_func_alpha='prod',
                   texture_type='vertex')
+
+
+def label_palette(n):
+    """n distinct RGB colours in 0..255 for the part visualisation (the reference uses a Cityscapes colour map,
+    nnutils/geom_utils.py:97-254; only used for logging)."""
+    out = []
+    for i in range(n):
+        h = (i * 0.61803398875) % 1.0
+        k = int(h * 6)
+        f = h * 6 - k
+        q, t = 1 - f, f
+        r, g, b = [(1, t, 0), (q, 1, 0), (0, 1, t), (0, q, 1), (t, 0, 1), (1, 0, q)][k % 6]
+        out.append([255 * r, 255 * g, 255 * b])
+    return np.asarray(out, np.float32)
