@@ -34,7 +34,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from lasr_amd import _lib, synth  # noqa: E402
+from lasr_amd import _lib, parallel, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 IS = 256
@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--frames', type=int, default=64, help='frames per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
     return ap.parse_args()
 
 
@@ -126,6 +127,35 @@ def cpu_baseline(F):
                       % (n, cores, dt)}
 
 
+def optimize_leg(dev, iters):
+    """BASELINE.json's second figure: optimize.py iterations/s on the spot3 stage-0 configuration
+    (scripts/spot3.sh:24: B=1 pair, 8 hypotheses, 21 bones, icosphere-3, 256x256), synthetic 3-frame sequence,
+    full step = encoder + LBS + 3 render calls fwd/bwd + loss tables + regularisers + AdamW."""
+    import optimize
+    from lasr_amd.nnutils import train_utils
+    opts = optimize.parse_flags(['--name', 'bench', '--checkpoint_dir', '', '--only_mean_sym', '--nouse_gtpose',
+                                 '--subdivide', '3', '--n_bones', '21', '--n_hypo', '8', '--num_epochs', '5',
+                                 '--batch_size', '1', '--opt_tex', 'yes', '--iters_per_epoch', str(iters + 3)])
+    opts.local_rank = dev.index
+    torch.manual_seed(0)
+    tr = train_utils.LASRTrainer(opts).init_training()
+    tr.model.train()
+    tr.reinit_bones()
+    for i in range(3):
+        tr.module.iters = i
+        tr.train_step(tr.set_input(tr.dataloader[i]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        tr.module.iters = 3 + i
+        loss, _ = tr.train_step(tr.set_input(tr.dataloader[3 + i]))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'iters_per_s': iters / dt, 'ms_per_iter': dt / iters * 1e3, 'iters': iters, 'final_loss': float(loss),
+            'config': 'spot3 stage 0: batch 1 pair, n_hypo 8, n_bones 21, V=642/F=1280, 256x256, 48 images '
+                      'rasterised fwd+bwd per iteration, random-init encoder + perceptual net'}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -133,6 +163,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != a.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if world == 1 and a.gpus > 1:
+        raise SystemExit('--gpus %d needs torch.distributed.run (one process per GPU)' % a.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no HIP device visible); there is no CPU fallback')
     torch.cuda.set_device(local)
@@ -144,12 +176,12 @@ def main():
         dist.init_process_group('nccl', device_id=dev)   # 'nccl' == RCCL on ROCm
 
     B = a.frames
+    # frames shard across ranks: rank r renders yaw positions r*B .. r*B+B-1 of the cycle (weak scaling)
     job = RasterStep(dev, B, first_frame=rank * B)
 
     def one_step():
         mg = job.step()
-        if dist is not None:
-            dist.all_reduce(mg)                      # mesh-parameter gradient, [2,V,3] fp32 over xGMI
+        parallel.allreduce_grads_([mg], average=False)   # mesh-parameter gradient, [2,V,3] fp32, one RCCL message
         return mg
 
     def barrier():
@@ -202,6 +234,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(F)
+        if world == 1 and a.lasr_iters > 0:
+            out['optimize_py'] = optimize_leg(dev, a.lasr_iters)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
