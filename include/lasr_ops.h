@@ -42,15 +42,22 @@ int lasr_pinhole_backward(const float* verts, const float* pp, const float* fl, 
                           float* grad_verts, float* grad_pp, float* grad_fl, int N, int V, void* hip_stream);
 
 /*
+ * The three loss tables below split every (image, hypothesis) row into chunks so that small tables still fill
+ * the chip, and fold the chunk partials in a fixed order.  `scratch` (lasr_loss_scratch_floats(I,H,P) floats,
+ * caller-allocated) carries the partials and the per-row counts from a forward call to the matching backward call.
+ */
+size_t lasr_loss_scratch_floats(int I, int H, int P);
+
+/*
  * Silhouette loss table, nnutils/mesh_net.py:374-388:
  *   loss[i,j] = 0.5 * mean_{p : occ[i,p] != 0} (mask_pred[i,j,p] - masks[i,p])^2
  * mask_pred [I,H,P], masks [I,P], occ [I,P] -> loss [I,H].  (Empty selection -> NaN like torch's mean of
  * an empty tensor.)  Backward: grad_pred [I,H,P] = grad_loss[i,j] * (pred - mask) / count on selected pixels.
  */
 int lasr_mask_loss_forward(const float* mask_pred, const float* masks, const float* occ, float* loss,
-                           int I, int H, int P, void* hip_stream);
+                           float* scratch, int I, int H, int P, void* hip_stream);
 int lasr_mask_loss_backward(const float* mask_pred, const float* masks, const float* occ, const float* grad_loss,
-                            float* grad_pred, int I, int H, int P, void* hip_stream);
+                            const float* scratch, float* grad_pred, int I, int H, int P, void* hip_stream);
 
 /*
  * Optical-flow loss table, nnutils/mesh_net.py:393-413:
@@ -60,7 +67,7 @@ int lasr_mask_loss_backward(const float* mask_pred, const float* masks, const fl
  * flow_rd [I,H,P,2], flow_obs: channel planes of P floats, images obs_image_stride floats apart (the first two
  * channels of the [I,3,P] observation), bg [I,H,P] uint8,
  * occ/masks [I,P] -> loss [I,H], and the weighted error map flow_rd_map [I,H,P] the trainer logs.
- * `scratch` holds 2*I floats.  Backward: gradient w.r.t. flow_rd only (the weights are data).
+ * Backward: gradient w.r.t. flow_rd only (the weights are data).
  */
 int lasr_flow_loss_forward(const float* flow_rd, const float* flow_obs, const unsigned char* bg, const float* occ,
                            const float* masks, float* loss, float* flow_rd_map, float* scratch,
@@ -77,10 +84,11 @@ int lasr_flow_loss_backward(const float* flow_rd, const float* flow_obs, const u
  * Backward: grad_rnd [I,H,3,P] and grad_fg [I,H,P] (overwritten).
  */
 int lasr_tex_loss_forward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
-                          const float* occ, float* loss, float wt, int I, int H, int P, void* hip_stream);
+                          const float* occ, float* loss, float* scratch, float wt, int I, int H, int P,
+                          void* hip_stream);
 int lasr_tex_loss_backward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
-                           const float* occ, const float* grad_loss, float* grad_rnd, float* grad_fg, float wt,
-                           int I, int H, int P, void* hip_stream);
+                           const float* occ, const float* grad_loss, const float* scratch, float* grad_rnd,
+                           float* grad_fg, float wt, int I, int H, int P, void* hip_stream);
 
 /*
  * Mesh regularisers on sparse adjacency instead of dense [V,V] operators.

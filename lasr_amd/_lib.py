@@ -25,12 +25,13 @@ SIGNATURES = {
     'lasr_lbs_backward': (_i, [_p] * 9 + [_i, _i, _i, _i, _p]),
     'lasr_pinhole_forward': (_i, [_p, _p, _p, _p, _i, _i, _p]),
     'lasr_pinhole_backward': (_i, [_p] * 7 + [_i, _i, _p]),
-    'lasr_mask_loss_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
-    'lasr_mask_loss_backward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_loss_scratch_floats': (_sz, [_i, _i, _i]),
+    'lasr_mask_loss_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_mask_loss_backward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_flow_loss_forward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),
     'lasr_flow_loss_backward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),
-    'lasr_tex_loss_forward': (_i, [_p] * 6 + [_f, _i, _i, _i, _p]),
-    'lasr_tex_loss_backward': (_i, [_p] * 8 + [_f, _i, _i, _i, _p]),
+    'lasr_tex_loss_forward': (_i, [_p] * 7 + [_f, _i, _i, _i, _p]),
+    'lasr_tex_loss_backward': (_i, [_p] * 9 + [_f, _i, _i, _i, _p]),
     'lasr_arap_forward': (_i, [_p] * 5 + [_i, _i, _p]),
     'lasr_arap_backward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_laplacian_forward': (_i, [_p] * 4 + [_i, _i, _p]),

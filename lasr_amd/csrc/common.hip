@@ -14,7 +14,8 @@ const char* const kKernelNames[K_NUM_KERNELS] = {
     "sr_setup_kernel", "sr_forward_kernel", "sr_backward_kernel",
     "lbs_forward_kernel", "lbs_backward_kernel", "pinhole_forward_kernel", "pinhole_backward_kernel",
     "mask_loss_forward_kernel", "mask_loss_backward_kernel", "flow_loss_stats_kernel", "flow_loss_forward_kernel",
-    "flow_loss_backward_kernel", "tex_loss_forward_kernel", "tex_loss_backward_kernel", "arap_forward_kernel",
+    "flow_loss_backward_kernel", "tex_loss_forward_kernel", "tex_loss_backward_kernel", "loss_finalize_kernel",
+    "arap_forward_kernel",
     "arap_backward_kernel", "laplacian_forward_kernel", "laplacian_backward_kernel"};
 }  // namespace
 

@@ -247,74 +247,134 @@ __global__ __launch_bounds__(256) void pinhole_backward_kernel(const float4* __r
 }
 
 // ===========================================================================
-// Image-loss tables: one block per (image i, hypothesis j)
+// Image-loss tables.  Each (image i, hypothesis j) row of P pixels is split into NCH chunks so that even
+// a 2 x 1 table fills the chip; chunk partials go to scratch and a tiny second kernel folds them in a fixed
+// order (deterministic).  Scratch layout (floats): part[IH][NCH][4] | tot[IH][4] | img[I][4] | ipart[I][H*NCH][2].
+// Backward kernels are plain elementwise launches over (IH, NCH) that read tot / img.
 // ===========================================================================
+constexpr int LOSS_PX_PER_BLOCK = 2048;     // 256 threads x 8 pixels
+
+__host__ __device__ inline int loss_nch(int P) { int n = (P + LOSS_PX_PER_BLOCK - 1) / LOSS_PX_PER_BLOCK; return n < 1 ? 1 : (n > 64 ? 64 : n); }
+
+struct LossScratch {
+    float* part; float* tot; float* img; float* ipart;
+};
+__host__ __device__ inline LossScratch loss_scratch(float* base, int I, int H, int P)
+{
+    const int nch = loss_nch(P);
+    LossScratch s;
+    s.part = base;
+    s.tot = s.part + (size_t)I * H * nch * 4;
+    s.img = s.tot + (size_t)I * H * 4;
+    s.ipart = s.img + (size_t)I * 4;
+    return s;
+}
+
+__device__ __forceinline__ void chunk_range(int P, int nch, int ch, int& p0, int& p1)
+{
+    const int per = (P + nch - 1) / nch;
+    p0 = ch * per;
+    p1 = min(P, p0 + per);
+}
+
+// fold part[ij][0..nch) -> tot[ij]; MODE selects how the loss is formed from the totals
+template <int MODE>
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, float* __restrict__ tot,
+                                                            float* __restrict__ loss, int IH, int nch, float scale)
+{
+    const int ij = blockIdx.x * 256 + threadIdx.x;
+    if (ij >= IH) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int k = 0; k < nch; k++) {
+        const float* q = part + ((size_t)ij * nch + k) * 4;
+        a += q[0]; b += q[1]; c += q[2];
+    }
+    tot[4 * ij] = a; tot[4 * ij + 1] = b; tot[4 * ij + 2] = c;
+    if (MODE == 0) loss[ij] = 0.5f * (a / c);                         // mask: 0.5 * mean (NaN when empty, like torch)
+    else if (MODE == 1) loss[ij] = c > 0.f ? 0.5f * (a / c) : 0.f;    // flow: 0 when nothing selected (mesh_net.py:412)
+    else loss[ij] = (a / c + b / c) * scale;                          // texture: 2*wt*(mean1 + mean2)
+}
+
 __global__ __launch_bounds__(256) void mask_loss_forward_kernel(const float* __restrict__ pred, const float* __restrict__ masks,
-                                                                const float* __restrict__ occ, float* __restrict__ loss,
-                                                                int H, int P)
+                                                                const float* __restrict__ occ, float* __restrict__ part,
+                                                                int H, int P, int nch)
 {
     __shared__ float red[4];
-    const int ij = blockIdx.x, i = ij / H;
+    const int ij = blockIdx.x, i = ij / H, ch = blockIdx.y;
     const float* a = pred + (size_t)ij * P;
     const float* m = masks + (size_t)i * P;
     const float* oc = occ + (size_t)i * P;
+    int p0, p1;
+    chunk_range(P, nch, ch, p0, p1);
     float s = 0.f, c = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256)
+    for (int p = p0 + threadIdx.x; p < p1; p += 256)
         if (oc[p] != 0.f) { const float d = a[p] - m[p]; s += d * d; c += 1.f; }
     s = block_sum(s, red); c = block_sum(c, red);
-    if (threadIdx.x == 0) loss[ij] = 0.5f * (s / c);
+    if (threadIdx.x == 0) { float* q = part + ((size_t)ij * nch + ch) * 4; q[0] = s; q[1] = 0.f; q[2] = c; q[3] = 0.f; }
 }
 
 __global__ __launch_bounds__(256) void mask_loss_backward_kernel(const float* __restrict__ pred, const float* __restrict__ masks,
                                                                  const float* __restrict__ occ, const float* __restrict__ gloss,
-                                                                 float* __restrict__ gpred, int H, int P)
+                                                                 const float* __restrict__ tot, float* __restrict__ gpred,
+                                                                 int H, int P, int nch)
 {
-    __shared__ float red[4];
     const int ij = blockIdx.x, i = ij / H;
     const float* a = pred + (size_t)ij * P;
     const float* m = masks + (size_t)i * P;
     const float* oc = occ + (size_t)i * P;
-    float c = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) c += oc[p] != 0.f ? 1.f : 0.f;
-    c = block_sum(c, red);
-    const float k = gloss[ij] / c;            // 0.5 * 2 * g / count
-    for (int p = threadIdx.x; p < P; p += 256) gpred[(size_t)ij * P + p] = oc[p] != 0.f ? k * (a[p] - m[p]) : 0.f;
+    const float k = gloss[ij] / tot[4 * ij + 2];            // 0.5 * 2 * g / count
+    int p0, p1;
+    chunk_range(P, nch, blockIdx.y, p0, p1);
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) gpred[(size_t)ij * P + p] = oc[p] != 0.f ? k * (a[p] - m[p]) : 0.f;
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-// per image: sum and count of sigmoid(-occ) over sel[i] (all hypotheses)  -> scratch[2i], scratch[2i+1]
+// per image: sum and count of sigmoid(-occ) over sel[i] (all hypotheses): partials per (j, chunk)
 __global__ __launch_bounds__(256) void flow_loss_stats_kernel(const unsigned char* __restrict__ bg, const float* __restrict__ occ,
-                                                              const float* __restrict__ masks, float* __restrict__ scratch,
-                                                              int H, int P)
+                                                              const float* __restrict__ masks, float* __restrict__ ipart,
+                                                              int H, int P, int nch)
 {
     __shared__ float red[4];
-    const int i = blockIdx.x;
+    const int i = blockIdx.x, j = blockIdx.y / nch, ch = blockIdx.y - j * nch;
     const float* oc = occ + (size_t)i * P;
     const float* m = masks + (size_t)i * P;
+    int p0, p1;
+    chunk_range(P, nch, ch, p0, p1);
     float s = 0.f, c = 0.f;
-    for (int j = 0; j < H; j++)
-        for (int p = threadIdx.x; p < P; p += 256)
-            if (!bg[((size_t)i * H + j) * P + p] && oc[p] != 0.f && m[p] > 0.f) { s += sigmoid_f(-oc[p]); c += 1.f; }
+    for (int p = p0 + threadIdx.x; p < p1; p += 256)
+        if (!bg[((size_t)i * H + j) * P + p] && oc[p] != 0.f && m[p] > 0.f) { s += sigmoid_f(-oc[p]); c += 1.f; }
     s = block_sum(s, red); c = block_sum(c, red);
-    if (threadIdx.x == 0) { scratch[2 * i] = s; scratch[2 * i + 1] = c; }
+    if (threadIdx.x == 0) { float* q = ipart + ((size_t)i * H * nch + blockIdx.y) * 2; q[0] = s; q[1] = c; }
+}
+
+__global__ __launch_bounds__(256) void flow_loss_stats_fold_kernel(const float* __restrict__ ipart, float* __restrict__ img,
+                                                                   int I, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    float s = 0.f, c = 0.f;
+    for (int k = 0; k < n; k++) { s += ipart[((size_t)i * n + k) * 2]; c += ipart[((size_t)i * n + k) * 2 + 1]; }
+    img[4 * i] = s; img[4 * i + 1] = c;
 }
 
 __global__ __launch_bounds__(256) void flow_loss_forward_kernel(const float2* __restrict__ flow_rd, const float* __restrict__ obs,
                                                                 const unsigned char* __restrict__ bg, const float* __restrict__ occ,
-                                                                const float* __restrict__ masks, const float* __restrict__ scratch,
-                                                                float* __restrict__ loss, float* __restrict__ fmap,
-                                                                int H, int P, int obs_stride)
+                                                                const float* __restrict__ masks, const float* __restrict__ img,
+                                                                float* __restrict__ part, float* __restrict__ fmap,
+                                                                int H, int P, int obs_stride, int nch)
 {
     __shared__ float red[4];
-    const int ij = blockIdx.x, i = ij / H;
+    const int ij = blockIdx.x, i = ij / H, ch = blockIdx.y;
     const float* oc = occ + (size_t)i * P;
     const float* m = masks + (size_t)i * P;
     const float* ox = obs + (size_t)i * obs_stride;
     const float* oy = ox + P;
-    const float wmean = scratch[2 * i] / scratch[2 * i + 1];
+    const float wmean = img[4 * i] / img[4 * i + 1];
+    int p0, p1;
+    chunk_range(P, nch, ch, p0, p1);
     float s = 0.f, c = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) {
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
         const float2 f = flow_rd[(size_t)ij * P + p];
         const float dx = f.x - ox[p], dy = f.y - oy[p];
         const float e = sqrtf(dx * dx + dy * dy) * (sigmoid_f(-oc[p]) / wmean);
@@ -322,28 +382,26 @@ __global__ __launch_bounds__(256) void flow_loss_forward_kernel(const float2* __
         if (!bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f) { s += e; c += 1.f; }
     }
     s = block_sum(s, red); c = block_sum(c, red);
-    if (threadIdx.x == 0) loss[ij] = c > 0.f ? 0.5f * (s / c) : 0.f;
+    if (threadIdx.x == 0) { float* q = part + ((size_t)ij * nch + ch) * 4; q[0] = s; q[1] = 0.f; q[2] = c; q[3] = 0.f; }
 }
 
 __global__ __launch_bounds__(256) void flow_loss_backward_kernel(const float2* __restrict__ flow_rd, const float* __restrict__ obs,
                                                                  const unsigned char* __restrict__ bg, const float* __restrict__ occ,
-                                                                 const float* __restrict__ masks, const float* __restrict__ scratch,
-                                                                 const float* __restrict__ gloss, float2* __restrict__ gflow,
-                                                                 int H, int P, int obs_stride)
+                                                                 const float* __restrict__ masks, const float* __restrict__ img,
+                                                                 const float* __restrict__ tot, const float* __restrict__ gloss,
+                                                                 float2* __restrict__ gflow, int H, int P, int obs_stride, int nch)
 {
-    __shared__ float red[4];
     const int ij = blockIdx.x, i = ij / H;
     const float* oc = occ + (size_t)i * P;
     const float* m = masks + (size_t)i * P;
     const float* ox = obs + (size_t)i * obs_stride;
     const float* oy = ox + P;
-    const float wmean = scratch[2 * i] / scratch[2 * i + 1];
-    float c = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256)
-        c += (!bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f) ? 1.f : 0.f;
-    c = block_sum(c, red);
+    const float wmean = img[4 * i] / img[4 * i + 1];
+    const float c = tot[4 * ij + 2];
     const float k = c > 0.f ? 0.5f * gloss[ij] / c : 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) {
+    int p0, p1;
+    chunk_range(P, nch, blockIdx.y, p0, p1);
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
         // d loss / d map = k on selected pixels, 0 elsewhere; d map / d norm = w.  When image i has no selected
         // pixel at all, w is NaN and 0 * NaN = NaN reaches every pixel -- exactly what autograd does with the
         // reference code (its trainer then drops the step, nnutils/train_utils.py:289-290).  Kept on purpose.
@@ -362,43 +420,43 @@ __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f 
 
 __global__ __launch_bounds__(256) void tex_loss_forward_kernel(const float* __restrict__ img_obs, const float* __restrict__ img_white,
                                                                const float* __restrict__ rnd, const float* __restrict__ fg,
-                                                               const float* __restrict__ occ, float* __restrict__ loss,
-                                                               float wt, int H, int P)
+                                                               const float* __restrict__ occ, float* __restrict__ part,
+                                                               int H, int P, int nch)
 {
     __shared__ float red[4];
-    const int ij = blockIdx.x, i = ij / H;
+    const int ij = blockIdx.x, i = ij / H, ch = blockIdx.y;
     const float* oc = occ + (size_t)i * P;
+    int p0, p1;
+    chunk_range(P, nch, ch, p0, p1);
     float s1 = 0.f, s2 = 0.f, c = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) {
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
         if (oc[p] == 0.f) continue;
         const float a = fg[(size_t)ij * P + p];
         float e1 = 0.f, e2 = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const float r = rnd[((size_t)ij * 3 + ch) * P + p];
-            e1 += fabsf(img_obs[((size_t)i * 3 + ch) * P + p] - r * a);
-            e2 += fabsf(img_white[((size_t)i * 3 + ch) * P + p] - r);
+        for (int k = 0; k < 3; k++) {
+            const float r = rnd[((size_t)ij * 3 + k) * P + p];
+            e1 += fabsf(img_obs[((size_t)i * 3 + k) * P + p] - r * a);
+            e2 += fabsf(img_white[((size_t)i * 3 + k) * P + p] - r);
         }
         s1 += e1 / 3.f; s2 += e2 / 3.f; c += 1.f;
     }
     s1 = block_sum(s1, red); s2 = block_sum(s2, red); c = block_sum(c, red);
-    if (threadIdx.x == 0) loss[ij] = (s1 / c + s2 / c) * (2.f * wt);
+    if (threadIdx.x == 0) { float* q = part + ((size_t)ij * nch + ch) * 4; q[0] = s1; q[1] = s2; q[2] = c; q[3] = 0.f; }
 }
 
 __global__ __launch_bounds__(256) void tex_loss_backward_kernel(const float* __restrict__ img_obs, const float* __restrict__ img_white,
                                                                 const float* __restrict__ rnd, const float* __restrict__ fg,
-                                                                const float* __restrict__ occ, const float* __restrict__ gloss,
-                                                                float* __restrict__ grnd, float* __restrict__ gfg,
-                                                                float wt, int H, int P)
+                                                                const float* __restrict__ occ, const float* __restrict__ tot,
+                                                                const float* __restrict__ gloss, float* __restrict__ grnd,
+                                                                float* __restrict__ gfg, float wt, int H, int P, int nch)
 {
-    __shared__ float red[4];
     const int ij = blockIdx.x, i = ij / H;
     const float* oc = occ + (size_t)i * P;
-    float c = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) c += oc[p] != 0.f ? 1.f : 0.f;
-    c = block_sum(c, red);
-    const float k = gloss[ij] * (2.f * wt) / (3.f * c);
-    for (int p = threadIdx.x; p < P; p += 256) {
+    const float k = gloss[ij] * (2.f * wt) / (3.f * tot[4 * ij + 2]);
+    int p0, p1;
+    chunk_range(P, nch, blockIdx.y, p0, p1);
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
         const bool on = oc[p] != 0.f;
         const float a = fg[(size_t)ij * P + p];
         float ga = 0.f;
@@ -583,26 +641,43 @@ extern "C" int lasr_pinhole_backward(const float* verts, const float* pp, const 
 
 static int check_ihp(int I, int H, int P) { return (I < 0 || H < 0 || P < 0) ? LASR_E_BADARG : LASR_OK; }
 
+extern "C" size_t lasr_loss_scratch_floats(int I, int H, int P)
+{
+    if (I < 0 || H < 0 || P < 0) return 0;
+    const size_t nch = (size_t)loss_nch(P);
+    return (size_t)I * H * nch * 4 + (size_t)I * H * 4 + (size_t)I * 4 + (size_t)I * H * nch * 2 + 16;
+}
+
 extern "C" int lasr_mask_loss_forward(const float* mask_pred, const float* masks, const float* occ, float* loss,
-                                      int I, int H, int P, void* hip_stream)
+                                      float* scratch, int I, int H, int P, void* hip_stream)
 {
     if (check_ihp(I, H, P)) return LASR_E_BADARG;
     if (I * H == 0) return LASR_OK;
-    if (!mask_pred || !masks || !occ || !loss) return LASR_E_BADARG;
+    if (!mask_pred || !masks || !occ || !loss || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_MASK_LOSS_FORWARD, mask_loss_forward_kernel, dim3(I * H), dim3(256), 0, mask_pred, masks, occ, loss, H, P);
+    const int nch = loss_nch(P);
+    const LossScratch sc = loss_scratch(scratch, I, H, P);
+    LASR_LAUNCH(K_MASK_LOSS_FORWARD, mask_loss_forward_kernel, dim3(I * H, nch), dim3(256), 0, mask_pred, masks, occ,
+                sc.part, H, P, nch);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_LOSS_FINALIZE, loss_finalize_kernel<0>, dim3((I * H + 255) / 256), dim3(256), 0, sc.part, sc.tot, loss,
+                I * H, nch, 1.f);
     return launch_ok();
 }
 
 extern "C" int lasr_mask_loss_backward(const float* mask_pred, const float* masks, const float* occ,
-                                       const float* grad_loss, float* grad_pred, int I, int H, int P, void* hip_stream)
+                                       const float* grad_loss, const float* scratch, float* grad_pred, int I, int H, int P,
+                                       void* hip_stream)
 {
     if (check_ihp(I, H, P)) return LASR_E_BADARG;
     if (I * H == 0) return LASR_OK;
-    if (!mask_pred || !masks || !occ || !grad_loss || !grad_pred) return LASR_E_BADARG;
+    if (!mask_pred || !masks || !occ || !grad_loss || !grad_pred || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_MASK_LOSS_BACKWARD, mask_loss_backward_kernel, dim3(I * H), dim3(256), 0, mask_pred, masks, occ,
-                grad_loss, grad_pred, H, P);
+    const int nch = loss_nch(P);
+    const LossScratch sc = loss_scratch(const_cast<float*>(scratch), I, H, P);
+    LASR_LAUNCH(K_MASK_LOSS_BACKWARD, mask_loss_backward_kernel, dim3(I * H, nch), dim3(256), 0, mask_pred, masks, occ,
+                grad_loss, sc.tot, grad_pred, H, P, nch);
     return launch_ok();
 }
 
@@ -614,11 +689,18 @@ extern "C" int lasr_flow_loss_forward(const float* flow_rd, const float* flow_ob
     if (I * H == 0) return LASR_OK;
     if (!flow_rd || !flow_obs || !bg || !occ || !masks || !loss || !flow_rd_map || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_FLOW_LOSS_STATS, flow_loss_stats_kernel, dim3(I), dim3(256), 0, bg, occ, masks, scratch, H, P);
+    const int nch = loss_nch(P);
+    const LossScratch sc = loss_scratch(scratch, I, H, P);
+    LASR_LAUNCH(K_FLOW_LOSS_STATS, flow_loss_stats_kernel, dim3(I, H * nch), dim3(256), 0, bg, occ, masks, sc.ipart, H, P, nch);
     int rc = launch_ok();
     if (rc) return rc;
-    LASR_LAUNCH(K_FLOW_LOSS_FORWARD, flow_loss_forward_kernel, dim3(I * H), dim3(256), 0, (const float2*)flow_rd, flow_obs,
-                bg, occ, masks, scratch, loss, flow_rd_map, H, P, obs_image_stride);
+    LASR_LAUNCH(K_LOSS_FINALIZE, flow_loss_stats_fold_kernel, dim3((I + 255) / 256), dim3(256), 0, sc.ipart, sc.img, I, H * nch);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_FLOW_LOSS_FORWARD, flow_loss_forward_kernel, dim3(I * H, nch), dim3(256), 0, (const float2*)flow_rd,
+                flow_obs, bg, occ, masks, sc.img, sc.part, flow_rd_map, H, P, obs_image_stride, nch);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_LOSS_FINALIZE, loss_finalize_kernel<1>, dim3((I * H + 255) / 256), dim3(256), 0, sc.part, sc.tot, loss,
+                I * H, nch, 1.f);
     return launch_ok();
 }
 
@@ -631,33 +713,44 @@ extern "C" int lasr_flow_loss_backward(const float* flow_rd, const float* flow_o
     if (I * H == 0) return LASR_OK;
     if (!flow_rd || !flow_obs || !bg || !occ || !masks || !scratch || !grad_loss || !grad_flow_rd) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_FLOW_LOSS_BACKWARD, flow_loss_backward_kernel, dim3(I * H), dim3(256), 0, (const float2*)flow_rd,
-                flow_obs, bg, occ, masks, scratch, grad_loss, (float2*)grad_flow_rd, H, P, obs_image_stride);
+    const int nch = loss_nch(P);
+    const LossScratch sc = loss_scratch(const_cast<float*>(scratch), I, H, P);
+    LASR_LAUNCH(K_FLOW_LOSS_BACKWARD, flow_loss_backward_kernel, dim3(I * H, nch), dim3(256), 0, (const float2*)flow_rd,
+                flow_obs, bg, occ, masks, sc.img, sc.tot, grad_loss, (float2*)grad_flow_rd, H, P, obs_image_stride, nch);
     return launch_ok();
 }
 
 extern "C" int lasr_tex_loss_forward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
-                                     const float* occ, float* loss, float wt, int I, int H, int P, void* hip_stream)
+                                     const float* occ, float* loss, float* scratch, float wt, int I, int H, int P,
+                                     void* hip_stream)
 {
     if (check_ihp(I, H, P)) return LASR_E_BADARG;
     if (I * H == 0) return LASR_OK;
-    if (!img_obs || !img_white || !rnd || !fg || !occ || !loss) return LASR_E_BADARG;
+    if (!img_obs || !img_white || !rnd || !fg || !occ || !loss || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_TEX_LOSS_FORWARD, tex_loss_forward_kernel, dim3(I * H), dim3(256), 0, img_obs, img_white, rnd, fg, occ,
-                loss, wt, H, P);
+    const int nch = loss_nch(P);
+    const LossScratch sc = loss_scratch(scratch, I, H, P);
+    LASR_LAUNCH(K_TEX_LOSS_FORWARD, tex_loss_forward_kernel, dim3(I * H, nch), dim3(256), 0, img_obs, img_white, rnd, fg,
+                occ, sc.part, H, P, nch);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_LOSS_FINALIZE, loss_finalize_kernel<2>, dim3((I * H + 255) / 256), dim3(256), 0, sc.part, sc.tot, loss,
+                I * H, nch, 2.f * wt);
     return launch_ok();
 }
 
 extern "C" int lasr_tex_loss_backward(const float* img_obs, const float* img_white, const float* rnd, const float* fg,
-                                      const float* occ, const float* grad_loss, float* grad_rnd, float* grad_fg,
-                                      float wt, int I, int H, int P, void* hip_stream)
+                                      const float* occ, const float* grad_loss, const float* scratch, float* grad_rnd,
+                                      float* grad_fg, float wt, int I, int H, int P, void* hip_stream)
 {
     if (check_ihp(I, H, P)) return LASR_E_BADARG;
     if (I * H == 0) return LASR_OK;
-    if (!img_obs || !img_white || !rnd || !fg || !occ || !grad_loss || !grad_rnd || !grad_fg) return LASR_E_BADARG;
+    if (!img_obs || !img_white || !rnd || !fg || !occ || !grad_loss || !grad_rnd || !grad_fg || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_TEX_LOSS_BACKWARD, tex_loss_backward_kernel, dim3(I * H), dim3(256), 0, img_obs, img_white, rnd, fg,
-                occ, grad_loss, grad_rnd, grad_fg, wt, H, P);
+    const int nch = loss_nch(P);
+    const LossScratch sc = loss_scratch(const_cast<float*>(scratch), I, H, P);
+    LASR_LAUNCH(K_TEX_LOSS_BACKWARD, tex_loss_backward_kernel, dim3(I * H, nch), dim3(256), 0, img_obs, img_white, rnd, fg,
+                occ, sc.tot, grad_loss, grad_rnd, grad_fg, wt, H, P, nch);
     return launch_ok();
 }
 

@@ -6,6 +6,11 @@ from torch.autograd import Function
 from .. import _lib
 
 
+def _scratch(device, I, H, P):
+    """Chunk partials + per-row counts; allocated per call because it is saved for the backward pass."""
+    return torch.empty(_lib.lib().lasr_loss_scratch_floats(I, H, P), dtype=torch.float32, device=device)
+
+
 class _MaskLoss(Function):
     @staticmethod
     def forward(ctx, pred, masks, occ):
@@ -14,17 +19,18 @@ class _MaskLoss(Function):
         P = pred[0, 0].numel()
         pred, masks, occ = pred.contiguous().float(), masks.contiguous().float(), occ.contiguous().float()
         loss = torch.empty(I, H, dtype=torch.float32, device=pred.device)
+        scratch = _scratch(pred.device, I, H, P)
         guard, st = _lib.stream_of(pred)
         with guard:
             rc = _lib.lib().lasr_mask_loss_forward(pred.data_ptr(), masks.data_ptr(), occ.data_ptr(), loss.data_ptr(),
-                                                   I, H, P, st)
+                                                   scratch.data_ptr(), I, H, P, st)
         _lib.check(rc, 'lasr_mask_loss_forward')
-        ctx.save_for_backward(pred, masks, occ)
+        ctx.save_for_backward(pred, masks, occ, scratch)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        pred, masks, occ = ctx.saved_tensors
+        pred, masks, occ, scratch = ctx.saved_tensors
         I, H = pred.shape[:2]
         P = pred[0, 0].numel()
         g = g.contiguous().float()
@@ -32,7 +38,7 @@ class _MaskLoss(Function):
         guard, st = _lib.stream_of(pred)
         with guard:
             rc = _lib.lib().lasr_mask_loss_backward(pred.data_ptr(), masks.data_ptr(), occ.data_ptr(), g.data_ptr(),
-                                                    gp.data_ptr(), I, H, P, st)
+                                                    scratch.data_ptr(), gp.data_ptr(), I, H, P, st)
         _lib.check(rc, 'lasr_mask_loss_backward')
         return gp, None, None
 
@@ -56,7 +62,7 @@ class _FlowLoss(Function):
         occ, masks = occ.contiguous().float(), masks.contiguous().float()
         loss = torch.empty(I, H, dtype=torch.float32, device=flow_rd.device)
         fmap = torch.empty(flow_rd.shape[:-1], dtype=torch.float32, device=flow_rd.device)
-        scratch = torch.empty(2 * I, dtype=torch.float32, device=flow_rd.device)
+        scratch = _scratch(flow_rd.device, I, H, P)
         guard, st = _lib.stream_of(flow_rd)
         with guard:
             rc = _lib.lib().lasr_flow_loss_forward(flow_rd.data_ptr(), flow_obs.data_ptr(), bg8.data_ptr(), occ.data_ptr(),
@@ -97,17 +103,19 @@ class _TexLoss(Function):
         P = occ[0].numel()
         ts = [t.contiguous().float() for t in (img_obs, img_white, rnd, fg, occ)]
         loss = torch.empty(I, H, dtype=torch.float32, device=rnd.device)
+        scratch = _scratch(rnd.device, I, H, P)
         guard, st = _lib.stream_of(rnd)
         with guard:
-            rc = _lib.lib().lasr_tex_loss_forward(*[t.data_ptr() for t in ts], loss.data_ptr(), float(wt), I, H, P, st)
+            rc = _lib.lib().lasr_tex_loss_forward(*[t.data_ptr() for t in ts], loss.data_ptr(), scratch.data_ptr(),
+                                                  float(wt), I, H, P, st)
         _lib.check(rc, 'lasr_tex_loss_forward')
-        ctx.save_for_backward(*ts)
+        ctx.save_for_backward(*ts, scratch)
         ctx.wt = float(wt)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        ts = ctx.saved_tensors
+        *ts, scratch = ctx.saved_tensors
         rnd, fg, occ = ts[2], ts[3], ts[4]
         I, H = rnd.shape[:2]
         P = occ[0].numel()
@@ -115,8 +123,8 @@ class _TexLoss(Function):
         grnd, gfg = torch.empty_like(rnd), torch.empty_like(fg)
         guard, st = _lib.stream_of(rnd)
         with guard:
-            rc = _lib.lib().lasr_tex_loss_backward(*[t.data_ptr() for t in ts], g.data_ptr(), grnd.data_ptr(),
-                                                   gfg.data_ptr(), ctx.wt, I, H, P, st)
+            rc = _lib.lib().lasr_tex_loss_backward(*[t.data_ptr() for t in ts], g.data_ptr(), scratch.data_ptr(),
+                                                   grnd.data_ptr(), gfg.data_ptr(), ctx.wt, I, H, P, st)
         _lib.check(rc, 'lasr_tex_loss_backward')
         return None, None, grnd, gfg, None, None
 
