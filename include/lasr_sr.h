@@ -80,6 +80,30 @@ int lasr_sr_backward(const float* faces, const float* textures, const float* sof
                      int double_side, void* hip_stream);
 
 /*
+ * Same two calls with near/far read from device memory (`near_far_dev` -> {near, far}, two floats).  LASR derives
+ * the clipping planes from the projected vertices on every iteration (nnutils/mesh_net.py:304-311) and the
+ * reference turns those 0-dim device tensors into Python floats at each extension call, i.e. one device->host
+ * synchronisation per call; these variants keep the values on the device.
+ */
+int lasr_sr_forward_dev(const float* faces, const float* textures, float* faces_info,
+                        float* aggrs_info, float* soft_colors,
+                        void* workspace, size_t workspace_bytes,
+                        int N, int F, int T, int IS,
+                        const float* near_far_dev, float eps, float sigma_val,
+                        int func_id_dist, float dist_eps, float gamma_val,
+                        int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                        int double_side, void* hip_stream);
+int lasr_sr_backward_dev(const float* faces, const float* textures, const float* soft_colors,
+                         const float* faces_info, const float* aggrs_info,
+                         float* grad_faces, float* grad_textures, const float* grad_soft_colors,
+                         void* workspace, size_t workspace_bytes,
+                         int N, int F, int T, int IS,
+                         const float* near_far_dev, float eps, float sigma_val,
+                         int func_id_dist, float dist_eps, float gamma_val,
+                         int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                         int double_side, void* hip_stream);
+
+/*
  * Optional per-kernel timing for benchmarks (no reference counterpart: the
  * reference has no profiling hooks).  While enabled, every
  * kernel launch of this library is bracketed by hipEvents on its stream;

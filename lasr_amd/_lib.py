@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'liblasr_hip.so')
 # every symbol include/lasr_sr.h and include/lasr_ops.h declare (checked by tests/test_abi.py)
 _f, _i, _p, _sz = ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 _RASTER_SCALARS = [_i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]
+_RASTER_SCALARS_DEV = [_i, _i, _i, _i, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]
 SIGNATURES = {
     'lasr_abi_version': (_i, []),
     'lasr_strerror': (ctypes.c_char_p, [_i]),
@@ -36,6 +37,8 @@ SIGNATURES = {
     'lasr_arap_backward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_laplacian_forward': (_i, [_p] * 4 + [_i, _i, _p]),
     'lasr_laplacian_backward': (_i, [_p] * 6 + [_i, _i, _p]),
+    'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
+    'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_prof_enable': (_i, [_i]),
     'lasr_prof_kernel_count': (_i, []),
     'lasr_prof_kernel_name': (ctypes.c_char_p, [_i]),

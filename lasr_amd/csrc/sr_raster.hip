@@ -41,6 +41,7 @@ struct RasterArgs {
     const float* __restrict__ textures;  // [N,F,T,3]
     int N, F, T, res, IS;
     float near, far, eps, sigma, gamma, thr;
+    const float* __restrict__ near_far_dev;   // optional: {near, far} read on the device (no host sync)
     Modes m;
 };
 
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
 
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
+    if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
 
     const int IS = A.IS, P = IS * IS;
     const int tiles_x = (IS + TILE - 1) / TILE;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     __shared__ unsigned int s_ring[4][QCAP];
     constexpr bool FM = BWD_FM;
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
+    if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
     const int lane = threadIdx.x & 63;
     unsigned int* ring = s_ring[threadIdx.x >> 6];
     const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -496,11 +499,13 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     RasterArgs A;
     A.recs = *recs; A.bboxes = *bboxes; A.textures = textures;
     A.N = N; A.F = F; A.T = T; A.res = (int)sqrt((double)T); A.IS = IS;   // K.cu:696
-    A.near = near; A.far = far; A.eps = eps; A.sigma = sigma; A.gamma = gamma;
+    A.near = near; A.far = far; A.near_far_dev = nullptr; A.eps = eps; A.sigma = sigma; A.gamma = gamma;
     A.thr = dist_eps * sigma;                                              // K.cu:352 (float product)
     A.m = Modes{dist, rgb, alpha, tex, double_side ? 1 : 0};
     return A;
 }
+
+static thread_local const float* g_near_far_dev = nullptr;   // set by the *_dev entry points around the call
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -519,6 +524,7 @@ extern "C" int lasr_sr_forward(const float* faces, const float* textures, float*
     float* recs; float4* bboxes;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
                              gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &bboxes);
+    A.near_far_dev = g_near_far_dev;
     const int total = N * F;
     if (total > 0) {
         {
@@ -556,6 +562,7 @@ extern "C" int lasr_sr_backward(const float* faces, const float* textures, const
     float* recs; float4* bboxes;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
                              gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &bboxes);
+    A.near_far_dev = g_near_far_dev;
     const int total = N * F;
     {
         ProfScope ps(K_SR_SETUP, st);
@@ -574,4 +581,40 @@ extern "C" int lasr_sr_backward(const float* faces, const float* textures, const
                                grad_soft_colors, grad_faces, grad_textures);
     }
     return launch_ok();
+}
+
+// near/far taken from device memory ({near, far} as two floats): LASR recomputes them from the projected
+// vertices every iteration (nnutils/mesh_net.py:304-311); the reference converts the 0-dim tensors to Python
+// floats at each extension call (an implicit device->host sync per call), this variant never leaves the device.
+extern "C" int lasr_sr_forward_dev(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
+                                   float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
+                                   const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                                   float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                                   int double_side, void* hip_stream)
+{
+    if (!near_far_dev) return LASR_E_BADARG;
+    g_near_far_dev = near_far_dev;
+    const int rc = lasr_sr_forward(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T,
+                                   IS, 0.f, 0.f, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb,
+                                   func_id_alpha, texture_sample_type, double_side, hip_stream);
+    g_near_far_dev = nullptr;
+    return rc;
+}
+
+extern "C" int lasr_sr_backward_dev(const float* faces, const float* textures, const float* soft_colors,
+                                    const float* faces_info, const float* aggrs_info, float* grad_faces,
+                                    float* grad_textures, const float* grad_soft_colors, void* workspace,
+                                    size_t workspace_bytes, int N, int F, int T, int IS, const float* near_far_dev,
+                                    float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                                    int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                                    void* hip_stream)
+{
+    if (!near_far_dev) return LASR_E_BADARG;
+    g_near_far_dev = near_far_dev;
+    const int rc = lasr_sr_backward(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces, grad_textures,
+                                    grad_soft_colors, workspace, workspace_bytes, N, F, T, IS, 0.f, 0.f, eps, sigma_val,
+                                    func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha, texture_sample_type,
+                                    double_side, hip_stream);
+    g_near_far_dev = nullptr;
+    return rc;
 }

@@ -39,8 +39,16 @@ def _workspace(device, stream, nbytes):
 
 
 def _as_float(v):
-    # LASR stores 0-dim device tensors in rasterizer.near/far (mesh_net.py:306-311)
     return float(v.item()) if torch.is_tensor(v) else float(v)
+
+
+def _near_far_dev(near, far, dev):
+    """LASR stores 0-dim DEVICE tensors in rasterizer.near/far (mesh_net.py:306-311).  Returns a 2-float device tensor
+    for the *_dev entry points (no host sync), or None when both are plain numbers."""
+    if torch.is_tensor(near) and near.device.type == 'cuda' or torch.is_tensor(far) and far.device.type == 'cuda':
+        return torch.stack([torch.as_tensor(near, dtype=torch.float32, device=dev).reshape(()),
+                            torch.as_tensor(far, dtype=torch.float32, device=dev).reshape(())]).detach()
+    return None
 
 
 class SoftRasterizeFunction(Function):
@@ -62,9 +70,11 @@ class SoftRasterizeFunction(Function):
         IS = int(image_size)
 
         ctx.geom = (N, F, T, IS)
-        ctx.scalars = (_as_float(near), _as_float(far), float(eps), float(sigma_val), _DIST[dist_func],
-                       float(math.log(1. / dist_eps - 1.)), float(gamma_val), _RGB[aggr_func_rgb],
-                       _ALPHA[aggr_func_alpha], _TEX[texture_type], 1 if fill_back else 0)
+        nf = _near_far_dev(near, far, dev)
+        tail = (float(eps), float(sigma_val), _DIST[dist_func], float(math.log(1. / dist_eps - 1.)), float(gamma_val),
+                _RGB[aggr_func_rgb], _ALPHA[aggr_func_alpha], _TEX[texture_type], 1 if fill_back else 0)
+        ctx.nf = nf
+        ctx.scalars = ((nf.data_ptr(),) if nf is not None else (_as_float(near), _as_float(far))) + tail
         ctx.in_shapes = (face_vertices.shape, textures.shape)
 
         aggrs_info = torch.empty(N, 2, IS, IS, dtype=torch.float32, device=dev)
@@ -79,9 +89,10 @@ class SoftRasterizeFunction(Function):
             stream = torch.cuda.current_stream(dev).cuda_stream
             nbytes = h.lasr_sr_workspace_bytes(N, F, T, IS)
             ws = _workspace(dev, stream, nbytes)
-            rc = h.lasr_sr_forward(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
-                                   soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
-                                   N, F, T, IS, *ctx.scalars, stream)
+            fn = h.lasr_sr_forward_dev if nf is not None else h.lasr_sr_forward
+            rc = fn(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
+                    soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
+                    N, F, T, IS, *ctx.scalars, stream)
         _lib.check(rc, 'lasr_sr_forward')
         ctx.save_for_backward(fv, tx, soft_colors, aggrs_info)
         ctx.mark_non_differentiable(aggrs_info)
@@ -100,10 +111,11 @@ class SoftRasterizeFunction(Function):
             stream = torch.cuda.current_stream(dev).cuda_stream
             nbytes = h.lasr_sr_workspace_bytes(N, F, T, IS)
             ws = _workspace(dev, stream, nbytes)
-            rc = h.lasr_sr_backward(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
-                                    aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
-                                    g.data_ptr(), ws.data_ptr(), ws.numel(),
-                                    N, F, T, IS, *ctx.scalars, stream)
+            fn = h.lasr_sr_backward_dev if ctx.nf is not None else h.lasr_sr_backward
+            rc = fn(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
+                    aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
+                    g.data_ptr(), ws.data_ptr(), ws.numel(),
+                    N, F, T, IS, *ctx.scalars, stream)
         _lib.check(rc, 'lasr_sr_backward')
         fshape, tshape = ctx.in_shapes
         return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),

@@ -83,7 +83,9 @@ def test_every_parameter_group_gets_a_finite_gradient(tmp_path, cuda):
 
 
 def test_training_reduces_the_loss_and_checkpoints(tmp_path, cuda):
-    tr = make_trainer(tmp_path, iters_per_epoch=12, n_bones=1, n_hypo=1, batch_size=1)
+    # Adam's first steps are sign-like, so run-to-run float noise (gather/scatter atomics in torch) moves individual
+    # losses by several percent; compare window means over 40 iterations
+    tr = make_trainer(tmp_path, iters_per_epoch=40, n_bones=1, n_hypo=1, batch_size=1)
     tr.model.train()
     losses = []
     for i, ids in enumerate(tr.dataloader):
@@ -91,7 +93,7 @@ def test_training_reduces_the_loss_and_checkpoints(tmp_path, cuda):
         l, _ = tr.train_step(tr.set_input(ids))
         losses.append(float(l))
     assert np.isfinite(losses).all()
-    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    assert np.mean(losses[-10:]) < np.mean(losses[:10]), losses
     tr.epoch_nscore = torch.zeros(1, device=cuda)
     tr.save('latest')
     assert os.path.exists(os.path.join(tr.save_dir, 'pred_net_latest.pth'))

@@ -166,3 +166,15 @@ def test_cpu_tensor_is_rejected_like_the_reference():
     t = torch.zeros(1, 1, 3, 3)
     with pytest.raises(TypeError):
         srf.soft_rasterize(t, t, 8)
+
+
+def test_device_resident_near_far_match_host_floats(cuda):
+    # LASR keeps near/far as 0-dim device tensors (mesh_net.py:306-311): the *_dev entry points must give the
+    # same bits as passing the floats, forward and backward, without a host sync
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    g = synth.upstream_grad(2, 64)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    a = run_hip(cuda, fv, ft, 64, g=g, **kw)
+    kw_dev = dict(kw, near=torch.tensor(near, device=cuda), far=torch.tensor(far, device=cuda))
+    b = run_hip(cuda, fv, ft, 64, g=g, **kw_dev)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
