@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'liblasr_hip.so')
+LIB_PATH = os.environ.get('LASR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblasr_hip.so')   # env override: kernel A/B builds
 
 # every symbol include/lasr_sr.h and include/lasr_ops.h declare (checked by tests/test_abi.py)
 _f, _i, _p, _sz = ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t

@@ -24,8 +24,9 @@ namespace lasr {
 //                 bit4 well-conditioned (the cheap line-distance reject below may be used)
 // [31..33] hk2  : squared height of vertex k over its opposite edge (own addition: w_k * h_k is the
 //                 signed distance of a pixel to that edge's line, a lower bound of the true distance)
-// [34..37] bbox : xmin-m, xmax+m, ymin-m, ymax+m (m = sqrt(threshold)), K.cu:33-38 hoisted
-// [38..39] pad to 160 B (16-B multiple so records start on a dwordx4 boundary)
+// [34..35] rect : the pixels that pass the bbox test of K.cu:33-38, as EXACT integer bounds (own addition):
+//                 [34] = x0 | x1 << 16 (columns), [35] = r0 | r1 << 16 (rows from the top); empty = x0 > x1
+// [36..39] pad to 160 B (16-B multiple so records start on a dwordx4 boundary)
 constexpr int REC = 40;
 constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30, R_HK2 = 31, R_BB = 34;
 
@@ -47,8 +48,31 @@ __device__ __forceinline__ float pix_center(int i, int is)
     return (float)(2 * i + 1 - is) / (float)is;
 }
 
+// Pixel-index bounds equivalent to the float test `lo <= pix_center(i) <= hi` (pix_center is monotone in i):
+// an estimate from the inverse map, then fixed up with the exact function so the integer test decides
+// exactly like the reference's float comparisons.  NaN bounds never reject (K.cu:33-38 compares with > / <).
+__device__ __forceinline__ int first_pixel_ge(float lo, int IS)
+{
+    if (lo != lo) return 0;
+    const float e = ceilf((lo * (float)IS + (float)IS - 1.f) * 0.5f);
+    int i = e < 0.f ? 0 : (e > (float)IS ? IS : (int)e);
+    for (int k = 0; k < 4 && i > 0 && pix_center(i - 1, IS) >= lo; k++) i--;
+    for (int k = 0; k < 4 && i < IS && pix_center(i, IS) < lo; k++) i++;
+    return i;                                   // in [0, IS]; IS = no pixel
+}
+__device__ __forceinline__ int last_pixel_le(float hi, int IS)
+{
+    if (hi != hi) return IS - 1;
+    const float e = floorf((hi * (float)IS + (float)IS - 1.f) * 0.5f);
+    int i = e < -1.f ? -1 : (e > (float)(IS - 1) ? IS - 1 : (int)e);
+    for (int k = 0; k < 4 && i < IS - 1 && pix_center(i + 1, IS) <= hi; k++) i++;
+    for (int k = 0; k < 4 && i >= 0 && pix_center(i, IS) > hi; k++) i--;
+    return i;                                   // in [-1, IS-1]; -1 = no pixel
+}
+
 __device__ __forceinline__ void build_record(const float* __restrict__ f, float* __restrict__ rec,
-                                             float4* __restrict__ bbox, float margin, float* __restrict__ info27)
+                                             short4* __restrict__ rect, float margin, int IS,
+                                             float* __restrict__ info27)
 {
     const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
     float adj[9];
@@ -107,12 +131,17 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
         if (ok) flags |= 16;
     }
     rec[R_FLAGS] = __int_as_float(flags);
-    rec[R_BB + 4] = 0.f; rec[R_BB + 5] = 0.f;
     // K.cu:33-38 with the max/min +- margin hoisted (same float ops, done once)
     const float xmax = fmaxf(fmaxf(x0, x1), x2) + margin, xmin = fminf(fminf(x0, x1), x2) - margin;
     const float ymax = fmaxf(fmaxf(y0, y1), y2) + margin, ymin = fminf(fminf(y0, y1), y2) - margin;
-    *bbox = make_float4(xmin, xmax, ymin, ymax);
-    rec[R_BB + 0] = xmin; rec[R_BB + 1] = xmax; rec[R_BB + 2] = ymin; rec[R_BB + 3] = ymax;
+    int px0 = first_pixel_ge(xmin, IS), px1 = last_pixel_le(xmax, IS);
+    const int yi0 = first_pixel_ge(ymin, IS), yi1 = last_pixel_le(ymax, IS);    // yi counts from the bottom (K.cu:343)
+    int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;                                    // rows from the top
+    if (px0 > px1 || r0 > r1) { px0 = 32767; px1 = -1; r0 = 32767; r1 = -1; }    // empty
+    *rect = make_short4((short)px0, (short)px1, (short)r0, (short)r1);
+    rec[R_BB + 0] = __int_as_float((px0 & 0xffff) | (px1 << 16));
+    rec[R_BB + 1] = __int_as_float((r0 & 0xffff) | (r1 << 16));
+    rec[R_BB + 2] = 0.f; rec[R_BB + 3] = 0.f; rec[R_BB + 4] = 0.f; rec[R_BB + 5] = 0.f;
     if (info27) {   // reference layout, for callers that still want the tensor
 #pragma unroll
         for (int k = 0; k < 9; k++) { info27[k] = inv[k]; info27[9 + k] = sym[k]; }

@@ -33,11 +33,11 @@
 namespace lasr {
 
 constexpr int TILE = 16;        // pixels per tile side (4 waves of 8x8)
-constexpr int LIST_CAP = 4096;  // faces scanned per round == LDS list capacity (u16 ids, 8 KB)
+constexpr int LIST_CAP = 2048;  // faces scanned per round == capacity of each LDS list (u16 ids; 5 lists = 20 KB)
 
 struct RasterArgs {
     const float* __restrict__ recs;      // [N*F, REC]
-    const float4* __restrict__ bboxes;   // [N*F]
+    const short4* __restrict__ rects;    // [N*F] exact pixel rectangle (x0,x1,row0,row1) of the bbox test
     const float* __restrict__ textures;  // [N,F,T,3]
     int N, F, T, res, IS;
     float near, far, eps, sigma, gamma, thr;
@@ -47,12 +47,12 @@ struct RasterArgs {
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__ faces, float* __restrict__ recs,
-                                                       float4* __restrict__ bboxes, float* __restrict__ info27,
-                                                       int total, float margin)
+                                                       short4* __restrict__ rects, float* __restrict__ info27,
+                                                       int total, float margin, int IS)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    build_record(faces + (size_t)i * 9, recs + (size_t)i * REC, bboxes + i, margin,
+    build_record(faces + (size_t)i * 9, recs + (size_t)i * REC, rects + i, margin, IS,
                  info27 ? info27 + (size_t)i * 27 : nullptr);
 }
 
@@ -117,7 +117,8 @@ template <bool LASR_FAST>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
 {
-    __shared__ unsigned short s_face[LIST_CAP];   // candidate face ids (relative to the round's base), index order
+    __shared__ unsigned short s_all[LIST_CAP];        // faces whose pixel rect touches the 16x16 tile, index order
+    __shared__ unsigned short s_mine[4][LIST_CAP];    // per wave: the subset touching its 8x8 quadrant, index order
     __shared__ int s_wcnt[2][4];
 
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
@@ -133,17 +134,13 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
-    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;   // this wave's quadrant
+    const int px = qx0 + (lane & 7);
+    const int py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
     const int pn = py * IS + px;
     const float xp = pix_center(px, IS);
     const float yp = pix_center(IS - 1 - py, IS);
-
-    // NDC extent of the tile's pixel centres (same rounding as the per-pixel values)
-    const int tx1 = min(tx * TILE + TILE - 1, IS - 1), ty1 = min(ty * TILE + TILE - 1, IS - 1);
-    const float t_xlo = pix_center(tx * TILE, IS), t_xhi = pix_center(tx1, IS);
-    const float t_yhi = pix_center(IS - 1 - ty * TILE, IS), t_ylo = pix_center(IS - 1 - ty1, IS);
 
     PixState s;
     s.a = (m.alpha == 2) ? 1.f : 0.f;
@@ -161,43 +158,61 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
         s.r = bg0 * s.ssum; s.g = bg1 * s.ssum; s.b = bg2 * s.ssum;
     }
 
-    const float4* __restrict__ bb = A.bboxes + (size_t)bn * A.F;
+    const short4* __restrict__ rects = A.rects + (size_t)bn * A.F;
     const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * 3;
     const int texstride = A.T * 3;
     const float thr_pad = A.thr * 1.05f;   // slack of the conservative "certainly far" reject
+    const int tX0 = tx * TILE, tX1 = tX0 + TILE - 1, tY0 = ty * TILE, tY1 = tY0 + TILE - 1;
+    unsigned short* mine = s_mine[wave];
 
     for (int base = 0; base < A.F; base += LIST_CAP) {      // one round unless F > LIST_CAP
         const int end = min(base + LIST_CAP, A.F);
-        if (base > 0) __syncthreads();                      // the previous round's list is still being walked
-        // ---- ordered compaction of faces [base,end) whose bbox touches this 16x16 tile
+        if (base > 0) __syncthreads();                      // the previous round's lists are still being walked
+        // ---- level 1 (workgroup): ordered compaction of faces [base,end) whose rect touches the 16x16 tile
         int count = 0, flip = 0;
         for (int c = base; c < end; c += 256, flip ^= 1) {
             const int f = c + tid;
             bool hit = false;
             if (f < end) {
-                const float4 b = bb[f];
-                hit = !(t_xlo > b.y || t_xhi < b.x || t_ylo > b.w || t_yhi < b.z);
+                const short4 q = rects[f];
+                hit = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
             }
             const unsigned long long mask = __ballot(hit);
             if (lane == 0) s_wcnt[flip][wave] = __popcll(mask);
             __syncthreads();
             const int c0 = s_wcnt[flip][0], c1 = s_wcnt[flip][1], c2 = s_wcnt[flip][2], c3 = s_wcnt[flip][3];
             const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-            if (hit) s_face[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+            if (hit) s_all[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
             count += c0 + c1 + c2 + c3;
         }
         __syncthreads();
-        // ---- every wave walks the list for its own 8x8 quadrant; no barrier until the next round
+        // ---- level 2 (wave, no barriers from here on): 64 list entries at a time, keep those touching the quadrant
+        int n_mine = 0;
         for (int i0 = 0; i0 < count; i0 += 64) {
-            const int mine = (i0 + lane < count) ? (int)s_face[i0 + lane] : 0;
-            const int n = min(64, count - i0);
+            bool hit = false;
+            int e = 0;
+            if (i0 + lane < count) {
+                e = s_all[i0 + lane];
+                const short4 q = rects[base + e];
+                hit = !(q.x > qx0 + 7 || q.y < qx0 || q.z > qy0 + 7 || q.w < qy0);
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (hit) mine[n_mine + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)e;
+            n_mine += __popcll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- walk: every entry has at least one candidate pixel in this wave
+        for (int i0 = 0; i0 < n_mine; i0 += 64) {
+            const int chunk = (i0 + lane < n_mine) ? (int)mine[i0 + lane] : 0;
+            const int n = min(64, n_mine - i0);
             for (int j = 0; j < n; j++) {
-                const int fn = base + __builtin_amdgcn_readlane(mine, j);   // wave-uniform -> scalar loads
+                const int fn = base + __builtin_amdgcn_readlane(chunk, j);     // wave-uniform -> scalar loads
                 const cptr_t rec = as_const(recs + (size_t)fn * REC);
-                bool cand = valid && !(xp > rec[R_BB + 1] || xp < rec[R_BB + 0] ||
-                                       yp > rec[R_BB + 3] || yp < rec[R_BB + 2]);            // K.cu:375
-                if (__ballot(cand) == 0ull) continue;                                        // wave-uniform skip
+                const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
+                // exact integer form of the bbox test K.cu:375 (see first_pixel_ge / last_pixel_le)
+                bool cand = valid && px >= (int)(short)(rx & 0xffff) && px <= (rx >> 16) &&
+                            py >= (int)(short)(ry & 0xffff) && py <= (ry >> 16);
                 float w0, w1, w2;
                 barycentric(rec, xp, yp, w0, w1, w2);
                 if (m.dist == 2 && (__float_as_int(rec[R_FLAGS]) & 16)) {
@@ -268,18 +283,13 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     const int IS = A.IS, P = IS * IS;
     const cptr_t rec = as_const(A.recs + (size_t)gw * REC);
     const cptr_t tex = as_const(A.textures + (size_t)gw * A.T * 3);
-    const float4 b = A.bboxes[gw];
+    const short4 rc4 = A.rects[gw];
     const int flags = __float_as_int(rec[R_FLAGS]);
 
-    // conservative pixel rectangle of the bbox; the exact test is repeated per pixel
-    // xp = (2 xi + 1 - IS)/IS  =>  xi = (xp IS + IS - 1)/2
-    const float half = 0.5f * (float)IS;
-    int x0 = (int)floorf(b.x * half + half - 0.5f) - 1, x1 = (int)ceilf(b.y * half + half - 0.5f) + 1;
-    int yi0 = (int)floorf(b.z * half + half - 0.5f) - 1, yi1 = (int)ceilf(b.w * half + half - 0.5f) + 1;
-    x0 = max(x0, 0); x1 = min(x1, IS - 1);
-    yi0 = max(yi0, 0); yi1 = min(yi1, IS - 1);
-    const int bw = x1 - x0 + 1, bh = yi1 - yi0 + 1;
-    const bool empty = !(bw > 0 && bh > 0);      // also catches NaN / inverted boxes
+    // exact pixel rectangle of the bbox test (columns x0..x1, rows r0..r1 from the top); empty when x0 > x1
+    const int x0 = rc4.x, x1 = rc4.y, r0 = rc4.z, r1 = rc4.w;
+    const int bw = x1 - x0 + 1, bh = r1 - r0 + 1;
+    const bool empty = !(bw > 0 && bh > 0);
     const int npx = empty ? 0 : bw * bh;
 
     float gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2)
@@ -290,7 +300,6 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     // cheap reject only for the soft distance modes and well-conditioned faces; 2 % slack on thr
     const bool use_far = (m.dist == 2) && (flags & 16);
     const float thr_pad = A.thr * 1.05f;
-    const float inv_is = 1.f / (float)IS;
 
     // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
     int r = 0, c = 0;
@@ -301,25 +310,19 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     while (true) {
         if (base < npx) {
             // ---------------- stage 1
-            const int xi = x0 + c, yi = yi0 + r;
+            const int xi = x0 + c, row = r0 + r;
             const bool in_range = base + lane < npx;
             c += dc; r += dr;
             if (c >= bw) { c -= bw; r += 1; }
             base += 64;
-            bool keep = false;
-            if (in_range) {
-                const float xp = pix_center(xi, IS), yp = pix_center(yi, IS);
-                if (!outside_bbox(xp, yp, b)) {
-                    keep = true;
-                    if (use_far) {
-                        float w0, w1, w2;
-                        barycentric(rec, xp, yp, w0, w1, w2);
-                        keep = !certainly_far(rec, w0, w1, w2, thr_pad);
-                    }
-                }
+            bool keep = in_range;                              // every pixel of the rect passes the bbox test
+            if (in_range && use_far) {
+                float w0, w1, w2;
+                barycentric(rec, pix_center(xi, IS), pix_center(IS - 1 - row, IS), w0, w1, w2);
+                keep = !certainly_far(rec, w0, w1, w2, thr_pad);
             }
             const unsigned long long mask = __ballot(keep);
-            if (keep) ring[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (unsigned)xi | ((unsigned)yi << 16);
+            if (keep) ring[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (unsigned)xi | ((unsigned)row << 16);
             tail += __popcll(mask);
         }
         const int avail = tail - head;
@@ -333,10 +336,9 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
         const unsigned int packed = ring[(head + lane) & (QCAP - 1)];
         head += min(avail, 64);
         if (!active) continue;
-        const int xi = packed & 0xffff, yi = packed >> 16;
-        const int pn = (IS - 1 - yi) * IS + xi;
-        const float xp = pix_center(xi, IS), yp = pix_center(yi, IS);
-        (void)inv_is;
+        const int xi = packed & 0xffff, row = packed >> 16;
+        const int pn = row * IS + xi;
+        const float xp = pix_center(xi, IS), yp = pix_center(IS - 1 - row, IS);
 
         float w0, w1, w2;
         Frag fr;
@@ -476,7 +478,7 @@ extern "C" size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS)
     (void)T; (void)IS;
     if (N < 0 || F < 0) return 0;
     const size_t nf = (size_t)N * (size_t)F;
-    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(float4), 256) + 256;
+    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) + 256;
 }
 
 static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alpha, int tex)
@@ -490,14 +492,14 @@ static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alph
 
 static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T, int IS, float near, float far,
                             float eps, float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
-                            int tex, int double_side, float** recs, float4** bboxes)
+                            int tex, int double_side, float** recs, short4** rects)
 {
     const size_t nf = (size_t)N * (size_t)F;
     char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     *recs = (float*)p;
-    *bboxes = (float4*)(p + align_up(nf * REC * sizeof(float), 256));
+    *rects = (short4*)(p + align_up(nf * REC * sizeof(float), 256));
     RasterArgs A;
-    A.recs = *recs; A.bboxes = *bboxes; A.textures = textures;
+    A.recs = *recs; A.rects = *rects; A.textures = textures;
     A.N = N; A.F = F; A.T = T; A.res = (int)sqrt((double)T); A.IS = IS;   // K.cu:696
     A.near = near; A.far = far; A.near_far_dev = nullptr; A.eps = eps; A.sigma = sigma; A.gamma = gamma;
     A.thr = dist_eps * sigma;                                              // K.cu:352 (float product)
@@ -521,16 +523,16 @@ extern "C" int lasr_sr_forward(const float* faces, const float* textures, float*
     if (!aggrs_info || !soft_colors || (F > 0 && (!faces || !textures))) return LASR_E_BADARG;
     if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, IS)) return LASR_E_WORKSPACE;
     hipStream_t st = (hipStream_t)hip_stream;
-    float* recs; float4* bboxes;
+    float* recs; short4* rects;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
-                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &bboxes);
+                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
     A.near_far_dev = g_near_far_dev;
     const int total = N * F;
     if (total > 0) {
         {
             ProfScope ps(K_SR_SETUP, st);
-            hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, bboxes,
-                               faces_info, total, sqrtf(A.thr));
+            hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, rects,
+                               faces_info, total, sqrtf(A.thr), IS);
         }
         if ((rc = launch_ok())) return rc;
     }
@@ -559,15 +561,15 @@ extern "C" int lasr_sr_backward(const float* faces, const float* textures, const
         return LASR_E_BADARG;
     if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, IS)) return LASR_E_WORKSPACE;
     hipStream_t st = (hipStream_t)hip_stream;
-    float* recs; float4* bboxes;
+    float* recs; short4* rects;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
-                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &bboxes);
+                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
     A.near_far_dev = g_near_far_dev;
     const int total = N * F;
     {
         ProfScope ps(K_SR_SETUP, st);
-        hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, bboxes,
-                           (float*)nullptr, total, sqrtf(A.thr));
+        hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, rects,
+                           (float*)nullptr, total, sqrtf(A.thr), IS);
     }
     if ((rc = launch_ok())) return rc;
     const dim3 grid((unsigned)((total + 3) / 4));   // 4 waves (faces) per 256-thread workgroup
