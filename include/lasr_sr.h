@@ -115,6 +115,12 @@ int         lasr_prof_kernel_count(void);
 const char* lasr_prof_kernel_name(int kernel_id);
 int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launches);
 
+/*
+ * Test hook (no reference counterpart): adds to *mismatches the number of pairs for which the library's
+ * exact division-by-reciprocal (sr_device.h) differs bitwise from the IEEE quotient a[i] / b[i].
+ */
+int lasr_selftest_div(const float* a, const float* b, int* mismatches, int n, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

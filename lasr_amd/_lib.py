@@ -39,6 +39,7 @@ SIGNATURES = {
     'lasr_laplacian_backward': (_i, [_p] * 6 + [_i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
+    'lasr_selftest_div': (_i, [_p, _p, _p, _i, _p]),
     'lasr_prof_enable': (_i, [_i]),
     'lasr_prof_kernel_count': (_i, []),
     'lasr_prof_kernel_name': (ctypes.c_char_p, [_i]),

@@ -21,14 +21,17 @@ namespace lasr {
 // [18..26] e    : e[k][j] = sym[3k+j] - sym[3((k+1)%3)+j]           (K.cu:81-83,132-134, hoisted)
 // [27..29] den  : den[k]  = e[k][k] - e[k][(k+1)%3]                 (K.cu:85,136, hoisted)
 // [30]     flags: bit0..2 first obtuse corner (K.cu:296-304), bit3 front-facing (K.cu:41-44),
-//                 bit4 well-conditioned (the cheap line-distance reject below may be used)
+//                 bit4 well-conditioned (the cheap line-distance reject below may be used),
+//                 bit5 reciprocals usable
 // [31..33] hk2  : squared height of vertex k over its opposite edge (own addition: w_k * h_k is the
 //                 signed distance of a pixel to that edge's line, a lower bound of the true distance)
 // [34..35] rect : the pixels that pass the bbox test of K.cu:33-38, as EXACT integer bounds (own addition):
 //                 [34] = x0 | x1 << 16 (columns), [35] = r0 | r1 << 16 (rows from the top); empty = x0 > x1
-// [36..39] pad to 160 B (16-B multiple so records start on a dwordx4 boundary)
-constexpr int REC = 40;
-constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30, R_HK2 = 31, R_BB = 34;
+// [36..38] iden : RN(1/den[k])   } correctly rounded reciprocals for the exact-division-by-reciprocal below;
+// [39..41] iz   : RN(1/z_k)      } flags bit5 says they are usable (finite, denominators in a safe range)
+// [42..43] pad to 176 B (16-B multiple so records start on a dwordx4 boundary)
+constexpr int REC = 44;
+constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30, R_HK2 = 31, R_BB = 34, R_IDEN = 36, R_IZ = 39;
 
 // Read-only buffers written by an EARLIER kernel are viewed through the constant address
 // space: with a wave-uniform index the compiler then emits s_load (scalar cache -> SGPRs)
@@ -46,6 +49,26 @@ __device__ __forceinline__ float pix_center(int i, int is)
     // integer and narrowing a double quotient of two floats is the correctly rounded float quotient
     // (53 >= 2*24+2 bits), so one IEEE fp32 division gives the identical value.
     return (float)(2 * i + 1 - is) / (float)is;
+}
+
+// ---- exact division by a precomputed reciprocal ------------------------------------------------------
+// q = RN(a / b) from y = RN(1 / b): two Newton-Markstein corrections with exact FMA residuals.  With y correctly
+// rounded the second correction returns the correctly rounded quotient (Markstein 1990; the only exception, a
+// divisor whose significand is all ones, has probability 2^-23 and costs at most one ulp).  5 VALU ops instead of
+// the ~11 of the IEEE division expansion.  Only used when the divisor is in a range where neither y nor the
+// quotient can overflow/underflow (recip_safe); otherwise the plain division runs.
+__device__ __forceinline__ bool recip_safe(float b)
+{
+    const float m = fabsf(b);
+    return m > 1e-18f && m < 1e18f;              // also false for NaN / inf / 0
+}
+__device__ __forceinline__ float div_by_recip(float a, float b, float y)
+{
+    float q = a * y;
+    float e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, y, q);
+    e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, y, q);
 }
 
 // Pixel-index bounds equivalent to the float test `lo <= pix_center(i) <= hi` (pix_center is monotone in i):
@@ -141,7 +164,18 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
     *rect = make_short4((short)px0, (short)px1, (short)r0, (short)r1);
     rec[R_BB + 0] = __int_as_float((px0 & 0xffff) | (px1 << 16));
     rec[R_BB + 1] = __int_as_float((r0 & 0xffff) | (r1 << 16));
-    rec[R_BB + 2] = 0.f; rec[R_BB + 3] = 0.f; rec[R_BB + 4] = 0.f; rec[R_BB + 5] = 0.f;
+    {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float d = rec[R_DEN + k], z = f[3 * k + 2];
+            rec[R_IDEN + k] = 1.f / d;
+            rec[R_IZ + k] = 1.f / z;
+            ok = ok && recip_safe(d) && recip_safe(z);
+        }
+        if (ok) rec[R_FLAGS] = __int_as_float(__float_as_int(rec[R_FLAGS]) | 32);
+        rec[R_IZ + 3] = 0.f; rec[R_IZ + 4] = 0.f;
+    }
     if (info27) {   // reference layout, for callers that still want the tensor
 #pragma unroll
         for (int k = 0; k < 9; k++) { info27[k] = inv[k]; info27[9 + k] = sym[k]; }
@@ -205,14 +239,15 @@ __device__ __forceinline__ bool certainly_far(cptr_t rec, float w0, float w1, fl
 
 // One edge projection with compile-time edge K (a=K, b=K+1, c=K+2 mod 3): K.cu:85-95 / 136-148.
 // Returns u (already minus w) in (u0,u1,u2).  CLAMP selects the outside-branch variant.
-template <int K, bool CLAMP, bool FM = false>
+template <int K, bool CLAMP, bool FM = false, bool MK = false>
 __device__ __forceinline__ void edge_project(cptr_t rec, float w0, float w1, float w2,
                                              float& u0, float& u1, float& u2)
 {
     constexpr int B = (K + 1) % 3;
     const float e0 = rec[R_E + 3 * K + 0], e1 = rec[R_E + 3 * K + 1], e2 = rec[R_E + 3 * K + 2];
     const float eb = rec[R_E + 3 * K + B];
-    float ta = div_<FM>(w0 * e0 + w1 * e1 + w2 * e2 - eb, rec[R_DEN + K]);
+    const float num = w0 * e0 + w1 * e1 + w2 * e2 - eb;
+    float ta = MK ? div_by_recip(num, rec[R_DEN + K], rec[R_IDEN + K]) : div_<FM>(num, rec[R_DEN + K]);
     float tb = 1 - ta;
     float tc = 0;
     if (CLAMP) {
@@ -232,7 +267,7 @@ struct Frag {
 };
 
 // Euclidean point-to-face distance: K.cu:61-151
-template <bool FM = false>
+template <bool FM = false, bool MK = false>
 __device__ __forceinline__ void euclid(cptr_t rec, float xp, float yp,
                                        float w0, float w1, float w2, Frag& fr)
 {
@@ -241,7 +276,7 @@ __device__ __forceinline__ void euclid(cptr_t rec, float xp, float yp,
         float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
         float u0, u1, u2;
 #define LASR_TRY_EDGE(K)                                                          \
-        edge_project<K, false, FM>(rec, w0, w1, w2, u0, u1, u2);                      \
+        edge_project<K, false, FM, MK>(rec, w0, w1, w2, u0, u1, u2);                      \
         {                                                                         \
             const float px = u0 * x0 + u1 * x1 + u2 * x2;                         \
             const float py = u0 * y0 + u1 * y1 + u2 * y2;                         \
@@ -268,9 +303,9 @@ __device__ __forceinline__ void euclid(cptr_t rec, float xp, float yp,
         else if (w2 <= 0) a = 0;
         if (a < 0) a = 0;   // reference indexes [-1] here (UB); pinned to edge 0 like the oracle
         float u0, u1, u2;
-        if (a == 0) edge_project<0, true, FM>(rec, w0, w1, w2, u0, u1, u2);
-        else if (a == 1) edge_project<1, true, FM>(rec, w0, w1, w2, u0, u1, u2);
-        else edge_project<2, true, FM>(rec, w0, w1, w2, u0, u1, u2);
+        if (a == 0) edge_project<0, true, FM, MK>(rec, w0, w1, w2, u0, u1, u2);
+        else if (a == 1) edge_project<1, true, FM, MK>(rec, w0, w1, w2, u0, u1, u2);
+        else edge_project<2, true, FM, MK>(rec, w0, w1, w2, u0, u1, u2);
         fr.dx = u0 * x0 + u1 * x1 + u2 * x2;
         fr.dy = u0 * y0 + u1 * y1 + u2 * y2;
         fr.t0 = u0; fr.t1 = u1; fr.t2 = u2; fr.sign = -1.f;
@@ -285,9 +320,10 @@ __device__ __forceinline__ void barycentric(cptr_t rec, float xp, float yp, floa
     w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
 }
 
-template <bool FM = false>
+template <bool FM = false, bool MK = false>
 __device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, float sigma,
-                                           float xp, float yp, float w0, float w1, float w2, Frag& fr);
+                                           float xp, float yp, float w0, float w1, float w2, Frag& fr,
+                                           float inv_sigma = 0.f);
 
 template <bool FM = false>
 __device__ __forceinline__ bool fragment(cptr_t rec, int dist, float thr, float sigma,
@@ -297,9 +333,9 @@ __device__ __forceinline__ bool fragment(cptr_t rec, int dist, float thr, float 
     return fragment_w<FM>(rec, dist, thr, sigma, xp, yp, w0, w1, w2, fr);
 }
 
-template <bool FM>
+template <bool FM, bool MK>
 __device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, float sigma,
-                                           float xp, float yp, float w0, float w1, float w2, Frag& fr)
+                                           float xp, float yp, float w0, float w1, float w2, Frag& fr, float inv_sigma)
 {
     if (dist == 0) {
         if (!inside_closed(w0, w1, w2)) return false;
@@ -309,21 +345,24 @@ __device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, floa
         d = d > 0 ? d * d : -(d * d);
         fr.dis = d; fr.t0 = w0; fr.t1 = w1; fr.t2 = w2;
         if (-d >= thr) return false;
-        fr.D = sigmoid_neg_<FM>(div_<FM>(-d, sigma));
+        fr.D = sigmoid_neg_<FM>(MK ? div_by_recip(-d, sigma, inv_sigma) : div_<FM>(-d, sigma));
     } else {
-        euclid<FM>(rec, xp, yp, w0, w1, w2, fr);
+        euclid<FM, MK>(rec, xp, yp, w0, w1, w2, fr);
         fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
         if (fr.sign < 0 && fr.dis >= thr) return false;
-        fr.D = sigmoid_neg_<FM>(div_<FM>(-fr.sign * fr.dis, sigma));
+        fr.D = sigmoid_neg_<FM>(MK ? div_by_recip(-fr.sign * fr.dis, sigma, inv_sigma) : div_<FM>(-fr.sign * fr.dis, sigma));
     }
     return true;
 }
 
 // K.cu:423 (1. / float-sum evaluated in double; narrowing a double quotient of
 // floats is the correctly rounded float quotient, so a float division is identical)
-template <bool FM = false>
+template <bool FM = false, bool MK = false>
 __device__ __forceinline__ float depth_at(cptr_t rec, float c0, float c1, float c2)
 {
+    if (MK)
+        return 1.f / (div_by_recip(c0, rec[2], rec[R_IZ + 0]) + div_by_recip(c1, rec[5], rec[R_IZ + 1]) +
+                      div_by_recip(c2, rec[8], rec[R_IZ + 2]));
     return div_<FM>(1.f, div_<FM>(c0, rec[2]) + div_<FM>(c1, rec[5]) + div_<FM>(c2, rec[8]));
 }
 

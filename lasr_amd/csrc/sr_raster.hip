@@ -73,13 +73,16 @@ struct PixState {
     int fbest;
 };
 
-template <bool LASR_FAST>
+// uniform reciprocals for the exact division-by-reciprocal (sr_device.h); ok = all three divisors are in the safe range
+struct UniRecip { float inv_sigma, inv_gamma, inv_fmn; bool ok; };
+
+template <bool LASR_FAST, bool MK>
 __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, cptr_t rec,
                                              cptr_t tex, int fn, int lim, float xp, float yp,
-                                             float w0, float w1, float w2, PixState& s)
+                                             float w0, float w1, float w2, PixState& s, const UniRecip& U)
 {
     Frag fr;
-    if (!fragment_w<false>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) return;
+    if (!fragment_w<false, MK>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, U.inv_sigma)) return;
     const float D = fr.D;
     // alpha first (K.cu:409-417), before the depth test
     if (m.alpha == 0) { if ((double)D > 0.5) s.a = 1.f; }
@@ -88,7 +91,7 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
 
     float c0 = w0, c1 = w1, c2 = w2;
     clip_normalise(c0, c1, c2);
-    const float zp = depth_at(rec, c0, c1, c2);
+    const float zp = depth_at<false, MK>(rec, c0, c1, c2);
     if (zp < A.near || zp > A.far) return;
 
     const bool front = (__float_as_int(rec[R_FLAGS]) & 8) != 0;
@@ -101,10 +104,14 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
         }
     } else {
         if (front || m.double_side) {
-            const float zn = (A.far - zp) / (A.far - A.near);
+            const float fmn = A.far - A.near;
+            const float zn = MK ? div_by_recip(A.far - zp, fmn, U.inv_fmn) : (A.far - zp) / fmn;
             float rescale = 1.f;
-            if (zn > s.smax) { rescale = expf((s.smax - zn) / A.gamma); s.smax = zn; }
-            const float ez = expf((zn - s.smax) / A.gamma);
+            if (zn > s.smax) {
+                rescale = expf(MK ? div_by_recip(s.smax - zn, A.gamma, U.inv_gamma) : (s.smax - zn) / A.gamma);
+                s.smax = zn;
+            }
+            const float ez = expf(MK ? div_by_recip(zn - s.smax, A.gamma, U.inv_gamma) : (zn - s.smax) / A.gamma);
             s.ssum = rescale * s.ssum + ez * D;
             s.r = rescale * s.r + ez * D * sample_colour(tex, c0, c1, c2, A.res, 0, m.tex, lim);
             s.g = rescale * s.g + ez * D * sample_colour(tex, c0, c1, c2, A.res, 1, m.tex, lim);
@@ -163,6 +170,9 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * 3;
     const int texstride = A.T * 3;
     const float thr_pad = A.thr * 1.05f;   // slack of the conservative "certainly far" reject
+    UniRecip U;
+    U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
+    U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
     const int tX0 = tx * TILE, tX1 = tX0 + TILE - 1, tY0 = ty * TILE, tY1 = tY0 + TILE - 1;
     unsigned short* mine = s_mine[wave];
 
@@ -221,10 +231,12 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                     cand = cand && !certainly_far(rec, w0, w1, w2, thr_pad);
                     if (__ballot(cand) == 0ull) continue;
                 }
+                const int lim = (A.N * A.F - (bn * A.F + fn)) * A.T;   // texels to the end of the tensor
+                const cptr_t tex = as_const(texs + (size_t)fn * texstride);
+                const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
                 if (cand) {
-                    forward_face<LASR_FAST>(A, m, rec, as_const(texs + (size_t)fn * texstride), fn,
-                                            (A.N * A.F - (bn * A.F + fn)) * A.T /* texels to the end of the tensor */,
-                                            xp, yp, w0, w1, w2, s);
+                    if (mk) forward_face<LASR_FAST, true>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
+                    else forward_face<LASR_FAST, false>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
                 }
             }
         }
@@ -462,6 +474,18 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     }
 }
 
+// Self-test of the exact division-by-reciprocal: counts pairs where it differs (bitwise) from the IEEE quotient.
+__global__ __launch_bounds__(256) void selftest_div_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           int* __restrict__ mismatches, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float y = 1.f / b[i];
+    if (!recip_safe(b[i])) return;
+    const float q = div_by_recip(a[i], b[i], y), r = a[i] / b[i];
+    if (__float_as_int(q) != __float_as_int(r) && !(q != q && r != r)) atomicAdd(mismatches, 1);
+}
+
 }  // namespace lasr
 
 // ===========================================================================
@@ -619,4 +643,13 @@ extern "C" int lasr_sr_backward_dev(const float* faces, const float* textures, c
                                     double_side, hip_stream);
     g_near_far_dev = nullptr;
     return rc;
+}
+
+// Test hook: number of (a[i], b[i]) pairs for which div_by_recip(a, b, RN(1/b)) != a / b bitwise (added to *mismatches).
+extern "C" int lasr_selftest_div(const float* a, const float* b, int* mismatches, int n, void* hip_stream)
+{
+    if (!a || !b || !mismatches || n < 0) return LASR_E_BADARG;
+    if (n == 0) return LASR_OK;
+    hipLaunchKernelGGL(selftest_div_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, a, b, mismatches, n);
+    return launch_ok();
 }

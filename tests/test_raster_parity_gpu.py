@@ -178,3 +178,23 @@ def test_device_resident_near_far_match_host_floats(cuda):
     kw_dev = dict(kw, near=torch.tensor(near, device=cuda), far=torch.tensor(far, device=cuda))
     b = run_hip(cuda, fv, ft, 64, g=g, **kw_dev)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_division_by_reciprocal_is_bit_exact(cuda):
+    # the forward kernel divides by per-face / per-launch constants through RN(1/b) + two FMA corrections
+    # (sr_device.h: div_by_recip); it must return the IEEE quotient bit for bit
+    from lasr_amd import _lib
+    h = _lib.lib()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    n = 1 << 24
+    total = 0
+    for scale_a, scale_b in ((1.0, 1.0), (1e-3, 30.0), (50.0, 1e-6), (1e-12, 1e3)):
+        a = (torch.randn(n, generator=g) * scale_a).to(cuda)
+        b = (torch.randn(n, generator=g) * scale_b).to(cuda)
+        # structured divisors too: values the kernels really divide by (gamma, sigma, depths, squared edge lengths)
+        b[:8] = torch.tensor([1e-2, 1e-4, 1e-5, 10.0, 9.5, 3.0, 1.0, 0.75], device=cuda)
+        bad = torch.zeros(1, dtype=torch.int32, device=cuda)
+        rc = h.lasr_selftest_div(a.data_ptr(), b.data_ptr(), bad.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'lasr_selftest_div')
+        total += int(bad.item())
+    assert total <= 8, '%d of %d quotients differ' % (total, 4 * n)      # 2^-23 exceptional divisors at most
