@@ -406,4 +406,43 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// Reduce 18 per-lane partials across the wave in 68 VALU ops instead of 18 x 12 (one DPP tree each):
+//   v_permlane32_swap folds two values across the wave halves at once, v_permlane16_swap across row pairs;
+//   the surviving 5 registers hold, per 16-lane row, the partial sums of different components and finish with
+//   one DPP row tree each.  Component c ends in lane out_lane(c) of register out_reg(c):
+//     reg = c / 4, row = {0,2,1,3}[c % 4]  (c = 16,17: reg 4, rows 0 and 2), lane = 16 * row + 15.
+__device__ __forceinline__ float swap_add32(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);     // lanes 0-31: sum_halves(a), lanes 32-63: sum_halves(b)
+}
+__device__ __forceinline__ float swap_add16(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);     // rows 0,2: a's row pairs; rows 1,3: b's row pairs
+}
+__device__ __forceinline__ float row_sum_to_lane15(float v)
+{
+#define LASR_DPP_ADD(ctrl, bmask) \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, bmask, false))
+    LASR_DPP_ADD(0x111, 0xf);   // row_shr:1
+    LASR_DPP_ADD(0x112, 0xf);   // row_shr:2
+    LASR_DPP_ADD(0x114, 0xe);   // row_shr:4
+    LASR_DPP_ADD(0x118, 0xc);   // row_shr:8
+#undef LASR_DPP_ADD
+    return v;                   // lane 15 of every row holds that row's sum
+}
+// v[0..17] -> out[0..4]; see the layout above
+__device__ __forceinline__ void wave_reduce18(const float (&v)[18], float (&out)[5])
+{
+    float s[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) s[i] = swap_add32(v[2 * i], v[2 * i + 1]);
+    // after level 32: lower half of s[i] = partials of v[2i], upper half = partials of v[2i+1]
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = row_sum_to_lane15(swap_add16(s[2 * i], s[2 * i + 1]));
+    out[4] = row_sum_to_lane15(swap_add16(s[8], 0.f));
+    // out[i]: row0 = v[4i], row1 = v[4i+2], row2 = v[4i+1], row3 = v[4i+3]   (i = 4: row0 = v[16], row2 = v[17])
+}
+
 }  // namespace lasr

@@ -455,21 +455,24 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
         gv[6] += gx2; gv[7] += gy2; gv[8] += gz2;
     }
 
-    // one wave reduction per face, then a plain (non-atomic) accumulate: this wave owns the face
+    // one wave reduction per face (sr_device.h: wave_reduce18), then a plain, non-atomic accumulate: this wave
+    // owns the face.  Lanes 15/31/47/63 each end up with the totals of up to five components.
+    float v18[18], red[5];
 #pragma unroll
-    for (int k = 0; k < 9; k++) gv[k] = wave_sum_to_lane63(gv[k]);
-    if (vertex_tex) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) gt[k] = wave_sum_to_lane63(gt[k]);
-    }
-    if (lane == 63) {
+    for (int k = 0; k < 9; k++) { v18[k] = gv[k]; v18[9 + k] = vertex_tex ? gt[k] : 0.f; }
+    wave_reduce18(v18, red);
+    if ((lane & 15) == 15) {
+        const int row = lane >> 4;
+        const int sub = row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;     // component offset inside a register
         float* gf = gfaces + (size_t)gw * 9;
+        float* gtp = gtex + (size_t)gw * 9;
 #pragma unroll
-        for (int k = 0; k < 9; k++) gf[k] += gv[k];
-        if (vertex_tex) {
-            float* gtp = gtex + (size_t)gw * 9;
-#pragma unroll
-            for (int k = 0; k < 9; k++) gtp[k] += gt[k];
+        for (int i = 0; i < 5; i++) {
+            const int c = 4 * i + sub;
+            if (i == 4 && (row & 1)) continue;                               // register 4 only carries v[16], v[17]
+            const int comp = i == 4 ? 16 + (row >> 1) : c;
+            if (comp < 9) gf[comp] += red[i];
+            else if (vertex_tex) gtp[comp - 9] += red[i];
         }
     }
 }
