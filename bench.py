@@ -156,6 +156,21 @@ def optimize_leg(dev, iters):
                       'rasterised fwd+bwd per iteration, random-init encoder + perceptual net'}
 
 
+def measured_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, latest round), scaled
+    to this run's frames per launch.  PMC counters cannot be read from inside this process; the file records the
+    exact command they came from.  None if no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    k = d.get('kernels', {}).get(kernel)
+    if not k:
+        return None, None
+    return k['bytes'] * frames_per_launch / d['frames_per_launch'], os.path.basename(files[-1])
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -217,6 +232,7 @@ def main():
                'sr_setup_kernel': (36 + 160) * F * B}
         dom = max((k for k in ktimes if k != 'sr_setup_kernel'), key=lambda k: ktimes[k][0])
         achieved = alg[dom] / (ktimes[dom][0] * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(dom, B)
         frames = world * B * a.steps
         out = {
             'metric': 'rasterizer fwd+bwd frames/sec at 256x256, 2.3k faces',
@@ -228,7 +244,7 @@ def main():
                        'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
                        'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ktimes[dom][0],
                          'all_kernels_avg_ms': {k: v[0] for k, v in ktimes.items()}},
         }
