@@ -7,7 +7,7 @@
 
 Workload (BASELINE configs[1]): mesh M2 (geodesic nu=11, V=1212, F=2420,
 the "~1.2k vert / 2.3k face" mesh), 256x256, LASR's raster modes (euclidean / softmax /
-prod / vertex colours, sigma 1e-4, gamma 1e-2), B synthetic yaw-rotated frames per GPU per
+prod / vertex colours, sigma 1e-4, gamma 1e-2), B=256 synthetic yaw-rotated frames per GPU per
 step, upstream gradient N(0,1)/P.  Inputs are resident in HBM before the timed region.
 
 One step = for the rank's B frames: fill soft_colors with the background, zero the gradient
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--frames', type=int, default=64, help='frames per GPU per step')
+    ap.add_argument('--frames', type=int, default=256, help='frames per GPU per step (SURVEY 8d batches: 1/16/64/256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
     return ap.parse_args()
