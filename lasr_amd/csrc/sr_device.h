@@ -230,7 +230,8 @@ template <bool FM> __device__ __forceinline__ float sigmoid_neg_(float neg_arg)
 
 // Conservative reject for the compaction stages: true only if the pixel is certainly farther than
 // sqrt(thr) from the face (so the reference's `dis >= threshold` test would skip it as well).
-__device__ __forceinline__ bool certainly_far(cptr_t rec, float w0, float w1, float w2, float thr_pad)
+template <typename RP>
+__device__ __forceinline__ bool certainly_far(RP rec, float w0, float w1, float w2, float thr_pad)
 {
     return (w0 < 0.f && w0 * w0 * rec[R_HK2 + 0] > thr_pad) ||
            (w1 < 0.f && w1 * w1 * rec[R_HK2 + 1] > thr_pad) ||
@@ -239,8 +240,8 @@ __device__ __forceinline__ bool certainly_far(cptr_t rec, float w0, float w1, fl
 
 // One edge projection with compile-time edge K (a=K, b=K+1, c=K+2 mod 3): K.cu:85-95 / 136-148.
 // Returns u (already minus w) in (u0,u1,u2).  CLAMP selects the outside-branch variant.
-template <int K, bool CLAMP, bool FM = false, bool MK = false>
-__device__ __forceinline__ void edge_project(cptr_t rec, float w0, float w1, float w2,
+template <int K, bool CLAMP, bool FM = false, bool MK = false, typename RP = cptr_t>
+__device__ __forceinline__ void edge_project(RP rec, float w0, float w1, float w2,
                                              float& u0, float& u1, float& u2)
 {
     constexpr int B = (K + 1) % 3;
@@ -267,8 +268,8 @@ struct Frag {
 };
 
 // Euclidean point-to-face distance: K.cu:61-151
-template <bool FM = false, bool MK = false>
-__device__ __forceinline__ void euclid(cptr_t rec, float xp, float yp,
+template <bool FM = false, bool MK = false, typename RP = cptr_t>
+__device__ __forceinline__ void euclid(RP rec, float xp, float yp,
                                        float w0, float w1, float w2, Frag& fr)
 {
     const float x0 = rec[0], y0 = rec[1], x1 = rec[3], y1 = rec[4], x2 = rec[6], y2 = rec[7];
@@ -313,28 +314,29 @@ __device__ __forceinline__ void euclid(cptr_t rec, float xp, float yp,
 }
 
 // Fragment probability of the face in `rec` at (xp,yp): K.cu:387-404.  false = face skipped.
-__device__ __forceinline__ void barycentric(cptr_t rec, float xp, float yp, float& w0, float& w1, float& w2)
+template <typename RP>
+__device__ __forceinline__ void barycentric(RP rec, float xp, float yp, float& w0, float& w1, float& w2)
 {
     w0 = rec[R_INV + 0] * xp + rec[R_INV + 1] * yp + rec[R_INV + 2];   // K.cu:24-29
     w1 = rec[R_INV + 3] * xp + rec[R_INV + 4] * yp + rec[R_INV + 5];
     w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
 }
 
-template <bool FM = false, bool MK = false>
-__device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, float sigma,
+template <bool FM = false, bool MK = false, typename RP = cptr_t>
+__device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float sigma,
                                            float xp, float yp, float w0, float w1, float w2, Frag& fr,
                                            float inv_sigma = 0.f);
 
-template <bool FM = false>
-__device__ __forceinline__ bool fragment(cptr_t rec, int dist, float thr, float sigma,
+template <bool FM = false, typename RP = cptr_t>
+__device__ __forceinline__ bool fragment(RP rec, int dist, float thr, float sigma,
                                          float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
 {
     barycentric(rec, xp, yp, w0, w1, w2);
     return fragment_w<FM>(rec, dist, thr, sigma, xp, yp, w0, w1, w2, fr);
 }
 
-template <bool FM, bool MK>
-__device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, float sigma,
+template <bool FM, bool MK, typename RP>
+__device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float sigma,
                                            float xp, float yp, float w0, float w1, float w2, Frag& fr, float inv_sigma)
 {
     if (dist == 0) {
@@ -357,8 +359,8 @@ __device__ __forceinline__ bool fragment_w(cptr_t rec, int dist, float thr, floa
 
 // K.cu:423 (1. / float-sum evaluated in double; narrowing a double quotient of
 // floats is the correctly rounded float quotient, so a float division is identical)
-template <bool FM = false, bool MK = false>
-__device__ __forceinline__ float depth_at(cptr_t rec, float c0, float c1, float c2)
+template <bool FM = false, bool MK = false, typename RP = cptr_t>
+__device__ __forceinline__ float depth_at(RP rec, float c0, float c1, float c2)
 {
     if (MK)
         return 1.f / (div_by_recip(c0, rec[2], rec[R_IZ + 0]) + div_by_recip(c1, rec[5], rec[R_IZ + 1]) +
@@ -379,7 +381,8 @@ __device__ __forceinline__ int surface_texel(float c0, float c1, int res)
 }
 
 // K.cu:178-194
-__device__ __forceinline__ float sample_colour(cptr_t tex, float c0, float c1, float c2,
+template <typename TP>
+__device__ __forceinline__ float sample_colour(TP tex, float c0, float c1, float c2,
                                                int res, int ch, int tex_type, int lim)
 {
     if (tex_type == 0) {
