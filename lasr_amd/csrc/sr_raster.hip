@@ -169,7 +169,6 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * 3;
     const int texstride = A.T * 3;
-    const float thr_pad = A.thr * 1.05f;   // slack of the conservative "certainly far" reject
     UniRecip U;
     U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
     U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
@@ -212,8 +211,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 if (hit && m.dist == 2) {
                     // Tighter cull, lanes = list entries: the barycentric w_k is linear in the pixel position, so if
                     // all four corners of the quadrant lie beyond edge k's line by more than sqrt(1.10 thr), every
-                    // pixel of the quadrant does too and the per-pixel reject below (slack 1.05) would drop all of
-                    // them.  Same faces contribute, ~20 % fewer entries to walk.  Well-conditioned faces only.
+                    // pixel of the quadrant does too, i.e. the reference's `dis >= threshold` test (K.cu:402) drops
+                    // every one of them.  Same faces contribute, ~20 % fewer entries to walk.  Well-conditioned faces only.
                     const float* R = recs + (size_t)(base + e) * REC;
                     if (__float_as_int(R[R_FLAGS]) & 16) {
 #pragma unroll
@@ -245,12 +244,6 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                             py >= (int)(short)(ry & 0xffff) && py <= (ry >> 16);
                 float w0, w1, w2;
                 barycentric(rec, xp, yp, w0, w1, w2);
-                if (m.dist == 2 && (__float_as_int(rec[R_FLAGS]) & 16)) {
-                    // well-conditioned face: pixels certainly farther than sqrt(threshold) are the ones the
-                    // reference drops at K.cu:402; skip the distance code when that is the whole wave
-                    cand = cand && !certainly_far(rec, w0, w1, w2, thr_pad);
-                    if (__ballot(cand) == 0ull) continue;
-                }
                 const int lim = (A.N * A.F - (bn * A.F + fn)) * A.T;   // texels to the end of the tensor
                 const cptr_t tex = as_const(texs + (size_t)fn * texstride);
                 const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
@@ -536,6 +529,7 @@ static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alph
     if (N < 0 || F < 0 || T < 1 || IS < 0) return LASR_E_BADARG;
     if (dist < 0 || dist > 2 || rgb < 0 || rgb > 1 || alpha < 0 || alpha > 2 || tex < 0 || tex > 1) return LASR_E_BADMODE;
     if ((long long)N * F > 0x7fffffffLL / 64 || (long long)N * IS * IS > 0x7fffffffLL) return LASR_E_BADARG;
+    if (IS > 32767) return LASR_E_BADARG;   // pixel rects are stored as int16
     return LASR_OK;
 }
 
