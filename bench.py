@@ -135,25 +135,26 @@ def optimize_leg(dev, iters):
     from lasr_amd.nnutils import train_utils
     opts = optimize.parse_flags(['--name', 'bench', '--checkpoint_dir', '', '--only_mean_sym', '--nouse_gtpose',
                                  '--subdivide', '3', '--n_bones', '21', '--n_hypo', '8', '--num_epochs', '5',
-                                 '--batch_size', '1', '--opt_tex', 'yes', '--iters_per_epoch', str(iters + 3)])
+                                 '--batch_size', '1', '--opt_tex', 'yes', '--iters_per_epoch', str(iters + 6), '--use_graph'])
     opts.local_rank = dev.index
     torch.manual_seed(0)
     tr = train_utils.LASRTrainer(opts).init_training()
     tr.model.train()
     tr.reinit_bones()
-    for i in range(3):
+    for i in range(6):                               # iteration 0 renders the part image; 1.. capture + replay the graph
         tr.module.iters = i
         tr.train_step(tr.set_input(tr.dataloader[i]))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(iters):
-        tr.module.iters = 3 + i
-        loss, _ = tr.train_step(tr.set_input(tr.dataloader[3 + i]))
+        tr.module.iters = 6 + i
+        loss, _ = tr.train_step(tr.set_input(tr.dataloader[6 + i]))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {'iters_per_s': iters / dt, 'ms_per_iter': dt / iters * 1e3, 'iters': iters, 'final_loss': float(loss),
             'config': 'spot3 stage 0: batch 1 pair, n_hypo 8, n_bones 21, V=642/F=1280, 256x256, 48 images '
-                      'rasterised fwd+bwd per iteration, random-init encoder + perceptual net'}
+                      'rasterised fwd+bwd per iteration, random-init encoder + perceptual net; forward+backward replayed '
+                      'as one HIP graph (--use_graph), optimiser eager'}
 
 
 def measured_traffic(kernel, frames_per_launch):

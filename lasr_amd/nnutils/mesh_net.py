@@ -361,9 +361,8 @@ def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0,
     (mesh_net.py:75-104).  Returns flow [B*H,IS,IS,2], bgmask (bool), fgmask."""
     n_hypo = verts.shape[0] // faces.shape[0]
     faces = faces[:, None].repeat(1, n_hypo, 1, 1).view(-1, faces.shape[1], 3)
-    eye = torch.tensor(renderer_soft.transform.transformer._eye, dtype=verts.dtype, device=verts.device)[None, None]
-    verts_pre = verts[:, :, :3] + eye
-    verts_pre = verts_pre * verts_pre.new_tensor([1, -1, 1])
+    eye = sr.functional.const_tensor(renderer_soft.transform.transformer._eye, verts.device)[None, None]
+    verts_pre = (verts[:, :, :3] + eye) * sr.functional.const_tensor([1, -1, 1], verts.device)
     nb = verts.shape[0]
     px = renderer_soft.render_mesh(sr.Mesh(torch.cat([verts_pre, verts_pre], 0), torch.cat([faces, faces], 0),
                                            textures=torch.cat([verts_pos0[:, :, :3], verts_pos1[:, :, :3]], 0),
@@ -373,7 +372,7 @@ def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0,
     p0 = px[:nb].permute(0, 2, 3, 1)
     p1 = px[nb:].permute(0, 2, 3, 1)
     bgmask = (p0[:, :, :, 2] < 1e-9) | (p1[:, :, :, 2] < 1e-9)
-    ten = p0.new_tensor(10.)
+    ten = sr.functional.const_tensor([10.], p0.device)[0]
     p0 = torch.where(bgmask[..., None], ten, p0)
     p1 = torch.where(bgmask[..., None], ten, p1)
 
@@ -523,8 +522,8 @@ class LASR(MeshNet):
 
         # ---- 3) texture + silhouette rendering (:348-363).  The reference recomputes LBS + projection here from
         # a clone of the same Rmat (verts_tex == verts_fl) and once more for a never-rendered verts_mask: reused.
-        eye3 = torch.tensor(self.renderer_softtex.transform.transformer._eye, device=verts_fl.device)[None, None]
-        verts_pre = (verts_fl[:, :, :3] + eye3) * verts_fl.new_tensor([1, -1, 1])
+        eye3 = sr.functional.const_tensor(self.renderer_softtex.transform.transformer._eye, verts_fl.device)[None, None]
+        verts_pre = (verts_fl[:, :, :3] + eye3) * sr.functional.const_tensor([1, -1, 1], verts_fl.device)
         self.renderer_softtex.rasterizer.background_color = [1, 1, 1]
         faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
         tex_img = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=tex, texture_type='vertex'))
@@ -575,11 +574,11 @@ class LASR(MeshNet):
         total = total + self.triangle_loss
         if (not opts.symmetric) and opts.symmetric_loss:                          # symmetry (:461-478)
             pa = pred_v.view(n2, H, -1, 3)[0]
-            pb = pa * pa.new_tensor([-1, 1, 1])
+            pb = pa * sr.functional.const_tensor([-1, 1, 1], pa.device)
             total = total + point_mesh_face_distance(pa, self.faces, pb) + point_mesh_face_distance(pb, self.faces, pa)
             if opts.opt_tex == 'yes':
                 p1 = pred_v[:1].detach()
-                idx1 = nearest_index(p1, p1 * p1.new_tensor([-1, 1, 1]))
+                idx1 = nearest_index(p1, p1 * sr.functional.const_tensor([-1, 1, 1], p1.device))
                 total = total + (self.tex[0][idx1[0]].detach() - self.tex[0]).abs().mean() * 1e-3
         # 5) deformation (:481-497)
         if K > 1:
@@ -590,7 +589,7 @@ class LASR(MeshNet):
             total = total + self.arap_loss
             if opts.symmetric_loss:                                              # bone symmetry (:500-503)
                 ca = self.ctl_ts.view(H, -1, 3)
-                total = total + 0.1 * chamfer_distance(ca, ca * ca.new_tensor([-1, 1, 1]))
+                total = total + 0.1 * chamfer_distance(ca, ca * sr.functional.const_tensor([-1, 1, 1], ca.device))
         # 7) camera (:506-522)
         if opts.use_gtpose:
             cam = geodesic_distance(quat.view(-1, 3, 3), quat_pred.view(-1, 3, 3)).mean()

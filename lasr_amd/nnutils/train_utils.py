@@ -90,6 +90,9 @@ class LASRTrainer:
     # ---- optimisation -----------------------------------------------------------------------
     def init_training(self):
         opts = self.opts
+        if getattr(opts, 'use_graph', False) and self.device.type == 'cuda' and not self.distributed:
+            self._stream = torch.cuda.Stream(self.device)     # see _graphed_forward_backward
+            torch.cuda.set_stream(self._stream)
         self.init_dataset()
         self.define_model()
         m = self.module
@@ -107,12 +110,63 @@ class LASRTrainer:
             anneal_strategy='linear', final_div_factor=1. / 25)
         return self
 
+    # ---- HIP-graph replay of forward + backward -------------------------------------------------
+    # The step issues ~2.6k small kernels (ResNet-18, loss glue) and is bound by host launch cost, not by the GPU.
+    # With --use_graph the forward + backward of one iteration is captured once per (epoch, configuration) into a
+    # HIP graph and replayed with the batch copied into static buffers; clipping, the NaN guard, AdamW and the LR
+    # schedule stay eager.  Single-process only (DDP's bucketed all-reduce hooks are left uncaptured on purpose).
+    def _graph_key(self):
+        m, o = self.module, self.opts
+        noisy = o.noise and m.epoch > 0 and 1 < m.iters < 100
+        if self.distributed or not getattr(o, 'use_graph', False) or self.device.type != 'cuda':
+            return None
+        if noisy or m.iters == 0:                       # python-side branches that change the op sequence
+            return None
+        return (m.epoch, int(m.optim_idx))
+
+    def _graphed_forward_backward(self, batch, key):
+        g = self._graphs.get(key) if hasattr(self, '_graphs') else None
+        if g is None:
+            if not hasattr(self, '_graphs'):
+                self._graphs, self._static = {}, {k: v.clone() for k, v in batch.items()}
+            for k, v in batch.items():
+                self._static[k].copy_(v)
+            # Everything (eager iterations included) runs on self._stream, a non-default stream chosen in
+            # init_training: the captured backward then never has to hand gradients to an AccumulateGrad node that
+            # lives on another stream (a cross-stream dependency inside a capture crashes hipStreamEndCapture here).
+            import gc
+            m = self.module
+            for k, v in list(vars(m).items()):          # and no stale autograd graph stays alive
+                if torch.is_tensor(v) and v.grad_fn is not None:
+                    setattr(m, k, v.detach())
+            gc.collect()
+            for _ in range(2):                          # warm up allocator / MIOpen for exactly this op sequence
+                self.optimizer.zero_grad(set_to_none=True)
+                loss, _ = self.model(self._static)
+                loss.mean().backward()
+            del loss
+            self.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self._stream):
+                loss, aux = self.model(self._static)
+                loss.mean().backward()
+            g = self._graphs[key] = (graph, loss, aux)
+        for k, v in batch.items():
+            self._static[k].copy_(v)
+        g[0].replay()
+        return g[1], g[2]
+
     def train_step(self, batch):
         """forward, backward (DDP all-reduces the gradients), clipping + NaN guard, AdamW, OneCycleLR (:274-296)."""
         m = self.module
-        self.optimizer.zero_grad()
-        total_loss, aux = self.model(batch)
-        total_loss.mean().backward()
+        key = self._graph_key()
+        if key is not None:
+            total_loss, aux = self._graphed_forward_backward(batch, key)
+        else:
+            self.optimizer.zero_grad(set_to_none=not hasattr(self, '_graphs'))
+            total_loss, aux = self.model(batch)
+            total_loss.mean().backward()
         cam_grad, finite = [], []
         for name, p in m.named_parameters():
             if p.grad is None:
@@ -124,7 +178,7 @@ class LASRTrainer:
             finite.append(p.grad.sum())
         self.grad_cam_norm = torch.nn.utils.clip_grad_norm_(cam_grad, 10.) if cam_grad else None
         if finite and not bool(torch.isfinite(torch.stack(finite).sum())):     # one sync (the reference: ~70)
-            self.optimizer.zero_grad()
+            self.optimizer.zero_grad(set_to_none=not hasattr(self, '_graphs'))
         self.optimizer.step()
         self.scheduler.step()
         return total_loss.detach(), aux

@@ -7,10 +7,24 @@ import torch
 import torch.nn.functional as F
 
 
+_CONSTS = {}
+
+
+def const_tensor(values, device):
+    """Device tensor for a small Python constant (eye position, light colour, axis flips ...), created once per
+    (device, value): building it anew on every call is a pageable host->device copy, which costs a launch each time
+    and is illegal while a HIP graph is being captured."""
+    key = (str(device), tuple(float(v) for v in values))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(list(key[1]), dtype=torch.float32, device=device)
+    return t
+
+
 def _vec(x, device, batch):
     """list/tuple/ndarray/tensor -> float32 tensor [batch or 1, 3] on `device`."""
     if isinstance(x, (list, tuple)):
-        x = torch.tensor(x, dtype=torch.float32, device=device)
+        x = const_tensor(x, device)
     elif isinstance(x, np.ndarray):
         x = torch.from_numpy(x).to(device)
     else:

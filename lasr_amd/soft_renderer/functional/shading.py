@@ -7,7 +7,8 @@ import torch.nn.functional as F
 
 def _rgb(x, device):
     if isinstance(x, (tuple, list)):
-        x = torch.tensor(x, dtype=torch.float32, device=device)
+        from .cameras import const_tensor
+        x = const_tensor(x, device)
     elif isinstance(x, np.ndarray):
         x = torch.from_numpy(x).float().to(device)
     return x[None, :] if x.ndimension() == 1 else x

@@ -104,3 +104,26 @@ def test_training_reduces_the_loss_and_checkpoints(tmp_path, cuda):
     assert torch.allclose(tr2.module.mean_v[0], full, atol=1e-6)
     l, _ = tr2.model.train()(tr2.set_input(tr2.dataloader[0]))
     assert torch.isfinite(l)
+
+
+def test_graph_replay_matches_eager_forward(tmp_path, cuda):
+    # --use_graph replays forward+backward as one HIP graph; same batch + same parameters must give the eager loss
+    tr = make_trainer(tmp_path, iters_per_epoch=6, use_graph=True)
+    tr.model.train()
+    tr.reinit_bones()
+    m = tr.module
+    for i in range(3):                                   # iteration 0 eager (part render), then capture + replay
+        m.iters = i
+        tr.train_step(tr.set_input(tr.dataloader[i]))
+    assert hasattr(tr, '_graphs') and len(tr._graphs) == 1
+    m.iters = 3
+    batch = tr.set_input(tr.dataloader[3])
+    with torch.no_grad():
+        pass
+    eager_loss, _ = tr.model({k: v.clone() for k, v in batch.items()})
+    eager_loss = float(eager_loss.detach())
+    graph_loss, _ = tr._graphed_forward_backward(batch, tr._graph_key())
+    assert abs(float(graph_loss.detach()) - eager_loss) <= 1e-4 * max(1.0, abs(eager_loss))
+    g = m.mean_v.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    torch.cuda.set_stream(torch.cuda.default_stream())   # the trainer switched the current stream; restore for other tests
