@@ -93,6 +93,12 @@ __device__ __forceinline__ int last_pixel_le(float hi, int IS)
     return i;                                   // in [-1, IS-1]; -1 = no pixel
 }
 
+// same value, cheaper when the image size is a power of two (1/IS and the product are then exact)
+__device__ __forceinline__ float pix_center_p2(int i, int is, float inv_is, bool pow2)
+{
+    return pow2 ? (float)(2 * i + 1 - is) * inv_is : pix_center(i, is);
+}
+
 __device__ __forceinline__ void build_record(const float* __restrict__ f, float* __restrict__ rec,
                                              short4* __restrict__ rect, float margin, int IS,
                                              float* __restrict__ info27)
@@ -221,11 +227,22 @@ template <bool FM> __device__ __forceinline__ float div_(float a, float b)
 {
     return FM ? a * __builtin_amdgcn_rcpf(b) : a / b;
 }
-template <bool FM> __device__ __forceinline__ float exp_(float x) { return FM ? __expf(x) : expf(x); }
+// exp(x) to ~1 ulp in 7 VALU ops: n = rint(x log2 e), f = x log2 e - n evaluated with a two-term log2 e (so the
+// reduction error does not grow with |x|), 2^f by v_exp_f32 (|f| <= 0.5), scaled by 2^n with v_ldexp_f32.
+// The library expf spends about twice that on special cases that cannot occur here (|x| < ~110, results that
+// underflow simply flush towards 0 as exp() itself does).
+__device__ __forceinline__ float exp_1ulp(float x)
+{
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+    const float n = rintf(x * L2E_HI);
+    const float f = __builtin_fmaf(x, L2E_LO, __builtin_fmaf(x, L2E_HI, -n));
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+template <bool FM> __device__ __forceinline__ float exp_(float x) { return FM ? __expf(x) : exp_1ulp(x); }
 template <bool FM> __device__ __forceinline__ float sigmoid_neg_(float neg_arg)
 {
     if (FM) return __builtin_amdgcn_rcpf(1.f + __expf(neg_arg));
-    return (float)(1. / (1. + (double)expf(neg_arg)));   // K.cu:397,403 promote this to double
+    return (float)(1. / (1. + (double)exp_1ulp(neg_arg)));   // K.cu:397,403 promote this to double
 }
 
 // Conservative reject for the compaction stages: true only if the pixel is certainly farther than

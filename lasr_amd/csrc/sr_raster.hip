@@ -108,10 +108,10 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
             const float zn = MK ? div_by_recip(A.far - zp, fmn, U.inv_fmn) : (A.far - zp) / fmn;
             float rescale = 1.f;
             if (zn > s.smax) {
-                rescale = expf(MK ? div_by_recip(s.smax - zn, A.gamma, U.inv_gamma) : (s.smax - zn) / A.gamma);
+                rescale = exp_1ulp(MK ? div_by_recip(s.smax - zn, A.gamma, U.inv_gamma) : (s.smax - zn) / A.gamma);
                 s.smax = zn;
             }
-            const float ez = expf(MK ? div_by_recip(zn - s.smax, A.gamma, U.inv_gamma) : (zn - s.smax) / A.gamma);
+            const float ez = exp_1ulp(MK ? div_by_recip(zn - s.smax, A.gamma, U.inv_gamma) : (zn - s.smax) / A.gamma);
             s.ssum = rescale * s.ssum + ez * D;
             s.r = rescale * s.r + ez * D * sample_colour(tex, c0, c1, c2, A.res, 0, m.tex, lim);
             s.g = rescale * s.g + ez * D * sample_colour(tex, c0, c1, c2, A.res, 1, m.tex, lim);
@@ -328,6 +328,8 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     // cheap reject only for the soft distance modes and well-conditioned faces; 2 % slack on thr
     const bool use_far = (m.dist == 2) && (flags & 16);
     const float thr_pad = A.thr * 1.05f;
+    const float inv_is = 1.f / (float)IS;
+    const bool pow2 = (IS & (IS - 1)) == 0;      // then n * (1/IS) == n / IS exactly: skip the division per pixel
 
     // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
     int r = 0, c = 0;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
             bool keep = in_range;                              // every pixel of the rect passes the bbox test
             if (in_range && use_far) {
                 float w0, w1, w2;
-                barycentric(rec, pix_center(xi, IS), pix_center(IS - 1 - row, IS), w0, w1, w2);
+                barycentric(rec, pix_center_p2(xi, IS, inv_is, pow2), pix_center_p2(IS - 1 - row, IS, inv_is, pow2), w0, w1, w2);
                 keep = !certainly_far(rec, w0, w1, w2, thr_pad);
             }
             const unsigned long long mask = __ballot(keep);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
         if (!active) continue;
         const int xi = packed & 0xffff, row = packed >> 16;
         const int pn = row * IS + xi;
-        const float xp = pix_center(xi, IS), yp = pix_center(IS - 1 - row, IS);
+        const float xp = pix_center_p2(xi, IS, inv_is, pow2), yp = pix_center_p2(IS - 1 - row, IS, inv_is, pow2);
 
         float w0, w1, w2;
         Frag fr;
