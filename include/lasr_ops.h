@@ -27,9 +27,10 @@ extern "C" {
  */
 int lasr_lbs_forward(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out,
                      int N, int V, int K, int tocam, void* hip_stream);
+size_t lasr_lbs_backward_scratch_floats(int N, int V, int K);     /* chunk partials of the transform gradients */
 int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                       const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
-                      float* grad_skin, int N, int V, int K, int tocam, void* hip_stream);
+                      float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream);
 
 /*
  * Pinhole projection, nnutils/geom_utils.py:27-34 (pinhole_cam), with pp / fl already expanded per mesh:

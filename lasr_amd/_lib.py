@@ -23,7 +23,8 @@ SIGNATURES = {
     'lasr_sr_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
     # include/lasr_ops.h
     'lasr_lbs_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    'lasr_lbs_backward': (_i, [_p] * 9 + [_i, _i, _i, _i, _p]),
+    'lasr_lbs_backward_scratch_floats': (_sz, [_i, _i, _i]),
+    'lasr_lbs_backward': (_i, [_p] * 10 + [_i, _i, _i, _i, _p]),
     'lasr_pinhole_forward': (_i, [_p, _p, _p, _p, _i, _i, _p]),
     'lasr_pinhole_backward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_loss_scratch_floats': (_sz, [_i, _i, _i]),

@@ -98,26 +98,32 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(const float* __restric
     }
 }
 
-// Backward: one block per mesh (tiny problem: V ~ 1e3, K ~ 30).  Phase A, thread per vertex: blend
-// matrix, g_verts, g_skin, and the 12 body-transform accumulators.  Phase B, thread per (bone, 1/8 of the
-// vertices): g_R / g_T of the part bones, folded across the 8 partial lanes with DPP.  No atomics.
+// Backward.  Pass 1, one block per (mesh, 256-vertex chunk): thread per vertex -> g_verts, g_skin and the block's
+// partial sums of the transform gradients: the body transform through block_sum, the part bones as
+// partial[k][c] = sum_{v in chunk} skin[k][v] * G[v][c] with G (= d out / d blended transform, 12 columns) staged
+// in LDS and one thread per (bone, column).  Pass 2 folds the chunk partials in a fixed order.  No atomics.
+constexpr int LBS_CHUNK = 256;
+
 __global__ __launch_bounds__(256) void lbs_backward_kernel(const float* __restrict__ verts, const float* __restrict__ Rmat,
                                                            const float* __restrict__ Tmat, const float* __restrict__ skin,
                                                            const float* __restrict__ gout, float* __restrict__ gverts,
-                                                           float* __restrict__ gR, float* __restrict__ gT,
-                                                           float* __restrict__ gskin, int N, int V, int K, int tocam)
+                                                           float* __restrict__ gskin, float* __restrict__ partial,
+                                                           int N, int V, int K, int tocam)
 {
-    extern __shared__ float lds[];          // [K*12] transforms, then 4 floats for block_sum
-    const int n = blockIdx.x, tid = threadIdx.x, nb = K - 1;
+    extern __shared__ float lds[];          // RT[K*12] | G[256*13] | red[4]
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, tid = threadIdx.x, nb = K - 1;
     float* RT = lds;                        // RT[k*12 + c], k = 0 body
-    float* red = lds + K * 12;
+    float* Gs = lds + K * 12;               // G[v_local*13 + c] (13: odd stride, conflict-free column reads)
+    float* red = Gs + LBS_CHUNK * 13;
     for (int i = tid; i < K * 12; i += 256) {
         const int k = i / 12, c = i - k * 12;
         RT[i] = c < 9 ? Rmat[((size_t)n * K + k) * 9 + c] : Tmat[((size_t)n * K + k) * 3 + (c - 9)];
     }
     __syncthreads();
+    const int v = chunk * LBS_CHUNK + tid;
     float accR0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, accT0[3] = {0, 0, 0};
-    for (int v = tid; v < V; v += 256) {
+    float G[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (v < V) {
         const size_t o = ((size_t)n * V + v) * 3;
         const float px = verts[o], py = verts[o + 1], pz = verts[o + 2];
         const float g0 = gout[o], g1 = gout[o + 1], g2 = gout[o + 2];
@@ -132,13 +138,14 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(const float* __restri
 #pragma unroll
             for (int c = 0; c < 12; c++) M[c] = 0.f;
             // G[c] = d out / d RT_blend[c] contracted with g_vs: (v_i * h_j | h_j)
-            const float G[12] = {px * h0, px * h1, px * h2, py * h0, py * h1, py * h2, pz * h0, pz * h1, pz * h2, h0, h1, h2};
+            G[0] = px * h0; G[1] = px * h1; G[2] = px * h2; G[3] = py * h0; G[4] = py * h1; G[5] = py * h2;
+            G[6] = pz * h0; G[7] = pz * h1; G[8] = pz * h2; G[9] = h0; G[10] = h1; G[11] = h2;
             for (int k = 0; k < nb; k++) {
-                const float s = skin[((size_t)n * nb + k) * V + v];
+                const float sk = skin[((size_t)n * nb + k) * V + v];
                 const float* b = RT + (k + 1) * 12;
                 float d = 0.f;
 #pragma unroll
-                for (int c = 0; c < 12; c++) { M[c] += s * b[c]; d += G[c] * b[c]; }
+                for (int c = 0; c < 12; c++) { M[c] += sk * b[c]; d += G[c] * b[c]; }
                 if (gskin) gskin[((size_t)n * nb + k) * V + v] = d;
             }
         }
@@ -151,59 +158,40 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(const float* __restri
             const float s0 = px * M[0] + py * M[3] + pz * M[6] + M[9];
             const float s1 = px * M[1] + py * M[4] + pz * M[7] + M[10];
             const float s2 = px * M[2] + py * M[5] + pz * M[8] + M[11];
-            accR0[0] += s0 * g0; accR0[1] += s0 * g1; accR0[2] += s0 * g2;
-            accR0[3] += s1 * g0; accR0[4] += s1 * g1; accR0[5] += s1 * g2;
-            accR0[6] += s2 * g0; accR0[7] += s2 * g1; accR0[8] += s2 * g2;
-            accT0[0] += g0; accT0[1] += g1; accT0[2] += g2;
+            accR0[0] = s0 * g0; accR0[1] = s0 * g1; accR0[2] = s0 * g2;
+            accR0[3] = s1 * g0; accR0[4] = s1 * g1; accR0[5] = s1 * g2;
+            accR0[6] = s2 * g0; accR0[7] = s2 * g1; accR0[8] = s2 * g2;
+            accT0[0] = g0; accT0[1] = g1; accT0[2] = g2;
         }
     }
-    // body bone (k = 0)
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        const float t = block_sum(accR0[c], red);
-        if (tid == 0 && gR) gR[((size_t)n * K) * 9 + c] = tocam ? t : 0.f;
+    for (int c = 0; c < 12; c++) Gs[tid * 13 + c] = G[c];      // zeros for v >= V
+    float* P = partial + ((size_t)n * nchunks + chunk) * K * 12;
+#pragma unroll
+    for (int c = 0; c < 9; c++) { const float t = block_sum(accR0[c], red); if (tid == 0) P[c] = tocam ? t : 0.f; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float t = block_sum(accT0[c], red); if (tid == 0) P[9 + c] = tocam ? t : 0.f; }
+    __syncthreads();
+    const int nv = min(LBS_CHUNK, V - chunk * LBS_CHUNK);
+    for (int i = tid; i < nb * 12; i += 256) {               // thread per (part bone, column)
+        const int k = i / 12, c = i - k * 12;
+        const float* sk = skin + ((size_t)n * nb + k) * V + (size_t)chunk * LBS_CHUNK;
+        float a = 0.f;
+        for (int u = 0; u < nv; u++) a += sk[u] * Gs[u * 13 + c];
+        P[(k + 1) * 12 + c] = a;
     }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float t = block_sum(accT0[c], red);
-        if (tid == 0 && gT) gT[((size_t)n * K) * 3 + c] = tocam ? t : 0.f;
-    }
-    // part bones: thread (k, part) with k = tid / 8, part = tid % 8; bones beyond 32 in further rounds
-    for (int kb = 0; kb < nb; kb += 32) {
-        const int k = kb + (tid >> 3), part = tid & 7;
-        float a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (k < nb) {
-            for (int v = part; v < V; v += 8) {
-                const size_t o = ((size_t)n * V + v) * 3;
-                const float px = verts[o], py = verts[o + 1], pz = verts[o + 2];
-                const float g0 = gout[o], g1 = gout[o + 1], g2 = gout[o + 2];
-                float h0 = g0, h1 = g1, h2 = g2;
-                if (tocam) {
-                    h0 = g0 * RT[0] + g1 * RT[1] + g2 * RT[2];
-                    h1 = g0 * RT[3] + g1 * RT[4] + g2 * RT[5];
-                    h2 = g0 * RT[6] + g1 * RT[7] + g2 * RT[8];
-                }
-                const float s = skin[((size_t)n * nb + k) * V + v];
-                a[0] += s * px * h0; a[1] += s * px * h1; a[2] += s * px * h2;
-                a[3] += s * py * h0; a[4] += s * py * h1; a[5] += s * py * h2;
-                a[6] += s * pz * h0; a[7] += s * pz * h1; a[8] += s * pz * h2;
-                a[9] += s * h0; a[10] += s * h1; a[11] += s * h2;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 12; c++) {       // fold the 8 partial lanes (aligned group of 8 inside a DPP row)
-            float x = a[c];
-            x += dpp_f(x, 0x111);            // row_shr:1
-            x += dpp_f(x, 0x112);            // row_shr:2
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, false));   // row_shr:4
-            a[c] = x;                        // lane part == 7 holds the sum of its group
-        }
-        if (k < nb && part == 7) {
-#pragma unroll
-            for (int c = 0; c < 9; c++) if (gR) gR[((size_t)n * K + k + 1) * 9 + c] = a[c];
-#pragma unroll
-            for (int c = 0; c < 3; c++) if (gT) gT[((size_t)n * K + k + 1) * 3 + c] = a[9 + c];
-        }
+}
+
+__global__ __launch_bounds__(256) void lbs_backward_fold_kernel(const float* __restrict__ partial, float* __restrict__ gR,
+                                                                float* __restrict__ gT, int K, int nchunks)
+{
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < K * 12; i += 256) {
+        float a = 0.f;
+        for (int ch = 0; ch < nchunks; ch++) a += partial[((size_t)n * nchunks + ch) * K * 12 + i];
+        const int k = i / 12, c = i - k * 12;
+        if (c < 9) { if (gR) gR[((size_t)n * K + k) * 9 + c] = a; }
+        else if (gT) gT[((size_t)n * K + k) * 3 + (c - 9)] = a;
     }
 }
 
@@ -601,16 +589,27 @@ extern "C" int lasr_lbs_forward(const float* verts, const float* Rmat, const flo
     return launch_ok();
 }
 
+extern "C" size_t lasr_lbs_backward_scratch_floats(int N, int V, int K)
+{
+    if (N < 0 || V < 0 || K < 1) return 0;
+    return (size_t)N * ((V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1) * K * 12;
+}
+
 extern "C" int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                                  const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
-                                 float* grad_skin, int N, int V, int K, int tocam, void* hip_stream)
+                                 float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream)
 {
     if (N < 0 || V < 0 || K < 1 || K > 1024) return LASR_E_BADARG;
     if (N == 0) return LASR_OK;
-    if (!verts || !Rmat || !Tmat || !grad_out || (K > 1 && !skin)) return LASR_E_BADARG;
+    if (!verts || !Rmat || !Tmat || !grad_out || !scratch || (K > 1 && !skin)) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_kernel, dim3(N), dim3(256), (K * 12 + 4) * sizeof(float), verts, Rmat, Tmat,
-                skin, grad_out, grad_verts, grad_Rmat, grad_Tmat, grad_skin, N, V, K, tocam);
+    const int nchunks = (V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1;
+    const size_t lds = (size_t)(K * 12 + LBS_CHUNK * 13 + 4) * sizeof(float);
+    LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_kernel, dim3(nchunks, N), dim3(256), lds, verts, Rmat, Tmat, skin, grad_out,
+                grad_verts, grad_skin, scratch, N, V, K, tocam);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_fold_kernel, dim3(N), dim3(256), 0, scratch, grad_Rmat, grad_Tmat, K, nchunks);
     return launch_ok();
 }
 

@@ -35,12 +35,14 @@ class _LBS(Function):
         gR = torch.empty_like(Rmat)
         gT = torch.empty_like(Tmat)
         gs = torch.empty(N, K - 1, V, dtype=torch.float32, device=verts.device) if K > 1 else None
+        h = _lib.lib()
+        scratch = torch.empty(h.lasr_lbs_backward_scratch_floats(N, V, K), dtype=torch.float32, device=verts.device)
         guard, st = _lib.stream_of(verts)
         with guard:
-            rc = _lib.lib().lasr_lbs_backward(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(),
-                                              skin.data_ptr() if K > 1 else None, gout.data_ptr(), gv.data_ptr(),
-                                              gR.data_ptr(), gT.data_ptr(), gs.data_ptr() if K > 1 else None,
-                                              N, V, K, 1 if tocam else 0, st)
+            rc = h.lasr_lbs_backward(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(),
+                                     skin.data_ptr() if K > 1 else None, gout.data_ptr(), gv.data_ptr(),
+                                     gR.data_ptr(), gT.data_ptr(), gs.data_ptr() if K > 1 else None,
+                                     scratch.data_ptr(), N, V, K, 1 if tocam else 0, st)
         _lib.check(rc, 'lasr_lbs_backward')
         return gv, gR, gT, gs, None, None
 
