@@ -6,10 +6,11 @@
 // -ffp-contract=off, the geometry (barycentrics, edge projections, depth) is
 // bit-identical to an un-contracted fp32 evaluation of the reference; only
 // exp() may differ by an ulp from a host libm.  What is NOT taken from the
-// reference is the execution shape: per-face constants live in a 36-float
+// reference is the execution shape: per-face constants live in a 44-float
 // record that a wave reads through the scalar cache (the face index is
-// wave-uniform), the bbox reject is precomputed, and runtime-indexed arrays are
-// replaced by compile-time edge indices so nothing spills to scratch.
+// wave-uniform), the bbox reject becomes an exact integer pixel rectangle, divisions by
+// per-face constants go through correctly rounded reciprocals, and runtime-indexed arrays
+// are replaced by compile-time edge indices so nothing spills to scratch.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -191,11 +192,6 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
     }
 }
 
-__device__ __forceinline__ bool outside_bbox(float x, float y, const float4 b)
-{
-    return x > b.y || x < b.x || y > b.w || y < b.z;
-}
-
 __device__ __forceinline__ bool inside_closed(float w0, float w1, float w2)
 {
     return w0 <= 1 && w0 >= 0 && w1 <= 1 && w1 >= 0 && w2 <= 1 && w2 >= 0;   // K.cu:47-50
@@ -211,12 +207,6 @@ __device__ __forceinline__ void clip_normalise(float& w0, float& w1, float& w2)
     const float s = fmaxf(w0 + w1 + w2, 1e-5f);   // (float)max((double)s, 1e-5) == fmaxf(s, 1e-5f) for every float s
     if (FM) { const float r = __builtin_amdgcn_rcpf(s); w0 *= r; w1 *= r; w2 *= r; }
     else { w0 /= s; w1 /= s; w2 /= s; }
-}
-
-// sigmoid through double exactly as K.cu:397,403 promotes it
-__device__ __forceinline__ float sigmoid_neg(float neg_arg)
-{
-    return (float)(1. / (1. + (double)expf(neg_arg)));
 }
 
 // ---- math flavours -----------------------------------------------------------------

@@ -1,28 +1,26 @@
 // sr_raster.hip -- soft-rasteriser forward/backward for MI355X (gfx950, wave64) + the C ABI.
 //
-// Replaces the three reference kernels (soft_rasterize_cuda_kernel.cu "K.cu":245-305,
-// 308-483, 486-668) with a different execution shape:
+// Replaces the three reference kernels (soft_rasterize_cuda_kernel.cu "K.cu":245-305, 308-483, 486-668) with a
+// different execution shape:
 //
-//   setup    1 thread / face      : 36-float record + margin-inflated bbox (sr_device.h)
+//   setup    1 thread / face : 44-float record (geometry, hoisted edge vectors, correctly rounded reciprocals, flags)
+//            + the EXACT integer pixel rectangle of the reference's float bbox test (sr_device.h).
 //   forward  1 workgroup / 16x16 px tile, 1 wave / 8x8 quadrant, 1 lane / pixel.
-//            The workgroup scans the image's face bboxes with coalesced float4
-//            loads and compacts, IN FACE-INDEX ORDER (wave ballots + prefix), the
-//            faces that can touch the tile into LDS.  Each wave then walks that
-//            list; the face index is wave-uniform, so the record is fetched
-//            through the scalar cache into SGPRs and only the per-pixel state
-//            lives in VGPRs.  Index order is preserved, so the alpha product, the
-//            online depth-softmax and the hard z-buffer tie-break see exactly the
-//            reference's sequence of faces.
-//   backward 1 wave / (image, face), FACE-major: lanes enumerate the pixels of the
-//            face's bbox, accumulate the 9+9 gradient components in registers,
-//            one DPP wave reduction per face, one plain read-modify-write per
-//            component.  The backward pass has no cross-face dependence (it only
-//            needs the finished per-pixel aggregates), so this removes every
-//            global atomic of the reference and makes the gradients deterministic.
-//            (Surface textures, T != 3 texels, scatter with atomics: cold path.)
+//            level 1: the workgroup scans the image's pixel rects (coalesced 8-B loads) and compacts, IN FACE-INDEX
+//            ORDER (wave ballots + prefix), the faces touching the tile into LDS; level 2: each wave filters that
+//            list 64 entries at a time down to its quadrant (rect overlap + conservative corner cull); walk: the
+//            face index is wave-uniform, so the record is fetched through the scalar cache into SGPRs and only the
+//            per-pixel state lives in VGPRs.  Index order is preserved, so the alpha product, the online
+//            depth-softmax and the hard z-buffer tie-break see exactly the reference's sequence of faces.
+//   backward 1 wave / (image, face), FACE-major: lanes enumerate the pixels of the face's rect; a cheap stage
+//            compacts the pixels that can be within the distance threshold into an LDS ring, the heavy stage runs
+//            on dense batches of 64, accumulates the 9+9 gradient components in registers, one permlane/DPP wave
+//            reduction per face, one plain read-modify-write per component.  The backward pass has no cross-face
+//            dependence (it only needs the finished per-pixel aggregates), so this removes every global atomic of
+//            the reference and makes the gradients deterministic.  (Surface textures, T != 3 texels, scatter with
+//            atomics: cold path.)
 //
-// Brute force in the reference is N*P*F pair tests; here a pixel only ever sees
-// the faces binned to its tile (~40-100 instead of 1280-2560).
+// Brute force in the reference is N*P*F pair tests; here a pixel only ever sees the faces binned to its quadrant.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -127,3 +127,22 @@ def test_graph_replay_matches_eager_forward(tmp_path, cuda):
     g = m.mean_v.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
     torch.cuda.set_stream(torch.cuda.default_stream())   # the trainer switched the current stream; restore for other tests
+
+
+@pytest.mark.parametrize('name,over', [
+    # BASELINE configs[2]/[3]: camel stages 3-4 -- 2 pairs per GPU, one hypothesis, 36 bones, 512x512
+    ('camel', dict(img_size=512, subdivide=3, n_bones=36, n_hypo=1, batch_size=2, symmetric=False, only_mean_sym=False)),
+    # BASELINE configs[4]: dog15 stage 0 -- 3 pairs, 16 camera hypotheses, 21 bones (25-bone LBS comes with stage 1)
+    ('dog15', dict(img_size=128, subdivide=3, n_bones=26, n_hypo=16, batch_size=3, n_frames=15)),
+])
+def test_other_baseline_configurations_step(tmp_path, cuda, name, over):
+    tr = make_trainer(tmp_path, name=name, iters_per_epoch=2, **over)
+    tr.model.train()
+    tr.reinit_bones()
+    for i, ids in enumerate(tr.dataloader):
+        tr.module.iters = i
+        loss, aux = tr.train_step(tr.set_input(ids))
+    assert torch.isfinite(loss)
+    H = over['n_hypo']
+    assert aux['current_nscore'].shape == (H,) and torch.isfinite(aux['current_nscore']).all()
+    assert aux['mask_pred'].shape[0] == 2 * over['batch_size'] * H

@@ -198,3 +198,11 @@ def test_division_by_reciprocal_is_bit_exact(cuda):
         _lib.check(rc, 'lasr_selftest_div')
         total += int(bad.item())
     assert total <= 8, '%d of %d quotients differ' % (total, 4 * n)      # 2^-23 exceptional divisors at most
+
+
+def test_lasr_config_m2_512(oracle, cuda):
+    # BASELINE configs[2] renders at 512x512 (--img_size 512)
+    fv, ft, near, far = synth.raster_batch(11, 3, count=1)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    err = compare(oracle, cuda, fv, ft, 512, kw)
+    print('M2 512x512 image max-abs err %.3e' % err)
