@@ -104,6 +104,27 @@ int lasr_sr_backward_dev(const float* faces, const float* textures, const float*
                          int double_side, void* hip_stream);
 
 /*
+ * Multi-attribute rasterisation.  LASR's flow renders rasterise the SAME geometry twice
+ * in one call, once per 3-channel vertex attribute (camera-space positions of frame t and t', nnutils/mesh_net.py:85-87).
+ * These entry points interpolate and depth-blend `channels` (3 or 6) per-vertex attributes in one pass: the per-channel
+ * arithmetic is that of the 3-channel kernels, so channels [0,3) and [3,6) equal two separate renders and the face
+ * gradient equals the sum of theirs.  Only LASR's mode combination (2,1,2,1, double sided) is accepted for 6 channels.
+ *   textures [N,F,3,channels]   soft_colors / grad_soft_colors [N,channels+1,IS,IS] (alpha is the LAST plane)
+ *   grad_textures [N,F,3,channels]   near_far_dev: optional {near, far} on the device (else the two floats are used)
+ */
+int lasr_sr_forward_attr(const float* faces, const float* textures, float* aggrs_info, float* soft_colors,
+                         void* workspace, size_t workspace_bytes, int N, int F, int channels, int IS,
+                         float near, float far, const float* near_far_dev, float eps, float sigma_val,
+                         int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb, int func_id_alpha,
+                         int texture_sample_type, int double_side, void* hip_stream);
+int lasr_sr_backward_attr(const float* faces, const float* textures, const float* soft_colors,
+                          const float* aggrs_info, float* grad_faces, float* grad_textures,
+                          const float* grad_soft_colors, void* workspace, size_t workspace_bytes, int N, int F,
+                          int channels, int IS, float near, float far, const float* near_far_dev, float eps,
+                          float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                          int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream);
+
+/*
  * Optional per-kernel timing for benchmarks (no reference counterpart: the
  * reference has no profiling hooks).  While enabled, every
  * kernel launch of this library is bracketed by hipEvents on its stream;

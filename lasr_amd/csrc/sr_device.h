@@ -390,13 +390,13 @@ __device__ __forceinline__ int surface_texel(float c0, float c1, int res)
 // K.cu:178-194
 template <typename TP>
 __device__ __forceinline__ float sample_colour(TP tex, float c0, float c1, float c2,
-                                               int res, int ch, int tex_type, int lim)
+                                               int res, int ch, int tex_type, int lim, int nch = 3)
 {
     if (tex_type == 0) {
         const int j = max(min(surface_texel(c0, c1, res), lim - 1), 0);
         return tex[j * 3 + ch];
     }
-    return c0 * tex[ch] + c1 * tex[3 + ch] + c2 * tex[6 + ch];
+    return c0 * tex[ch] + c1 * tex[nch + ch] + c2 * tex[2 * nch + ch];   // vertex attributes, [3 vertices][nch channels]
 }
 
 // ---- wave64 helpers ----------------------------------------------------------

@@ -65,8 +65,10 @@ __device__ __forceinline__ int xcd_remap(int b, int total)
 
 // ---------------------------------------------------------------------------
 // Per-pixel forward state (K.cu:354-368)
+template <int NCH>
 struct PixState {
-    float r, g, b, a;     // accumulators
+    float c[NCH];         // colour / attribute accumulators (3 = RGB; 6 = two attribute triples in one pass)
+    float a;              // alpha accumulator
     float ssum, smax;     // softmax running (sum, max)  | hard: (zbest, -)
     int fbest;
 };
@@ -74,10 +76,10 @@ struct PixState {
 // uniform reciprocals for the exact division-by-reciprocal (sr_device.h); ok = all three divisors are in the safe range
 struct UniRecip { float inv_sigma, inv_gamma, inv_fmn; bool ok; };
 
-template <bool LASR_FAST, bool MK>
+template <bool LASR_FAST, bool MK, int NCH>
 __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, cptr_t rec,
                                              cptr_t tex, int fn, int lim, float xp, float yp,
-                                             float w0, float w1, float w2, PixState& s, const UniRecip& U)
+                                             float w0, float w1, float w2, PixState<NCH>& s, const UniRecip& U)
 {
     Frag fr;
     if (!fragment_w<false, MK>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, U.inv_sigma)) return;
@@ -96,9 +98,8 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
     if (m.rgb == 0) {
         if (zp < s.ssum && inside_closed(w0, w1, w2) && (m.double_side || front)) {
             s.ssum = zp; s.fbest = fn;
-            s.r = sample_colour(tex, c0, c1, c2, A.res, 0, m.tex, lim);
-            s.g = sample_colour(tex, c0, c1, c2, A.res, 1, m.tex, lim);
-            s.b = sample_colour(tex, c0, c1, c2, A.res, 2, m.tex, lim);
+#pragma unroll
+            for (int k = 0; k < NCH; k++) s.c[k] = sample_colour(tex, c0, c1, c2, A.res, k, m.tex, lim, NCH);
         }
     } else {
         if (front || m.double_side) {
@@ -111,14 +112,17 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
             }
             const float ez = exp_1ulp(MK ? div_by_recip(zn - s.smax, A.gamma, U.inv_gamma) : (zn - s.smax) / A.gamma);
             s.ssum = rescale * s.ssum + ez * D;
-            s.r = rescale * s.r + ez * D * sample_colour(tex, c0, c1, c2, A.res, 0, m.tex, lim);
-            s.g = rescale * s.g + ez * D * sample_colour(tex, c0, c1, c2, A.res, 1, m.tex, lim);
-            s.b = rescale * s.b + ez * D * sample_colour(tex, c0, c1, c2, A.res, 2, m.tex, lim);
+#pragma unroll
+            for (int k = 0; k < NCH; k++)
+                s.c[k] = rescale * s.c[k] + ez * D * sample_colour(tex, c0, c1, c2, A.res, k, m.tex, lim, NCH);
         }
     }
 }
 
-template <bool LASR_FAST>
+// NCH = attribute channels per vertex: 3 (RGB, every mode) or 6 (two attribute triples rendered in ONE pass over the
+// geometry -- LASR's flow renders, nnutils/mesh_net.py:85-87, rasterise the same mesh twice with two different
+// per-vertex attributes; channels are independent, so the result equals the two separate renders).
+template <bool LASR_FAST, int NCH>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
 {
@@ -147,26 +151,21 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const float xp = pix_center(px, IS);
     const float yp = pix_center(IS - 1 - py, IS);
 
-    PixState s;
+    PixState<NCH> s;
     s.a = (m.alpha == 2) ? 1.f : 0.f;
     s.fbest = -1;
-    float bg0 = 1.f, bg1 = 1.f, bg2 = 1.f;
-    if (valid) {
-        bg0 = colors[((size_t)bn * 4 + 0) * P + pn];
-        bg1 = colors[((size_t)bn * 4 + 1) * P + pn];
-        bg2 = colors[((size_t)bn * 4 + 2) * P + pn];
-    }
-    if (m.rgb == 0) { s.r = bg0; s.g = bg1; s.b = bg2; s.ssum = 10000000.f; s.smax = 0.f; }
-    else {
-        s.ssum = expf(A.eps / A.gamma);
-        s.smax = A.eps;
-        s.r = bg0 * s.ssum; s.g = bg1 * s.ssum; s.b = bg2 * s.ssum;
+    if (m.rgb == 0) { s.ssum = 10000000.f; s.smax = 0.f; }
+    else { s.ssum = expf(A.eps / A.gamma); s.smax = A.eps; }
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        const float bg = valid ? colors[((size_t)bn * (NCH + 1) + k) * P + pn] : 1.f;
+        s.c[k] = m.rgb == 0 ? bg : bg * s.ssum;
     }
 
     const short4* __restrict__ rects = A.rects + (size_t)bn * A.F;
     const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
-    const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * 3;
-    const int texstride = A.T * 3;
+    const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
+    const int texstride = A.T * NCH;
     UniRecip U;
     U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
     U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
@@ -246,8 +245,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 const cptr_t tex = as_const(texs + (size_t)fn * texstride);
                 const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
                 if (cand) {
-                    if (mk) forward_face<LASR_FAST, true>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
-                    else forward_face<LASR_FAST, false>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
+                    if (mk) forward_face<LASR_FAST, true, NCH>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
+                    else forward_face<LASR_FAST, false, NCH>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
                 }
             }
         }
@@ -259,19 +258,17 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     if (m.alpha == 0) a_out = s.a;
     else if (m.alpha == 1) a_out = s.a / A.F;
     else a_out = (float)(1. - (double)s.a);
-    colors[((size_t)bn * 4 + 3) * P + pn] = a_out;
+    colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = a_out;
     if (m.rgb == 0) {
         if (s.fbest != -1) {
-            colors[((size_t)bn * 4 + 0) * P + pn] = s.r;
-            colors[((size_t)bn * 4 + 1) * P + pn] = s.g;
-            colors[((size_t)bn * 4 + 2) * P + pn] = s.b;
+#pragma unroll
+            for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k];
         }
         aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
         aggrs[((size_t)bn * 2 + 1) * P + pn] = (float)s.fbest;
     } else {
-        colors[((size_t)bn * 4 + 0) * P + pn] = s.r / s.ssum;
-        colors[((size_t)bn * 4 + 1) * P + pn] = s.g / s.ssum;
-        colors[((size_t)bn * 4 + 2) * P + pn] = s.b / s.ssum;
+#pragma unroll
+        for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k] / s.ssum;
         aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
         aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
     }
@@ -288,7 +285,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
 constexpr bool BWD_FM = true;
 constexpr int QCAP = 128;   // ring entries per wave (power of two, >= 2 * 64)
 
-template <bool LASR_FAST>
+template <bool LASR_FAST, int NCH>
 __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
                                                           const float* __restrict__ aggrs,
                                                           const float* __restrict__ gcolors,
@@ -308,7 +305,7 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     const int bn = gw / A.F, fn = gw - bn * A.F;
     const int IS = A.IS, P = IS * IS;
     const cptr_t rec = as_const(A.recs + (size_t)gw * REC);
-    const cptr_t tex = as_const(A.textures + (size_t)gw * A.T * 3);
+    const cptr_t tex = as_const(A.textures + (size_t)gw * A.T * NCH);
     const short4 rc4 = A.rects[gw];
     const int flags = __float_as_int(rec[R_FLAGS]);
 
@@ -319,7 +316,9 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     const int npx = empty ? 0 : bw * bh;
 
     float gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2)
-    float gt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // vertex colours: [vertex j][channel k] at 3j+k
+    float gt[18];                                // vertex attributes: [vertex j][channel k] at NCH*j + k (3*NCH used)
+#pragma unroll
+    for (int k = 0; k < 18; k++) gt[k] = 0.f;
     const bool front = (flags & 8) != 0;
     const bool vertex_tex = (m.tex == 1);
     const int lim = (A.N * A.F - gw) * A.T;      // texels from this face to the end of the tensor
@@ -374,10 +373,10 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
         const float D = fr.D;
 
         // alpha path (K.cu:583-593); hard alpha: the reference still adds g_alpha into C
-        float Ca = gcolors[((size_t)bn * 4 + 3) * P + pn];
+        float Ca = gcolors[((size_t)bn * (NCH + 1) + NCH) * P + pn];
         if (m.alpha == 1) Ca = div_<FM>(Ca, (float)A.F);
         else if (m.alpha == 2) {
-            const float a_out = colors[((size_t)bn * 4 + 3) * P + pn];
+            const float a_out = colors[((size_t)bn * (NCH + 1) + NCH) * P + pn];
             Ca *= div_<FM>(1 - a_out, fmaxf(1 - D, 1e-6f));
         }
         float C = Ca;
@@ -391,18 +390,19 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
         float gz0 = 0, gz1 = 0, gz2 = 0;
         if (m.rgb == 0) {
             if ((float)fn == aggrs[((size_t)bn * 2 + 1) * P + pn]) {       // K.cu:603
-                const float g0 = gcolors[((size_t)bn * 4 + 0) * P + pn];
-                const float g1 = gcolors[((size_t)bn * 4 + 1) * P + pn];
-                const float g2 = gcolors[((size_t)bn * 4 + 2) * P + pn];
+                float g[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; k++) g[k] = gcolors[((size_t)bn * (NCH + 1) + k) * P + pn];
                 if (vertex_tex) {
-                    gt[0] += w0 * g0; gt[1] += w0 * g1; gt[2] += w0 * g2;
-                    gt[3] += w1 * g0; gt[4] += w1 * g1; gt[5] += w1 * g2;
-                    gt[6] += w2 * g0; gt[7] += w2 * g1; gt[8] += w2 * g2;
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) {
+                        gt[k] += w0 * g[k]; gt[NCH + k] += w1 * g[k]; gt[2 * NCH + k] += w2 * g[k];
+                    }
                 } else {
                     const int j = surface_texel(w0, w1, A.res);
                     if (j >= 0 && j < A.T) {   // the reference only credits texels j < T (K.cu:605)
                         float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
-                        atomicAdd(gtp + 0, g0); atomicAdd(gtp + 1, g1); atomicAdd(gtp + 2, g2);
+                        atomicAdd(gtp + 0, g[0]); atomicAdd(gtp + 1, g[1]); atomicAdd(gtp + 2, g[2]);
                     }
                 }
             }
@@ -411,24 +411,26 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
             const float smax = aggrs[((size_t)bn * 2 + 1) * P + pn];
             const float zn = div_<FM>(A.far - zp, A.far - A.near);
             const float sm = div_<FM>(D * exp_<FM>(div_<FM>(zn - smax, A.gamma)), ssum);
-            const float g0 = gcolors[((size_t)bn * 4 + 0) * P + pn];
-            const float g1 = gcolors[((size_t)bn * 4 + 1) * P + pn];
-            const float g2 = gcolors[((size_t)bn * 4 + 2) * P + pn];
+            float g[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) g[k] = gcolors[((size_t)bn * (NCH + 1) + k) * P + pn];
             if (vertex_tex) {
-                gt[0] += sm * (w0 * g0); gt[1] += sm * (w0 * g1); gt[2] += sm * (w0 * g2);
-                gt[3] += sm * (w1 * g0); gt[4] += sm * (w1 * g1); gt[5] += sm * (w1 * g2);
-                gt[6] += sm * (w2 * g0); gt[7] += sm * (w2 * g1); gt[8] += sm * (w2 * g2);
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+                    gt[k] += sm * (w0 * g[k]); gt[NCH + k] += sm * (w1 * g[k]); gt[2 * NCH + k] += sm * (w2 * g[k]);
+                }
             } else {
                 const int j = surface_texel(w0, w1, A.res);
                 if (j >= 0 && j < A.T) {       // K.cu:620
                     float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
-                    atomicAdd(gtp + 0, sm * g0); atomicAdd(gtp + 1, sm * g1); atomicAdd(gtp + 2, sm * g2);
+                    atomicAdd(gtp + 0, sm * g[0]); atomicAdd(gtp + 1, sm * g[1]); atomicAdd(gtp + 2, sm * g[2]);
                 }
             }
             float Crgb = 0.f;
-            Crgb += g0 * (sample_colour(tex, w0, w1, w2, A.res, 0, m.tex, lim) - colors[((size_t)bn * 4 + 0) * P + pn]);
-            Crgb += g1 * (sample_colour(tex, w0, w1, w2, A.res, 1, m.tex, lim) - colors[((size_t)bn * 4 + 1) * P + pn]);
-            Crgb += g2 * (sample_colour(tex, w0, w1, w2, A.res, 2, m.tex, lim) - colors[((size_t)bn * 4 + 2) * P + pn]);
+#pragma unroll
+            for (int k = 0; k < NCH; k++)
+                Crgb += g[k] * (sample_colour(tex, w0, w1, w2, A.res, k, m.tex, lim, NCH) -
+                                colors[((size_t)bn * (NCH + 1) + k) * P + pn]);
             Crgb *= sm;
             C += div_<FM>(Crgb, D);
             const float Cz = div_<FM>(div_<FM>(Crgb, A.gamma), A.near - A.far) * zp * zp;
@@ -474,21 +476,29 @@ __global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const fl
     // one wave reduction per face (sr_device.h: wave_reduce18), then a plain, non-atomic accumulate: this wave
     // owns the face.  Lanes 15/31/47/63 each end up with the totals of up to five components.
     float v18[18], red[5];
+    const int lane_row = lane >> 4;
+    const int sub = lane_row == 0 ? 0 : lane_row == 1 ? 2 : lane_row == 2 ? 1 : 3;   // component offset inside a register
+    float* gf = gfaces + (size_t)gw * 9;
+    float* gtp = gtex + (size_t)gw * 3 * NCH;
+    // pass 0: 9 face components + the first 9 attribute components; pass 1 (NCH = 6 only): attribute components 9..17
 #pragma unroll
-    for (int k = 0; k < 9; k++) { v18[k] = gv[k]; v18[9 + k] = vertex_tex ? gt[k] : 0.f; }
-    wave_reduce18(v18, red);
-    if ((lane & 15) == 15) {
-        const int row = lane >> 4;
-        const int sub = row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;     // component offset inside a register
-        float* gf = gfaces + (size_t)gw * 9;
-        float* gtp = gtex + (size_t)gw * 9;
+    for (int pass = 0; pass < (NCH == 6 ? 2 : 1); pass++) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const int c = 4 * i + sub;
-            if (i == 4 && (row & 1)) continue;                               // register 4 only carries v[16], v[17]
-            const int comp = i == 4 ? 16 + (row >> 1) : c;
-            if (comp < 9) gf[comp] += red[i];
-            else if (vertex_tex) gtp[comp - 9] += red[i];
+        for (int k = 0; k < 9; k++) {
+            v18[k] = pass == 0 ? gv[k] : (vertex_tex ? gt[9 + k] : 0.f);
+            v18[9 + k] = pass == 0 ? (vertex_tex ? gt[k] : 0.f) : 0.f;
+        }
+        wave_reduce18(v18, red);
+        if ((lane & 15) == 15) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (i == 4 && (lane_row & 1)) continue;                          // register 4 only carries v[16], v[17]
+                const int comp = i == 4 ? 16 + (lane_row >> 1) : 4 * i + sub;
+                if (pass == 0) {
+                    if (comp < 9) gf[comp] += red[i];
+                    else if (vertex_tex) gtp[comp - 9] += red[i];
+                } else if (comp < 9 && vertex_tex) gtp[9 + comp] += red[i];
+            }
         }
     }
 }
@@ -555,11 +565,11 @@ static thread_local const float* g_near_far_dev = nullptr;   // set by the *_dev
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
-extern "C" int lasr_sr_forward(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
-                               float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
-                               float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps,
-                               float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
-                               int double_side, void* hip_stream)
+static int forward_impl(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
+                        float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
+                        float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                        float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                        int double_side, void* hip_stream, int nch)
 {
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
     if (rc) return rc;
@@ -584,18 +594,19 @@ extern "C" int lasr_sr_forward(const float* faces, const float* textures, float*
     const dim3 grid((unsigned)(N * tiles_x * tiles_x));
     {
         ProfScope ps(K_SR_FORWARD, st);
-        if (is_lasr_fast(A.m)) hipLaunchKernelGGL(sr_forward_kernel<true>, grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else hipLaunchKernelGGL(sr_forward_kernel<false>, grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (is_lasr_fast(A.m)) hipLaunchKernelGGL((sr_forward_kernel<true, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else hipLaunchKernelGGL((sr_forward_kernel<false, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
     }
     return launch_ok();
 }
 
-extern "C" int lasr_sr_backward(const float* faces, const float* textures, const float* soft_colors,
-                                const float* faces_info, const float* aggrs_info, float* grad_faces,
-                                float* grad_textures, const float* grad_soft_colors, void* workspace,
-                                size_t workspace_bytes, int N, int F, int T, int IS, float near, float far, float eps,
-                                float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
-                                int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream)
+static int backward_impl(const float* faces, const float* textures, const float* soft_colors,
+                         const float* faces_info, const float* aggrs_info, float* grad_faces,
+                         float* grad_textures, const float* grad_soft_colors, void* workspace,
+                         size_t workspace_bytes, int N, int F, int T, int IS, float near, float far, float eps,
+                         float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                         int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream, int nch)
 {
     (void)faces_info;
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
@@ -619,14 +630,85 @@ extern "C" int lasr_sr_backward(const float* faces, const float* textures, const
     const dim3 grid((unsigned)((total + 3) / 4));   // 4 waves (faces) per 256-thread workgroup
     {
         ProfScope ps(K_SR_BACKWARD, st);
-        if (is_lasr_fast(A.m))
-            hipLaunchKernelGGL(sr_backward_kernel<true>, grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
+        if (nch == 6)
+            hipLaunchKernelGGL((sr_backward_kernel<true, 6>), grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
+                               grad_soft_colors, grad_faces, grad_textures);
+        else if (is_lasr_fast(A.m))
+            hipLaunchKernelGGL((sr_backward_kernel<true, 3>), grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
                                grad_soft_colors, grad_faces, grad_textures);
         else
-            hipLaunchKernelGGL(sr_backward_kernel<false>, grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
+            hipLaunchKernelGGL((sr_backward_kernel<false, 3>), grid, dim3(256), 0, st, A, soft_colors, aggrs_info,
                                grad_soft_colors, grad_faces, grad_textures);
     }
     return launch_ok();
+}
+
+static int check_nch(int channels, int dist, int rgb, int alpha, int tex, int double_side, int T)
+{
+    if (channels == 3) return LASR_OK;
+    // the 6-channel pass exists for LASR's flow renders only: euclidean / softmax / prod / vertex attributes, double sided
+    if (channels != 6 || T != 3 || !(dist == 2 && rgb == 1 && alpha == 2 && tex == 1 && double_side)) return LASR_E_BADMODE;
+    return LASR_OK;
+}
+
+extern "C" int lasr_sr_forward(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
+                               float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
+                               float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                               float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                               int double_side, void* hip_stream)
+{
+    return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
+                        far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                        texture_sample_type, double_side, hip_stream, 3);
+}
+
+extern "C" int lasr_sr_backward(const float* faces, const float* textures, const float* soft_colors,
+                                const float* faces_info, const float* aggrs_info, float* grad_faces,
+                                float* grad_textures, const float* grad_soft_colors, void* workspace,
+                                size_t workspace_bytes, int N, int F, int T, int IS, float near, float far, float eps,
+                                float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                                int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream)
+{
+    return backward_impl(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces, grad_textures, grad_soft_colors,
+                         workspace, workspace_bytes, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
+                         gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, hip_stream, 3);
+}
+
+// Multi-attribute variants: `channels` per-vertex attributes (3 or 6) interpolated and depth-blended in ONE pass over the
+// geometry.  textures [N,F,3,channels], soft_colors / grad_soft_colors [N,channels+1,IS,IS] (alpha last), grad_textures
+// [N,F,3,channels].  near_far_dev may be NULL (then near/far are used).  See include/lasr_sr.h.
+extern "C" int lasr_sr_forward_attr(const float* faces, const float* textures, float* aggrs_info, float* soft_colors,
+                                    void* workspace, size_t workspace_bytes, int N, int F, int channels, int IS,
+                                    float near, float far, const float* near_far_dev, float eps, float sigma_val,
+                                    int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb, int func_id_alpha,
+                                    int texture_sample_type, int double_side, void* hip_stream)
+{
+    const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, 3);
+    if (rc) return rc;
+    g_near_far_dev = near_far_dev;
+    const int out = forward_impl(faces, textures, nullptr, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, 3, IS,
+                                 near, far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                                 texture_sample_type, double_side, hip_stream, channels);
+    g_near_far_dev = nullptr;
+    return out;
+}
+
+extern "C" int lasr_sr_backward_attr(const float* faces, const float* textures, const float* soft_colors,
+                                     const float* aggrs_info, float* grad_faces, float* grad_textures,
+                                     const float* grad_soft_colors, void* workspace, size_t workspace_bytes, int N, int F,
+                                     int channels, int IS, float near, float far, const float* near_far_dev, float eps,
+                                     float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                                     int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream)
+{
+    const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, 3);
+    if (rc) return rc;
+    g_near_far_dev = near_far_dev;
+    const int out = backward_impl(faces, textures, soft_colors, nullptr, aggrs_info, grad_faces, grad_textures,
+                                  grad_soft_colors, workspace, workspace_bytes, N, F, 3, IS, near, far, eps, sigma_val,
+                                  func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha, texture_sample_type,
+                                  double_side, hip_stream, channels);
+    g_near_far_dev = nullptr;
+    return out;
 }
 
 // near/far taken from device memory ({near, far} as two floats): LASR recomputes them from the projected

@@ -363,14 +363,14 @@ def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0,
     faces = faces[:, None].repeat(1, n_hypo, 1, 1).view(-1, faces.shape[1], 3)
     eye = sr.functional.const_tensor(renderer_soft.transform.transformer._eye, verts.device)[None, None]
     verts_pre = (verts[:, :, :3] + eye) * sr.functional.const_tensor([1, -1, 1], verts.device)
-    nb = verts.shape[0]
-    px = renderer_soft.render_mesh(sr.Mesh(torch.cat([verts_pre, verts_pre], 0), torch.cat([faces, faces], 0),
-                                           textures=torch.cat([verts_pos0[:, :, :3], verts_pos1[:, :, :3]], 0),
+    # The reference renders the batch [verts_pre; verts_pre] with textures [pos0; pos1]: the same geometry twice.
+    # One pass with 6 attribute channels gives the same two images (and the same alpha) for half the raster work.
+    px = renderer_soft.render_mesh(sr.Mesh(verts_pre, faces,
+                                           textures=torch.cat([verts_pos0[:, :, :3], verts_pos1[:, :, :3]], -1),
                                            texture_type='vertex'))
-    fgmask = px[:nb, -1]
-    px = px[:, :3]
-    p0 = px[:nb].permute(0, 2, 3, 1)
-    p1 = px[nb:].permute(0, 2, 3, 1)
+    fgmask = px[:, -1]
+    p0 = px[:, 0:3].permute(0, 2, 3, 1)
+    p1 = px[:, 3:6].permute(0, 2, 3, 1)
     bgmask = (p0[:, :, :, 2] < 1e-9) | (p1[:, :, :, 2] < 1e-9)
     ten = sr.functional.const_tensor([10.], p0.device)[0]
     p0 = torch.where(bgmask[..., None], ten, p0)

@@ -52,6 +52,11 @@ def _near_far_dev(near, far, dev):
 
 
 class SoftRasterizeFunction(Function):
+    """face_vertices [N,F,3,3], textures [N,F,T,3] (T = 3 vertex colours or R*R surface texels) -> [N,4,IS,IS].
+
+    Extension over the reference: vertex textures may carry 6 channels, [N,F,3,6] -> [N,7,IS,IS] (alpha last): two
+    attribute triples depth-blended in ONE pass over the geometry (lasr_sr_*_attr), equal to two 3-channel renders.
+    """
 
     @staticmethod
     def forward(ctx, face_vertices, textures, image_size=256,
@@ -65,34 +70,45 @@ class SoftRasterizeFunction(Function):
         dev = face_vertices.device
         N, F = face_vertices.shape[:2]
         fv = face_vertices.detach().reshape(N, F, 9).contiguous()
-        T = _texels(textures)
-        tx = textures.detach().reshape(N, F, T, 3).contiguous()
+        C = int(textures.shape[-1]) if textures.ndimension() == 4 else 3
+        if C == 3:
+            T = _texels(textures)
+            tx = textures.detach().reshape(N, F, T, 3).contiguous()
+        elif C == 6 and texture_type == 'vertex' and textures.shape[2] == 3:
+            T = 3
+            tx = textures.detach().contiguous()
+        else:
+            raise ValueError('textures must be [N,F,T,3], or [N,F,3,6] vertex attributes')
         IS = int(image_size)
-
-        ctx.geom = (N, F, T, IS)
         nf = _near_far_dev(near, far, dev)
         tail = (float(eps), float(sigma_val), _DIST[dist_func], float(math.log(1. / dist_eps - 1.)), float(gamma_val),
                 _RGB[aggr_func_rgb], _ALPHA[aggr_func_alpha], _TEX[texture_type], 1 if fill_back else 0)
-        ctx.nf = nf
-        ctx.scalars = ((nf.data_ptr(),) if nf is not None else (_as_float(near), _as_float(far))) + tail
+        ctx.geom, ctx.nf, ctx.tail, ctx.C = (N, F, T, IS), nf, tail, C
+        ctx.near_far = (0.0, 0.0) if nf is not None else (_as_float(near), _as_float(far))
         ctx.in_shapes = (face_vertices.shape, textures.shape)
 
         aggrs_info = torch.empty(N, 2, IS, IS, dtype=torch.float32, device=dev)
-        soft_colors = torch.empty(N, 4, IS, IS, dtype=torch.float32, device=dev)
-        soft_colors[:, 0] = float(background_color[0])
-        soft_colors[:, 1] = float(background_color[1])
-        soft_colors[:, 2] = float(background_color[2])
-        soft_colors[:, 3] = 1.0
+        soft_colors = torch.empty(N, C + 1, IS, IS, dtype=torch.float32, device=dev)
+        for k in range(C):
+            soft_colors[:, k] = float(background_color[k % 3])
+        soft_colors[:, C] = 1.0
 
         h = _lib.lib()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            nbytes = h.lasr_sr_workspace_bytes(N, F, T, IS)
-            ws = _workspace(dev, stream, nbytes)
-            fn = h.lasr_sr_forward_dev if nf is not None else h.lasr_sr_forward
-            rc = fn(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
-                    soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
-                    N, F, T, IS, *ctx.scalars, stream)
+            ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
+            if C == 6:
+                rc = h.lasr_sr_forward_attr(fv.data_ptr(), tx.data_ptr(), aggrs_info.data_ptr(), soft_colors.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), N, F, C, IS, *ctx.near_far,
+                                            nf.data_ptr() if nf is not None else None, *tail, stream)
+            elif nf is not None:
+                rc = h.lasr_sr_forward_dev(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
+                                           soft_colors.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS,
+                                           nf.data_ptr(), *tail, stream)
+            else:
+                rc = h.lasr_sr_forward(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
+                                       soft_colors.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS,
+                                       *ctx.near_far, *tail, stream)
         _lib.check(rc, 'lasr_sr_forward')
         ctx.save_for_backward(fv, tx, soft_colors, aggrs_info)
         ctx.mark_non_differentiable(aggrs_info)
@@ -102,20 +118,30 @@ class SoftRasterizeFunction(Function):
     def backward(ctx, grad_soft_colors):
         fv, tx, soft_colors, aggrs_info = ctx.saved_tensors
         N, F, T, IS = ctx.geom
+        C, nf, tail = ctx.C, ctx.nf, ctx.tail
         dev = fv.device
         grad_faces = torch.zeros(N, F, 9, dtype=torch.float32, device=dev)
-        grad_textures = torch.zeros(N, F, T, 3, dtype=torch.float32, device=dev)
+        grad_textures = torch.zeros(tx.shape, dtype=torch.float32, device=dev)
         g = grad_soft_colors.contiguous().float()
         h = _lib.lib()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            nbytes = h.lasr_sr_workspace_bytes(N, F, T, IS)
-            ws = _workspace(dev, stream, nbytes)
-            fn = h.lasr_sr_backward_dev if ctx.nf is not None else h.lasr_sr_backward
-            rc = fn(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
-                    aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
-                    g.data_ptr(), ws.data_ptr(), ws.numel(),
-                    N, F, T, IS, *ctx.scalars, stream)
+            ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
+            if C == 6:
+                rc = h.lasr_sr_backward_attr(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), aggrs_info.data_ptr(),
+                                             grad_faces.data_ptr(), grad_textures.data_ptr(), g.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), N, F, C, IS, *ctx.near_far,
+                                             nf.data_ptr() if nf is not None else None, *tail, stream)
+            elif nf is not None:
+                rc = h.lasr_sr_backward_dev(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
+                                            aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
+                                            g.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS, nf.data_ptr(), *tail,
+                                            stream)
+            else:
+                rc = h.lasr_sr_backward(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
+                                        aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
+                                        g.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS, *ctx.near_far, *tail,
+                                        stream)
         _lib.check(rc, 'lasr_sr_backward')
         fshape, tshape = ctx.in_shapes
         return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),

@@ -45,5 +45,7 @@ class Lighting(nn.Module):
             if d.light_intensity == 0:
                 continue
             light = d(light, mesh.vertex_normals if per_vertex else mesh.surface_normals)
+        if per_vertex and mesh.textures.shape[-1] != 3:        # [B,V,3k] attribute stacks: the same light per triple
+            light = light.repeat(1, 1, mesh.textures.shape[-1] // 3)
         mesh.textures = mesh.textures * (light if per_vertex else light[:, :, None, :])
         return mesh

@@ -206,3 +206,37 @@ def test_lasr_config_m2_512(oracle, cuda):
     kw = dict(synth.LASR_MODES, near=near, far=far)
     err = compare(oracle, cuda, fv, ft, 512, kw)
     print('M2 512x512 image max-abs err %.3e' % err)
+
+
+def test_six_channel_pass_equals_two_three_channel_renders(oracle, cuda):
+    # two per-vertex attribute triples blended in one pass over the geometry
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    rng = np.random.default_rng(9)
+    ft2 = rng.uniform(-2, 2, ft.shape).astype(np.float32)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    IS = 64
+    g = np.concatenate([synth.upstream_grad(2, IS, 2)[:, :3], synth.upstream_grad(2, IS, 3)], 1)   # [2,7,IS,IS]
+    tfv = torch.from_numpy(fv).to(cuda).requires_grad_(True)
+    t6 = torch.from_numpy(np.concatenate([ft, ft2], -1)).to(cuda).requires_grad_(True)
+    img6 = srf.soft_rasterize(tfv, t6, IS, **kw)
+    assert img6.shape == (2, 7, IS, IS)
+    img6.backward(torch.from_numpy(g).to(cuda))
+    # the same through two ordinary renders; the alpha gradient is counted once
+    ga = np.concatenate([g[:, 0:3], g[:, 6:7]], 1)
+    gb = np.concatenate([g[:, 3:6], np.zeros_like(g[:, 6:7])], 1)
+    ia, gfa, gta = run_hip(cuda, fv, ft, IS, g=ga, **kw)
+    ib, gfb, gtb = run_hip(cuda, fv, ft2, IS, g=gb, **kw)
+    out = img6.detach().cpu().numpy()
+    assert np.array_equal(out[:, 0:3], ia[:, :3]) and np.array_equal(out[:, 3:6], ib[:, :3])
+    assert np.array_equal(out[:, 6], ia[:, 3])
+    gf = tfv.grad.cpu().numpy()
+    scale = np.abs(gfa + gfb).max()
+    assert np.abs(gf - (gfa + gfb)).max() <= 1e-5 * scale
+    gt6 = t6.grad.cpu().numpy()
+    assert np.abs(gt6[..., 0:3] - gta).max() <= 1e-5 * np.abs(gta).max()
+    assert np.abs(gt6[..., 3:6] - gtb).max() <= 1e-5 * np.abs(gtb).max()
+    # and against the oracle
+    ref = oracle.forward(fv, ft2, IS, **kw)
+    assert np.abs(out[:, 3:6] - ref['soft_colors'][:, :3]).max() <= IMG_TOL
+    with pytest.raises(Exception):          # 6 channels exist for LASR's mode combination only
+        srf.soft_rasterize(tfv, t6, IS, **dict(kw, aggr_func_rgb='hard'))
