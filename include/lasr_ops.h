@@ -112,6 +112,22 @@ int lasr_laplacian_forward(const float* x, const int* row_ptr, const int* col, f
 int lasr_laplacian_backward(const float* x, const int* row_ptr, const int* col, const float* grad_loss,
                             float* grad_x, float* scratch_lx /*[N,V,3]*/, int N, int V, void* hip_stream);
 
+/*
+ * Flow reprojection, nnutils/mesh_net.py:93-104 (the tail of render_flow_soft_2 after the render).
+ * px [N,7,P] = the 6-attribute render (lasr_sr_forward_attr): planes 0-2 camera-space position of frame t seen at each
+ * pixel, planes 3-5 of frame t', plane 6 alpha.  bgmask = (px[2] < 1e-9) | (px[5] < 1e-9); background pixels take the
+ * point (10,10,10) (:93-95); flow[n,p] = proj(p1; pp1[n], fl1[n]) - proj(p0; pp0[n], fl0[n]) with
+ * proj(q; pp, fl) = pp + (q.xy * fl) / q.z (:98-101).  pp0/pp1 [N,2], fl0/fl1 [N] -> flow [N,P,2], bgmask [N,P] (0/1 bytes).
+ * Backward: the frame-t projection and all background pixels are detached (:102-103), so the gradient reaches
+ * px planes 3-5 (grad_px [N,7,P] is overwritten whole, zeros elsewhere), pp1 [N,2] and fl1 [N].
+ * scratch: lasr_flow_reproject_scratch_floats(N, P) floats.
+ */
+size_t lasr_flow_reproject_scratch_floats(int N, int P);
+int lasr_flow_reproject_forward(const float* px, const float* pp0, const float* pp1, const float* fl0, const float* fl1,
+                                float* flow, unsigned char* bgmask, int N, int P, void* hip_stream);
+int lasr_flow_reproject_backward(const float* px, const float* fl1, const float* grad_flow, float* grad_px,
+                                 float* grad_pp1, float* grad_fl1, float* scratch, int N, int P, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

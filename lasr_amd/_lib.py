@@ -38,6 +38,9 @@ SIGNATURES = {
     'lasr_arap_backward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_laplacian_forward': (_i, [_p] * 4 + [_i, _i, _p]),
     'lasr_laplacian_backward': (_i, [_p] * 6 + [_i, _i, _p]),
+    'lasr_flow_reproject_scratch_floats': (_sz, [_i, _i]),
+    'lasr_flow_reproject_forward': (_i, [_p] * 7 + [_i, _i, _p]),
+    'lasr_flow_reproject_backward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),

@@ -12,6 +12,7 @@
 #include "../../include/lasr_ops.h"
 #include "host_common.h"
 #include "sr_device.h"
+#include "ops_common.h"
 
 namespace lasr {
 
@@ -29,16 +30,6 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl)
         case 0xAA: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xAA, 0xf, 0xf, false));
         default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFF, 0xf, 0xf, false));
     }
-}
-
-// Sum over a 256-thread block; every thread gets the total.  `red` = 4 floats of LDS.
-__device__ __forceinline__ float block_sum(float v, float* red)
-{
-    v = wave_sum_to_lane63(v);
-    __syncthreads();                       // protect `red` from the previous use
-    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ===========================================================================
@@ -571,11 +562,6 @@ __global__ __launch_bounds__(256) void laplacian_backward_kernel(const float* __
 // ===========================================================================
 using namespace lasr;
 
-#define LASR_LAUNCH(ID, KERNEL, GRID, BLOCK, LDS, ...)                                   \
-    do {                                                                                 \
-        ProfScope ps_(ID, st);                                                           \
-        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, st, __VA_ARGS__);                   \
-    } while (0)
 
 extern "C" int lasr_lbs_forward(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out,
                                 int N, int V, int K, int tocam, void* hip_stream)

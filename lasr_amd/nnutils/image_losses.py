@@ -58,7 +58,8 @@ class _FlowLoss(Function):
         flow_rd = flow_rd.contiguous().float()
         flow_obs = flow_obs.contiguous().float()                  # [I, C>=2, IS, IS]
         stride = flow_obs[0].numel()
-        bg8 = bg.contiguous().to(torch.uint8)
+        bg8 = bg.contiguous()
+        bg8 = bg8.view(torch.uint8) if bg8.dtype == torch.bool else bg8.to(torch.uint8)       # bool: same bytes, no copy
         occ, masks = occ.contiguous().float(), masks.contiguous().float()
         loss = torch.empty(I, H, dtype=torch.float32, device=flow_rd.device)
         fmap = torch.empty(flow_rd.shape[:-1], dtype=torch.float32, device=flow_rd.device)

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from .. import soft_renderer as sr
 from .. import synth
-from . import image_losses
+from . import fused_ops, image_losses
 from .geom_utils import obj_to_cam, pinhole_cam
 
 
@@ -316,6 +316,9 @@ class MeshNet(nn.Module):
             flip = torch.ones(1, 3)
             flip[0, opts.symidx] = -1
             self.register_buffer('flip', flip)
+            mask = torch.ones(num_sym_output + num_sym, 3)          # vertices on the symmetry plane stay on it
+            mask[:num_indept, opts.symidx] = 0
+            self.register_buffer('sym_mask', mask, persistent=False)
         else:
             self.num_output = num_verts
             mean_v = torch.from_numpy(verts)
@@ -332,26 +335,24 @@ class MeshNet(nn.Module):
                                             n_hypo=opts.n_hypo)
 
     def symmetrize(self, V):
-        """[num_indept+num_sym,3] -> full mesh (ext_nnutils/mesh_net.py:128-149); identity if not symmetric."""
+        """[..., num_indept+num_sym, 3] -> full mesh (ext_nnutils/mesh_net.py:128-149); identity if not symmetric.
+        Leading dimensions (the hypotheses) are batched: one cat + one multiply for all of them."""
         if not self.symmetric:
             return V
-        left = self.flip * V[-self.num_sym:]
-        out = torch.cat([V, left], 0)
-        mask = torch.ones_like(out)
-        mask[:self.num_indept, self.opts.symidx] = 0
-        return out * mask
+        out = torch.cat([V, self.flip * V[..., -self.num_sym:, :]], -2)
+        return out * self.sym_mask
 
     def symmetrize_color(self, V):
-        return torch.cat([V, V[-self.num_sym:]], 0) if self.symmetric else V
+        return torch.cat([V, V[..., -self.num_sym:, :]], -2) if self.symmetric else V
 
     def get_mean_shape(self, local_batch_size):
         """-> mean_v [2B*H,V,3], tex [2B*H,V,3] (sigmoid), faces [2B,F,3] (ext_nnutils/mesh_net.py:171-185)."""
-        mean_v = torch.stack([self.symmetrize(v) for v in self.mean_v], 0)
-        tex = torch.stack([self.symmetrize_color(t) for t in self.tex], 0)
+        mean_v = self.symmetrize(self.mean_v)
+        tex = self.symmetrize_color(self.tex)
         n2 = 2 * local_batch_size
         faces = self.faces[None].repeat(n2, 1, 1)
         mean_v = mean_v[None].repeat(n2, 1, 1, 1).view(n2 * mean_v.shape[0], -1, 3)
-        tex = tex[None].repeat(n2, 1, 1, 1).sigmoid().view(n2 * tex.shape[0], -1, 3)
+        tex = tex.sigmoid()[None].repeat(n2, 1, 1, 1).view(n2 * tex.shape[0], -1, 3)      # sigmoid once per hypothesis
         return mean_v, tex, faces
 
 
@@ -369,19 +370,7 @@ def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0,
                                            textures=torch.cat([verts_pos0[:, :, :3], verts_pos1[:, :, :3]], -1),
                                            texture_type='vertex'))
     fgmask = px[:, -1]
-    p0 = px[:, 0:3].permute(0, 2, 3, 1)
-    p1 = px[:, 3:6].permute(0, 2, 3, 1)
-    bgmask = (p0[:, :, :, 2] < 1e-9) | (p1[:, :, :, 2] < 1e-9)
-    ten = sr.functional.const_tensor([10.], p0.device)[0]
-    p0 = torch.where(bgmask[..., None], ten, p0)
-    p1 = torch.where(bgmask[..., None], ten, p1)
-
-    def reproject(p, pp, fl):
-        x = pp[:, 0:1, None] + p[:, :, :, 0] * fl[:, :1, None] / p[:, :, :, 2]
-        y = pp[:, 1:2, None] + p[:, :, :, 1] * fl[:, :1, None] / p[:, :, :, 2]
-        return torch.stack([x, y], -1)
-    flow = reproject(p1, pp1, proj_cam1) - reproject(p0, pp0, proj_cam0).detach()
-    flow = torch.where(bgmask[..., None], flow.detach(), flow)
+    flow, bgmask = fused_ops.flow_reproject(px, pp0, pp1, proj_cam0[:, :1], proj_cam1[:, :1])      # (:93-104)
     return flow, bgmask, fgmask
 
 
@@ -623,10 +612,11 @@ class LASR(MeshNet):
             aux['ctl_proj'] = self.ctl_proj
         aux['current_nscore'] = self.texture_loss_sub.mean(0) + self.flow_rd_loss_sub.mean(0) + self.mask_loss_sub.mean(0)
         if H > 1:
-            for h in range(H):
-                aux['mask_hypo_%d' % h] = self.mask_loss_sub[:, h].mean()
-                aux['flow_hypo_%d' % h] = self.flow_rd_loss_sub[:, h].mean()
-                aux['tex_hypo_%d' % h] = self.texture_loss_sub[:, h].mean()
+            per_hypo = torch.stack([self.mask_loss_sub, self.flow_rd_loss_sub, self.texture_loss_sub], 0).detach().mean(1)
+            for h in range(H):                                                   # views of one [3,H] table
+                aux['mask_hypo_%d' % h] = per_hypo[0, h]
+                aux['flow_hypo_%d' % h] = per_hypo[1, h]
+                aux['tex_hypo_%d' % h] = per_hypo[2, h]
         aux['texture_render'] = self.texture_render
         if hasattr(self, 'part_render'):
             aux['part_render'] = self.part_render

@@ -175,9 +175,10 @@ class LASRTrainer:
                 self.grad_meanv_norm = torch.nn.utils.clip_grad_norm_(p, 1.)
             elif 'code_predictor' in name or 'encoder' in name:
                 cam_grad.append(p)
-            finite.append(p.grad.sum())
+            finite.append(p.grad)
         self.grad_cam_norm = torch.nn.utils.clip_grad_norm_(cam_grad, 10.) if cam_grad else None
-        if finite and not bool(torch.isfinite(torch.stack(finite).sum())):     # one sync (the reference: ~70)
+        # a NaN/Inf anywhere makes its tensor's norm non-finite: one multi-tensor launch and one sync (reference: ~70)
+        if finite and not bool(torch.isfinite(torch.stack(torch._foreach_norm(finite)).sum())):
             self.optimizer.zero_grad(set_to_none=not hasattr(self, '_graphs'))
         self.optimizer.step()
         self.scheduler.step()

@@ -106,3 +106,21 @@ def laplacian(x, faces):
             L[i, :] /= L[i, i]
     y = torch.matmul(torch.from_numpy(L).to(x.dtype), x)
     return y.pow(2).sum((1, 2))
+
+
+def flow_reproject(px, pp0, pp1, fl0, fl1):
+    """nnutils/mesh_net.py:87-104 after the render: px [N,7,S,S] = (position at frame t, at frame t', alpha).
+    -> flow [N,S,S,2], bgmask [N,S,S] bool.  Frame t's projection and background pixels are detached."""
+    p0 = px[:, 0:3].permute(0, 2, 3, 1).clone()
+    p1 = px[:, 3:6].permute(0, 2, 3, 1).clone()
+    bg = (p0[..., 2] < 1e-9) | (p1[..., 2] < 1e-9)
+    p0[bg] = 10
+    p1[bg] = 10
+
+    def proj(p, pp, fl):
+        x = pp[:, 0:1, None] + p[..., 0] * fl[:, :1, None] / p[..., 2]
+        y = pp[:, 1:2, None] + p[..., 1] * fl[:, :1, None] / p[..., 2]
+        return torch.stack([x, y], -1)
+    flow = proj(p1, pp1, fl1) - proj(p0, pp0, fl0).detach()
+    flow = torch.where(bg[..., None], flow.detach(), flow)
+    return flow, bg

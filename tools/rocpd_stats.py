@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd database (kernel-trace) into a per-kernel stats table.
 
-    python tools/rocpd_stats.py gpurun_out/prof_x/x_results.db > profiles/rNN_kernel_stats.txt
+    python tools/rocpd_stats.py gpurun_out/prof_x/x_results.db [LAST_MS] > profiles/rNN_kernel_stats.txt
 
 Same columns as `rocprofv3 --stats` kernel_stats.csv (calls, total, average, min, max, percentage).
 With --pmc the database also carries counter samples; those are averaged per kernel.
@@ -10,13 +10,19 @@ import sqlite3
 import sys
 
 
-def main(path):
+def main(path, last_ms=None):
     c = sqlite3.connect(path)
+    where = ''
+    if last_ms is not None:      # steady state only: dispatches that started in the last `last_ms` of the trace
+        t_end = c.execute('select max(end) from rocpd_kernel_dispatch').fetchone()[0]
+        where = 'where d.start >= %d' % (t_end - int(last_ms * 1e6))
     q = """select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start),
                   max(d.end-d.start), max(s.arch_vgpr_count), max(s.sgpr_count), max(d.group_segment_size)
            from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-           group by s.kernel_name order by 3 desc"""
+           %s group by s.kernel_name order by 3 desc""" % where
     rows = list(c.execute(q))
+    if last_ms is not None:
+        print('# window: last %.1f ms of the trace; kernel-busy time %.2f ms' % (last_ms, sum(r[2] for r in rows) / 1e6))
     total = sum(r[2] for r in rows) or 1
     print('# source: %s' % path)
     print('%-70s %7s %14s %12s %12s %12s %7s %5s %5s %7s' % ('Name', 'Calls', 'TotalNs', 'AvgNs', 'MinNs', 'MaxNs',
@@ -40,4 +46,4 @@ def main(path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else None)
