@@ -100,8 +100,6 @@ int lasr_tex_loss_backward(const float* img_obs, const float* img_white, const f
  *   vertices without neighbours contribute 0 (the reference leaves their row at zero, :50-51).
  * Both take the mesh adjacency as CSR (row_ptr [V+1], col [nnz], unique neighbours, symmetric), x/dx [N,V,3]
  * -> loss [N].  Backward entry points overwrite the gradients and are deterministic (vertex-centric gathers).
- * (FlattenLoss, ext_nnutils/loss_utils.py:110-152, is already edge-based in the reference and stays a
- * chain of torch ops in the host mirror.)
  */
 int lasr_arap_forward(const float* dx, const float* x, const int* row_ptr, const int* col, float* loss,
                       int N, int V, void* hip_stream);
@@ -127,6 +125,42 @@ int lasr_flow_reproject_forward(const float* px, const float* pp0, const float* 
                                 float* flow, unsigned char* bgmask, int N, int P, void* hip_stream);
 int lasr_flow_reproject_backward(const float* px, const float* fl1, const float* grad_flow, float* grad_px,
                                  float* grad_pp1, float* grad_fl1, float* scratch, int N, int P, void* hip_stream);
+
+/*
+ * Unit quaternion -> rotation matrix, kornia 0.5.3 `quaternion_to_rotation_matrix` semantics (not vendored in the
+ * reference; call sites nnutils/mesh_net.py:232,250,265 and third_party/ext_nnutils/net_blocks.py:359): coefficient
+ * order (x,y,z,w); the quaternion is normalised first (q / max(|q|, 1e-12));
+ *   R = [[1-2(yy+zz), 2(xy-zw), 2(xz+yw)], [2(xy+zw), 1-2(xx+zz), 2(yz-xw)], [2(xz-yw), 2(yz+xw), 1-2(xx+yy)]].
+ * quat [M,4] -> rotmat [M,9] row-major.  Backward: grad_rotmat [M,9] -> grad_quat [M,4] (overwritten).
+ */
+int lasr_quat_to_rotmat_forward(const float* quat, float* rotmat, int M, void* hip_stream);
+int lasr_quat_to_rotmat_backward(const float* quat, const float* grad_rotmat, float* grad_quat, int M, void* hip_stream);
+
+/*
+ * GMM skinning weights, nnutils/mesh_net.py:264-271:
+ *   skin[h,k,v] = softmax over k of  -10 * sum_d exp(log_ctl[h,k,d]) * ((ctl_ts[h,k] - verts[h,v]) * R(ctl_rs[h,k]))_d^2
+ * ctl_ts, log_ctl [H*J,3], ctl_rs [H*J,4] (x,y,z,w, normalised inside), verts [H,V,3] (frame-0 mean shape, a constant:
+ * :266 detaches it) -> skin [H,J,V].  J <= 64.
+ * Backward: grad_skin [H,J,V] -> grad_ts [H*J,3], grad_rs [H*J,4], grad_log_ctl [H*J,3] (overwritten);
+ * scratch: H*V floats.
+ */
+int lasr_skin_weights_forward(const float* ctl_ts, const float* ctl_rs, const float* log_ctl, const float* verts,
+                              float* skin, int H, int J, int V, void* hip_stream);
+int lasr_skin_weights_backward(const float* ctl_ts, const float* ctl_rs, const float* log_ctl, const float* verts,
+                               const float* skin, const float* grad_skin, float* grad_ts, float* grad_rs,
+                               float* grad_log_ctl, float* scratch, int H, int J, int V, void* hip_stream);
+
+/*
+ * Flatten loss, third_party/ext_nnutils/loss_utils.py:110-152: loss[n] = sum over the listed interior edges of
+ * (cos + 1)^2 where cos is the cosine between the parts of (v2 - v0) and (v3 - v0) orthogonal to the edge (v1 - v0),
+ * every eps = 1e-6 as in the reference (:120-147).  quads [E,4] int32 = (v0,v1,v2,v3) per edge (built on the host from
+ * the faces, :73-108), x [N,V,3] -> loss [N].
+ * Backward: per-edge gradients into scratch (N*E*12 floats), then a vertex-centric gather through the incidence lists
+ * inc_ptr [V+1], inc [4E] (entry = edge*4 + slot, ascending) -> grad_x [N,V,3] (overwritten, deterministic).
+ */
+int lasr_flatten_forward(const float* x, const int* quads, float* loss, int N, int V, int E, void* hip_stream);
+int lasr_flatten_backward(const float* x, const int* quads, const int* inc_ptr, const int* inc, const float* grad_loss,
+                          float* grad_x, float* scratch, int N, int V, int E, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,9 @@
 // In the reference each of these is a chain of 20-100 eager elementwise launches per call (forward and again in
 // autograd's backward); at LASR's sizes every one of them is launch-bound, so each chain becomes one kernel pair:
 //   flow reprojection   nnutils/mesh_net.py:93-104   (background fill, two pinhole reprojections, difference, detach rules)
+//   quaternion -> R     kornia 0.5.3 quaternion_to_rotation_matrix, call sites mesh_net.py:232,250,265, net_blocks.py:359
+//   GMM skin weights    nnutils/mesh_net.py:264-271   (Mahalanobis distance to every bone, softmax over bones)
+//   flatten loss        third_party/ext_nnutils/loss_utils.py:110-152   (dihedral cosine over interior edges)
 // Reductions are deterministic (fixed tree inside a block, fixed-order fold of block partials; no float atomics).
 #include <hip/hip_runtime.h>
 
@@ -90,6 +93,290 @@ __global__ __launch_bounds__(256) void flow_reproject_fold_kernel(const float* _
     gpp1[2 * n] = a; gpp1[2 * n + 1] = b; gfl1[n] = c;
 }
 
+// ===========================================================================
+// Quaternion (x,y,z,w) -> rotation matrix with normalisation (eps 1e-12 like F.normalize).
+// ===========================================================================
+struct Quat { float x, y, z, w, inv_n; };
+
+__device__ __forceinline__ Quat load_quat(const float* q)
+{
+    Quat r;
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    r.inv_n = 1.f / fmaxf(n, 1e-12f);
+    r.x = q[0] * r.inv_n; r.y = q[1] * r.inv_n; r.z = q[2] * r.inv_n; r.w = q[3] * r.inv_n;
+    return r;
+}
+
+__device__ __forceinline__ void quat_matrix(const Quat& q, float* m)
+{
+    const float tx = 2.f * q.x, ty = 2.f * q.y, tz = 2.f * q.z;
+    m[0] = 1.f - (ty * q.y + tz * q.z); m[1] = tx * q.y - tz * q.w;         m[2] = tx * q.z + ty * q.w;
+    m[3] = tx * q.y + tz * q.w;         m[4] = 1.f - (tx * q.x + tz * q.z); m[5] = ty * q.z - tx * q.w;
+    m[6] = tx * q.z - ty * q.w;         m[7] = ty * q.z + tx * q.w;         m[8] = 1.f - (tx * q.x + ty * q.y);
+}
+
+// gradient w.r.t. the raw quaternion given the gradient of the 9 matrix entries
+__device__ __forceinline__ void quat_matrix_backward(const Quat& q, const float* g, float* gq)
+{
+    const float x = q.x, y = q.y, z = q.z, w = q.w;
+    const float gx = 2.f * (y * (g[1] + g[3]) + z * (g[2] + g[6]) + w * (g[7] - g[5]) - 2.f * x * (g[4] + g[8]));
+    const float gy = 2.f * (x * (g[1] + g[3]) + z * (g[5] + g[7]) + w * (g[2] - g[6]) - 2.f * y * (g[0] + g[8]));
+    const float gz = 2.f * (x * (g[2] + g[6]) + y * (g[5] + g[7]) + w * (g[3] - g[1]) - 2.f * z * (g[0] + g[4]));
+    const float gw = 2.f * (z * (g[3] - g[1]) + y * (g[2] - g[6]) + x * (g[7] - g[5]));
+    // through q / max(|q|, eps): (g - qhat (qhat . g)) / |q| ; with the eps clamp active the norm is a constant
+    const bool clamped = q.inv_n >= 1e12f;
+    const float d = clamped ? 0.f : (x * gx + y * gy + z * gz + w * gw);
+    gq[0] = (gx - x * d) * q.inv_n; gq[1] = (gy - y * d) * q.inv_n;
+    gq[2] = (gz - z * d) * q.inv_n; gq[3] = (gw - w * d) * q.inv_n;
+}
+
+__global__ __launch_bounds__(256) void quat_forward_kernel(const float* __restrict__ q, float* __restrict__ R, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float m[9];
+    quat_matrix(load_quat(q + 4 * (size_t)i), m);
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[9 * (size_t)i + k] = m[k];
+}
+
+__global__ __launch_bounds__(256) void quat_backward_kernel(const float* __restrict__ q, const float* __restrict__ gR,
+                                                            float* __restrict__ gq, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float g[9], o[4];
+#pragma unroll
+    for (int k = 0; k < 9; k++) g[k] = gR[9 * (size_t)i + k];
+    quat_matrix_backward(load_quat(q + 4 * (size_t)i), g, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) gq[4 * (size_t)i + k] = o[k];
+}
+
+// ===========================================================================
+// GMM skinning weights, mesh_net.py:264-271:
+//   skin[h,k,v] = softmax_k( -10 * sum_d exp(log_ctl[h,k,d]) * ((ctl_ts[h,k] - verts[h,v]) R(ctl_rs[h,k]))_d^2 )
+// ctl_ts, log_ctl [H*J,3], ctl_rs [H*J,4] (x,y,z,w), verts [H,V,3] (constant) -> skin [H,J,V].
+// ===========================================================================
+constexpr int SKIN_MAX_BONES = 64;
+
+struct Bone { float t[3]; float R[9]; float w[3]; };
+
+__device__ __forceinline__ float bone_logit(const Bone& b, float vx, float vy, float vz, float* r)
+{
+    const float d0 = b.t[0] - vx, d1 = b.t[1] - vy, d2 = b.t[2] - vz;
+    r[0] = d0 * b.R[0] + d1 * b.R[3] + d2 * b.R[6];
+    r[1] = d0 * b.R[1] + d1 * b.R[4] + d2 * b.R[7];
+    r[2] = d0 * b.R[2] + d1 * b.R[5] + d2 * b.R[8];
+    return -10.f * (b.w[0] * (r[0] * r[0]) + b.w[1] * (r[1] * r[1]) + b.w[2] * (r[2] * r[2]));
+}
+
+__device__ __forceinline__ void load_bones(Bone* bones, const float* ts, const float* rs, const float* lc, int h, int J)
+{
+    for (int k = threadIdx.x; k < J; k += blockDim.x) {
+        const size_t i = (size_t)h * J + k;
+        Bone b;
+        for (int d = 0; d < 3; d++) { b.t[d] = ts[3 * i + d]; b.w[d] = expf(lc[3 * i + d]); }
+        quat_matrix(load_quat(rs + 4 * i), b.R);
+        bones[k] = b;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void skin_forward_kernel(const float* __restrict__ ts, const float* __restrict__ rs,
+                                                           const float* __restrict__ lc, const float* __restrict__ verts,
+                                                           float* __restrict__ skin, int V, int J)
+{
+    __shared__ Bone bones[SKIN_MAX_BONES];
+    const int h = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    load_bones(bones, ts, rs, lc, h, J);
+    if (v >= V) return;
+    const float* p = verts + ((size_t)h * V + v) * 3;
+    const float vx = p[0], vy = p[1], vz = p[2];
+    float r[3], mx = -INFINITY;
+    for (int k = 0; k < J; k++) mx = fmaxf(mx, bone_logit(bones[k], vx, vy, vz, r));
+    float z = 0.f;
+    for (int k = 0; k < J; k++) z += expf(bone_logit(bones[k], vx, vy, vz, r) - mx);
+    for (int k = 0; k < J; k++) skin[((size_t)h * J + k) * V + v] = expf(bone_logit(bones[k], vx, vy, vz, r) - mx) / z;
+}
+
+// backward, stage 1: dot[h,v] = sum_k skin * gskin (the softmax Jacobian's common term)
+__global__ __launch_bounds__(256) void skin_backward_dot_kernel(const float* __restrict__ skin, const float* __restrict__ gskin,
+                                                                float* __restrict__ dot, int V, int J)
+{
+    const int h = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    float d = 0.f;
+    for (int k = 0; k < J; k++) { const size_t i = ((size_t)h * J + k) * V + v; d += skin[i] * gskin[i]; }
+    dot[(size_t)h * V + v] = d;
+}
+
+// backward, stage 2: one block per (h, bone): sums over the vertices, then the quaternion / log-scale chain
+__global__ __launch_bounds__(256) void skin_backward_kernel(const float* __restrict__ ts, const float* __restrict__ rs,
+                                                            const float* __restrict__ lc, const float* __restrict__ verts,
+                                                            const float* __restrict__ skin, const float* __restrict__ gskin,
+                                                            const float* __restrict__ dot, float* __restrict__ gts,
+                                                            float* __restrict__ grs, float* __restrict__ glc, int V, int J)
+{
+    __shared__ float red[4];
+    const int hk = blockIdx.x, h = hk / J;
+    Bone b;
+    for (int d = 0; d < 3; d++) { b.t[d] = ts[3 * (size_t)hk + d]; b.w[d] = expf(lc[3 * (size_t)hk + d]); }
+    const Quat q = load_quat(rs + 4 * (size_t)hk);
+    quat_matrix(q, b.R);
+    float acc[15];                                   // g_ts[3] | g_lc[3] | g_R[9]
+#pragma unroll
+    for (int i = 0; i < 15; i++) acc[i] = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float* p = verts + ((size_t)h * V + v) * 3;
+        const size_t i = (size_t)hk * V + v;
+        const float ge = -10.f * (skin[i] * (gskin[i] - dot[(size_t)h * V + v]));     // d loss / d (sum_d w_d r_d^2)
+        float r[3];
+        const float d0 = b.t[0] - p[0], d1 = b.t[1] - p[1], d2 = b.t[2] - p[2];
+        r[0] = d0 * b.R[0] + d1 * b.R[3] + d2 * b.R[6];
+        r[1] = d0 * b.R[1] + d1 * b.R[4] + d2 * b.R[7];
+        r[2] = d0 * b.R[2] + d1 * b.R[5] + d2 * b.R[8];
+        float gr[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            acc[3 + d] += ge * b.w[d] * (r[d] * r[d]);           // d/d log_ctl: w = exp(log_ctl)
+            gr[d] = 2.f * ge * b.w[d] * r[d];
+        }
+        acc[0] += gr[0] * b.R[0] + gr[1] * b.R[1] + gr[2] * b.R[2];
+        acc[1] += gr[0] * b.R[3] + gr[1] * b.R[4] + gr[2] * b.R[5];
+        acc[2] += gr[0] * b.R[6] + gr[1] * b.R[7] + gr[2] * b.R[8];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { acc[6 + c] += d0 * gr[c]; acc[9 + c] += d1 * gr[c]; acc[12 + c] += d2 * gr[c]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 15; i++) acc[i] = block_sum(acc[i], red);
+    if (threadIdx.x == 0) {
+        float gq[4];
+        quat_matrix_backward(q, acc + 6, gq);
+        for (int d = 0; d < 3; d++) { gts[3 * (size_t)hk + d] = acc[d]; glc[3 * (size_t)hk + d] = acc[3 + d]; }
+        for (int d = 0; d < 4; d++) grs[4 * (size_t)hk + d] = gq[d];
+    }
+}
+
+// ===========================================================================
+// Flatten loss, ext_nnutils/loss_utils.py:110-152: for every listed interior edge (v0,v1) with opposite vertices v2, v3
+//   loss[n] = sum_e (cos_e + 1)^2, cos_e = the cosine between the components of (v2-v0), (v3-v0) orthogonal to (v1-v0)
+// quads [E,4] int32 (v0,v1,v2,v3), x [N,V,3] -> loss [N].
+// ===========================================================================
+constexpr float FLAT_EPS = 1e-6f;
+
+struct FlatSide { float b[3], cb[3], bl1, ab, den, cosb, sinb, t, nb; };
+
+__device__ __forceinline__ void flat_side(const float* a, float al2, float sq_al2, const float* v0, const float* vb, FlatSide& s)
+{
+    float bl2 = 0.f; s.ab = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { s.b[d] = vb[d] - v0[d]; bl2 += s.b[d] * s.b[d]; s.ab += a[d] * s.b[d]; }
+    s.bl1 = sqrtf(bl2 + FLAT_EPS);
+    s.den = sq_al2 * s.bl1 + FLAT_EPS;
+    s.cosb = s.ab / s.den;
+    s.sinb = sqrtf(1.f - s.cosb * s.cosb + FLAT_EPS);
+    s.t = s.ab / (al2 + FLAT_EPS);
+#pragma unroll
+    for (int d = 0; d < 3; d++) s.cb[d] = s.b[d] - a[d] * s.t;
+    s.nb = s.bl1 * s.sinb;
+}
+
+struct FlatEdge { float a[3], al2, sq_al2; FlatSide s1, s2; float S, D, cos; };
+
+__device__ __forceinline__ void flat_edge(const float* x, const int* q, FlatEdge& e)
+{
+    const float* v0 = x + 3 * (size_t)q[0];
+    const float* v1 = x + 3 * (size_t)q[1];
+    e.al2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { e.a[d] = v1[d] - v0[d]; e.al2 += e.a[d] * e.a[d]; }
+    e.sq_al2 = sqrtf(e.al2 + FLAT_EPS);
+    flat_side(e.a, e.al2, e.sq_al2, v0, x + 3 * (size_t)q[2], e.s1);
+    flat_side(e.a, e.al2, e.sq_al2, v0, x + 3 * (size_t)q[3], e.s2);
+    e.S = e.s1.cb[0] * e.s2.cb[0] + e.s1.cb[1] * e.s2.cb[1] + e.s1.cb[2] * e.s2.cb[2];
+    e.D = e.s1.nb * e.s2.nb + FLAT_EPS;
+    e.cos = e.S / e.D;
+}
+
+__global__ __launch_bounds__(256) void flatten_forward_kernel(const float* __restrict__ x, const int* __restrict__ quads,
+                                                              float* __restrict__ loss, int V, int E)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float* xn = x + (size_t)n * V * 3;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        FlatEdge fe;
+        flat_edge(xn, quads + 4 * (size_t)e, fe);
+        acc += (fe.cos + 1.f) * (fe.cos + 1.f);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) loss[n] = acc;
+}
+
+// per-edge gradients w.r.t. its four vertices -> gedge [N,E,4,3]
+__device__ __forceinline__ void flat_side_backward(const FlatEdge& e, const FlatSide& s, const float* g_cb, float g_n,
+                                                   float* g_a, float* g_b)
+{
+    float g_bl1 = g_n * s.sinb;
+    const float g_cosb = (g_n * s.bl1) * (-s.cosb / s.sinb);
+    float a_gcb = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) a_gcb += e.a[d] * g_cb[d];
+    const float g_t = -a_gcb;
+    const float al2e = e.al2 + FLAT_EPS;
+    const float g_ab = g_t / al2e + g_cosb / s.den;
+    const float g_den = -g_cosb * s.ab / (s.den * s.den);
+    float g_al2 = -g_t * s.ab / (al2e * al2e) + (g_den * s.bl1) / (2.f * e.sq_al2);
+    g_bl1 += g_den * e.sq_al2;
+    const float g_bl2 = g_bl1 / (2.f * s.bl1);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        g_b[d] = g_cb[d] + 2.f * s.b[d] * g_bl2 + e.a[d] * g_ab;
+        g_a[d] += -s.t * g_cb[d] + s.b[d] * g_ab + 2.f * e.a[d] * g_al2;
+    }
+}
+
+__global__ __launch_bounds__(256) void flatten_backward_edge_kernel(const float* __restrict__ x, const int* __restrict__ quads,
+                                                                    const float* __restrict__ gloss, float* __restrict__ gedge,
+                                                                    int V, int E)
+{
+    const int n = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    FlatEdge fe;
+    flat_edge(x + (size_t)n * V * 3, quads + 4 * (size_t)e, fe);
+    const float gcos = 2.f * (fe.cos + 1.f) * gloss[n];
+    const float gD = -gcos * fe.S / (fe.D * fe.D);
+    float g_cb1[3], g_cb2[3], g_a[3] = {0.f, 0.f, 0.f}, g_b1[3], g_b2[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { g_cb1[d] = gcos / fe.D * fe.s2.cb[d]; g_cb2[d] = gcos / fe.D * fe.s1.cb[d]; }
+    flat_side_backward(fe, fe.s1, g_cb1, gD * fe.s2.nb, g_a, g_b1);
+    flat_side_backward(fe, fe.s2, g_cb2, gD * fe.s1.nb, g_a, g_b2);
+    float* o = gedge + ((size_t)n * E + e) * 12;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        o[d] = -(g_a[d] + g_b1[d] + g_b2[d]); o[3 + d] = g_a[d]; o[6 + d] = g_b1[d]; o[9 + d] = g_b2[d];
+    }
+}
+
+// vertex-centric gather of the edge gradients: inc_ptr [V+1], inc [nnz] = edge * 4 + slot, ascending (deterministic)
+__global__ __launch_bounds__(256) void flatten_backward_vertex_kernel(const float* __restrict__ gedge, const int* __restrict__ inc_ptr,
+                                                                      const int* __restrict__ inc, float* __restrict__ gx,
+                                                                      int V, int E)
+{
+    const int n = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float* g = gedge + (size_t)n * E * 12;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = inc_ptr[v]; i < inc_ptr[v + 1]; i++) {
+        const float* o = g + 3 * (size_t)inc[i];
+        a0 += o[0]; a1 += o[1]; a2 += o[2];
+    }
+    float* out = gx + ((size_t)n * V + v) * 3;
+    out[0] = a0; out[1] = a1; out[2] = a2;
+}
+
 }  // namespace lasr
 
 // ===========================================================================
@@ -132,5 +419,88 @@ extern "C" int lasr_flow_reproject_backward(const float* px, const float* fl1, c
     if (rc) return rc;
     LASR_LAUNCH(K_FLOW_REPROJECT_BACKWARD, flow_reproject_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, scratch, grad_pp1,
                 grad_fl1, N, nch);
+    return launch_ok();
+}
+
+extern "C" int lasr_quat_to_rotmat_forward(const float* quat, float* rotmat, int M, void* hip_stream)
+{
+    if (M < 0) return LASR_E_BADARG;
+    if (M == 0) return LASR_OK;
+    if (!quat || !rotmat) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_QUAT_FORWARD, quat_forward_kernel, dim3((M + 255) / 256), dim3(256), 0, quat, rotmat, M);
+    return launch_ok();
+}
+
+extern "C" int lasr_quat_to_rotmat_backward(const float* quat, const float* grad_rotmat, float* grad_quat, int M,
+                                            void* hip_stream)
+{
+    if (M < 0) return LASR_E_BADARG;
+    if (M == 0) return LASR_OK;
+    if (!quat || !grad_rotmat || !grad_quat) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_QUAT_BACKWARD, quat_backward_kernel, dim3((M + 255) / 256), dim3(256), 0, quat, grad_rotmat, grad_quat, M);
+    return launch_ok();
+}
+
+extern "C" int lasr_skin_weights_forward(const float* ctl_ts, const float* ctl_rs, const float* log_ctl,
+                                         const float* verts, float* skin, int H, int J, int V, void* hip_stream)
+{
+    if (H < 0 || J < 0 || V < 0 || J > SKIN_MAX_BONES) return LASR_E_BADARG;
+    if (H == 0 || J == 0 || V == 0) return LASR_OK;
+    if (!ctl_ts || !ctl_rs || !log_ctl || !verts || !skin) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_SKIN_FORWARD, skin_forward_kernel, dim3((V + 255) / 256, H), dim3(256), 0, ctl_ts, ctl_rs, log_ctl, verts,
+                skin, V, J);
+    return launch_ok();
+}
+
+extern "C" int lasr_skin_weights_backward(const float* ctl_ts, const float* ctl_rs, const float* log_ctl,
+                                          const float* verts, const float* skin, const float* grad_skin,
+                                          float* grad_ts, float* grad_rs, float* grad_log_ctl, float* scratch,
+                                          int H, int J, int V, void* hip_stream)
+{
+    if (H < 0 || J < 0 || V < 0 || J > SKIN_MAX_BONES) return LASR_E_BADARG;
+    if (H == 0 || J == 0) return LASR_OK;
+    if (!ctl_ts || !ctl_rs || !log_ctl || !verts || !skin || !grad_skin || !grad_ts || !grad_rs || !grad_log_ctl || !scratch)
+        return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (V > 0) {
+        LASR_LAUNCH(K_SKIN_BACKWARD, skin_backward_dot_kernel, dim3((V + 255) / 256, H), dim3(256), 0, skin, grad_skin,
+                    scratch, V, J);
+        int rc = launch_ok();
+        if (rc) return rc;
+    }
+    LASR_LAUNCH(K_SKIN_BACKWARD, skin_backward_kernel, dim3(H * J), dim3(256), 0, ctl_ts, ctl_rs, log_ctl, verts, skin,
+                grad_skin, scratch, grad_ts, grad_rs, grad_log_ctl, V, J);
+    return launch_ok();
+}
+
+extern "C" int lasr_flatten_forward(const float* x, const int* quads, float* loss, int N, int V, int E, void* hip_stream)
+{
+    if (N < 0 || V < 0 || E < 0) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!x || !loss || (E > 0 && !quads)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_FLATTEN_FORWARD, flatten_forward_kernel, dim3(N), dim3(256), 0, x, quads, loss, V, E);
+    return launch_ok();
+}
+
+extern "C" int lasr_flatten_backward(const float* x, const int* quads, const int* inc_ptr, const int* inc,
+                                     const float* grad_loss, float* grad_x, float* scratch, int N, int V, int E,
+                                     void* hip_stream)
+{
+    if (N < 0 || V < 0 || E < 0) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!x || !inc_ptr || !grad_loss || !grad_x || (E > 0 && (!quads || !inc || !scratch))) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (E > 0) {
+        LASR_LAUNCH(K_FLATTEN_BACKWARD, flatten_backward_edge_kernel, dim3((E + 255) / 256, N), dim3(256), 0, x, quads,
+                    grad_loss, scratch, V, E);
+        int rc = launch_ok();
+        if (rc) return rc;
+    }
+    LASR_LAUNCH(K_FLATTEN_BACKWARD, flatten_backward_vertex_kernel, dim3((V + 255) / 256, N), dim3(256), 0, scratch, inc_ptr,
+                inc, grad_x, V, E);
     return launch_ok();
 }

@@ -53,3 +53,109 @@ def flow_reproject(px, pp0, pp1, fl0, fl1):
     of frame t', alpha), pp0/pp1 [N,2], fl0/fl1 [N] or [N,1] -> flow [N,IS,IS,2], bgmask [N,IS,IS] bool."""
     N = px.shape[0]
     return _FlowReproject.apply(px, pp0, pp1, fl0.reshape(N, -1)[:, 0], fl1.reshape(N, -1)[:, 0])
+
+
+class _QuatToRotmat(Function):
+    @staticmethod
+    def forward(ctx, q):
+        _lib.need_cuda(q)
+        q = q.contiguous().float()
+        M = q.shape[0]
+        R = torch.empty(M, 9, dtype=torch.float32, device=q.device)
+        guard, st = _lib.stream_of(q)
+        with guard:
+            rc = _lib.lib().lasr_quat_to_rotmat_forward(q.data_ptr(), R.data_ptr(), M, st)
+        _lib.check(rc, 'lasr_quat_to_rotmat_forward')
+        ctx.save_for_backward(q)
+        return R
+
+    @staticmethod
+    def backward(ctx, gR):
+        q, = ctx.saved_tensors
+        gR = gR.contiguous().float()
+        gq = torch.empty_like(q)
+        guard, st = _lib.stream_of(q)
+        with guard:
+            rc = _lib.lib().lasr_quat_to_rotmat_backward(q.data_ptr(), gR.data_ptr(), gq.data_ptr(), q.shape[0], st)
+        _lib.check(rc, 'lasr_quat_to_rotmat_backward')
+        return gq
+
+
+def quat_to_rotmat(q):
+    """(x,y,z,w) quaternions [...,4] -> rotation matrices [...,3,3], normalising first (kornia 0.5.3
+    quaternion_to_rotation_matrix as called at /root/reference/nnutils/mesh_net.py:232,250,265)."""
+    return _QuatToRotmat.apply(q.reshape(-1, 4)).reshape(q.shape[:-1] + (3, 3))
+
+
+class _SkinWeights(Function):
+    @staticmethod
+    def forward(ctx, ts, rs, lc, verts):
+        _lib.need_cuda(ts, rs, lc, verts)
+        H, V = verts.shape[:2]
+        J = ts.shape[0] // H
+        ts, rs, lc, verts = (t.contiguous().float() for t in (ts, rs, lc, verts))
+        skin = torch.empty(H, J, V, dtype=torch.float32, device=ts.device)
+        guard, st = _lib.stream_of(ts)
+        with guard:
+            rc = _lib.lib().lasr_skin_weights_forward(ts.data_ptr(), rs.data_ptr(), lc.data_ptr(), verts.data_ptr(),
+                                                      skin.data_ptr(), H, J, V, st)
+        _lib.check(rc, 'lasr_skin_weights_forward')
+        ctx.save_for_backward(ts, rs, lc, verts, skin)
+        return skin
+
+    @staticmethod
+    def backward(ctx, g):
+        ts, rs, lc, verts, skin = ctx.saved_tensors
+        H, J, V = skin.shape
+        g = g.contiguous().float()
+        gts, grs, glc = torch.empty_like(ts), torch.empty_like(rs), torch.empty_like(lc)
+        scratch = torch.empty(H * V + 1, dtype=torch.float32, device=ts.device)
+        guard, st = _lib.stream_of(ts)
+        with guard:
+            rc = _lib.lib().lasr_skin_weights_backward(ts.data_ptr(), rs.data_ptr(), lc.data_ptr(), verts.data_ptr(),
+                                                       skin.data_ptr(), g.data_ptr(), gts.data_ptr(), grs.data_ptr(),
+                                                       glc.data_ptr(), scratch.data_ptr(), H, J, V, st)
+        _lib.check(rc, 'lasr_skin_weights_backward')
+        return gts, grs, glc, None
+
+
+def skin_weights(ctl_ts, ctl_rs, log_ctl, verts):
+    """GMM skinning weights (/root/reference/nnutils/mesh_net.py:264-271): ctl_ts, log_ctl [H*J,3], ctl_rs [H*J,4],
+    verts [H,V,3] (treated as a constant, :266) -> [H,J,V]."""
+    return _SkinWeights.apply(ctl_ts, ctl_rs, log_ctl, verts.detach())
+
+
+class _Flatten(Function):
+    @staticmethod
+    def forward(ctx, x, quads, inc_ptr, inc):
+        _lib.need_cuda(x, quads, inc_ptr, inc)
+        x = x.contiguous().float()
+        N, V = x.shape[:2]
+        E = quads.shape[0]
+        loss = torch.empty(N, dtype=torch.float32, device=x.device)
+        guard, st = _lib.stream_of(x)
+        with guard:
+            rc = _lib.lib().lasr_flatten_forward(x.data_ptr(), quads.data_ptr(), loss.data_ptr(), N, V, E, st)
+        _lib.check(rc, 'lasr_flatten_forward')
+        ctx.save_for_backward(x, quads, inc_ptr, inc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, quads, inc_ptr, inc = ctx.saved_tensors
+        N, V = x.shape[:2]
+        E = quads.shape[0]
+        g = g.contiguous().float()
+        gx = torch.empty_like(x)
+        scratch = torch.empty(N * E * 12 + 1, dtype=torch.float32, device=x.device)
+        guard, st = _lib.stream_of(x)
+        with guard:
+            rc = _lib.lib().lasr_flatten_backward(x.data_ptr(), quads.data_ptr(), inc_ptr.data_ptr(), inc.data_ptr(),
+                                                  g.data_ptr(), gx.data_ptr(), scratch.data_ptr(), N, V, E, st)
+        _lib.check(rc, 'lasr_flatten_backward')
+        return gx, None, None, None
+
+
+def flatten_loss(x, quads, inc_ptr, inc):
+    """x [N,V,3], quads [E,4] int32, incidence CSR -> [N] (/root/reference/third_party/ext_nnutils/loss_utils.py:110-152)."""
+    return _Flatten.apply(x, quads, inc_ptr, inc)

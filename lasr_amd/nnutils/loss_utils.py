@@ -2,7 +2,7 @@
 
 ARAPLoss      /root/reference/nnutils/loss_utils.py:29-64                 (dense [N,V,V] x 6 in the reference)
 LaplacianLoss /root/reference/third_party/ext_nnutils/loss_utils.py:34-65 (dense [V,V] matmul in the reference)
-FlattenLoss   /root/reference/third_party/ext_nnutils/loss_utils.py:67-152 (already edge based; torch ops)
+FlattenLoss   /root/reference/third_party/ext_nnutils/loss_utils.py:67-152 (edge based; ~60 eager launches there)
 """
 import numpy as np
 import torch
@@ -10,6 +10,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from .. import _lib
+from . import fused_ops
 
 
 def adjacency_csr(faces, nv):
@@ -126,6 +127,16 @@ class FlattenLoss(nn.Module):
                          np.int64).reshape(-1, 4)
         for i, name in enumerate(('v0s', 'v1s', 'v2s', 'v3s')):
             self.register_buffer(name, torch.from_numpy(quads[:, i].copy()))
+        # for the HIP kernels: the same quads as int32 and, for the backward gather, the (edge, slot) pairs touching
+        # each vertex in ascending order
+        nv = int(f.max()) + 1 if f.size else 0
+        flat = quads.reshape(-1)
+        order = np.argsort(flat, kind='stable')
+        ptr = np.zeros(nv + 1, np.int64)
+        np.add.at(ptr, flat + 1, 1)
+        self.register_buffer('quads', torch.from_numpy(quads.astype(np.int32)), persistent=False)
+        self.register_buffer('inc_ptr', torch.from_numpy(np.cumsum(ptr).astype(np.int32)), persistent=False)
+        self.register_buffer('inc', torch.from_numpy(order.astype(np.int32)), persistent=False)
 
     @staticmethod
     def _rejection(a, b, eps):
@@ -137,6 +148,12 @@ class FlattenLoss(nn.Module):
         return b - a * (ab / (al2 + eps))[:, :, None], bl1 * sin
 
     def forward(self, vertices, eps=1e-6):
+        if vertices.is_cuda and eps == 1e-6:                              # one HIP kernel forward, two backward
+            dev, ptr = vertices.device, self.inc_ptr
+            if ptr.numel() < vertices.shape[1] + 1:                       # trailing vertices no face refers to
+                ptr = torch.cat([ptr, ptr[-1:].repeat(vertices.shape[1] + 1 - ptr.numel())])
+            loss = fused_ops.flatten_loss(vertices, self.quads.to(dev), ptr.to(dev), self.inc.to(dev))
+            return loss.sum() / vertices.size(0) if self.average else loss
         v0, v1 = vertices[:, self.v0s], vertices[:, self.v1s]
         a = v1 - v0
         cb1, n1 = self._rejection(a, vertices[:, self.v2s] - v0, eps)

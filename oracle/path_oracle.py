@@ -124,3 +124,22 @@ def flow_reproject(px, pp0, pp1, fl0, fl1):
     flow = proj(p1, pp1, fl1) - proj(p0, pp0, fl0).detach()
     flow = torch.where(bg[..., None], flow.detach(), flow)
     return flow, bg
+
+
+def quaternion_to_rotation_matrix(q):
+    """kornia 0.5.3 semantics (not vendored): (x,y,z,w), normalised first."""
+    q = torch.nn.functional.normalize(q, p=2, dim=-1, eps=1e-12)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    m = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)
+    return m.reshape(q.shape[:-1] + (3, 3))
+
+
+def skin_weights(ctl_ts, ctl_rs, log_ctl, verts):
+    """nnutils/mesh_net.py:264-271; ctl_* [H*J,.], verts [H,V,3] -> [H,J,V]."""
+    H = verts.shape[0]
+    dis = ctl_ts.view(H, -1, 1, 3) - verts[:, None].detach()
+    dis = dis.matmul(quaternion_to_rotation_matrix(ctl_rs).view(H, -1, 3, 3))
+    dis = log_ctl.exp().view(H, -1, 1, 3) * dis.pow(2)
+    return (-10 * dis.sum(3)).softmax(1)

@@ -220,3 +220,64 @@ def test_flow_reproject_matches_restatement(cuda):
             continue
         scale = float(b.grad.abs().max()) + 1e-30
         assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-6 * scale, name
+
+
+def test_quat_to_rotmat_matches_restatement(cuda):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(37, 4, generator=g)
+    q[3] = torch.tensor([0., 0., 0., 1.])
+    q[4] *= 1e-3                                        # far from unit length: the normalisation matters
+    gout = torch.randn(37, 3, 3, generator=g)
+    a = q.clone().requires_grad_(True)
+    ra = po.quaternion_to_rotation_matrix(a)
+    (ra * gout).sum().backward()
+    b = q.clone().to(cuda).requires_grad_(True)
+    rb = fused_ops.quat_to_rotmat(b)
+    (rb * gout.to(cuda)).sum().backward()
+    assert float((rb.detach().cpu() - ra.detach()).abs().max()) <= 1e-6
+    eye = torch.eye(3).expand(37, 3, 3)
+    assert float((rb.detach().cpu() @ rb.detach().cpu().transpose(1, 2) - eye).abs().max()) <= 1e-5
+    rel = (b.grad.cpu() - a.grad).abs().max(1)[0] / (a.grad.abs().max(1)[0] + 1e-12)
+    assert float(rel.max()) <= 1e-4
+
+
+@pytest.mark.parametrize('H,J,V', [(1, 1, 70), (2, 5, 300), (8, 20, 642), (1, 35, 1282)])
+def test_skin_weights_match_restatement(cuda, H, J, V):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(H * 100 + J)
+    verts = torch.randn(H, V, 3, generator=g) * 0.4
+    ts = verts[:, torch.randperm(V, generator=g)[:J]].reshape(-1, 3) + 0.01 * torch.randn(H * J, 3, generator=g)
+    rs = torch.randn(H * J, 4, generator=g) * 0.2 + torch.tensor([0., 0., 0., 1.])
+    lc = torch.randn(H * J, 3, generator=g) * 0.3 + 1.0
+    gout = torch.randn(H, J, V, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (ts, rs, lc)]
+    ref = po.skin_weights(*ref_in, verts)
+    (ref * gout).sum().backward()
+    dev_in = [t.clone().to(cuda).requires_grad_(True) for t in (ts, rs, lc)]
+    out = fused_ops.skin_weights(*dev_in, verts.to(cuda))
+    (out * gout.to(cuda)).sum().backward()
+    assert out.shape == (H, J, V)
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 2e-6
+    assert float((out.sum(1) - 1).abs().max()) <= 1e-5
+    for name, a, b in zip(('ctl_ts', 'ctl_rs', 'log_ctl'), dev_in, ref_in):
+        scale = float(b.grad.abs().max()) + 1e-20
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-4 * scale, name
+
+
+@pytest.mark.parametrize('level,N', [(1, 2), (3, 5)])
+def test_flatten_loss_hip_matches_torch_path(cuda, level, N):
+    # the torch path is the restatement pinned to the reference by tests/golden/mesh_losses.npz (CPU suite)
+    v, f = synth.geodesic_sphere(2 ** level)
+    crit = loss_utils.FlattenLoss(torch.from_numpy(np.asarray(f, np.int64)))
+    g = torch.Generator().manual_seed(level)
+    x = (torch.from_numpy(v).float()[None] * torch.tensor([1.0, 0.6, 0.8]) + 0.03 * torch.randn(N, len(v), 3, generator=g))
+    gout = torch.rand(N, generator=g) + 0.5
+    a = x.clone().requires_grad_(True)
+    la = crit(a)
+    (la * gout).sum().backward()
+    b = x.clone().to(cuda).requires_grad_(True)
+    lb = crit.to(cuda)(b)
+    (lb * gout.to(cuda)).sum().backward()
+    assert float(((lb.detach().cpu() - la.detach()).abs() / la.detach().abs()).max()) <= 1e-5
+    assert float((b.grad.cpu() - a.grad).abs().max()) <= 1e-4 * float(a.grad.abs().max())

@@ -54,18 +54,35 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
         tr.module.iters = i + 1
         tr.train_step(tr.set_input(tr.dataloader[i]))
     torch.cuda.synchronize()
+def section_of(e):
+    p = e
+    while p is not None:
+        if p.name.startswith('SEC:'):
+            return p.name[4:]
+        p = p.cpu_parent
+    return None
+
+
+# forward ops carry a sequence number that their autograd node repeats in the backward pass
+seq2sec = {}
+for e in prof.events():
+    if e.sequence_nr is not None and e.sequence_nr >= 0 and not e.name.startswith('autograd::engine'):
+        sec = section_of(e)
+        if sec is not None and 'Backward' not in e.name:
+            seq2sec.setdefault(e.sequence_nr, sec)
 by = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():
     ks = getattr(e, 'kernels', None)
     if not ks:
         continue
-    where, p = None, e
-    while p is not None:
-        if p.name.startswith('SEC:'):
-            where = p.name[4:]; break
-        if p.name.startswith('autograd::engine') or 'Backward' in p.name:
-            where = 'backward: ' + e.name[:50]; break
-        p = p.cpu_parent
+    where = section_of(e)
+    if where is None:
+        p = e
+        while p is not None:
+            if p.name.startswith('autograd::engine::evaluate_function'):
+                where = 'bwd of ' + seq2sec.get(p.sequence_nr, 'forward (other) [%s]' % p.name.split(': ')[-1][:40])
+                break
+            p = p.cpu_parent
     if where is None:
         where = 'forward (other): ' + e.name[:50]
     by[where][0] += len(ks)
