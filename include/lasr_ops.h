@@ -162,6 +162,18 @@ int lasr_flatten_forward(const float* x, const int* quads, float* loss, int N, i
 int lasr_flatten_backward(const float* x, const int* quads, const int* inc_ptr, const int* inc, const float* grad_loss,
                           float* grad_x, float* scratch, int N, int V, int E, void* hip_stream);
 
+/*
+ * Per-face gather of per-vertex attributes, third_party/softras/soft_renderer/functional/face_vertices.py:4-22:
+ *   out[n,f,c,:] = attr[n, faces[n,f,c], :]      attr [N,V,C], faces [N,F,3] int64 (torch's index type) -> out [N,F,3,C].
+ * Indices must lie in [0,V) (the reference asserts nothing either; out-of-range is undefined behaviour).
+ * Backward: grad_out [N,F,3,C] -> grad_attr [N,V,C], overwritten; the sum over a vertex's corners runs in ascending
+ * corner order (deterministic; the reference's autograd uses atomic index_add_).
+ */
+int lasr_face_gather_forward(const float* attr, const long long* faces, float* out, int N, int V, int F, int C,
+                             void* hip_stream);
+int lasr_face_gather_backward(const float* grad_out, const long long* faces, float* grad_attr, int N, int V, int F, int C,
+                              void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,8 @@ SIGNATURES = {
     'lasr_skin_weights_backward': (_i, [_p] * 10 + [_i, _i, _i, _p]),
     'lasr_flatten_forward': (_i, [_p, _p, _p, _i, _i, _i, _p]),
     'lasr_flatten_backward': (_i, [_p] * 7 + [_i, _i, _i, _p]),
+    'lasr_face_gather_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_face_gather_backward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),

@@ -6,6 +6,7 @@
 //   quaternion -> R     kornia 0.5.3 quaternion_to_rotation_matrix, call sites mesh_net.py:232,250,265, net_blocks.py:359
 //   GMM skin weights    nnutils/mesh_net.py:264-271   (Mahalanobis distance to every bone, softmax over bones)
 //   flatten loss        third_party/ext_nnutils/loss_utils.py:110-152   (dihedral cosine over interior edges)
+//   face gather         third_party/softras/soft_renderer/functional/face_vertices.py:4-22 (+ index_add_ in backward)
 // Reductions are deterministic (fixed tree inside a block, fixed-order fold of block partials; no float atomics).
 #include <hip/hip_runtime.h>
 
@@ -377,6 +378,70 @@ __global__ __launch_bounds__(256) void flatten_backward_vertex_kernel(const floa
     out[0] = a0; out[1] = a1; out[2] = a2;
 }
 
+// ===========================================================================
+// Per-face gather of per-vertex attributes, face_vertices.py:4-22: out[n,f,c,:] = attr[n, faces[n,f,c], :].
+// Backward: a vertex-centric sum without a precomputed incidence structure and without float atomics.  One block owns
+// 64 vertices of one mesh: all threads scan the mesh's 3F corner indices once and file the corners that point into the
+// block's vertex range into per-vertex LDS lists; each list (<= GATHER_CAP entries, mesh valence) is sorted so that the
+// summation order -- ascending corner index -- does not depend on the order the scan happened to fill it in.
+// ===========================================================================
+constexpr int GATHER_VERTS = 64, GATHER_CAP = 30;
+
+__global__ __launch_bounds__(256) void face_gather_forward_kernel(const float* __restrict__ attr, const long long* __restrict__ faces,
+                                                                  float* __restrict__ out, int V, int F3, int C)
+{
+    const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F3) return;
+    const long long vi = faces[(size_t)n * F3 + c];
+    const float* src = attr + ((size_t)n * V + (size_t)vi) * C;
+    float* dst = out + ((size_t)n * F3 + c) * C;
+    for (int k = 0; k < C; k++) dst[k] = src[k];
+}
+
+__global__ __launch_bounds__(256) void face_gather_backward_kernel(const float* __restrict__ gout, const long long* __restrict__ faces,
+                                                                   float* __restrict__ gattr, int V, int F3, int C)
+{
+    __shared__ int cnt[GATHER_VERTS];
+    __shared__ int lists[GATHER_VERTS][GATHER_CAP];
+    const int n = blockIdx.y, v0 = blockIdx.x * GATHER_VERTS, tid = threadIdx.x;
+    const long long* fn = faces + (size_t)n * F3;
+    if (tid < GATHER_VERTS) cnt[tid] = 0;
+    __syncthreads();
+    for (int c = tid; c < F3; c += 256) {
+        const long long d = fn[c] - v0;
+        if (d >= 0 && d < GATHER_VERTS) {
+            const int slot = atomicAdd(&cnt[(int)d], 1);
+            if (slot < GATHER_CAP) lists[(int)d][slot] = c;
+        }
+    }
+    __syncthreads();
+    if (tid < GATHER_VERTS && cnt[tid] <= GATHER_CAP) {           // insertion sort of a handful of corner ids
+        int* l = lists[tid];
+        const int m = cnt[tid];
+        for (int i = 1; i < m; i++) {
+            const int key = l[i];
+            int j = i - 1;
+            while (j >= 0 && l[j] > key) { l[j + 1] = l[j]; j--; }
+            l[j + 1] = key;
+        }
+    }
+    __syncthreads();
+    const float* g = gout + (size_t)n * F3 * C;
+    for (int item = tid; item < GATHER_VERTS * C; item += 256) {
+        const int vi = item / C, ch = item - vi * C;
+        if (v0 + vi >= V) continue;
+        float acc = 0.f;
+        const int m = cnt[vi];
+        if (m <= GATHER_CAP) {
+            for (int i = 0; i < m; i++) acc += g[(size_t)lists[vi][i] * C + ch];
+        } else {                                                   // valence beyond the list: ordered rescan
+            for (int c = 0; c < F3; c++)
+                if (fn[c] == v0 + vi) acc += g[(size_t)c * C + ch];
+        }
+        gattr[((size_t)n * V + v0 + vi) * C + ch] = acc;
+    }
+}
+
 }  // namespace lasr
 
 // ===========================================================================
@@ -502,5 +567,29 @@ extern "C" int lasr_flatten_backward(const float* x, const int* quads, const int
     }
     LASR_LAUNCH(K_FLATTEN_BACKWARD, flatten_backward_vertex_kernel, dim3((V + 255) / 256, N), dim3(256), 0, scratch, inc_ptr,
                 inc, grad_x, V, E);
+    return launch_ok();
+}
+
+extern "C" int lasr_face_gather_forward(const float* attr, const long long* faces, float* out, int N, int V, int F, int C,
+                                        void* hip_stream)
+{
+    if (N < 0 || V < 0 || F < 0 || C < 1) return LASR_E_BADARG;
+    if (N == 0 || F == 0) return LASR_OK;
+    if (!attr || !faces || !out) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_FACE_GATHER_FORWARD, face_gather_forward_kernel, dim3((3 * F + 255) / 256, N), dim3(256), 0, attr, faces, out,
+                V, 3 * F, C);
+    return launch_ok();
+}
+
+extern "C" int lasr_face_gather_backward(const float* grad_out, const long long* faces, float* grad_attr, int N, int V, int F,
+                                         int C, void* hip_stream)
+{
+    if (N < 0 || V < 0 || F < 0 || C < 1) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!grad_attr || (F > 0 && (!grad_out || !faces))) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_kernel, dim3((V + GATHER_VERTS - 1) / GATHER_VERTS, N), dim3(256), 0,
+                grad_out, faces, grad_attr, V, 3 * F, C);
     return launch_ok();
 }

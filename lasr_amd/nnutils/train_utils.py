@@ -103,7 +103,9 @@ class LASRTrainer:
             p = getattr(m, n)
             if isinstance(p, nn.Parameter):
                 groups.append({'params': [p], 'lr': 50 * opts.learning_rate})
-        self.optimizer = torch.optim.AdamW(groups, lr=opts.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4)
+        # fused: one multi-tensor launch per parameter group instead of ~9 foreach launches
+        self.optimizer = torch.optim.AdamW(groups, lr=opts.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
+                                           fused=self.device.type == 'cuda')
         max_lr = [opts.learning_rate] + [50 * opts.learning_rate] * (len(groups) - 1)
         self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
             self.optimizer, max_lr, 200 * len(self.dataloader), pct_start=0.01, cycle_momentum=False,

@@ -47,10 +47,29 @@ def _apply(vertices, eye, r):
     return torch.matmul(vertices - eye, r.transpose(1, 2))
 
 
+_LOOK_AT = {}
+
+
+def _const_look_at(eye, at, up, device):
+    """Constant camera: the basis is built once per (eye, at, up, device) with the same ops as the general path and
+    reused: -> (eye [1,1,3], R^T [3,3] or None when R is exactly the identity, e.g. LASR's eye on the -z axis)."""
+    key = (str(device), tuple(map(float, eye)), tuple(map(float, at)), tuple(map(float, up)))
+    hit = _LOOK_AT.get(key)
+    if hit is None:
+        e, a, u = _vec(list(eye), device, 1), _vec(list(at), device, 1), _vec(list(up), device, 1)
+        r = _basis(a - e, u)[0]
+        identity = bool(torch.equal(r.cpu(), torch.eye(3)))            # (v - eye) @ I == v - eye bit for bit
+        hit = _LOOK_AT[key] = (e[:, None, :].clone(), None if identity else r.t().contiguous())
+    return hit
+
+
 def look_at(vertices, eye, at=[0, 0, 0], up=[0, 1, 0]):
     """World -> camera looking from `eye` towards `at` (look_at.py:6-62)."""
     if vertices.ndimension() != 3:
         raise ValueError('vertices Tensor should have 3 dimensions')
+    if all(isinstance(x, (list, tuple)) for x in (eye, at, up)):
+        e, rt = _const_look_at(eye, at, up, vertices.device)
+        return vertices - e if rt is None else torch.matmul(vertices - e, rt)
     bs, dev = vertices.shape[0], vertices.device
     eye, at, up = _vec(eye, dev, bs), _vec(at, dev, bs), _vec(up, dev, bs)
     return _apply(vertices, eye, _basis(at - eye, up))
@@ -70,6 +89,10 @@ def orthogonal(vertices, scale):
     """x,y scaled, z kept (orthogonal.py:4-17)."""
     if vertices.ndimension() != 3:
         raise ValueError('vertices Tensor should have 3 dimensions')
+    if isinstance(scale, (int, float)):
+        if scale == 1:
+            return vertices                                           # x * 1 is x: nothing to launch
+        return vertices * const_tensor([scale, scale, 1], vertices.device)
     return torch.stack((vertices[:, :, 0] * scale, vertices[:, :, 1] * scale, vertices[:, :, 2]), dim=2)
 
 

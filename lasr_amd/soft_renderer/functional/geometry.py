@@ -8,6 +8,39 @@ import torch
 import torch.nn.functional as F
 
 
+class _FaceGather(torch.autograd.Function):
+    """lasr_face_gather_* (include/lasr_ops.h)."""
+
+    @staticmethod
+    def forward(ctx, attr, faces):
+        from ... import _lib
+        attr = attr.contiguous()
+        faces = faces.contiguous().long()
+        N, V, C = attr.shape
+        F_ = faces.shape[1]
+        out = torch.empty(N, F_, 3, C, dtype=torch.float32, device=attr.device)
+        guard, st = _lib.stream_of(attr)
+        with guard:
+            rc = _lib.lib().lasr_face_gather_forward(attr.data_ptr(), faces.data_ptr(), out.data_ptr(), N, V, F_, C, st)
+        _lib.check(rc, 'lasr_face_gather_forward')
+        ctx.save_for_backward(faces)
+        ctx.dims = (N, V, F_, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ... import _lib
+        faces, = ctx.saved_tensors
+        N, V, F_, C = ctx.dims
+        g = g.contiguous().float()
+        ga = torch.empty(N, V, C, dtype=torch.float32, device=g.device)
+        guard, st = _lib.stream_of(g)
+        with guard:
+            rc = _lib.lib().lasr_face_gather_backward(g.data_ptr(), faces.data_ptr(), ga.data_ptr(), N, V, F_, C, st)
+        _lib.check(rc, 'lasr_face_gather_backward')
+        return ga, None
+
+
 def _flat_index(faces, num_vertices):
     bs = faces.shape[0]
     offs = torch.arange(bs, device=faces.device, dtype=torch.long) * num_vertices
@@ -20,6 +53,8 @@ def face_vertices(vertices, faces):
         raise AssertionError('vertices and faces must be 3-dimensional')
     if vertices.shape[0] != faces.shape[0] or faces.shape[2] != 3:
         raise AssertionError('batch sizes must agree and faces must be [B,F,3]')
+    if vertices.is_cuda and vertices.dtype == torch.float32:
+        return _FaceGather.apply(vertices, faces)                   # one kernel each way; ordered backward sum
     bs, nv, ch = vertices.shape
     nf = faces.shape[1]
     flat = vertices.reshape(bs * nv, ch)

@@ -12,6 +12,7 @@ import torch
 from torch.autograd import Function
 
 from ... import _lib
+from .cameras import const_tensor
 
 _DIST = {'hard': 0, 'barycentric': 1, 'euclidean': 2}
 _RGB = {'hard': 0, 'softmax': 1}
@@ -88,10 +89,11 @@ class SoftRasterizeFunction(Function):
         ctx.in_shapes = (face_vertices.shape, textures.shape)
 
         aggrs_info = torch.empty(N, 2, IS, IS, dtype=torch.float32, device=dev)
-        soft_colors = torch.empty(N, C + 1, IS, IS, dtype=torch.float32, device=dev)
-        for k in range(C):
-            soft_colors[:, k] = float(background_color[k % 3])
-        soft_colors[:, C] = 1.0
+        bg = [float(background_color[k % 3]) for k in range(C)] + [1.0]              # alpha plane starts at 1
+        if all(v == bg[0] for v in bg):
+            soft_colors = torch.full((N, C + 1, IS, IS), bg[0], dtype=torch.float32, device=dev)
+        else:
+            soft_colors = const_tensor(bg, dev).view(1, C + 1, 1, 1).repeat(N, 1, IS, IS)
 
         h = _lib.lib()
         with torch.cuda.device(dev):
@@ -120,8 +122,8 @@ class SoftRasterizeFunction(Function):
         N, F, T, IS = ctx.geom
         C, nf, tail = ctx.C, ctx.nf, ctx.tail
         dev = fv.device
-        grad_faces = torch.zeros(N, F, 9, dtype=torch.float32, device=dev)
-        grad_textures = torch.zeros(tx.shape, dtype=torch.float32, device=dev)
+        grads = torch.zeros(N * F * 9 + tx.numel(), dtype=torch.float32, device=dev)        # one fill for both
+        grad_faces, grad_textures = grads[:N * F * 9].view(N, F, 9), grads[N * F * 9:].view(tx.shape)
         g = grad_soft_colors.contiguous().float()
         h = _lib.lib()
         with torch.cuda.device(dev):

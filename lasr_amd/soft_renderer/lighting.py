@@ -34,14 +34,27 @@ class Lighting(nn.Module):
         self.directionals = nn.ModuleList([DirectionalLighting(intensity_directionals, color_directionals,
                                                                directions)])
 
+    def _constant_light(self):
+        """[r,g,b] when no directional light is on and the ambient colour is a python constant, else None."""
+        if any(d.light_intensity != 0 for d in self.directionals):
+            return None
+        c = self.ambient.light_color
+        if not isinstance(c, (list, tuple)) or not isinstance(self.ambient.light_intensity, (int, float)):
+            return None
+        return [float(self.ambient.light_intensity * v) for v in c]
+
     def forward(self, mesh):
         per_vertex = self.light_mode == 'vertex'
+        const = self._constant_light()
+        if const is not None:                      # light = 0 + intensity * colour, the same for every vertex / face
+            if any(v != 1.0 for v in const):       # (x * 1 is x: LASR's ambient-only white light launches nothing)
+                reps = mesh.textures.shape[-1] // 3
+                mesh.textures = mesh.textures * srf.const_tensor(const * reps, mesh.device)
+            return mesh
         shape_like = mesh.vertices if per_vertex else mesh.faces
         light = torch.zeros(shape_like.shape, dtype=torch.float32, device=mesh.device)
         light = self.ambient(light)
         for d in self.directionals:
-            # LASR renders with intensity_directionals = 0 (nnutils/mesh_net.py:136-149): the reference still
-            # builds the normals (3 index_add_ per call) only to multiply them by zero; skip that work.
             if d.light_intensity == 0:
                 continue
             light = d(light, mesh.vertex_normals if per_vertex else mesh.surface_normals)

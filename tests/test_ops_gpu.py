@@ -281,3 +281,30 @@ def test_flatten_loss_hip_matches_torch_path(cuda, level, N):
     (lb * gout.to(cuda)).sum().backward()
     assert float(((lb.detach().cpu() - la.detach()).abs() / la.detach().abs()).max()) <= 1e-5
     assert float((b.grad.cpu() - a.grad).abs().max()) <= 1e-4 * float(a.grad.abs().max())
+
+
+@pytest.mark.parametrize('C', [3, 6])
+def test_face_gather_matches_index_select(cuda, C):
+    # face_vertices.py:4-22; a fan of 40 faces around vertex 0 exceeds the kernel's per-vertex list (ordered rescan path)
+    import lasr_amd.soft_renderer.functional as srf
+    g = torch.Generator().manual_seed(C)
+    v, f = synth.geodesic_sphere(4)
+    f = np.asarray(f, np.int64)
+    fan = np.stack([np.zeros(40, np.int64), 1 + np.arange(40), 2 + np.arange(40)], 1)
+    faces = torch.from_numpy(np.concatenate([f, fan], 0))[None].repeat(3, 1, 1)
+    faces[1] = faces[1].flip(0)                                  # a different face order per mesh
+    attr = torch.randn(3, len(v), C, generator=g)
+    gout = torch.randn(3, faces.shape[1], 3, C, generator=g)
+    a = attr.clone().requires_grad_(True)
+    ra = srf.face_vertices(a, faces)                             # CPU tensors: the index_select restatement
+    (ra * gout).sum().backward()
+    b = attr.clone().to(cuda).requires_grad_(True)
+    rb = srf.face_vertices(b, faces.to(cuda))
+    (rb * gout.to(cuda)).sum().backward()
+    assert torch.equal(rb.detach().cpu(), ra.detach())
+    assert float((b.grad.cpu() - a.grad).abs().max()) <= 1e-5 * float(a.grad.abs().max())
+    b2 = attr.clone().to(cuda).requires_grad_(True)              # run-to-run identical: no float atomics
+    (srf.face_vertices(b2, faces.to(cuda)) * gout.to(cuda)).sum().backward()
+    assert torch.equal(b2.grad, b.grad)
+    i32 = srf.face_vertices(attr.to(cuda), faces.to(cuda).int())  # int32 faces as Mesh builds from numpy
+    assert torch.equal(i32.cpu(), ra.detach())
