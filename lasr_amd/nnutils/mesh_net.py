@@ -265,9 +265,13 @@ class PerceptualDistance(nn.Module):
             out.append(x)
         return out
 
-    def forward_pair(self, a, b):
+    def forward_pair(self, a, b, repeat=1):
+        """Distance between a[i // repeat] and b[i]: `a` holds each observed image once where the reference feeds the
+        network `repeat` identical copies of it (one per hypothesis, mesh_net.py:436-441)."""
         d = 0
         for fa, fb in zip(self._feats(a), self._feats(b)):
+            if repeat > 1:
+                fa = fa.repeat_interleave(repeat, 0)
             d = d + (1. - F.cosine_similarity(fa, fb, dim=1, eps=1e-10).mean((1, 2)))
         return d
 
@@ -489,9 +493,8 @@ class LASR(MeshNet):
         # ---- 1) flow rendering (:298-335)
         verts_cam = obj_to_cam(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
         verts_fl = torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1)
-        vp = verts_fl.view(n2, H, -1, 4)
-        verts_pos0 = vp[:B].reshape(B * H, -1, 4)
-        verts_pos1 = vp[B:].reshape(B * H, -1, 4)
+        # halves of the batch through unbind / chunk: one stack in the backward pass instead of zeros + copy per slice
+        verts_pos0, verts_pos1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)
         verts_fl = pinhole_cam(verts_fl, ppoint, scale)
         with torch.no_grad():                                                    # near/far stay on the device (:304-311)
             dmax, dmin = verts_fl[:, :, 2].max(), verts_fl[:, :, 2].min()
@@ -502,14 +505,13 @@ class LASR(MeshNet):
                 r.rasterizer.sigma_val = opts.sigval
         if opts.sigval != 1e-4:
             self.renderer_soft.rasterizer.sigma_val = opts.sigval
-        vf = verts_fl.view(n2, H, -1, 4)
-        pp_rep = ppoint[:, None].repeat(1, H, 1)
+        vf0, vf1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)
+        pp0, pp1 = ppoint[:, None].repeat(1, H, 1).view(2, B * H, 2).unbind(0)
+        sc0, sc1 = scale.reshape(2, B * H, 1).unbind(0)
         self.flow_fw, self.bgmask_fw, self.fgmask_flowf = render_flow_soft_2(
-            self.renderer_softflf, vf[:B].reshape(B * H, -1, 4), faces[:B], verts_pos0, verts_pos1,
-            pp_rep[:B].reshape(-1, 2), pp_rep[B:].reshape(-1, 2), scale[:B].reshape(-1, 1), scale[B:].reshape(-1, 1))
+            self.renderer_softflf, vf0, faces[:B], verts_pos0, verts_pos1, pp0, pp1, sc0, sc1)
         self.flow_bw, self.bgmask_bw, self.fgmask_flowb = render_flow_soft_2(
-            self.renderer_softflb, vf[B:].reshape(B * H, -1, 4), faces[B:], verts_pos1, verts_pos0,
-            pp_rep[B:].reshape(-1, 2), pp_rep[:B].reshape(-1, 2), scale[B:].reshape(-1, 1), scale[:B].reshape(-1, 1))
+            self.renderer_softflb, vf1, faces[B:], verts_pos1, verts_pos0, pp1, pp0, sc1, sc0)
         self.bgmask = torch.cat([self.bgmask_fw, self.bgmask_bw], 0)
         self.flow_rd = torch.cat([self.flow_fw, self.flow_bw], 0)
 
@@ -520,8 +522,8 @@ class LASR(MeshNet):
         self.renderer_softtex.rasterizer.background_color = [1, 1, 1]
         faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
         tex_img = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=tex, texture_type='vertex'))
-        self.mask_pred = tex_img[:, -1]
-        self.texture_render = tex_img[:, :3]
+        self.texture_render, alpha = tex_img.split([3, 1], 1)
+        self.mask_pred = alpha.squeeze(1)
         fg_obs = (self.masks > 0).float()[:, None]
         img_obs = self.imgs * fg_obs
         img_white = 1 - fg_obs + img_obs
@@ -549,10 +551,12 @@ class LASR(MeshNet):
                                           opts.l1tex_wt)
         if self.ptex_loss is not None:
             img_rnd = self.texture_render * self.mask_pred[:, None]
-            obspair = torch.cat([img_obs[:, None].repeat(1, H, 1, 1, 1).view(-1, 3, IS, IS),
-                                 img_white[:, None].repeat(1, H, 1, 1, 1).view(-1, 3, IS, IS)], 0)
+            # the observed side is the same image for all H hypotheses: its features are computed once per image
+            obspair = torch.cat([img_obs, img_white], 0)
             rndpair = torch.cat([img_rnd, self.texture_render], 0)
-            percept = self.ptex_loss.forward_pair(2 * obspair - 1, 2 * rndpair - 1)
+            with torch.no_grad():
+                obspair = 2 * obspair - 1
+            percept = self.ptex_loss.forward_pair(obspair, 2 * rndpair - 1, repeat=H)
             tmp = tmp + 0.005 * percept.view(2, -1).sum(0).view(n2, H)
         self.texture_loss_sub = 0.25 * tmp
         self.texture_loss = self.texture_loss_sub.mean()
@@ -578,7 +582,8 @@ class LASR(MeshNet):
             self.lmotion_loss_sub = factor * (self.deform_v - pred_v).norm(2, -1).mean(-1).view(n2, H)
             self.lmotion_loss = self.lmotion_loss_sub.mean()
             total = total + self.lmotion_loss
-            self.arap_loss = self.arap_loss_fn(self.deform_v[:B * H], self.deform_v[B * H:]).mean() * (4 ** opts.subdivide) / 64.
+            dv0, dv1 = self.deform_v.reshape(2, B * H, -1, 3).unbind(0)
+            self.arap_loss = self.arap_loss_fn(dv0, dv1).mean() * (4 ** opts.subdivide) / 64.
             total = total + self.arap_loss
             if opts.symmetric_loss:                                              # bone symmetry (:500-503)
                 ca = self.ctl_ts.view(H, -1, 3)
@@ -590,12 +595,13 @@ class LASR(MeshNet):
             cam = cam + (depth_pred - depth).abs().mean() + (ppoint_pred - ppoint).abs().mean()
             self.cam_loss = 0.2 * cam
         else:
-            q = quat.view(-1, H, K, 9)
-            self.cam_loss = 0.001 * geodesic_distance(q[:B].reshape(-1, 3, 3), q[B:].reshape(-1, 3, 3)).mean()
+            q0, q1 = quat.view(2, -1, 3, 3).unbind(0)
+            self.cam_loss = 0.001 * geodesic_distance(q0, q1).mean()
             if K > 1:
-                t4, d4 = trans.view(-1, H, K, 2), depth.view(-1, H, K, 1)
-                self.cam_loss = self.cam_loss + 0.01 * (t4[:B, :, 1:] - t4[B:, :, 1:]).abs().mean()
-                self.cam_loss = self.cam_loss + 0.01 * (d4[:B, :, 1:] - d4[B:, :, 1:]).abs().mean()
+                t0, t1 = trans.view(2, B * H, K, 2).unbind(0)
+                d0, d1 = depth.view(2, B * H, K, 1).unbind(0)
+                self.cam_loss = self.cam_loss + 0.01 * (t0 - t1)[:, 1:].abs().mean()
+                self.cam_loss = self.cam_loss + 0.01 * (d0 - d1)[:, 1:].abs().mean()
         total = total + self.cam_loss
         # 8) aux (:524-530)
         total = total + 0.02 * F.relu(2 - Tmat.view(-1, 1, K, 3)[:, :, :1, -1]).mean()

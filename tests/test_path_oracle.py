@@ -87,3 +87,18 @@ def test_tex_loss_hand_case():
     occ = torch.tensor([[[1.0, 1.0]]])
     # |0.5-0.25| and |0.5-0| -> mean .375 ; |1-.25| -> .75 ; (0.375+0.75)*2
     assert abs(po.tex_loss_table(obs, white, rnd, fg, occ).item() - 2.25) < 1e-6
+
+
+def test_perceptual_pairing_with_shared_observations():
+    # mesh_net.py:436-442 feeds H identical copies of every observed image through the feature network; computing
+    # the features once per image and repeating them pairs the same (observation, render) couples
+    import torch
+    from lasr_amd.nnutils.mesh_net import PerceptualDistance
+    torch.manual_seed(0)
+    net = PerceptualDistance()
+    H = 3
+    obs = torch.rand(4, 3, 64, 64) * 2 - 1
+    rnd = torch.rand(4 * H, 3, 64, 64) * 2 - 1
+    full = net.forward_pair(obs[:, None].repeat(1, H, 1, 1, 1).view(-1, 3, 64, 64), rnd)
+    shared = net.forward_pair(obs, rnd, repeat=H)
+    assert torch.allclose(full, shared, rtol=1e-5, atol=1e-6)
