@@ -152,9 +152,10 @@ def optimize_leg(dev, iters):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {'iters_per_s': iters / dt, 'ms_per_iter': dt / iters * 1e3, 'iters': iters, 'final_loss': float(loss),
-            'config': 'spot3 stage 0: batch 1 pair, n_hypo 8, n_bones 21, V=642/F=1280, 256x256, 48 images '
-                      'rasterised fwd+bwd per iteration, random-init encoder + perceptual net; forward+backward replayed '
-                      'as one HIP graph (--use_graph), optimiser eager'}
+            'config': 'spot3 stage 0: batch 1 pair, n_hypo 8, n_bones 21, V=642/F=1280, 256x256; per iteration 2 x 8 '
+                      'six-attribute flow renders + 16 texture renders fwd+bwd (the reference rasterises the same 48 '
+                      'images as 3-channel renders), random-init encoder + perceptual net; forward+backward replayed '
+                      'as one HIP graph (--use_graph), fused AdamW eager'}
 
 
 def measured_traffic(kernel, frames_per_launch):

@@ -174,6 +174,30 @@ int lasr_face_gather_forward(const float* attr, const long long* faces, float* o
 int lasr_face_gather_backward(const float* grad_out, const long long* faces, float* grad_attr, int N, int V, int F, int C,
                               void* hip_stream);
 
+/*
+ * Brute-force nearest neighbour between two small point sets (the idx1/dist1 outputs of third_party/chamfer3D/chamfer3D.cu
+ * as used at nnutils/mesh_net.py:477, and the inner minimum of pytorch3d's chamfer_distance, :503):
+ * a [N,P,3], b [N,Q,3] -> d2 [N,P] squared distance to, and idx [N,P] (int32) index of, the nearest b point
+ * (lowest index on ties).  No backward entry point: the caller differentiates |a - b[idx]|^2 with the indices fixed.
+ */
+int lasr_nearest_point(const float* a, const float* b, float* d2, int* idx, int N, int P, int Q, void* hip_stream);
+
+/*
+ * Point <-> triangle-mesh distance, pytorch3d.loss.point_mesh_face_distance as used at nnutils/mesh_net.py:470-471
+ * (pytorch3d 0.4.0 is not vendored: semantics restated, parity unpinned):
+ *   dmin_point[n,p] = min_f d2(points[n,p], tri[n,f]),  dmin_face[n,f] = min_p d2(points[n,p], tri[n,f])
+ * with the arg-min indices (int32, lowest index on ties); the caller forms mean_n(mean_p dmin_point + mean_f dmin_face).
+ * verts [N,V,3], faces [F,3] int64 shared by the batch, points [N,P,3].
+ * Backward: given d loss / d dmin_point = grad_point_term and d loss / d dmin_face = grad_face_term (uniform weights,
+ * as the means produce), writes grad_tri [N,F,3,3] (per face corner; reduce to vertices with lasr_face_gather_backward)
+ * and grad_points [N,P,3].  d d2/d p = 2 (p - q), d d2/d corner_i = -2 w_i (p - q) for the closest point q = sum w_i corner_i.
+ */
+int lasr_point_mesh_forward(const float* verts, const long long* faces, const float* points, float* dmin_point,
+                            int* arg_point, float* dmin_face, int* arg_face, int N, int V, int F, int P, void* hip_stream);
+int lasr_point_mesh_backward(const float* verts, const long long* faces, const float* points, const int* arg_point,
+                             const int* arg_face, float grad_point_term, float grad_face_term, float* grad_tri,
+                             float* grad_points, int N, int V, int F, int P, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,8 @@ const char* const kKernelNames[K_NUM_KERNELS] = {
     "arap_backward_kernel", "laplacian_forward_kernel", "laplacian_backward_kernel",
     "flow_reproject_forward_kernel", "flow_reproject_backward_kernel", "quat_forward_kernel", "quat_backward_kernel",
     "skin_forward_kernel", "skin_backward_kernel", "flatten_forward_kernel", "flatten_backward_kernel",
-    "face_gather_forward_kernel", "face_gather_backward_kernel"};
+    "face_gather_forward_kernel", "face_gather_backward_kernel", "nearest_point_kernel", "point_mesh_forward_kernel",
+    "point_mesh_backward_kernel"};
 }  // namespace
 
 int lasr_launch_ok()

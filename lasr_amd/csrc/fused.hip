@@ -7,6 +7,8 @@
 //   GMM skin weights    nnutils/mesh_net.py:264-271   (Mahalanobis distance to every bone, softmax over bones)
 //   flatten loss        third_party/ext_nnutils/loss_utils.py:110-152   (dihedral cosine over interior edges)
 //   face gather         third_party/softras/soft_renderer/functional/face_vertices.py:4-22 (+ index_add_ in backward)
+//   nearest neighbours  third_party/chamfer3D/chamfer3D.cu (idx1) and pytorch3d chamfer_distance, mesh_net.py:477,503
+//   point <-> mesh      pytorch3d.loss.point_mesh_face_distance, mesh_net.py:470-471
 // Reductions are deterministic (fixed tree inside a block, fixed-order fold of block partials; no float atomics).
 #include <hip/hip_runtime.h>
 
@@ -442,6 +444,185 @@ __global__ __launch_bounds__(256) void face_gather_backward_kernel(const float* 
     }
 }
 
+// ===========================================================================
+// Brute-force nearest neighbour: for each a[b,p] the nearest b[b,q] (squared distance, lowest index on ties).
+// The sets are the <= 35 control points (Chamfer term, mesh_net.py:503) or the V <= ~1.3k mesh vertices (:477).
+// ===========================================================================
+__global__ __launch_bounds__(256) void nearest_point_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ d2, int* __restrict__ idx, int P, int Q)
+{
+    __shared__ float tile[256 * 3];
+    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < P;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) { const float* s = a + ((size_t)n * P + p) * 3; x = s[0]; y = s[1]; z = s[2]; }
+    float best = INFINITY; int arg = 0;
+    for (int q0 = 0; q0 < Q; q0 += 256) {
+        const int m = min(256, Q - q0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < m * 3; i += 256) tile[i] = b[((size_t)n * Q + q0) * 3 + i];
+        __syncthreads();
+        for (int j = 0; j < m; j++) {
+            const float dx = x - tile[3 * j], dy = y - tile[3 * j + 1], dz = z - tile[3 * j + 2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; arg = q0 + j; }
+        }
+    }
+    if (live) { d2[(size_t)n * P + p] = best; idx[(size_t)n * P + p] = arg; }
+}
+
+// ===========================================================================
+// Point <-> triangle-mesh distance (pytorch3d point_mesh_face_distance semantics, squared Euclidean):
+//   loss = mean_b [ mean_p min_f d2(p, tri_f) + mean_f min_p d2(p, tri_f) ]
+// The closest point on a triangle is the interior projection when it falls inside, otherwise the nearest of the
+// three clamped edge projections (Ericson, Real-Time Collision Detection 5.1.5, written as a min over candidates so
+// that degenerate triangles fall back to their edges).  bary = barycentric weights of the closest point.
+// ===========================================================================
+struct Closest { float d2; float w[3]; };
+
+__device__ __forceinline__ float dot3(const float* u, const float* v) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; }
+
+__device__ __forceinline__ Closest point_triangle(const float* p, const float* a, const float* b, const float* c)
+{
+    float ab[3], ac[3], ap[3], bp[3], cp[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { ab[d] = b[d] - a[d]; ac[d] = c[d] - a[d]; ap[d] = p[d] - a[d]; bp[d] = p[d] - b[d]; cp[d] = p[d] - c[d]; }
+    const float d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    const float va = d3 * d6 - d5 * d4, vb = d5 * d2 - d1 * d6, vc = d1 * d4 - d3 * d2;
+    const float eps = 1e-12f;
+    Closest best;
+    best.d2 = INFINITY; best.w[0] = 1.f; best.w[1] = 0.f; best.w[2] = 0.f;
+    auto consider = [&](float w0, float w1, float w2) {
+        float e = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { const float q = w0 * a[d] + w1 * b[d] + w2 * c[d] - p[d]; e += q * q; }
+        if (e < best.d2) { best.d2 = e; best.w[0] = w0; best.w[1] = w1; best.w[2] = w2; }
+    };
+    if (va >= 0.f && vb >= 0.f && vc >= 0.f) {
+        const float den = fmaxf(va + vb + vc, eps);
+        const float v = vb / den, w = vc / den;
+        consider(1.f - v - w, v, w);
+    }
+    const float tab = fminf(fmaxf(d1 / fmaxf(d1 - d3, eps), 0.f), 1.f);
+    const float tac = fminf(fmaxf(d2 / fmaxf(d2 - d6, eps), 0.f), 1.f);
+    const float tbc = fminf(fmaxf((d4 - d3) / fmaxf((d4 - d3) + (d5 - d6), eps), 0.f), 1.f);
+    consider(1.f - tab, tab, 0.f);
+    consider(1.f - tac, 0.f, tac);
+    consider(0.f, 1.f - tbc, tbc);
+    return best;
+}
+
+__device__ __forceinline__ void load_tri(const float* verts, const long long* f, float* a, float* b, float* c)
+{
+#pragma unroll
+    for (int d = 0; d < 3; d++) { a[d] = verts[3 * f[0] + d]; b[d] = verts[3 * f[1] + d]; c[d] = verts[3 * f[2] + d]; }
+}
+
+// for each point the nearest face: dmin_p [B,P], arg_p [B,P]
+__global__ __launch_bounds__(256) void pmf_point_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
+                                                        const float* __restrict__ pts, float* __restrict__ dmin,
+                                                        int* __restrict__ arg, int V, int F, int P)
+{
+    __shared__ float tri[128 * 9];
+    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const float* vn = verts + (size_t)n * V * 3;
+    float q[3] = {0.f, 0.f, 0.f};
+    if (p < P) { const float* s = pts + ((size_t)n * P + p) * 3; q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; }
+    float best = INFINITY; int barg = 0;
+    for (int f0 = 0; f0 < F; f0 += 128) {
+        const int m = min(128, F - f0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < m * 9; i += 256) {
+            const int f = i / 9, r = i - 9 * f;
+            tri[i] = vn[3 * faces[(size_t)(f0 + f) * 3 + r / 3] + r % 3];
+        }
+        __syncthreads();
+        for (int j = 0; j < m; j++) {
+            const Closest c = point_triangle(q, tri + 9 * j, tri + 9 * j + 3, tri + 9 * j + 6);
+            if (c.d2 < best) { best = c.d2; barg = f0 + j; }
+        }
+    }
+    if (p < P) { dmin[(size_t)n * P + p] = best; arg[(size_t)n * P + p] = barg; }
+}
+
+// for each face the nearest point: dmin_f [B,F], arg_f [B,F]
+__global__ __launch_bounds__(256) void pmf_face_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
+                                                       const float* __restrict__ pts, float* __restrict__ dmin,
+                                                       int* __restrict__ arg, int V, int F, int P)
+{
+    __shared__ float tile[256 * 3];
+    const int n = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f};
+    if (f < F) load_tri(verts + (size_t)n * V * 3, faces + (size_t)f * 3, a, b, c);
+    float best = INFINITY; int barg = 0;
+    for (int p0 = 0; p0 < P; p0 += 256) {
+        const int m = min(256, P - p0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < m * 3; i += 256) tile[i] = pts[((size_t)n * P + p0) * 3 + i];
+        __syncthreads();
+        for (int j = 0; j < m; j++) {
+            const Closest cl = point_triangle(tile + 3 * j, a, b, c);
+            if (cl.d2 < best) { best = cl.d2; barg = p0 + j; }
+        }
+    }
+    if (f < F) { dmin[(size_t)n * F + f] = best; arg[(size_t)n * F + f] = barg; }
+}
+
+// Backward, face side: gtri[n,f,corner,:] = sum of the contributions of every pair this face takes part in:
+// its own nearest point (weight gf) and every point whose nearest face it is (weight gp), in ascending point order.
+__global__ __launch_bounds__(256) void pmf_backward_face_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
+                                                                const float* __restrict__ pts, const int* __restrict__ arg_p,
+                                                                const int* __restrict__ arg_f, float gp, float gf,
+                                                                float* __restrict__ gtri, int V, int F, int P)
+{
+    const int n = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float a[3], b[3], c[3], acc[9];
+    load_tri(verts + (size_t)n * V * 3, faces + (size_t)f * 3, a, b, c);
+#pragma unroll
+    for (int i = 0; i < 9; i++) acc[i] = 0.f;
+    auto add = [&](int p, float wgt) {
+        const float* q = pts + ((size_t)n * P + p) * 3;
+        const Closest cl = point_triangle(q, a, b, c);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float r = q[d] - (cl.w[0] * a[d] + cl.w[1] * b[d] + cl.w[2] * c[d]);        // p - closest point
+            acc[d] -= 2.f * wgt * cl.w[0] * r; acc[3 + d] -= 2.f * wgt * cl.w[1] * r; acc[6 + d] -= 2.f * wgt * cl.w[2] * r;
+        }
+    };
+    if (P > 0) add(arg_f[(size_t)n * F + f], gf);
+    for (int p = 0; p < P; p++)
+        if (arg_p[(size_t)n * P + p] == f) add(p, gp);
+    float* o = gtri + ((size_t)n * F + f) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o[i] = acc[i];
+}
+
+// Backward, point side: gpts[n,p,:] = own nearest face (weight gp) + every face whose nearest point it is (weight gf)
+__global__ __launch_bounds__(256) void pmf_backward_point_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
+                                                                 const float* __restrict__ pts, const int* __restrict__ arg_p,
+                                                                 const int* __restrict__ arg_f, float gp, float gf,
+                                                                 float* __restrict__ gpts, int V, int F, int P)
+{
+    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float* vn = verts + (size_t)n * V * 3;
+    const float* q = pts + ((size_t)n * P + p) * 3;
+    float acc[3] = {0.f, 0.f, 0.f};
+    auto add = [&](int f, float wgt) {
+        float a[3], b[3], c[3];
+        load_tri(vn, faces + (size_t)f * 3, a, b, c);
+        const Closest cl = point_triangle(q, a, b, c);
+#pragma unroll
+        for (int d = 0; d < 3; d++) acc[d] += 2.f * wgt * (q[d] - (cl.w[0] * a[d] + cl.w[1] * b[d] + cl.w[2] * c[d]));
+    };
+    if (F > 0) add(arg_p[(size_t)n * P + p], gp);
+    for (int f = 0; f < F; f++)
+        if (arg_f[(size_t)n * F + f] == p) add(f, gf);
+    float* o = gpts + ((size_t)n * P + p) * 3;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+}
+
 }  // namespace lasr
 
 // ===========================================================================
@@ -591,5 +772,49 @@ extern "C" int lasr_face_gather_backward(const float* grad_out, const long long*
     hipStream_t st = (hipStream_t)hip_stream;
     LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_kernel, dim3((V + GATHER_VERTS - 1) / GATHER_VERTS, N), dim3(256), 0,
                 grad_out, faces, grad_attr, V, 3 * F, C);
+    return launch_ok();
+}
+
+extern "C" int lasr_nearest_point(const float* a, const float* b, float* d2, int* idx, int N, int P, int Q, void* hip_stream)
+{
+    if (N < 0 || P < 0 || Q < 1) return LASR_E_BADARG;
+    if (N == 0 || P == 0) return LASR_OK;
+    if (!a || !b || !d2 || !idx) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_NEAREST_POINT, nearest_point_kernel, dim3((P + 255) / 256, N), dim3(256), 0, a, b, d2, idx, P, Q);
+    return launch_ok();
+}
+
+extern "C" int lasr_point_mesh_forward(const float* verts, const long long* faces, const float* points, float* dmin_point,
+                                       int* arg_point, float* dmin_face, int* arg_face, int N, int V, int F, int P,
+                                       void* hip_stream)
+{
+    if (N < 0 || V < 0 || F < 1 || P < 1) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!verts || !faces || !points || !dmin_point || !arg_point || !dmin_face || !arg_face) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_point_kernel, dim3((P + 255) / 256, N), dim3(256), 0, verts, faces, points, dmin_point,
+                arg_point, V, F, P);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_face_kernel, dim3((F + 255) / 256, N), dim3(256), 0, verts, faces, points, dmin_face,
+                arg_face, V, F, P);
+    return launch_ok();
+}
+
+extern "C" int lasr_point_mesh_backward(const float* verts, const long long* faces, const float* points, const int* arg_point,
+                                        const int* arg_face, float grad_point_term, float grad_face_term, float* grad_tri,
+                                        float* grad_points, int N, int V, int F, int P, void* hip_stream)
+{
+    if (N < 0 || V < 0 || F < 1 || P < 1) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!verts || !faces || !points || !arg_point || !arg_face || !grad_tri || !grad_points) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_POINT_MESH_BACKWARD, pmf_backward_face_kernel, dim3((F + 255) / 256, N), dim3(256), 0, verts, faces, points,
+                arg_point, arg_face, grad_point_term, grad_face_term, grad_tri, V, F, P);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_POINT_MESH_BACKWARD, pmf_backward_point_kernel, dim3((P + 255) / 256, N), dim3(256), 0, verts, faces, points,
+                arg_point, arg_face, grad_point_term, grad_face_term, grad_points, V, F, P);
     return launch_ok();
 }

@@ -159,3 +159,66 @@ class _Flatten(Function):
 def flatten_loss(x, quads, inc_ptr, inc):
     """x [N,V,3], quads [E,4] int32, incidence CSR -> [N] (/root/reference/third_party/ext_nnutils/loss_utils.py:110-152)."""
     return _Flatten.apply(x, quads, inc_ptr, inc)
+
+
+def nearest_point(a, b):
+    """a [N,P,3], b [N,Q,3] -> (squared distance [N,P], index [N,P] int64) of the nearest b point; not differentiable
+    (chamfer3D's dist1/idx1, /root/reference/nnutils/mesh_net.py:477)."""
+    _lib.need_cuda(a, b)
+    a, b = a.detach().contiguous().float(), b.detach().contiguous().float()
+    N, P = a.shape[:2]
+    d2 = torch.empty(N, P, dtype=torch.float32, device=a.device)
+    idx = torch.empty(N, P, dtype=torch.int32, device=a.device)
+    guard, st = _lib.stream_of(a)
+    with guard:
+        rc = _lib.lib().lasr_nearest_point(a.data_ptr(), b.data_ptr(), d2.data_ptr(), idx.data_ptr(), N, P, b.shape[1], st)
+    _lib.check(rc, 'lasr_nearest_point')
+    return d2, idx.long()
+
+
+class _PointMesh(Function):
+    @staticmethod
+    def forward(ctx, verts, faces, points):
+        _lib.need_cuda(verts, faces, points)
+        verts, points = verts.contiguous().float(), points.contiguous().float()
+        faces = faces.contiguous().long()
+        N, V = verts.shape[:2]
+        F_, P = faces.shape[0], points.shape[1]
+        dev = verts.device
+        dp, df = torch.empty(N, P, device=dev), torch.empty(N, F_, device=dev)
+        ap = torch.empty(N, P, dtype=torch.int32, device=dev)
+        af = torch.empty(N, F_, dtype=torch.int32, device=dev)
+        guard, st = _lib.stream_of(verts)
+        with guard:
+            rc = _lib.lib().lasr_point_mesh_forward(verts.data_ptr(), faces.data_ptr(), points.data_ptr(), dp.data_ptr(),
+                                                    ap.data_ptr(), df.data_ptr(), af.data_ptr(), N, V, F_, P, st)
+        _lib.check(rc, 'lasr_point_mesh_forward')
+        ctx.save_for_backward(verts, faces, points, ap, af)
+        return (dp.mean(1) + df.mean(1)).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        verts, faces, points, ap, af = ctx.saved_tensors
+        N, V = verts.shape[:2]
+        F_, P = faces.shape[0], points.shape[1]
+        h = _lib.lib()
+        gtri = torch.empty(N, F_, 3, 3, dtype=torch.float32, device=verts.device)
+        gpts = torch.empty_like(points)
+        gverts = torch.empty_like(verts)
+        faces_n = faces[None].expand(N, F_, 3).contiguous()
+        guard, st = _lib.stream_of(verts)
+        with guard:
+            # unit weights here; the incoming scalar gradient multiplies the results (it may live on the device)
+            rc = h.lasr_point_mesh_backward(verts.data_ptr(), faces.data_ptr(), points.data_ptr(), ap.data_ptr(),
+                                            af.data_ptr(), 1.0 / (N * P), 1.0 / (N * F_), gtri.data_ptr(), gpts.data_ptr(),
+                                            N, V, F_, P, st)
+            _lib.check(rc, 'lasr_point_mesh_backward')
+            rc = h.lasr_face_gather_backward(gtri.data_ptr(), faces_n.data_ptr(), gverts.data_ptr(), N, V, F_, 3, st)
+        _lib.check(rc, 'lasr_face_gather_backward')
+        return gverts * g, None, gpts * g
+
+
+def point_mesh_face_distance(verts, faces, points):
+    """mean_n [ mean_p min_f d2(p, f) + mean_f min_p d2(p, f) ]  (pytorch3d.loss.point_mesh_face_distance as used at
+    /root/reference/nnutils/mesh_net.py:470-471); verts [N,V,3], faces [F,3], points [N,P,3]."""
+    return _PointMesh.apply(verts, faces, points)

@@ -62,44 +62,27 @@ def reg_decay(curr_steps, max_steps, min_wt, max_wt):
 
 def chamfer_distance(a, b):
     """Symmetric squared Chamfer distance averaged over the batch (pytorch3d.loss.chamfer_distance()[0] as used
-    at mesh_net.py:503); brute force, the point sets here are the <= 35 control points."""
+    at mesh_net.py:503); the point sets here are the <= 35 control points."""
+    if a.is_cuda:                                     # nearest neighbours from one kernel; gradient through the gather
+        ib, ia = fused_ops.nearest_point(a, b)[1], fused_ops.nearest_point(b, a)[1]
+        da = (a - torch.gather(b, 1, ib[..., None].expand(-1, -1, 3))).pow(2).sum(-1)
+        db = (b - torch.gather(a, 1, ia[..., None].expand(-1, -1, 3))).pow(2).sum(-1)
+        return (da.mean(1) + db.mean(1)).mean()
     d = (a[:, :, None] - b[:, None]).pow(2).sum(-1)
     return (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
 
 
 def nearest_index(a, b):
     """For each point of a [1,V,3] the index of the nearest point of b [1,V,3] (idx1 of chamfer3D, mesh_net.py:477)."""
+    if a.is_cuda:
+        return fused_ops.nearest_point(a, b)[1]
     return (a[:, :, None] - b[:, None]).pow(2).sum(-1).argmin(2)
 
 
 def point_mesh_face_distance(verts, faces, points):
     """mean_p min_f d^2(p, f) + mean_f min_p d^2(p, f), averaged over the batch
-    (pytorch3d.loss.point_mesh_face_distance as used at mesh_net.py:470-471).  Brute force over V x F pairs."""
-    tri = verts[:, faces]                                                # [B,F,3,3]
-    a, b, c = tri[:, None, :, 0], tri[:, None, :, 1], tri[:, None, :, 2]  # [B,1,F,3]
-    p = points[:, :, None]                                                # [B,P,1,3]
-    ab, ac, ap = b - a, c - a, p - a
-    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
-    bp = p - b
-    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
-    cp = p - c
-    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
-    va, vb, vc = d3 * d6 - d5 * d4, d5 * d2 - d1 * d6, d1 * d4 - d3 * d2
-    eps = 1e-12
-    # closest point by Voronoi region (Ericson, Real-Time Collision Detection 5.1.5), branch-free
-    denom = (va + vb + vc).clamp_min(eps)
-    v, w = vb / denom, vc / denom
-    inside = a + ab * v[..., None] + ac * w[..., None]
-    t_ab = (d1 / (d1 - d3).clamp_min(eps)).clamp(0, 1)
-    t_ac = (d2 / (d2 - d6).clamp_min(eps)).clamp(0, 1)
-    t_bc = ((d4 - d3) / ((d4 - d3) + (d5 - d6)).clamp_min(eps)).clamp(0, 1)
-    cands = torch.stack([inside, a + ab * t_ab[..., None], a + ac * t_ac[..., None],
-                         b + (c - b) * t_bc[..., None], a.expand_as(inside), b.expand_as(inside), c.expand_as(inside)], 0)
-    ok_inside = (va >= 0) & (vb >= 0) & (vc >= 0)
-    d = (cands - p).pow(2).sum(-1)                                        # [7,B,P,F]
-    d_in = torch.where(ok_inside, d[0], torch.full_like(d[0], float('inf')))
-    dist = torch.minimum(d_in, d[1:].min(0)[0])                           # [B,P,F]
-    return (dist.min(2)[0].mean(1) + dist.min(1)[0].mean(1)).mean()
+    (pytorch3d.loss.point_mesh_face_distance as used at mesh_net.py:470-471)."""
+    return fused_ops.point_mesh_face_distance(verts, faces, points)       # HIP only; raises TypeError for CPU tensors
 
 
 # ----------------------------------------------------------------------------------------------

@@ -308,3 +308,53 @@ def test_face_gather_matches_index_select(cuda, C):
     assert torch.equal(b2.grad, b.grad)
     i32 = srf.face_vertices(attr.to(cuda), faces.to(cuda).int())  # int32 faces as Mesh builds from numpy
     assert torch.equal(i32.cpu(), ra.detach())
+
+
+def test_point_mesh_distance_known_answers(cuda):
+    # one triangle in z = 0; points above its interior, beyond an edge, beyond a vertex
+    from lasr_amd.nnutils import fused_ops
+    verts = torch.tensor([[[0., 0., 0.], [2., 0., 0.], [0., 2., 0.]]], device=cuda)
+    faces = torch.tensor([[0, 1, 2]], device=cuda)
+    pts = torch.tensor([[[0.5, 0.5, 3.0], [1.0, -2.0, 0.0], [-1.0, -1.0, 1.0], [2.0, 2.0, 0.0]]], device=cuda)
+    d2 = torch.tensor([9.0, 4.0, 3.0, 2.0])                       # interior, edge ab, vertex a, edge bc (closest (1,1,0))
+    out = fused_ops.point_mesh_face_distance(verts, faces, pts)
+    assert abs(float(out) - float(d2.mean() + d2.min())) < 1e-6
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_point_mesh_distance_matches_restatement(cuda, seed):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(seed)
+    v, f = synth.geodesic_sphere(3)
+    faces = torch.from_numpy(np.asarray(f, np.int64))
+    verts = torch.from_numpy(v).float()[None].repeat(2, 1, 1) * torch.tensor([0.7, 0.45, 0.5])
+    verts = verts + 0.02 * torch.randn(verts.shape, generator=g)
+    pts = verts * torch.tensor([-1., 1., 1.]) + 0.05 * torch.randn(verts.shape, generator=g)    # the mirrored mesh (:470)
+    a = [verts.clone().requires_grad_(True), pts.clone().requires_grad_(True)]
+    ra = po.point_mesh_face_distance(a[0], faces, a[1])
+    (ra * 1.7).backward()
+    b = [verts.clone().to(cuda).requires_grad_(True), pts.clone().to(cuda).requires_grad_(True)]
+    rb = fused_ops.point_mesh_face_distance(b[0], faces.to(cuda), b[1])
+    (rb * 1.7).backward()
+    assert abs(float(rb) - float(ra)) <= 1e-5 * abs(float(ra))
+    for name, x, y in zip(('verts', 'points'), b, a):
+        assert float((x.grad.cpu() - y.grad).abs().max()) <= 2e-4 * float(y.grad.abs().max()), name
+
+
+def test_nearest_point_and_chamfer(cuda):
+    from lasr_amd.nnutils import fused_ops, mesh_net
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(2, 300, 3, generator=g), torch.randn(2, 421, 3, generator=g)
+    d2, idx = fused_ops.nearest_point(a.to(cuda), b.to(cuda))
+    ref = (a[:, :, None] - b[:, None]).pow(2).sum(-1)
+    assert torch.equal(idx.cpu(), ref.argmin(2))
+    assert float((d2.cpu() - ref.min(2)[0]).abs().max()) <= 1e-6
+    ca = torch.randn(8, 20, 3, generator=g)
+    x = ca.clone().requires_grad_(True)
+    rx = po.chamfer_distance(x, x * torch.tensor([-1., 1., 1.]))
+    rx.backward()
+    y = ca.clone().to(cuda).requires_grad_(True)
+    ry = mesh_net.chamfer_distance(y, y * torch.tensor([-1., 1., 1.], device=cuda))
+    ry.backward()
+    assert abs(float(ry) - float(rx)) <= 1e-6 * abs(float(rx)) + 1e-9
+    assert float((y.grad.cpu() - x.grad).abs().max()) <= 1e-5 * float(x.grad.abs().max())
