@@ -76,9 +76,9 @@ struct PixState {
 // uniform reciprocals for the exact division-by-reciprocal (sr_device.h); ok = all three divisors are in the safe range
 struct UniRecip { float inv_sigma, inv_gamma, inv_fmn; bool ok; };
 
-template <bool LASR_FAST, bool MK, int NCH>
-__device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, cptr_t rec,
-                                             cptr_t tex, int fn, int lim, float xp, float yp,
+template <bool LASR_FAST, bool MK, int NCH, typename RP = cptr_t, typename TP = cptr_t>
+__device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, RP rec,
+                                             TP tex, int fn, int lim, float xp, float yp,
                                              float w0, float w1, float w2, PixState<NCH>& s, const UniRecip& U)
 {
     Frag fr;
