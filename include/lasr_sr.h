@@ -141,6 +141,9 @@ int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launch
  * exact division-by-reciprocal (sr_device.h) differs bitwise from the IEEE quotient a[i] / b[i].
  */
 int lasr_selftest_div(const float* a, const float* b, int* mismatches, int n, void* hip_stream);
+/* Same for the shared-divisor division of the clip/normalise step: a [n,3] with 0 <= a <= 1, b [n] in [1e-5, 3];
+ * adds the number of quotients (3 per row) that differ bitwise from a[i,k] / b[i]. */
+int lasr_selftest_div3(const float* a, const float* b, int* mismatches, int n, void* hip_stream);
 
 #ifdef __cplusplus
 }

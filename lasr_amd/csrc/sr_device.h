@@ -197,6 +197,26 @@ __device__ __forceinline__ bool inside_closed(float w0, float w1, float w2)
     return w0 <= 1 && w0 >= 0 && w1 <= 1 && w1 >= 0 && w2 <= 1 && w2 >= 0;   // K.cu:47-50
 }
 
+// Three IEEE-754 quotients a_k / b with one divisor.  This is the instruction sequence the compiler emits for a
+// float division (v_rcp_f32, one Newton step on the reciprocal, quotient, two residual corrections) with the
+// divisor-only part shared: 18 VALU ops instead of 3 x 11.  v_div_scale / v_div_fmas / v_div_fixup are identities
+// here -- the caller guarantees 1e-5 <= b <= 3 and a_k = 0 or 2^-100 <= a_k <= 1, so nothing is scaled and no special
+// value occurs -- hence the quotients are bit-identical to a_k / b (lasr_selftest_div covers this path as well).
+// (0 < a_k < 2^-100 would differ in the last denormal bit at most: a clipped barycentric of 1e-30.)
+__device__ __forceinline__ void div3_shared(float& a0, float& a1, float& a2, float b)
+{
+    float y = __builtin_amdgcn_rcpf(b);
+    y = __builtin_fmaf(__builtin_fmaf(-b, y, 1.f), y, y);
+#define LASR_QUOT(a)                                                     \
+    {                                                                    \
+        float q = a * y;                                                 \
+        q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);              \
+        a = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);              \
+    }
+    LASR_QUOT(a0) LASR_QUOT(a1) LASR_QUOT(a2)
+#undef LASR_QUOT
+}
+
 // K.cu:53-58
 template <bool FM = false>
 __device__ __forceinline__ void clip_normalise(float& w0, float& w1, float& w2)
@@ -206,7 +226,7 @@ __device__ __forceinline__ void clip_normalise(float& w0, float& w1, float& w2)
     w2 = fmaxf(fminf(w2, 1.f), 0.f);
     const float s = fmaxf(w0 + w1 + w2, 1e-5f);   // (float)max((double)s, 1e-5) == fmaxf(s, 1e-5f) for every float s
     if (FM) { const float r = __builtin_amdgcn_rcpf(s); w0 *= r; w1 *= r; w2 *= r; }
-    else { w0 /= s; w1 /= s; w2 /= s; }
+    else div3_shared(w0, w1, w2, s);
 }
 
 // ---- math flavours -----------------------------------------------------------------

@@ -515,6 +515,20 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(const float* __restri
     if (__float_as_int(q) != __float_as_int(r) && !(q != q && r != r)) atomicAdd(mismatches, 1);
 }
 
+// Self-test of the shared-divisor division of clip_normalise (sr_device.h: div3_shared) against the IEEE quotients.
+__global__ __launch_bounds__(256) void selftest_div3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            int* __restrict__ mismatches, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float q0 = a[3 * (size_t)i], q1 = a[3 * (size_t)i + 1], q2 = a[3 * (size_t)i + 2];
+    const float r0 = q0 / b[i], r1 = q1 / b[i], r2 = q2 / b[i];
+    div3_shared(q0, q1, q2, b[i]);
+    const int bad = (__float_as_int(q0) != __float_as_int(r0)) + (__float_as_int(q1) != __float_as_int(r1)) +
+                    (__float_as_int(q2) != __float_as_int(r2));
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace lasr
 
 // ===========================================================================
@@ -753,5 +767,13 @@ extern "C" int lasr_selftest_div(const float* a, const float* b, int* mismatches
     if (!a || !b || !mismatches || n < 0) return LASR_E_BADARG;
     if (n == 0) return LASR_OK;
     hipLaunchKernelGGL(selftest_div_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, a, b, mismatches, n);
+    return launch_ok();
+}
+
+extern "C" int lasr_selftest_div3(const float* a, const float* b, int* mismatches, int n, void* hip_stream)
+{
+    if (!a || !b || !mismatches || n < 0) return LASR_E_BADARG;
+    if (n == 0) return LASR_OK;
+    hipLaunchKernelGGL(selftest_div3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, a, b, mismatches, n);
     return launch_ok();
 }

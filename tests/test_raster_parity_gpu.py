@@ -200,6 +200,31 @@ def test_division_by_reciprocal_is_bit_exact(cuda):
     assert total <= 8, '%d of %d quotients differ' % (total, 4 * n)      # 2^-23 exceptional divisors at most
 
 
+def test_shared_divisor_division_is_bit_exact(cuda):
+    # clip/normalise (K.cu:53-58) divides three clipped barycentrics by their sum: one reciprocal refinement shared by the
+    # three quotients (sr_device.h: div3_shared) must give the IEEE quotients bit for bit over the values that occur
+    from lasr_amd import _lib
+    h = _lib.lib()
+    g = torch.Generator(device='cpu').manual_seed(4)
+    n = 1 << 23
+    total = 0
+    for mode in range(3):
+        a = torch.rand(n, 3, generator=g)
+        if mode == 1:
+            a = a * (torch.rand(n, 3, generator=g) < 0.6)                 # exact zeros from the clamp
+        if mode == 2:
+            a = a * 10.0 ** (-8 * torch.rand(n, 3, generator=g))          # small weights
+        b = a.sum(1).clamp_min(1e-5) if mode < 2 else torch.rand(n, generator=g) * 3 + 1e-5
+        a[:4] = torch.tensor([[1., 0., 0.], [0., 1., 1.], [1., 1., 1.], [0., 0., 0.]])
+        b[:4] = torch.tensor([1., 2., 3., 1e-5])
+        bad = torch.zeros(1, dtype=torch.int32, device=cuda)
+        a, b = a.to(cuda).contiguous(), b.to(cuda).contiguous()
+        rc = h.lasr_selftest_div3(a.data_ptr(), b.data_ptr(), bad.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'lasr_selftest_div3')
+        total += int(bad.item())
+    assert total == 0, '%d of %d quotients differ' % (total, 9 * n)
+
+
 def test_lasr_config_m2_512(oracle, cuda):
     # BASELINE configs[2] renders at 512x512 (--img_size 512)
     fv, ft, near, far = synth.raster_batch(11, 3, count=1)
