@@ -73,7 +73,16 @@ class LASRTrainer:
 
     # ---- data -------------------------------------------------------------------------------
     def init_dataset(self):
+        """A sequence on disk when configs/<dataname>.config names one (dataloader/vid.py:97-134), else the in-memory
+        synthetic sequence (there is no dataset on the benchmark machine)."""
         opts = self.opts
+        self.sequence = None
+        try:
+            from ..dataloader import vid
+            self.dataloader, self.n_frames_on_disk = vid.data_loader(opts, root=getattr(opts, 'data_root', '.'))
+            return
+        except FileNotFoundError:
+            pass
         self.sequence = synth_data.SyntheticSequence(self.device, opts.img_size, n_frames=opts.n_frames)
         npairs = len(self.sequence.pairs())
         # an epoch is padded to ~200 iterations per rank (dataloader/vid.py:78-80); pairs are dealt round-robin
@@ -84,8 +93,44 @@ class LASRTrainer:
         mine = order[self.rank::self.world]
         self.dataloader = [mine[i * opts.batch_size:(i + 1) * opts.batch_size].tolist() for i in range(per_epoch)]
 
-    def set_input(self, pair_ids):
-        return self.sequence.batch(pair_ids)
+    def set_input(self, batch):
+        if not isinstance(batch, dict):
+            return self.sequence.batch(batch)                    # list of pair ids of the synthetic sequence
+        return self._set_input_from_loader(batch)
+
+    def _set_input_from_loader(self, batch):
+        """Collated loader elements -> the model's batch dictionary (train_utils.py:125-181): frame t block then frame
+        t' block, ImageNet normalisation for the encoder input, final interleave."""
+        B, dev = self.opts.batch_size, self.device
+
+        def pair(a, b):
+            return torch.cat([batch[a].float(), batch[b].float()], 0).to(dev, non_blocking=True)
+
+        def both(name, *tail):                                   # [B,2,...] -> [2B,...], frame-major
+            t = batch[name].float().to(dev, non_blocking=True)
+            return t.transpose(0, 1).reshape(2 * B, *tail)
+        imgs = pair('img', 'imgn')
+        IS = imgs.shape[-1]
+        mean = imgs.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+        std = imgs.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        out = {
+            'input_imgs  ': (imgs - mean) / std,
+            'imgs        ': imgs,
+            'masks       ': both('mask', IS, IS),
+            'cams        ': pair('cam', 'camn'),
+            'depth_gt    ': pair('depth', 'depthn').reshape(2 * B, -1),
+            'flow        ': pair('flow', 'flown'),
+            'dts_barrier ': both('mask_dts', 1, IS, IS),
+            'ddts_barrier': both('dmask_dts', 1, IS, IS),
+            'mask_contour': both('mask_contour', 1, 1000, 2),
+            'pp          ': both('pps', 2),
+            'occ         ': pair('occ', 'occn'),
+            'oriimg_shape': batch['shape'][:1, :2].float().repeat(2 * B, 1).to(dev),
+            'is_canonical': pair('is_canonical', 'is_canonicaln'),
+            'frameid': pair('id0', 'id1'),
+            'dataid': torch.cat([batch['dataid'][:B], batch['dataid'][:B]], 0).float().to(dev),
+        }
+        return {k: v.view(2, B, -1).permute(1, 0, 2).reshape(v.shape) for k, v in out.items()}
 
     # ---- optimisation -----------------------------------------------------------------------
     def init_training(self):

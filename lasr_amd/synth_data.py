@@ -24,7 +24,6 @@ class SyntheticSequence:
     """n_frames views of the blobby mesh turning about y; frame pairs (i, i+dframe) with ground-truth flow."""
 
     def __init__(self, device, image_size=256, n_frames=3, nu=8, dframe=1, depth=10.0, focal=9.0):
-        from scipy import ndimage
         self.device, self.IS, self.n_frames, self.dframe = device, image_size, n_frames, dframe
         v, f, tex = synth.blobby_mesh(nu)
         V = v.shape[0]
@@ -52,11 +51,12 @@ class SyntheticSequence:
                     here = r.render_mesh(sr.Mesh(pre[i:i + 1], faces[:1], textures=proj[i:i + 1], texture_type='vertex'))
                     fl = (pos[0, :2] - here[0, :2]) * self.masks[i][None]
                     self.flow[(i, j)] = torch.cat([fl, self.masks[i][None]], 0)
-        m = self.masks.cpu().numpy() > 0
-        dts = np.stack([ndimage.distance_transform_edt(~mm) for mm in m]).astype(np.float32)
-        dts_in = np.stack([ndimage.distance_transform_edt(mm) for mm in m]).astype(np.float32)
-        self.dts = torch.from_numpy(dts / image_size).to(device)
-        self.ddts = torch.from_numpy((dts - dts_in) / image_size).to(device)
+        from .ext_utils import image as image_utils
+        m = (self.masks.cpu().numpy() > 0).astype(np.float64)
+        # the two distance transforms of the loader (dataloader/vidbase.py:184-185): outside the silhouette, and
+        # outside its 10-pixel dilation
+        self.dts = torch.from_numpy(np.stack([image_utils.compute_dt(mm, iters=0) for mm in m]).astype(np.float32)).to(device)
+        self.ddts = torch.from_numpy(np.stack([image_utils.compute_dt(mm, iters=10) for mm in m]).astype(np.float32)).to(device)
         self.mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
         self.std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
 

@@ -30,7 +30,7 @@ DEFAULTS = dict(
     model_path='', save_epoch_freq=100,                                           # nnutils/train_utils.py:58-68
     img_size=256, n_data_workers=4,                                               # dataloader/vid.py:34-35
     # additions of this build (not in the reference): synthetic data shape and the perceptual term switch
-    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=False)
+    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=False, data_root='.')
 
 
 def parse_flags(argv, defaults=DEFAULTS):

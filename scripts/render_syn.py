@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Render a synthetic video in the on-disk layout the video loader reads (reference: /root/reference/scripts/render_syn.py).
+
+    python scripts/render_syn.py --outdir syn-blob3f --nframes 3 [--obj mesh.obj] [--root .]
+
+Per frame i the object turns about y by 3*1.57 + alpha*6.28*i/nframes at depth 10 with focal length 10 (:145-160), is
+rendered with the hard rasteriser (lasr_sr_forward: hard distance / hard z-buffer), and written as
+  <root>/database/DAVIS/JPEGImages/Full-Resolution/<outdir>/%05d.jpg     colour, background = 255 - mean foreground
+  .../Annotations/.../%05d.png        128 * silhouette
+  .../Camera/.../%05d.txt             focal, tx, ty, quaternion (w, x, y, z), depth
+  .../FlowFW|FlowBW/.../flo-%05d.pfm  flow to the next / previous frame in pixels + validity; occ-%05d.pfm = -1
+  <root>/configs/<outdir>.config      the [data] section optimize.py --dataname <outdir> reads
+The reference renders spot_triangulated.obj with its surface texture (not available offline); here the default object
+is this repository's blobby geodesic sphere with per-vertex colours, or any .obj given with --obj.
+"""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lasr_amd import soft_renderer as sr          # noqa: E402
+from lasr_amd import synth                        # noqa: E402
+from lasr_amd.ext_utils import util_flow          # noqa: E402
+
+
+def rotmat_to_quat(m):
+    """3x3 rotation -> (x, y, z, w)."""
+    t = np.trace(m)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        return np.array([(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s])
+    i = int(np.argmax(np.diag(m)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = math.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2
+    q = np.zeros(4)
+    q[i], q[j], q[k], q[3] = 0.25 * s, (m[j, i] + m[i, j]) / s, (m[k, i] + m[i, k]) / s, (m[k, j] - m[j, k]) / s
+    return q
+
+
+def rodrigues(rx, ry, rz):
+    v = np.array([rx, ry, rz], np.float64)
+    th = np.linalg.norm(v)
+    if th < 1e-12:
+        return np.eye(3)
+    k = v / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+
+
+def render_flow(renderer, verts, faces, pos0, pos1, focal):
+    """Flow of the surface point seen at each pixel of frame 0 to its position in frame 1, NDC units (:47-63)."""
+    eye = torch.tensor(renderer.transform.transformer._eye, device=verts.device)[None, None]
+    pre = (verts[:, :, :3] - eye) * verts.new_tensor([1, -1, 1])        # as the reference: z ends up in front of near = 1
+    p0 = renderer.render_mesh(sr.Mesh(pre, faces, textures=pos0[:, :, :3].contiguous(), texture_type='vertex'))[:, :3]
+    p1 = renderer.render_mesh(sr.Mesh(pre, faces, textures=pos1[:, :, :3].contiguous(), texture_type='vertex'))[:, :3]
+    p0, p1 = p0.permute(0, 2, 3, 1).clone(), p1.permute(0, 2, 3, 1).clone()
+    bg = (p0[..., 2] < 1e-9) | (p1[..., 2] < 1e-9)
+    p0[bg] = 10
+    p1[bg] = 10
+    proj = lambda p: torch.stack([p[..., 0] * focal / p[..., 2], p[..., 1] * focal / p[..., 2]], -1)
+    return proj(p1) - proj(p0), bg
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='render data')
+    ap.add_argument('--outdir', default='syn-blob3f')
+    ap.add_argument('--obj', default='', help='mesh to render (default: the built-in blobby sphere)')
+    ap.add_argument('--nframes', default=3, type=int)
+    ap.add_argument('--alpha', default=1., type=float, help='0-1, fraction of a full turn')
+    ap.add_argument('--img_size', default=512, type=int)
+    ap.add_argument('--root', default='.')
+    ap.add_argument('--seed', default=0, type=int)
+    args = ap.parse_args(argv)
+    dev = torch.device('cuda', 0)
+    size, dframe, focal, depth = args.img_size, 1, 10.0, 10.0
+
+    if args.obj:
+        v, f = sr.functional.load_obj(args.obj)
+        overts, faces = v[None].to(dev).float(), f[None].to(dev)
+        colors = torch.ones_like(overts) * 0.7
+    else:
+        v, f, tex = synth.blobby_mesh(8)
+        overts = torch.from_numpy(v).to(dev)[None].float()
+        faces = torch.from_numpy(np.asarray(f, np.int64)).to(dev)[None]
+        colors = torch.from_numpy(tex).to(dev)[None].float()
+
+    base = os.path.join(args.root, 'database', 'DAVIS')
+    sub = {k: os.path.join(base, k, 'Full-Resolution', args.outdir) for k in
+           ('JPEGImages', 'Annotations', 'FlowFW', 'FlowBW', 'Meshes', 'Camera')}
+    for d in sub.values():
+        os.makedirs(d, exist_ok=True)
+    renderer = sr.SoftRenderer(image_size=size, sigma_val=1e-12, camera_mode='look_at', perspective=False,
+                               aggr_func_rgb='hard', dist_func='hard', aggr_func_alpha='hard', light_mode='vertex',
+                               light_intensity_ambient=1., light_intensity_directionals=0.)
+    from PIL import Image
+    rng = np.random.default_rng(args.seed)
+    verts_list, pos_list, bgcolor = [], [], None
+    eye = torch.tensor(renderer.transform.transformer._eye, device=dev)[None, None]
+    for i in range(args.nframes):
+        rotx = 0. if i == 0 else float(rng.random())
+        roty = 3 * 1.57 + args.alpha * 6.28 * i / args.nframes
+        rot = rodrigues(rotx, roty, 0.)
+        q = rotmat_to_quat(rot)
+        cam = np.array([focal, 0., 0., q[3], q[0], q[1], q[2], depth])
+        R = torch.from_numpy(rot.T.astype(np.float32)).to(dev)         # verts @ R(quat(-xyz, w)) == verts @ rot^T (:165)
+        pos = overts.matmul(R) + overts.new_tensor([0., 0., depth])
+        pos_list.append(torch.cat([pos, torch.ones_like(pos[:, :, :1])], -1))
+        z = pos[:, :, 2]
+        verts = torch.stack([pos[:, :, 0] * focal / z, pos[:, :, 1] * focal / z,
+                             (z - z.min()) / (z.max() - z.min()) - 0.5], -1)
+        verts_list.append(verts)
+        pre = (verts - eye) * verts.new_tensor([1, -1, 1])
+        with torch.no_grad():
+            out = renderer.render_mesh(sr.Mesh(pre, faces, textures=colors, texture_type='vertex'))
+        mask = out[0, -1].cpu().numpy() > 0.5
+        img = out[0, :3].permute(1, 2, 0).cpu().numpy() * 255
+        if bgcolor is None:
+            bgcolor = 255 - img[mask].mean(0)
+        img[~mask] = bgcolor[None]
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(os.path.join(sub['JPEGImages'], '%05d.jpg' % i), quality=95)
+        Image.fromarray((128 * mask).astype(np.uint8)).save(os.path.join(sub['Annotations'], '%05d.png' % i))
+        np.savetxt(os.path.join(sub['Camera'], '%05d.txt' % i), cam)
+        sr.functional.save_obj(os.path.join(sub['Meshes'], '%05d.obj' % i), pos[0].cpu(), faces[0].cpu())
+
+    occ = -np.ones((size, size), np.float32)
+    for i in range(dframe, args.nframes):
+        with torch.no_grad():
+            fw, bg_fw = render_flow(renderer, verts_list[i - dframe], faces, pos_list[i - dframe], pos_list[i], focal)
+            bw, bg_bw = render_flow(renderer, verts_list[i], faces, pos_list[i], pos_list[i - dframe], focal)
+        for name, fl, bg, idx in (('FlowFW', fw, bg_fw, i - dframe), ('FlowBW', bw, bg_bw, i)):
+            px = (fl / 2 * (size - 1))[0].cpu().numpy()
+            px = np.concatenate([px, 1 - bg[0].float().cpu().numpy()[:, :, None]], -1).astype(np.float32)
+            util_flow.write_pfm(os.path.join(sub[name], 'flo-%05d.pfm' % idx), px)
+            util_flow.write_pfm(os.path.join(sub[name], 'occ-%05d.pfm' % idx), occ)
+
+    os.makedirs(os.path.join(args.root, 'configs'), exist_ok=True)
+    with open(os.path.join(args.root, 'configs', '%s.config' % args.outdir), 'w') as fh:
+        fh.write('[data]\ndatapath = database/DAVIS/JPEGImages/Full-Resolution/%s/\ndframe = 1\ninit_frame  = 0\n'
+                 'end_frame = -1\ncan_frame = 0\n' % args.outdir)
+    print('wrote %d frames to %s' % (args.nframes, sub['JPEGImages']))
+
+
+if __name__ == '__main__':
+    main()
