@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--frames', type=int, default=256, help='frames per GPU per step (SURVEY 8d batches: 1/16/64/256)')
+    ap.add_argument('--image-size', type=int, default=256, help='256 = the headline metric; 512 = BASELINE configs[2] (camel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
     return ap.parse_args()
@@ -174,7 +175,9 @@ def measured_traffic(kernel, frames_per_launch):
 
 
 def main():
+    global IS
     a = parse()
+    IS = a.image_size
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -234,15 +237,15 @@ def main():
                'sr_setup_kernel': (36 + 160) * F * B}
         dom = max((k for k in ktimes if k != 'sr_setup_kernel'), key=lambda k: ktimes[k][0])
         achieved = alg[dom] / (ktimes[dom][0] * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(dom, B)
+        traffic, traffic_src = measured_traffic(dom, B) if IS == 256 else (None, None)   # PMC passes were taken at 256x256
         frames = world * B * a.steps
         out = {
-            'metric': 'rasterizer fwd+bwd frames/sec at 256x256, 2.3k faces',
+            'metric': 'rasterizer fwd+bwd frames/sec at %dx%d, 2.3k faces' % (IS, IS),
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'soft-rasteriser fwd+bwd, mesh M2 (V=1212,F=2420), 256x256, LASR modes '
-                                   '(euclidean/softmax/prod/vertex, sigma=1e-4, gamma=1e-2)',
+            'config': {'workload': 'soft-rasteriser fwd+bwd, mesh M2 (V=1212,F=2420), %dx%d, LASR modes '
+                                   '(euclidean/softmax/prod/vertex, sigma=1e-4, gamma=1e-2)' % (IS, IS),
                        'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
                        'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
