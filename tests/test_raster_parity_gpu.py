@@ -6,6 +6,7 @@ op-order-faithful oracle; hard-mode face-index map bit-exact; gradients within
 but deterministic, order than the reference's atomics).
 """
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,7 @@ from lasr_amd.soft_renderer import functional as srf
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMG_TOL = 1e-4
 GRAD_REL = 1e-3
 
@@ -265,3 +267,41 @@ def test_six_channel_pass_equals_two_three_channel_renders(oracle, cuda):
     assert np.abs(out[:, 3:6] - ref['soft_colors'][:, :3]).max() <= IMG_TOL
     with pytest.raises(Exception):          # 6 channels exist for LASR's mode combination only
         srf.soft_rasterize(tfv, t6, IS, **dict(kw, aggr_func_rgb='hard'))
+
+
+def test_integration_stub_binds_like_the_reference_extension(oracle, cuda):
+    # INTEGRATION.md "Option B": the ctypes module a reference maintainer would drop in for
+    # soft_renderer.cuda.soft_rasterize -- same two entry points, same argument order as the pybind functions
+    # (soft_rasterize_cuda.cpp:59-76, 94-114), called here exactly as functional/soft_rasterize.py:47-62, 86-100 does
+    import math
+    import re
+    import types
+    from lasr_amd import _lib
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    code = re.search(r'```python\n(# soft_renderer/cuda/soft_rasterize.py.*?)```', text, re.S).group(1)
+    code = code.replace("'/path/to/lasr_amd/csrc/liblasr_hip.so'", repr(_lib.LIB_PATH))
+    stub = types.ModuleType('soft_rasterize_stub')
+    exec(compile(code, 'INTEGRATION.md', 'exec'), stub.__dict__)
+
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    IS, N, F = 48, fv.shape[0], fv.shape[1]
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    faces = torch.from_numpy(fv).to(cuda).reshape(N, F, 3, 3).contiguous()
+    textures = torch.from_numpy(ft).to(cuda).reshape(N, F, 3, 3).contiguous()
+    faces_info = torch.zeros(N, F, 27, device=cuda)
+    aggrs_info = torch.zeros(N, 2, IS, IS, device=cuda)
+    soft_colors = torch.ones(N, 4, IS, IS, device=cuda)
+    scalars = (IS, near, far, kw['eps'], kw['sigma_val'], 2, math.log(1. / kw['dist_eps'] - 1.), kw['gamma_val'], 1, 2, 1, True)
+    out = stub.forward_soft_rasterize(faces, textures, faces_info, aggrs_info, soft_colors, *scalars)
+    assert out[2] is soft_colors
+    ref = oracle.forward(fv, ft, IS, **kw)
+    assert np.abs(soft_colors.cpu().numpy() - ref['soft_colors']).max() <= IMG_TOL
+    g = synth.upstream_grad(N, IS)
+    grad_faces, grad_textures = torch.zeros_like(faces), torch.zeros_like(textures)
+    stub.backward_soft_rasterize(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces, grad_textures,
+                                 torch.from_numpy(g).to(cuda), *scalars)
+    rgf, rgt = oracle.backward(ref, g, IS, **kw)
+    scale = np.abs(rgf).max()
+    assert np.abs(grad_faces.cpu().numpy().reshape(rgf.shape) - rgf).max() <= 1e-3 * scale
+    with pytest.raises(RuntimeError):                       # CHECK_INPUT of the pybind layer (soft_rasterize_cuda.cpp:54-56)
+        stub.forward_soft_rasterize(faces.cpu(), textures, faces_info, aggrs_info, soft_colors, *scalars)
