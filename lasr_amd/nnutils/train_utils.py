@@ -285,17 +285,81 @@ class LASRTrainer:
         torch.save(states, os.path.join(self.save_dir, 'pred_net_%s.pth' % label))
 
     def load_network(self, network, model_path):
-        """Warm start from the previous stage (:381-487): parameters whose shapes still match are copied; the best
-        hypothesis' shape/texture seed the new mesh when the vertex count is unchanged.  (Re-meshing through the
-        external Manifold binaries, :419-428, is not available offline.)"""
+        """Warm start from the previous stage (train_utils.py:381-487): pick the best camera hypothesis when the new
+        stage has fewer, re-mesh to --n_faces when the symmetry constraint is dropped (own re-mesher, see remesh.py),
+        keep the root bone's predictor rows and re-seed the part bones by k-means when the bone count changes, then load
+        whatever still fits."""
+        opts = self.opts
         states = torch.load(model_path, map_location='cpu')
-        best = int((-states['epoch_nscore']).argmax()) if states.get('epoch_nscore') is not None else 0
+        score_cams = -states['epoch_nscore'] if states.get('epoch_nscore') is not None else torch.zeros(1)
+        n_old = len(score_cams)
+        if opts.n_hypo < n_old:                                                  # select hypothesis (:387-416)
+            best = int(score_cams.argmax())
+            print('selecting hypothesis #%d' % best)
+            for head in ('quat_predictor', 'scale_predictor'):
+                w, b = ('code_predictor.%s.pred_layer.%s' % (head, x) for x in ('weight', 'bias'))
+                states[w] = states[w].view(n_old, -1, states[w].shape[-1])[best]
+                states[b] = states[b].view(n_old, -1)[best]
+            states['mean_v'] = states['mean_v'][best:best + 1]
+            states['tex'] = states['tex'][best:best + 1] if 'tex' in states else network.tex.data.cpu()
+            if states['mean_v'].shape[1] < int(states['faces'].max()):           # symmetric half -> full mesh
+                states['mean_v'] = states['full_shape'][best][None]
+                states['tex'] = states['full_tex'][best][None]
+            for name, width in (('ctl_rs', 4), ('rest_ts', 3), ('ctl_ts', 3), ('log_ctl', 3)):
+                if name in states:
+                    states[name] = states[name].view(n_old, -1, width)[best]
+
+        # ---- mean shape / topology (:418-450)
+        if (not opts.symmetric) and int(opts.n_faces) != states['faces'].shape[0]:
+            from . import remesh
+            src = states['mean_v'][0]
+            if src.shape[0] < int(states['faces'].max()) + 1:
+                src = states['full_shape'][0]
+            v, f = remesh.remesh_star(src.numpy(), states['faces'].numpy(), opts.n_faces)
+            mean_shape, faces = torch.from_numpy(v), torch.from_numpy(f)
+            tex = torch.zeros(1, mean_shape.shape[0], 3)
+        elif opts.symmetric:
+            mean_shape, faces, tex = None, states['faces'], states.get('tex')
+        else:
+            mean_shape, faces, tex = states['mean_v'][0], states['faces'], states.get('tex')
+            if int(faces.max()) + 1 > mean_shape.shape[0]:
+                mean_shape, tex = states['full_shape'][0], states['full_tex'][0][None]
+        network.faces = faces.to(network.faces.device)
+        if opts.symmetric:
+            if states['mean_v'].shape == network.mean_v.shape:
+                network.mean_v.data = states['mean_v'].clone()
+        else:
+            network.mean_v.data = mean_shape[None].repeat(opts.n_hypo, 1, 1)
+        if tex is not None and tex.shape[1:] == network.mean_v.shape[1:]:
+            network.tex.data = tex.expand(opts.n_hypo, -1, -1).clone()
+        elif not opts.symmetric:
+            network.tex.data = torch.zeros(opts.n_hypo, network.mean_v.shape[1], 3)
+        for k in ('mean_v', 'tex', 'faces'):
+            states.pop(k, None)
+
+        # ---- from a rigid body / fewer bones to more bones (:455-484)
+        key = 'code_predictor.depth_predictor.pred_layer.bias'
+        if key in states and states[key].shape[0] != opts.n_bones:
+            own = network.state_dict()
+            nfeat = states['code_predictor.quat_predictor.pred_layer.weight'].shape[-1]
+            for head, width, per_hypo in (('quat_predictor', 4, opts.n_hypo), ('trans_predictor', 2, 1), ('depth_predictor', 1, 1)):
+                w, b = ('code_predictor.%s.pred_layer.%s' % (head, x) for x in ('weight', 'bias'))
+                if states[w].shape[0] % (width * per_hypo) or own[w].shape[0] != opts.n_bones * width * per_hypo:
+                    states.pop(w), states.pop(b)
+                    continue
+                old_w = states[w].view(per_hypo, -1, width, nfeat)[:, :1]        # the root bone of every hypothesis
+                old_b = states[b].view(per_hypo, -1, width)[:, :1]
+                new_w = own[w].view(per_hypo, opts.n_bones, width, nfeat).clone()
+                new_b = own[b].view(per_hypo, opts.n_bones, width).clone()
+                new_w[:, :1], new_b[:, :1] = old_w, old_b
+                states[w], states[b] = new_w.reshape(own[w].shape), new_b.reshape(own[b].shape)
+            if opts.n_bones > 1:                                                  # initialise the skin from the mean shape
+                shape0 = network.symmetrize(network.mean_v.data[0]).detach().cpu()
+                centres = kmeans(shape0, opts.n_bones - 1)[1] if opts.n_bones > 2 else shape0.mean(0)[None]
+                states['rest_ts'] = centres.repeat(opts.n_hypo, 1)
+                states['ctl_ts'] = centres.repeat(opts.n_hypo, 1)
+                states['ctl_rs'] = network.ctl_rs.data.cpu()
+                states['log_ctl'] = network.log_ctl.data.cpu()
         own = network.state_dict()
-        for k, v in states.items():
-            if k in own and torch.is_tensor(v) and own[k].shape == v.shape:
-                own[k].copy_(v)
-        full = states.get('full_shape')
-        if full is not None and not network.symmetric and full[best].shape == own['mean_v'].shape[1:]:
-            own['mean_v'].copy_(full[best][None].expand_as(own['mean_v']))
-            own['tex'].copy_(states['full_tex'][best][None].expand_as(own['tex']))
-        network.load_state_dict(own)
+        network.load_state_dict({k: v for k, v in states.items()
+                                 if k in own and torch.is_tensor(v) and own[k].shape == v.shape}, strict=False)

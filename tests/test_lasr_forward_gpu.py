@@ -96,14 +96,50 @@ def test_training_reduces_the_loss_and_checkpoints(tmp_path, cuda):
     assert np.mean(losses[-10:]) < np.mean(losses[:10]), losses
     tr.epoch_nscore = torch.zeros(1, device=cuda)
     tr.save('latest')
-    assert os.path.exists(os.path.join(tr.save_dir, 'pred_net_latest.pth'))
-    # stage hand-off: warm start a non-symmetric model from the checkpoint (spot3.sh stage 0 -> 1)
-    tr2 = make_trainer(tmp_path, name='t2', symmetric=False, n_bones=1, n_hypo=1, batch_size=1,
-                       model_path=os.path.join(tr.save_dir, 'pred_net_latest.pth'))
+    ckpt = os.path.join(tr.save_dir, 'pred_net_latest.pth')
+    assert os.path.exists(ckpt)
+    # stage hand-off: warm start a non-symmetric model of the same topology from the checkpoint (spot3.sh stage 0 -> 1)
+    tr2 = make_trainer(tmp_path, name='t2', symmetric=False, n_bones=1, n_hypo=1, batch_size=1, n_faces='320', model_path=ckpt)
     full = tr.module.symmetrize(tr.module.mean_v[0]).detach()
     assert torch.allclose(tr2.module.mean_v[0], full, atol=1e-6)
     l, _ = tr2.model.train()(tr2.set_input(tr2.dataloader[0]))
     assert torch.isfinite(l)
+
+
+def test_stage_handoff_selects_hypothesis_remeshes_and_grows_bones(tmp_path, cuda):
+    # train_utils.py:381-487: fewer hypotheses -> the best one's predictor rows / shape / bones are kept; symmetry dropped
+    # with a different --n_faces -> re-meshed; more bones -> root bone's rows kept, part bones re-seeded by k-means
+    tr = make_trainer(tmp_path, n_bones=5, n_hypo=2)
+    with torch.no_grad():
+        tr.module.mean_v[1] *= torch.tensor([1.0, 0.7, 0.85], device=cuda)      # make the two hypotheses differ
+    tr.epoch_nscore = torch.tensor([0.3, 0.1], device=cuda)                      # lower score = better: #1 wins
+    tr.save('latest')
+    ckpt = os.path.join(tr.save_dir, 'pred_net_latest.pth')
+    tr2 = make_trainer(tmp_path, name='t2', symmetric=False, n_bones=5, n_hypo=1, batch_size=1, n_faces='320', model_path=ckpt)
+    full = tr.module.symmetrize(tr.module.mean_v[1]).detach()
+    assert torch.allclose(tr2.module.mean_v[0], full, atol=1e-6)
+    old_q = tr.module.code_predictor.quat_predictor.pred_layer.weight.view(2, 5, 4, -1)[1]
+    assert torch.allclose(tr2.module.code_predictor.quat_predictor.pred_layer.weight.view(5, 4, -1), old_q)
+    assert torch.allclose(tr2.module.ctl_ts, tr.module.ctl_ts.view(2, 4, 3)[1])
+    l, _ = tr2.model.train()(tr2.set_input(tr2.dataloader[0]))
+    assert torch.isfinite(l)
+    # re-meshing to --n_faces 500 (20 * 5^2 faces, 252 vertices) and 7 bones
+    tr3 = make_trainer(tmp_path, name='t3', symmetric=False, n_bones=7, n_hypo=1, batch_size=1, n_faces='500', model_path=ckpt)
+    m3 = tr3.module
+    assert m3.faces.shape == (500, 3) and m3.mean_v.shape == (1, 252, 3) and m3.tex.shape == (1, 252, 3)
+    r_old = (full - full.mean(0)).norm(dim=1)
+    r_new = (m3.mean_v[0] - m3.mean_v[0].mean(0)).norm(dim=1)
+    assert float(r_new.max()) <= float(r_old.max()) * 1.05 and float(r_new.min()) >= float(r_old.min()) * 0.85
+    assert m3.rest_ts.shape == (6, 3) and float((m3.rest_ts - m3.ctl_ts).abs().max()) == 0
+    d = (m3.rest_ts[:, None] - m3.mean_v[0][None]).norm(dim=-1).min(1)[0]
+    assert float(d.max()) < 0.5 * float(r_old.max())                              # bone centres sit in the shape
+    root = tr.module.code_predictor.depth_predictor.pred_layer.weight[0]
+    assert torch.allclose(m3.code_predictor.depth_predictor.pred_layer.weight[0], root)      # root bone's rows kept
+    tr3.model.train()
+    for i in range(3):
+        m3.iters = i
+        l3, _ = tr3.train_step(tr3.set_input(tr3.dataloader[i]))
+    assert torch.isfinite(l3)
 
 
 def test_graph_replay_matches_eager_forward(tmp_path, cuda):

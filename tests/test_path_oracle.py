@@ -102,3 +102,20 @@ def test_perceptual_pairing_with_shared_observations():
     full = net.forward_pair(obs[:, None].repeat(1, H, 1, 1, 1).view(-1, 3, 64, 64), rnd)
     shared = net.forward_pair(obs, rnd, repeat=H)
     assert torch.allclose(full, shared, rtol=1e-5, atol=1e-6)
+
+
+def test_star_remesh_lands_on_the_surface():
+    # nnutils/remesh.py (stands in for the Manifold binaries of train_utils.py:419-428): vertices of the new tessellation are
+    # ray hits on the old surface, face count = 20 nu^2 nearest to the request
+    import numpy as np
+    from lasr_amd import synth
+    from lasr_amd.nnutils import remesh
+    v, f = synth.geodesic_sphere(6)
+    v = v * np.array([1.0, 0.6, 0.8], np.float32)                    # an ellipsoid: every ray from the centre hits once
+    nv, nf = remesh.remesh_star(v, f, 1600)
+    assert nf.shape == (1620, 3) and nv.shape == (812, 3)
+    q = (nv / np.array([1.0, 0.6, 0.8])) ** 2                        # on the inscribed polyhedron: just inside the ellipsoid
+    r = np.sqrt(q.sum(1))
+    assert r.max() <= 1 + 1e-6 and r.min() > 0.97
+    t = remesh.ray_mesh_outermost(np.zeros(3), np.array([[0., 0., 1.], [0., 0., -1.]]), v.astype(np.float64), f)
+    assert np.allclose(t, 0.8, atol=1e-6)
