@@ -253,6 +253,21 @@ def main():
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ktimes[dom][0],
                          'all_kernels_avg_ms': {k: v[0] for k, v in ktimes.items()}},
         }
+        if world == 1:
+            # informational: the opt-in relaxed forward arithmetic (lasr_sr_set_forward_math(1), image within ~1e-5 of the
+            # default path; `value` above is the default, reference-faithful arithmetic)
+            h.lasr_sr_set_forward_math(1)
+            try:
+                job.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(min(a.steps, 10)):
+                    job.step()
+                torch.cuda.synchronize()
+                out['relaxed_forward_math'] = {'value': B * min(a.steps, 10) / (time.perf_counter() - t1), 'unit': 'frames/s',
+                                               'note': 'opt-in; distance + threshold decision bit-faithful, the rest fp32 rcp/exp'}
+            finally:
+                h.lasr_sr_set_forward_math(0)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(F)
         if world == 1 and a.lasr_iters > 0:

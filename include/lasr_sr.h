@@ -137,6 +137,15 @@ const char* lasr_prof_kernel_name(int kernel_id);
 int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launches);
 
 /*
+ * Arithmetic of the forward pass for LASR's mode combination (euclidean / softmax / prod / vertex / double-sided),
+ * process-wide (no reference counterpart).  0 (default): the reference's rounding sequence, image within ~2.4e-7 of the
+ * op-faithful oracle.  1: the point-to-face distance and the `dis >= threshold` decision stay bit-faithful, the sigmoid,
+ * alpha product, clip/normalise, depth and softmax weights use fp32 v_rcp / v_exp arithmetic: ~15 % faster forward, image
+ * within ~3e-5 of mode 0 (the north-star bar is 1e-4).  Other mode combinations and the backward pass are unaffected.
+ */
+int lasr_sr_set_forward_math(int mode);
+
+/*
  * Test hook (no reference counterpart): adds to *mismatches the number of pairs for which the library's
  * exact division-by-reciprocal (sr_device.h) differs bitwise from the IEEE quotient a[i] / b[i].
  */

@@ -76,22 +76,33 @@ struct PixState {
 // uniform reciprocals for the exact division-by-reciprocal (sr_device.h); ok = all three divisors are in the safe range
 struct UniRecip { float inv_sigma, inv_gamma, inv_fmn; bool ok; };
 
-template <bool LASR_FAST, bool MK, int NCH, typename RP = cptr_t, typename TP = cptr_t>
+// RX = relaxed arithmetic (opt-in, lasr_sr_set_forward_math(1); LASR's mode combination only): the distance and the
+// `dis >= threshold` decision stay bit-faithful -- that is where the reference is ill-conditioned -- but everything after
+// it (sigmoid, alpha product, clip/normalise, depth, softmax weights) uses fp32 v_rcp / v_exp arithmetic instead of the
+// reference's division / double-promotion sequence.  Rendered image within ~3e-5 of the exact path (bar: 1e-4).
+template <bool LASR_FAST, bool MK, int NCH, bool RX = false, typename RP = cptr_t, typename TP = cptr_t>
 __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m, RP rec,
                                              TP tex, int fn, int lim, float xp, float yp,
                                              float w0, float w1, float w2, PixState<NCH>& s, const UniRecip& U)
 {
     Frag fr;
-    if (!fragment_w<false, MK>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, U.inv_sigma)) return;
+    if (RX) {
+        euclid<false, MK>(rec, xp, yp, w0, w1, w2, fr);
+        fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
+        if (fr.sign < 0 && fr.dis >= A.thr) return;
+        fr.D = __builtin_amdgcn_rcpf(1.f + __expf(-fr.sign * fr.dis * U.inv_sigma));
+    } else if (!fragment_w<false, MK>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, U.inv_sigma)) return;
     const float D = fr.D;
     // alpha first (K.cu:409-417), before the depth test
     if (m.alpha == 0) { if ((double)D > 0.5) s.a = 1.f; }
     else if (m.alpha == 1) s.a += D;
+    else if (RX) s.a *= 1.f - D;
     else s.a = (float)((double)s.a * (1. - (double)D));
 
     float c0 = w0, c1 = w1, c2 = w2;
-    clip_normalise(c0, c1, c2);
-    const float zp = depth_at<false, MK>(rec, c0, c1, c2);
+    clip_normalise<RX>(c0, c1, c2);
+    const float zp = RX ? __builtin_amdgcn_rcpf(c0 * rec[R_IZ + 0] + c1 * rec[R_IZ + 1] + c2 * rec[R_IZ + 2])
+                        : depth_at<false, MK>(rec, c0, c1, c2);
     if (zp < A.near || zp > A.far) return;
 
     const bool front = (__float_as_int(rec[R_FLAGS]) & 8) != 0;
@@ -104,13 +115,16 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
     } else {
         if (front || m.double_side) {
             const float fmn = A.far - A.near;
-            const float zn = MK ? div_by_recip(A.far - zp, fmn, U.inv_fmn) : (A.far - zp) / fmn;
+            const float zn = RX ? (A.far - zp) * U.inv_fmn
+                                : (MK ? div_by_recip(A.far - zp, fmn, U.inv_fmn) : (A.far - zp) / fmn);
             float rescale = 1.f;
             if (zn > s.smax) {
-                rescale = exp_1ulp(MK ? div_by_recip(s.smax - zn, A.gamma, U.inv_gamma) : (s.smax - zn) / A.gamma);
+                rescale = RX ? __expf((s.smax - zn) * U.inv_gamma)
+                             : exp_1ulp(MK ? div_by_recip(s.smax - zn, A.gamma, U.inv_gamma) : (s.smax - zn) / A.gamma);
                 s.smax = zn;
             }
-            const float ez = exp_1ulp(MK ? div_by_recip(zn - s.smax, A.gamma, U.inv_gamma) : (zn - s.smax) / A.gamma);
+            const float ez = RX ? __expf((zn - s.smax) * U.inv_gamma)
+                                : exp_1ulp(MK ? div_by_recip(zn - s.smax, A.gamma, U.inv_gamma) : (zn - s.smax) / A.gamma);
             s.ssum = rescale * s.ssum + ez * D;
 #pragma unroll
             for (int k = 0; k < NCH; k++)
@@ -122,7 +136,7 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
 // NCH = attribute channels per vertex: 3 (RGB, every mode) or 6 (two attribute triples rendered in ONE pass over the
 // geometry -- LASR's flow renders, nnutils/mesh_net.py:85-87, rasterise the same mesh twice with two different
 // per-vertex attributes; channels are independent, so the result equals the two separate renders).
-template <bool LASR_FAST, int NCH>
+template <bool LASR_FAST, int NCH, bool RX = false>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
 {
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 const cptr_t tex = as_const(texs + (size_t)fn * texstride);
                 const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
                 if (cand) {
-                    if (mk) forward_face<LASR_FAST, true, NCH>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
+                    if (mk) forward_face<LASR_FAST, true, NCH, RX>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
                     else forward_face<LASR_FAST, false, NCH>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
                 }
             }
@@ -575,6 +589,7 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     return A;
 }
 
+static int g_forward_math = 0;                               // 0 = reference-faithful (default), 1 = relaxed, see forward_face
 static thread_local const float* g_near_far_dev = nullptr;   // set by the *_dev entry points around the call
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
@@ -608,7 +623,10 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const dim3 grid((unsigned)(N * tiles_x * tiles_x));
     {
         ProfScope ps(K_SR_FORWARD, st);
-        if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        const bool rx = g_forward_math == 1 && is_lasr_fast(A.m);
+        if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (is_lasr_fast(A.m)) hipLaunchKernelGGL((sr_forward_kernel<true, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else hipLaunchKernelGGL((sr_forward_kernel<false, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
     }
@@ -776,4 +794,11 @@ extern "C" int lasr_selftest_div3(const float* a, const float* b, int* mismatche
     if (n == 0) return LASR_OK;
     hipLaunchKernelGGL(selftest_div3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, a, b, mismatches, n);
     return launch_ok();
+}
+
+extern "C" int lasr_sr_set_forward_math(int mode)
+{
+    if (mode != 0 && mode != 1) return LASR_E_BADMODE;
+    g_forward_math = mode;
+    return LASR_OK;
 }
