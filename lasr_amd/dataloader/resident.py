@@ -1,0 +1,40 @@
+"""The whole sequence resident in HBM (288 GB per GPU).
+
+A LASR sequence is tens of frames; every distinct (frame, neighbour) pair, prepared exactly as the model consumes it
+(the batch dictionary of /root/reference/nnutils/train_utils.py:125-181, fp32), is ~5 MB.  Instead of decoding on
+worker processes, collating, pinning and copying a batch per iteration -- about 85 ms of host work per batch on the
+benchmark machine against a 9 ms optimisation step -- every pair is prepared ONCE, kept on the device, and a batch is a
+row gather.  The iteration order is still the sampler's (DistributedSampler over the padded pair list, vid.py:126-131).
+"""
+import torch
+from torch.utils.data.dataloader import default_collate
+
+
+class ResidentLoader:
+    def __init__(self, loader, to_model_batch, device):
+        """loader: the torch DataLoader of dataloader/vid.py (dataset + sampler + batch size);
+        to_model_batch: collated single-pair element -> model batch dictionary of [2, ...] tensors (frame t, frame t')."""
+        ds = loader.dataset
+        self.dataset, self.sampler, self.batch_size, self.device = ds, loader.sampler, loader.batch_size, device
+        key_of, self.pair_of_index = {}, []
+        for i in range(len(ds)):
+            a = ds.baselist[i]
+            k = (a, a + ds.dframe if ds.directlist[i] == 1 else a - ds.dframe)
+            if k not in key_of:
+                key_of[k] = (len(key_of), i)
+            self.pair_of_index.append(key_of[k][0])
+        rows = [to_model_batch(default_collate([ds[first]])) for _, first in sorted(key_of.values())]
+        self.table = {k: torch.stack([r[k] for r in rows]).to(device) for k in rows[0]}       # [pairs, 2, ...]
+        self.pair_of_index = torch.tensor(self.pair_of_index, device=device)
+        self.n_pairs = len(rows)
+
+    def __len__(self):
+        return len(self.sampler) // self.batch_size
+
+    def __iter__(self):
+        order = torch.tensor(list(iter(self.sampler)), device=self.device)
+        pairs = self.pair_of_index[order]
+        B = self.batch_size
+        for i in range(len(self)):
+            ids = pairs[i * B:(i + 1) * B]
+            yield {k: t.index_select(0, ids).flatten(0, 1) for k, t in self.table.items()}    # pair-major = interleaved

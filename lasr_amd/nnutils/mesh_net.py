@@ -386,9 +386,17 @@ class LASR(MeshNet):
         self.renderer_softtex = sr.SoftRenderer(gamma_val=1e-2, aggr_func_rgb='softmax', **common)
         self.renderer_softpart = sr.SoftRenderer(gamma_val=1e-4, aggr_func_rgb='softmax', **common)
         self.epoch, self.iters, self.total_steps = 0, 0, 0
+        self.register_buffer('reg_factor', torch.tensor(0.5), persistent=False)
+        self.register_buffer('noise_decay', torch.tensor(0.2), persistent=False)
         self.optim_idx = 0
         # criteria attached by the trainer in the reference (train_utils.py:113-123); None until then
         self.triangle_loss_fn_sr = self.arap_loss_fn = self.flatten_loss = self.ptex_loss = None
+
+    def schedule_scalars(self):
+        """Refresh the schedule-dependent scalars of forward() from (epoch, iters): the regulariser decay (:106-113, :449)
+        and the pose-noise amplitude (:221).  Called by the trainer before every step."""
+        self.reg_factor.fill_(reg_decay(self.epoch, self.opts.num_epochs, 0.05, 0.5))
+        self.noise_decay.fill_(0.2 * (1e-4) ** (self.iters / 100))
 
     def _skinning(self, pred_v, n2):
         """GMM skinning weights (mesh_net.py:264-271): softmax_k(-10 * sum_d exp(log_ctl) * ((ctl_ts - v) R(ctl_rs))_d^2)."""
@@ -432,7 +440,7 @@ class LASR(MeshNet):
 
         quat = quat.view(-1, 9)
         if opts.noise and self.epoch > 0 and 1 < self.iters < 100:               # pose / scale noise (:220-235)
-            decay = 0.2 * (1e-4) ** (self.iters / 100)
+            decay = self.noise_decay                          # 0.2 * 1e-4 ** (iters / 100), device scalar (schedule_scalars)
             axis = F.normalize(torch.randn(quat.shape[0], 3, device=quat.device), dim=1)
             ang = torch.rand(quat.shape[0], 1, device=quat.device) * math.pi * decay
             noise = torch.cat([axis * torch.sin(ang / 2), torch.cos(ang / 2)], 1)
@@ -475,6 +483,7 @@ class LASR(MeshNet):
 
         # ---- 1) flow rendering (:298-335)
         verts_cam = obj_to_cam(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
+        self.verts_cam = verts_cam.detach()                                      # per-frame shape in camera space (export)
         verts_fl = torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1)
         # halves of the batch through unbind / chunk: one stack in the backward pass instead of zeros + copy per slice
         verts_pos0, verts_pos1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)
@@ -546,7 +555,8 @@ class LASR(MeshNet):
         total = total + self.texture_loss
 
         # 4) shape smoothness (:449-459)
-        factor = 1 if H > 1 else reg_decay(self.epoch, opts.num_epochs, 0.05, 0.5)
+        # a device scalar the trainer refreshes (schedule_scalars), so that one captured graph serves every epoch
+        factor = 1 if H > 1 else self.reg_factor
         tri = factor * 0.005 * self.triangle_loss_fn_sr(pred_v) * (4 ** opts.subdivide) / 64.
         tri = tri + factor * 5e-4 * self.flatten_loss(pred_v) * (2 ** opts.subdivide / 8.0)
         self.triangle_loss_sub = tri.view(n2, H)

@@ -8,6 +8,7 @@ Differences, all behind the same calls:
   * k-means bone initialisation (:243-251, kmeans_pytorch) is a small Lloyd iteration with farthest-point seeding.
 """
 import os
+from types import SimpleNamespace
 
 import torch
 import torch.distributed as dist
@@ -78,8 +79,13 @@ class LASRTrainer:
         opts = self.opts
         self.sequence = None
         try:
-            from ..dataloader import vid
-            self.dataloader, self.n_frames_on_disk = vid.data_loader(opts, root=getattr(opts, 'data_root', '.'))
+            from ..dataloader import resident, vid
+            loader, self.n_frames_on_disk = vid.data_loader(opts, root=getattr(opts, 'data_root', '.'))
+            if self.device.type == 'cuda':         # prepare every distinct pair once and keep it in HBM
+                one = LASRTrainer.__new__(LASRTrainer)
+                one.opts, one.device = SimpleNamespace(batch_size=1), torch.device('cpu')
+                loader = resident.ResidentLoader(loader, one._set_input_from_loader, self.device)
+            self.dataloader = loader
             return
         except FileNotFoundError:
             pass
@@ -96,6 +102,8 @@ class LASRTrainer:
     def set_input(self, batch):
         if not isinstance(batch, dict):
             return self.sequence.batch(batch)                    # list of pair ids of the synthetic sequence
+        if 'input_imgs  ' in batch:
+            return batch                                         # ResidentLoader: already the model's dictionary, on the device
         return self._set_input_from_loader(batch)
 
     def _set_input_from_loader(self, batch):
@@ -167,9 +175,11 @@ class LASRTrainer:
         noisy = o.noise and m.epoch > 0 and 1 < m.iters < 100
         if self.distributed or not getattr(o, 'use_graph', False) or self.device.type != 'cuda':
             return None
-        if noisy or m.iters == 0:                       # python-side branches that change the op sequence
+        if m.iters == 0:                                # first iteration of an epoch: part rendering, logging only
             return None
-        return (m.epoch, int(m.optim_idx))
+        # epoch- and iteration-dependent scalars live in device buffers (LASR.schedule_scalars), so the op sequence only
+        # depends on whether the pose-noise branch runs and on which hypothesis is rendered for the parts
+        return ('noisy' if noisy else 'plain', int(m.optim_idx))
 
     def _graphed_forward_backward(self, batch, key):
         g = self._graphs.get(key) if hasattr(self, '_graphs') else None
@@ -198,15 +208,21 @@ class LASRTrainer:
             with torch.cuda.graph(graph, stream=self._stream):
                 loss, aux = self.model(self._static)
                 loss.mean().backward()
-            g = self._graphs[key] = (graph, loss, aux)
+            # the backward pass of the capture created the .grad tensors inside THIS graph's memory pool; with more than
+            # one live graph each replay has to point the parameters back at the gradients its graph writes
+            grads = [(p, p.grad) for p in self.module.parameters() if p.grad is not None]
+            g = self._graphs[key] = (graph, loss, aux, grads)
         for k, v in batch.items():
             self._static[k].copy_(v)
         g[0].replay()
+        for p, gr in g[3]:
+            p.grad = gr
         return g[1], g[2]
 
     def train_step(self, batch):
         """forward, backward (DDP all-reduces the gradients), clipping + NaN guard, AdamW, OneCycleLR (:274-296)."""
         m = self.module
+        m.schedule_scalars()
         key = self._graph_key()
         if key is not None:
             total_loss, aux = self._graphed_forward_backward(batch, key)

@@ -142,3 +142,25 @@ def test_trainer_batch_dictionary_from_loader(tmp_path):
     # interleaved pairs (train_utils.py:179-180): rows 0,1 = (frame t, frame t') of the first pair
     undo = batch['frameid'].view(B, 2).t().reshape(-1)
     assert undo.tolist() == [0., 0., 1., 1.]                      # elements 0 and 1 of the list are both the pair 0 -> 1
+
+
+def test_resident_loader_serves_the_same_batches(tmp_path):
+    # dataloader/resident.py: every pair prepared once and gathered by row must equal collate -> set_input per iteration
+    from lasr_amd.dataloader import resident
+    from lasr_amd.nnutils import train_utils
+    write_sequence(str(tmp_path))
+    opts = make_opts(batch_size=2)
+    loader, _ = vid.data_loader(opts, shuffle=True, root=str(tmp_path))
+    tr = train_utils.LASRTrainer.__new__(train_utils.LASRTrainer)
+    tr.opts, tr.device = opts, torch.device('cpu')
+    one = train_utils.LASRTrainer.__new__(train_utils.LASRTrainer)
+    one.opts, one.device = SimpleNamespace(batch_size=1), torch.device('cpu')
+    res = resident.ResidentLoader(loader, one._set_input_from_loader, torch.device('cpu'))
+    assert res.n_pairs == 6 and len(res) == len(loader)
+    for k, (a, b) in enumerate(zip(loader, res)):
+        ref = tr.set_input(a)
+        assert tr.set_input(b) is b and list(b.keys()) == list(ref.keys())
+        for key in ref:
+            assert torch.equal(ref[key], b[key]), key
+        if k == 4:
+            break

@@ -234,3 +234,38 @@ def test_mesh_evaluation_protocol(cuda):
     sphere = torch.nn.functional.normalize(v, dim=1)
     other = ev.evaluate_pair((sphere, f), (v, f))
     assert same < 0.05 and other > 5 * same
+
+
+def test_graph_replay_covers_the_pose_noise_iterations(tmp_path, cuda):
+    # epochs > 0 add random pose / scale noise on iterations 2..99 (mesh_net.py:220-235); its amplitude is a device scalar,
+    # so these iterations replay one captured graph as well, drawing fresh random numbers on every replay
+    tr = make_trainer(tmp_path, iters_per_epoch=8, use_graph=True, num_epochs=2)
+    steps = tr.train()
+    assert steps == 16 and {k[0] for k in tr._graphs} == {'plain', 'noisy'}
+    idx = int(tr.module.optim_idx)
+    m = tr.module
+    m.epoch, m.iters = 1, 5
+    batch = tr.set_input(tr.dataloader[0])
+    with torch.no_grad():
+        params = [p.detach().clone() for p in m.parameters()]
+    losses = []
+    for _ in range(2):                                  # same parameters, same batch: only the noise differs
+        with torch.no_grad():
+            for p, q in zip(m.parameters(), params):
+                p.copy_(q)
+        l, _ = tr.train_step(batch)
+        losses.append(float(l))
+    assert all(np.isfinite(losses)) and losses[0] != losses[1]
+    # with two live graphs the parameters' .grad must follow the graph that was replayed last
+    m.epoch, m.iters = 1, 150                                    # a plain iteration after noisy ones
+    m.schedule_scalars()
+    tr._graphed_forward_backward(batch, ('noisy', idx))
+    tr._graphed_forward_backward(batch, ('plain', idx))
+    g_graph = m.mean_v.grad.detach().clone()
+    tr.optimizer.zero_grad(set_to_none=True)
+    loss, _ = tr.model(batch)
+    loss.mean().backward()
+    g_eager = m.mean_v.grad.detach()
+    # (eager and captured runs may pick different convolution algorithms: percent-level agreement; stale gradients of the
+    # other graph would differ completely)
+    assert float((g_graph - g_eager).abs().max()) <= 0.05 * float(g_eager.abs().max())
