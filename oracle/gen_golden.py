@@ -10,6 +10,7 @@ What can be pinned this way is the Python part of the hot path (SURVEY.md sectio
   - nnutils.geom_utils.obj_to_cam / pinhole_cam (+ autograd gradients)
   - ext_nnutils.loss_utils.LaplacianLoss / FlattenLoss and nnutils.loss_utils.ARAPLoss (+ gradients)
   - ext_utils.meshzoo.iso_sphere (the mesh of the SURVEY App. B known-answer test)
+  - ext_utils.{mesh.make_symmetric, util_flow.readPFM/write_pfm, image.compute_dt*, util_rot geodesic distance}
 The compiled CUDA extension modules (soft_renderer.cuda.*) and skimage are absent here; they
 are replaced by empty placeholder modules so that `import soft_renderer` succeeds -- none of the
 functions captured below call into them (the rasterise call itself is intercepted to record its
@@ -31,7 +32,8 @@ def import_reference():
         if p not in sys.path:
             sys.path.insert(0, p)
     for name in ('soft_renderer.cuda', 'soft_renderer.cuda.soft_rasterize', 'soft_renderer.cuda.load_textures',
-                 'soft_renderer.cuda.create_texture_image', 'soft_renderer.cuda.voxelization', 'skimage', 'skimage.io'):
+                 'soft_renderer.cuda.create_texture_image', 'soft_renderer.cuda.voxelization', 'skimage', 'skimage.io',
+                 'cv2', 'png'):          # imported at module level by ext_utils/{image,util_flow}.py, not used below
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.modules['skimage.io'].imread = sys.modules['skimage.io'].imsave = None
     torch.Tensor.cuda = lambda self, *a, **k: self          # ARAPLoss.forward calls .cuda() (loss_utils.py:49-50)
@@ -157,6 +159,44 @@ def main():
             L['%s_g%d' % (name, i)] = gr.numpy()
     L.update(x=x.detach().numpy(), dx=dxv.detach().numpy(), w=wl.numpy(), base=v2.astype(np.float32), faces=f2.astype(np.int64))
     np.savez_compressed(os.path.join(OUT, 'mesh_losses.npz'), **L)
+
+    # ---- 5. host-side utilities either side of the path ----------
+    import tempfile
+    from ext_utils import image as ref_image
+    from ext_utils import mesh as ref_mesh
+    from ext_utils import util_flow as ref_flow
+    from ext_utils import util_rot as ref_rot
+    E = {}
+    sv, sf, n_ind, n_sym, _, _, order = ref_mesh.make_symmetric(v2, f2, 0)
+    E.update(sym_verts=sv.astype(np.float32), sym_faces=sf.astype(np.int64), sym_counts=np.array([n_ind, n_sym]),
+             sym_order=order.astype(np.int64))
+    flow = rng.standard_normal((7, 5, 3)).astype(np.float32)
+    occ = rng.standard_normal((7, 5)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        for name, arr in (('flow', flow), ('occ', occ)):
+            ref_flow.write_pfm(os.path.join(d, name + '.pfm'), arr)
+            E['pfm_%s_bytes' % name] = np.frombuffer(open(os.path.join(d, name + '.pfm'), 'rb').read(), np.uint8)
+            back, scale = ref_flow.readPFM(os.path.join(d, name + '.pfm'))
+            E['pfm_%s_read' % name] = np.ascontiguousarray(back)
+            assert scale == 1.0
+    E.update(pfm_flow=flow, pfm_occ=occ)
+    mask = np.zeros((40, 48))
+    mask[8:30, 10:37] = 1
+    mask[12:18, 20:25] = 0
+    E.update(dt_mask=mask, dt0=ref_image.compute_dt(mask, iters=0), dt10=ref_image.compute_dt(mask, iters=10),
+             dt_barrier=ref_image.compute_dt_barrier(mask, k=50))
+    qa = rng.standard_normal((6, 4))
+    qb = qa + 0.3 * rng.standard_normal((6, 4))
+
+    def rot(q):                                              # plain numpy, only to make valid rotation inputs
+        q = q / np.linalg.norm(q, axis=1, keepdims=True)
+        x, y, z, w = q.T
+        return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w),
+                         1 - 2 * (x * x + z * z), 2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w),
+                         1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3).astype(np.float32)
+    ra, rb = rot(qa), rot(qb)
+    E.update(rot_a=ra, rot_b=rb, rot_geodesic=ref_rot.compute_geodesic_distance_from_two_matrices(t(ra), t(rb)).numpy())
+    np.savez_compressed(os.path.join(OUT, 'ext_utils.npz'), **E)
 
     for n in sorted(os.listdir(OUT)):
         print('%-28s %8d bytes' % (n, os.path.getsize(os.path.join(OUT, n))))
