@@ -187,13 +187,19 @@ def main():
         raise SystemExit('--gpus %d needs torch.distributed.run (one process per GPU)' % a.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no HIP device visible); there is no CPU fallback')
+    backend = os.environ.get('LASR_BENCH_BACKEND', 'nccl')       # 'nccl' == RCCL on ROCm.  'gloo': functional check of the
+    if backend != 'nccl':                                        # multi-rank path with all ranks sharing GPU 0 (1-GPU box)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)   # 'nccl' == RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = a.frames
     # frames shard across ranks: rank r renders yaw positions r*B .. r*B+B-1 of the cycle (weak scaling)
