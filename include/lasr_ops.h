@@ -198,6 +198,22 @@ int lasr_point_mesh_backward(const float* verts, const long long* faces, const f
                              const int* arg_face, float grad_point_term, float grad_face_term, float* grad_tri,
                              float* grad_points, int N, int V, int F, int P, void* hip_stream);
 
+/*
+ * Perceptual-distance reduction, third_party/PerceptualSimilarity/util/util.py:71-83 (normalize_tensor, cos_sim) and
+ * models/networks_basic.py:51-57 (1 - cos_sim per feature layer), the reduction behind `ptex_loss.forward_pair` at
+ * nnutils/mesh_net.py:442:   dist[n] = 1 - mean_p sum_c a_hat[c,p] * b_hat[c,p],   x_hat = x / (sqrt(sum_c x_c^2) + 1e-10).
+ * feat_obs [N/rep, C, P] (features of the observed images, each shared by `rep` consecutive rendered images -- the
+ * reference feeds rep identical copies through the network), feat_rnd [N, C, P] -> dist [N].  scratch:
+ * lasr_cosdist_scratch_floats(N, P).  Backward: gradient w.r.t. feat_rnd only (grad_rnd [N,C,P], overwritten); the
+ * observed side is data.  Where a rendered feature vector is exactly zero the reference's autograd yields NaN
+ * (sqrt'(0)); here the ill-defined term is dropped (finite gradient).
+ */
+size_t lasr_cosdist_scratch_floats(int N, int P);
+int lasr_cosdist_forward(const float* feat_obs, const float* feat_rnd, float* dist, float* scratch, int N, int C, int P,
+                         int rep, void* hip_stream);
+int lasr_cosdist_backward(const float* feat_obs, const float* feat_rnd, const float* grad_dist, float* grad_rnd, int N,
+                          int C, int P, int rep, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,9 @@ SIGNATURES = {
     'lasr_nearest_point': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_point_mesh_forward': (_i, [_p] * 7 + [_i, _i, _i, _i, _p]),
     'lasr_point_mesh_backward': (_i, [_p] * 5 + [_f, _f, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_cosdist_scratch_floats': (_sz, [_i, _i]),
+    'lasr_cosdist_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_cosdist_backward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),

@@ -9,6 +9,7 @@
 //   face gather         third_party/softras/soft_renderer/functional/face_vertices.py:4-22 (+ index_add_ in backward)
 //   nearest neighbours  third_party/chamfer3D/chamfer3D.cu (idx1) and pytorch3d chamfer_distance, mesh_net.py:477,503
 //   point <-> mesh      pytorch3d.loss.point_mesh_face_distance, mesh_net.py:470-471
+//   perceptual reduce   third_party/PerceptualSimilarity/util/util.py:71-83 (feature normalisation, cosine, spatial mean)
 // Reductions are deterministic (fixed tree inside a block, fixed-order fold of block partials; no float atomics).
 #include <hip/hip_runtime.h>
 
@@ -623,6 +624,67 @@ __global__ __launch_bounds__(256) void pmf_backward_point_kernel(const float* __
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
 }
 
+// ===========================================================================
+// Perceptual-distance reduction, PerceptualSimilarity/util/util.py:71-83 + models/networks_basic.py:51-52:
+//   d[n] = 1 - mean_{pixels} sum_c a_hat[c] b_hat[c],   x_hat = x / (sqrt(sum_c x_c^2) + 1e-10)
+// fa [Na, C, P] (observed-image features; image n of fb pairs with fa[n / rep]), fb [N, C, P] (rendered-image features).
+// One thread per pixel walks the channels (plane stride P: coalesced across the wave); chunk partials, fixed-order fold.
+// ===========================================================================
+constexpr float COS_EPS = 1e-10f;
+constexpr int COS_PX = 256;
+
+__global__ __launch_bounds__(256) void cosdist_forward_kernel(const float* __restrict__ fa, const float* __restrict__ fb,
+                                                              float* __restrict__ part, int C, int P, int rep, int nch)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x, p = blockIdx.y * COS_PX + threadIdx.x;
+    float cosv = 0.f;
+    if (p < P) {
+        const float* a = fa + (size_t)(n / rep) * C * P + p;
+        const float* b = fb + (size_t)n * C * P + p;
+        float dot = 0.f, na = 0.f, nb = 0.f;
+        for (int c = 0; c < C; c++) {
+            const float x = a[(size_t)c * P], y = b[(size_t)c * P];
+            dot += x * y; na += x * x; nb += y * y;
+        }
+        cosv = dot / ((sqrtf(na) + COS_EPS) * (sqrtf(nb) + COS_EPS));
+    }
+    cosv = block_sum(cosv, red);
+    if (threadIdx.x == 0) part[(size_t)n * nch + blockIdx.y] = cosv;
+}
+
+__global__ __launch_bounds__(256) void cosdist_fold_kernel(const float* __restrict__ part, float* __restrict__ d, int N, int nch, int P)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < nch; k++) s += part[(size_t)n * nch + k];
+    d[n] = 1.f - s / (float)P;
+}
+
+// gradient w.r.t. fb only (the observed side is data): d cos / d b_c = a_c / (A B) - dot * b_c / (A * nb * B^2),
+// A = |a| + eps, B = |b| + eps, second term 0 where |b| = 0
+__global__ __launch_bounds__(256) void cosdist_backward_kernel(const float* __restrict__ fa, const float* __restrict__ fb,
+                                                               const float* __restrict__ gd, float* __restrict__ gfb,
+                                                               int C, int P, int rep)
+{
+    const int n = blockIdx.x, p = blockIdx.y * COS_PX + threadIdx.x;
+    if (p >= P) return;
+    const float* a = fa + (size_t)(n / rep) * C * P + p;
+    const float* b = fb + (size_t)n * C * P + p;
+    float* g = gfb + (size_t)n * C * P + p;
+    float dot = 0.f, na = 0.f, nb = 0.f;
+    for (int c = 0; c < C; c++) {
+        const float x = a[(size_t)c * P], y = b[(size_t)c * P];
+        dot += x * y; na += x * x; nb += y * y;
+    }
+    const float A = sqrtf(na) + COS_EPS, nbr = sqrtf(nb), B = nbr + COS_EPS;
+    const float k = -gd[n] / (float)P;                       // d = 1 - mean cos
+    const float ka = k / (A * B);
+    const float kb = nbr > 0.f ? k * dot / (A * nbr * B * B) : 0.f;
+    for (int c = 0; c < C; c++) g[(size_t)c * P] = ka * a[(size_t)c * P] - kb * b[(size_t)c * P];
+}
+
 }  // namespace lasr
 
 // ===========================================================================
@@ -816,5 +878,38 @@ extern "C" int lasr_point_mesh_backward(const float* verts, const long long* fac
     if (rc) return rc;
     LASR_LAUNCH(K_POINT_MESH_BACKWARD, pmf_backward_point_kernel, dim3((P + 255) / 256, N), dim3(256), 0, verts, faces, points,
                 arg_point, arg_face, grad_point_term, grad_face_term, grad_points, V, F, P);
+    return launch_ok();
+}
+
+extern "C" size_t lasr_cosdist_scratch_floats(int N, int P)
+{
+    if (N < 0 || P < 0) return 0;
+    return (size_t)N * ((P + COS_PX - 1) / COS_PX) + 4;
+}
+
+extern "C" int lasr_cosdist_forward(const float* feat_obs, const float* feat_rnd, float* dist, float* scratch, int N, int C,
+                                    int P, int rep, void* hip_stream)
+{
+    if (N < 0 || C < 1 || P < 1 || rep < 1) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!feat_obs || !feat_rnd || !dist || !scratch) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int nch = (P + COS_PX - 1) / COS_PX;
+    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_forward_kernel, dim3(N, nch), dim3(256), 0, feat_obs, feat_rnd, scratch, C, P, rep, nch);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, scratch, dist, N, nch, P);
+    return launch_ok();
+}
+
+extern "C" int lasr_cosdist_backward(const float* feat_obs, const float* feat_rnd, const float* grad_dist, float* grad_rnd,
+                                     int N, int C, int P, int rep, void* hip_stream)
+{
+    if (N < 0 || C < 1 || P < 1 || rep < 1) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!feat_obs || !feat_rnd || !grad_dist || !grad_rnd) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_COSDIST_BACKWARD, cosdist_backward_kernel, dim3(N, (P + COS_PX - 1) / COS_PX), dim3(256), 0, feat_obs, feat_rnd,
+                grad_dist, grad_rnd, C, P, rep);
     return launch_ok();
 }

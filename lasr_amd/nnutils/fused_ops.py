@@ -222,3 +222,42 @@ def point_mesh_face_distance(verts, faces, points):
     """mean_n [ mean_p min_f d2(p, f) + mean_f min_p d2(p, f) ]  (pytorch3d.loss.point_mesh_face_distance as used at
     /root/reference/nnutils/mesh_net.py:470-471); verts [N,V,3], faces [F,3], points [N,P,3]."""
     return _PointMesh.apply(verts, faces, points)
+
+
+class _CosDist(Function):
+    @staticmethod
+    def forward(ctx, fa, fb, rep):
+        _lib.need_cuda(fa, fb)
+        fa, fb = fa.detach().contiguous().float(), fb.contiguous().float()
+        N, C = fb.shape[:2]
+        P = fb[0, 0].numel()
+        h = _lib.lib()
+        d = torch.empty(N, dtype=torch.float32, device=fb.device)
+        scratch = torch.empty(h.lasr_cosdist_scratch_floats(N, P), dtype=torch.float32, device=fb.device)
+        guard, st = _lib.stream_of(fb)
+        with guard:
+            rc = h.lasr_cosdist_forward(fa.data_ptr(), fb.data_ptr(), d.data_ptr(), scratch.data_ptr(), N, C, P, rep, st)
+        _lib.check(rc, 'lasr_cosdist_forward')
+        ctx.save_for_backward(fa, fb)
+        ctx.rep = rep
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        fa, fb = ctx.saved_tensors
+        N, C = fb.shape[:2]
+        P = fb[0, 0].numel()
+        g = g.contiguous().float()
+        gb = torch.empty_like(fb)
+        guard, st = _lib.stream_of(fb)
+        with guard:
+            rc = _lib.lib().lasr_cosdist_backward(fa.data_ptr(), fb.data_ptr(), g.data_ptr(), gb.data_ptr(), N, C, P, ctx.rep, st)
+        _lib.check(rc, 'lasr_cosdist_backward')
+        return None, gb, None
+
+
+def cosine_distance(feat_obs, feat_rnd, repeat=1):
+    """1 - mean over pixels of the cosine between channel vectors (/root/reference/third_party/PerceptualSimilarity/
+    util/util.py:71-83, models/networks_basic.py:51-52): feat_obs [N/repeat,C,h,w] (no gradient), feat_rnd [N,C,h,w]
+    -> [N]."""
+    return _CosDist.apply(feat_obs, feat_rnd, repeat)

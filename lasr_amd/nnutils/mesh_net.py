@@ -253,10 +253,23 @@ class PerceptualDistance(nn.Module):
         network `repeat` identical copies of it (one per hypothesis, mesh_net.py:436-441)."""
         d = 0
         for fa, fb in zip(self._feats(a), self._feats(b)):
+            if fb.is_cuda and not fa.requires_grad:
+                d = d + fused_ops.cosine_distance(fa, fb, repeat)            # normalise + dot + spatial mean: one kernel
+                continue
             if repeat > 1:
                 fa = fa.repeat_interleave(repeat, 0)
-            d = d + (1. - F.cosine_similarity(fa, fb, dim=1, eps=1e-10).mean((1, 2)))
+            d = d + (1. - cos_sim(fa, fb))
         return d
+
+
+def normalize_tensor(x, eps=1e-10):
+    """PerceptualSimilarity/util/util.py:71-74."""
+    return x / (x.pow(2).sum(1, keepdim=True).sqrt() + eps)
+
+
+def cos_sim(a, b):
+    """PerceptualSimilarity/util/util.py:76-83: mean over pixels of the cosine between channel vectors -> [N]."""
+    return (normalize_tensor(a) * normalize_tensor(b)).sum(1).mean((1, 2))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -358,3 +358,25 @@ def test_nearest_point_and_chamfer(cuda):
     ry.backward()
     assert abs(float(ry) - float(rx)) <= 1e-6 * abs(float(rx)) + 1e-9
     assert float((y.grad.cpu() - x.grad).abs().max()) <= 1e-5 * float(x.grad.abs().max())
+
+
+@pytest.mark.parametrize('N,C,h,rep', [(6, 64, 15, 3), (4, 192, 7, 1), (8, 5, 33, 4)])
+def test_perceptual_cosine_reduction_matches_reference_formula(cuda, N, C, h, rep):
+    # PerceptualSimilarity/util/util.py:71-83 + networks_basic.py:51-52, restated in mesh_net.cos_sim (torch)
+    from lasr_amd.nnutils import fused_ops, mesh_net
+    g = torch.Generator().manual_seed(N * C)
+    fa = torch.relu(torch.randn(N // rep, C, h, h, generator=g))
+    fb = torch.relu(torch.randn(N, C, h, h, generator=g))
+    fb[0, :, 0, 0] = 0                                             # a dead pixel: all channels zero
+    gout = torch.randn(N, generator=g)
+    b_ref = fb.clone().requires_grad_(True)
+    ref = 1. - mesh_net.cos_sim(fa.repeat_interleave(rep, 0), b_ref)
+    (ref * gout).sum().backward()
+    b_dev = fb.clone().to(cuda).requires_grad_(True)
+    out = fused_ops.cosine_distance(fa.to(cuda), b_dev, rep)
+    (out * gout.to(cuda)).sum().backward()
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 2e-6
+    gr, gd = b_ref.grad.clone(), b_dev.grad.cpu()
+    assert torch.isnan(gr[0, :, 0, 0]).all() and torch.isfinite(gd).all()         # autograd: sqrt'(0); kernel: term dropped
+    dead = torch.isnan(gr)                                         # every all-zero channel vector of fb (few channels: several)
+    assert float((gd - gr)[~dead].abs().max()) <= 1e-5 * float(gr[~dead].abs().max())
