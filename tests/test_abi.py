@@ -62,3 +62,23 @@ def test_product_package_never_imports_the_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M) or 'sr_oracle' in src:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, 'product code references the oracle: %s' % bad
+
+
+def test_fused_operator_argument_validation():
+    # include/lasr_ops.h entry points of fused.hip reject bad sizes / null buffers on the host, before any launch
+    from lasr_amd import _lib
+    h = _lib.lib()
+    assert h.lasr_flow_reproject_forward(None, None, None, None, None, None, None, -1, 4, None) == -1
+    assert h.lasr_flow_reproject_forward(None, None, None, None, None, None, None, 2, 4, None) == -1      # null buffers
+    assert h.lasr_flow_reproject_forward(None, None, None, None, None, None, None, 0, 4, None) == 0       # empty batch
+    assert h.lasr_flow_reproject_scratch_floats(3, 65536) >= 3 * 32 * 4
+    assert h.lasr_skin_weights_forward(None, None, None, None, None, 1, 65, 10, None) == -1               # more than 64 bones
+    assert h.lasr_skin_weights_forward(None, None, None, None, None, 0, 5, 10, None) == 0
+    assert h.lasr_quat_to_rotmat_forward(None, None, 0, None) == 0 and h.lasr_quat_to_rotmat_forward(None, None, 3, None) == -1
+    assert h.lasr_flatten_forward(None, None, None, -2, 5, 5, None) == -1
+    assert h.lasr_face_gather_forward(None, None, None, 1, 5, 5, 0, None) == -1                           # zero channels
+    assert h.lasr_nearest_point(None, None, None, None, 1, 5, 0, None) == -1                              # empty target set
+    assert h.lasr_point_mesh_forward(None, None, None, None, None, None, None, 1, 5, 0, 5, None) == -1
+    assert h.lasr_cosdist_forward(None, None, None, None, 2, 8, 16, 0, None) == -1                        # rep must be >= 1
+    assert h.lasr_cosdist_scratch_floats(4, 1000) >= 16
+    assert h.lasr_sr_set_forward_math(0) == 0 and h.lasr_sr_set_forward_math(7) == -2
