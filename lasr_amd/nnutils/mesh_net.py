@@ -438,7 +438,7 @@ class LASR(MeshNet):
 
         pred_v, tex, faces = self.get_mean_shape(B)                              # [N,V,3], [N,V,3], [2B,F,3]
         for m in self.modules():                                                 # BN always in eval mode (:190-195)
-            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):                   # incl. SyncBatchNorm (class-name match in the reference)
                 m.eval()
         scale, trans, quat, depth, ppoint = self.code_predictor(self.encoder(self.input_imgs))
 

@@ -55,7 +55,15 @@ class LASRTrainer:
         if opts.model_path != '':
             self.load_network(self.model, model_path=opts.model_path)
         self.model = nn.SyncBatchNorm.convert_sync_batchnorm(self.model).to(self.device)
-        if self.distributed:
+        # Data parallel, two ways.  Default: DistributedDataParallel as the reference (bucketed all-reduce overlapped with the
+        # eager backward pass).  With --use_graph the forward + backward of a rank is ONE HIP-graph replay (DDP's reducer
+        # hooks cannot live inside a capture), so the gradients are all-reduced right after the replay as one flat RCCL
+        # message instead (lasr_amd/parallel.py): a 9 ms replay + one 57 MB all-reduce beats a 25 ms eager step with overlap.
+        self.manual_dp = self.distributed and getattr(opts, 'use_graph', False) and self.device.type == 'cuda'
+        if self.manual_dp:
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, 0)                 # what DDP's constructor does: start from rank 0's values
+        elif self.distributed:
             kw = dict(device_ids=[opts.local_rank], output_device=opts.local_rank) if self.device.type == 'cuda' else {}
             self.model = nn.parallel.DistributedDataParallel(self.model, find_unused_parameters=True, **kw)
         self.define_criterion_ddp()
@@ -143,7 +151,7 @@ class LASRTrainer:
     # ---- optimisation -----------------------------------------------------------------------
     def init_training(self):
         opts = self.opts
-        if getattr(opts, 'use_graph', False) and self.device.type == 'cuda' and not self.distributed:
+        if getattr(opts, 'use_graph', False) and self.device.type == 'cuda':
             self._stream = torch.cuda.Stream(self.device)     # see _graphed_forward_backward
             torch.cuda.set_stream(self._stream)
         self.init_dataset()
@@ -169,11 +177,11 @@ class LASRTrainer:
     # The step issues ~2.6k small kernels (ResNet-18, loss glue) and is bound by host launch cost, not by the GPU.
     # With --use_graph the forward + backward of one iteration is captured once per (epoch, configuration) into a
     # HIP graph and replayed with the batch copied into static buffers; clipping, the NaN guard, AdamW and the LR
-    # schedule stay eager.  Single-process only (DDP's bucketed all-reduce hooks are left uncaptured on purpose).
+    # schedule stay eager.  Under torch.distributed the gradients are all-reduced after the replay (define_model).
     def _graph_key(self):
         m, o = self.module, self.opts
         noisy = o.noise and m.epoch > 0 and 1 < m.iters < 100
-        if self.distributed or not getattr(o, 'use_graph', False) or self.device.type != 'cuda':
+        if not getattr(o, 'use_graph', False) or self.device.type != 'cuda':
             return None
         if m.iters == 0:                                # first iteration of an epoch: part rendering, logging only
             return None
@@ -230,6 +238,9 @@ class LASRTrainer:
             self.optimizer.zero_grad(set_to_none=not hasattr(self, '_graphs'))
             total_loss, aux = self.model(batch)
             total_loss.mean().backward()
+        if getattr(self, 'manual_dp', False):              # mean of the ranks' gradients, one flat message over RCCL
+            from .. import parallel
+            parallel.allreduce_grads_([p.grad for p in m.parameters() if p.grad is not None], average=True)
         cam_grad, finite = [], []
         for name, p in m.named_parameters():
             if p.grad is None:
