@@ -45,25 +45,13 @@ def run_stage(argv):
 
 
 def export_shapes(tr):
-    """frame id -> articulated shape [V,3] in camera space (bone transforms + predicted camera rotation, as the reference
-    evaluates it: eval_mesh.py:106-109) of the selected hypothesis."""
-    m = tr.module
-    H = tr.opts.n_hypo
-    best = int((-tr.epoch_nscore).argmax()) if H > 1 else 0
-    shapes = {}
-    tr.model.train()
-    with torch.no_grad():
-        for i, batch in enumerate(tr.dataloader):
-            m.iters = 1
-            bi = tr.set_input(batch)
-            tr.model(bi)
-            ids = bi['frameid'].view(-1, 2).t().reshape(-1)            # undo the pair interleave: frame-t block, frame-t' block
-            dv = m.verts_cam.view(len(ids), H, -1, 3)
-            for k, fid in enumerate(ids.tolist()):
-                shapes.setdefault(int(fid), dv[k, best].clone())
-            if len(shapes) >= tr.n_frames_on_disk:
-                break
-    return shapes, m.faces.clone()
+    """frame id -> articulated shape [V,3] in camera space of the selected hypothesis (extract.py), read back from the files."""
+    import extract
+    out_dir = os.path.join(tr.save_dir, 'export')
+    paths = extract.export(tr, out_dir)
+    dev = tr.device
+    shapes = {i: load_obj(p, device=dev)[0].float() for i, p in paths.items()}
+    return shapes, tr.module.faces.clone()
 
 
 def main(argv=None):

@@ -216,6 +216,20 @@ def test_rendered_sequence_on_disk_trains(tmp_path, cuda):
         if i == 5:
             break
     assert all(np.isfinite(losses))
+    # extract.py: the checkpoint's per-frame shapes as .obj files, scored by eval_mesh.py against the rendered ground truth
+    tr.epoch_nscore = torch.zeros(2, device=cuda)
+    tr.save('latest')
+    import extract
+    flags = ['--name', 't', '--checkpoint_dir', str(tmp_path), '--img_size', '64', '--subdivide', '2', '--n_bones', '5', '--n_hypo', '2',
+             '--batch_size', '1', '--opt_tex', 'yes', '--nouse_gtpose', '--only_mean_sym', '--noperceptual', '--dataname', 'syn-blob3f',
+             '--data_root', root, '--model_path', os.path.join(tr.save_dir, 'pred_net_latest.pth')]
+    out = extract.main(flags)
+    assert sorted(out) == [0, 1, 2] and all(os.path.exists(p) for p in out.values())
+    spec = importlib.util.spec_from_file_location('eval_mesh', os.path.join(ROOT, 'scripts', 'eval_mesh.py'))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    cds = ev.main(['--testdir', os.path.join(str(tmp_path), 't'), '--gtdir', os.path.join(seq, 'Meshes', 'Full-Resolution', 'syn-blob3f')])
+    assert len(cds) == 3 and all(np.isfinite(cds)) and max(cds) < 10
 
 
 def test_mesh_evaluation_protocol(cuda):
