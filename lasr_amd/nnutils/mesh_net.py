@@ -47,10 +47,14 @@ def quaternion_to_rotation_matrix(q):
 
 
 def geodesic_distance(m1, m2):
-    """Rotation angle between two batches of 3x3 matrices (ext_utils/util_rot.py:27-37)."""
+    """Rotation angle between two batches of 3x3 matrices (ext_utils/util_rot.py:27-37).  Same values; where the two
+    rotations coincide (cos rounds to +-1) the reference's acos(min(cos, 1)) back-propagates 0 * inf = NaN and its trainer
+    skips the step -- here that element simply has zero gradient."""
     m = torch.bmm(m1, m2.transpose(1, 2))
     cos = (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1) / 2
-    return torch.acos(cos.clamp(-1, 1))
+    inside = cos.abs() < 1
+    angle = torch.acos(torch.where(inside, cos, torch.zeros_like(cos)))
+    return torch.where(inside, angle, torch.where(cos > 0, torch.zeros_like(cos), torch.full_like(cos, math.pi)))
 
 
 def reg_decay(curr_steps, max_steps, min_wt, max_wt):

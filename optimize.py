@@ -30,7 +30,8 @@ DEFAULTS = dict(
     model_path='', save_epoch_freq=100,                                           # nnutils/train_utils.py:58-68
     img_size=256, n_data_workers=4,                                               # dataloader/vid.py:34-35
     # additions of this build (not in the reference): synthetic data shape and the perceptual term switch
-    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=False, data_root='.')
+    # use_graph: replay forward + backward as one HIP graph (on by default on a GPU; --nouse_graph = eager as the reference)
+    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=True, data_root='.')
 
 
 def parse_flags(argv, defaults=DEFAULTS):

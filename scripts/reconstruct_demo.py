@@ -69,7 +69,7 @@ def main(argv=None):
     ev = _load('eval_mesh')
     log = os.path.join(root, 'log')
     common = ['--checkpoint_dir', log, '--dataname', name, '--data_root', root, '--sil_path', 'none', '--ngpu', '1',
-              '--batch_size', '1', '--opt_tex', 'yes', '--nouse_gtpose', '--subdivide', '3'] + ([] if args.no_graph else ['--use_graph'])
+              '--batch_size', '1', '--opt_tex', 'yes', '--nouse_gtpose', '--subdivide', '3'] + (['--nouse_graph'] if args.no_graph else ['--use_graph'])
     # scripts/spot3.sh:24-25
     tr0, steps0, dt0 = run_stage(['--name', 'demo-0', '--only_mean_sym', '--n_bones', '21', '--n_hypo', str(args.n_hypo),
                                   '--num_epochs', str(args.epochs0)] + common)

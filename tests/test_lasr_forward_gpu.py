@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def make_trainer(tmp_path, **over):
     flags = dict(name='t', checkpoint_dir=str(tmp_path), img_size=64, subdivide=2, n_bones=5, n_hypo=2, batch_size=2,
                  num_epochs=1, opt_tex='yes', use_gtpose=False, only_mean_sym=True, n_frames=3, iters_per_epoch=3,
-                 perceptual=False)
+                 perceptual=False, use_graph=False)        # eager unless a test asks for graph replay
     flags.update(over)
     argv = []
     for k, v in flags.items():

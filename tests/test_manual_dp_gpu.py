@@ -21,7 +21,7 @@ def make_opts(tmp, use_graph=True):
     return optimize.parse_flags(['--name', 'dp', '--checkpoint_dir', tmp, '--img_size', '64', '--subdivide', '2', '--n_bones', '5',
                                  '--n_hypo', '2', '--batch_size', '1', '--num_epochs', '1', '--opt_tex', 'yes', '--nouse_gtpose',
                                  '--only_mean_sym', '--n_frames', '4', '--iters_per_epoch', '5', '--noperceptual']
-                                + (['--use_graph'] if use_graph else []))
+                                + (['--use_graph'] if use_graph else ['--nouse_graph']))
 
 
 def run_steps(tr, n=4):

@@ -8,7 +8,7 @@ from lasr_amd.nnutils import train_utils
 
 opts = optimize.parse_flags(['--name', 'b', '--checkpoint_dir', '', '--only_mean_sym', '--nouse_gtpose', '--subdivide', '3',
                              '--n_bones', '21', '--n_hypo', '8', '--num_epochs', '5', '--batch_size', '1', '--opt_tex', 'yes',
-                             '--iters_per_epoch', '40'] + sys.argv[1:])
+                             '--iters_per_epoch', '40', '--nouse_graph'] + sys.argv[1:])
 tr = train_utils.LASRTrainer(opts).init_training()
 tr.model.train(); tr.reinit_bones()
 m = tr.module
