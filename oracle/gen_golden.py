@@ -69,6 +69,7 @@ def main():
         captured['args'] = args
         return torch.zeros(face_vertices.shape[0], 4, 4, 4)
 
+    real_soft_rasterize = srf.soft_rasterize
     srf.soft_rasterize = fake_rasterize
     import soft_renderer.rasterizer as sr_rast
     sr_rast.srf.soft_rasterize = fake_rasterize
@@ -197,6 +198,33 @@ def main():
     ra, rb = rot(qa), rot(qb)
     E.update(rot_a=ra, rot_b=rb, rot_geodesic=ref_rot.compute_geodesic_distance_from_two_matrices(t(ra), t(rb)).numpy())
     np.savez_compressed(os.path.join(OUT, 'ext_utils.npz'), **E)
+
+    # ---- 6. public API surface of the operator package and the geometry / loss helpers (names + call signatures) -------
+    import inspect
+    import json
+
+    def sig(obj):
+        target = obj.__init__ if inspect.isclass(obj) else obj
+        params = list(inspect.signature(target).parameters.values())
+        if inspect.isclass(obj):
+            params = params[1:]
+        return [[p.name, None if p.default is inspect.Parameter.empty else repr(p.default)] for p in params]
+    api = {}
+    for mod_name, mod, names in (
+            ('soft_renderer', sr, ['SoftRenderer', 'SoftRasterizer', 'Mesh', 'Lighting', 'AmbientLighting', 'DirectionalLighting',
+                                   'Transform', 'LookAt', 'Look', 'Projection']),
+            ('soft_renderer.functional', srf, ['soft_rasterize', 'face_vertices', 'vertex_normals', 'look_at', 'look', 'orthogonal',
+                                               'perspective', 'projection', 'ambient_lighting', 'directional_lighting',
+                                               'get_points_from_angles', 'load_obj', 'save_obj']),
+            ('nnutils.geom_utils', geom_utils, ['obj_to_cam', 'pinhole_cam', 'orthographic_cam']),
+            ('nnutils.loss_utils', loss_utils, ['ARAPLoss']),
+            ('ext_nnutils.loss_utils', ext_loss, ['LaplacianLoss', 'FlattenLoss'])):
+        for n in names:
+            api['%s.%s' % (mod_name, n)] = sig(real_soft_rasterize if n == 'soft_rasterize' else getattr(mod, n))
+    api['soft_renderer.SoftRenderer.methods'] = sorted(n for n in vars(sr.SoftRenderer) if not n.startswith('_'))
+    api['soft_renderer.Mesh.methods'] = sorted(n for n in dir(sr.Mesh) if not n.startswith('_'))
+    with open(os.path.join(OUT, 'api_surface.json'), 'w') as fh:
+        json.dump(api, fh, indent=1, sort_keys=True)
 
     for n in sorted(os.listdir(OUT)):
         print('%-28s %8d bytes' % (n, os.path.getsize(os.path.join(OUT, n))))
