@@ -26,9 +26,9 @@ DEFAULTS = dict(
     noise=True, symmetric=True, symmetric_loss=True, nz_feat=200, texture=True, symmetric_texture=True,
     subdivide=3, symidx=0, n_bones=1, n_faces='1280', n_hypo=1, only_mean_sym=False, dataname='fashion',
     opt_tex='no', rscale=1.0, l1tex_wt=1.0, sigval=1e-4,                         # nnutils/mesh_net.py:54-73
-    name='exp_name', num_epochs=1000, learning_rate=1e-4, batch_size=4, checkpoint_dir='./logdir/',
-    model_path='', save_epoch_freq=100,                                           # nnutils/train_utils.py:58-68
-    img_size=256, n_data_workers=4,                                               # dataloader/vid.py:34-35
+    name='exp_name', num_epochs=1000, learning_rate=1e-4, batch_size=8, checkpoint_dir='./logdir',
+    model_path='', save_epoch_freq=1,                                           # nnutils/train_utils.py:58-68
+    img_size=256, n_data_workers=1,                                               # dataloader/vid.py:34-35
     # additions of this build (not in the reference): synthetic data shape and the perceptual term switch
     # use_graph: replay forward + backward as one HIP graph (on by default on a GPU; --nouse_graph = eager as the reference)
     n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=True, data_root='.')

@@ -226,6 +226,17 @@ def main():
     with open(os.path.join(OUT, 'api_surface.json'), 'w') as fh:
         json.dump(api, fh, indent=1, sort_keys=True)
 
+    # ---- 7. command-line flags of optimize.py (absl definitions scattered over four modules; parsed, not imported) -------
+    import ast
+    import re
+    flags_found = {}
+    for rel in ('optimize.py', 'nnutils/mesh_net.py', 'nnutils/train_utils.py', 'dataloader/vid.py'):
+        src = open(os.path.join(REF, rel)).read()
+        for kind, name, default in re.findall(r"flags\.DEFINE_(\w+)\(\s*'(\w+)'\s*,\s*([^,]+),", src):
+            flags_found[name] = [kind, ast.literal_eval(default.strip())]
+    with open(os.path.join(OUT, 'cli_flags.json'), 'w') as fh:
+        json.dump(flags_found, fh, indent=1, sort_keys=True)
+
     for n in sorted(os.listdir(OUT)):
         print('%-28s %8d bytes' % (n, os.path.getsize(os.path.join(OUT, n))))
 

@@ -54,3 +54,22 @@ def test_renderer_and_mesh_members():
     assert set(API['soft_renderer.SoftRenderer.methods']) <= mine
     mesh = {n for n in dir(sr.Mesh) if not n.startswith('_')}
     assert set(API['soft_renderer.Mesh.methods']) - {'voxelize'} <= mesh      # voxelisation: never called by LASR
+
+
+def test_command_line_flags_match_the_reference_definitions():
+    # tests/golden/cli_flags.json: every flags.DEFINE_* of optimize.py:33-36, nnutils/mesh_net.py:54-73,
+    # nnutils/train_utils.py:58-68 and dataloader/vid.py:34-35 with its default
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import optimize
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cli_flags.json')))
+    assert len(ref) == 30
+    for name, (kind, default) in ref.items():
+        assert name in optimize.DEFAULTS, name
+        assert optimize.DEFAULTS[name] == default and type(optimize.DEFAULTS[name]) is type(default), (name, optimize.DEFAULTS[name], default)
+    # the scripts' command lines (scripts/spot3.sh:24-25) parse, boolean negations included
+    o = optimize.parse_flags('--name=x-0 --checkpoint_dir log/ --only_mean_sym --nouse_gtpose --subdivide 3 --n_bones 21 --n_hypo 8 '
+                             '--num_epochs 5 --dataname spot3 --sil_path none --ngpu 1 --batch_size 1 --opt_tex yes'.split())
+    assert o.name == 'x-0' and o.only_mean_sym and not o.use_gtpose and o.n_hypo == 8 and o.opt_tex == 'yes'
+    o = optimize.parse_flags('--nosymmetric --n_faces 1600 --model_path log/x-0/pred_net_latest.pth'.split())
+    assert not o.symmetric and o.n_faces == '1600' and o.model_path.endswith('.pth')
