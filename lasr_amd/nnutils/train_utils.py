@@ -298,7 +298,8 @@ class LASRTrainer:
                 dist.all_reduce(self.epoch_nscore)
             if self.rank == 0 and opts.checkpoint_dir:
                 self.save('latest')
-                self.save(epoch + 1)
+                if (epoch + 1) % max(1, opts.save_epoch_freq) == 0:
+                    self.save(epoch + 1)
         return total_steps
 
     # ---- checkpoints (:363-378) ---------------------------------------------------------------
