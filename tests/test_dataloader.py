@@ -164,3 +164,19 @@ def test_resident_loader_serves_the_same_batches(tmp_path):
             assert torch.equal(ref[key], b[key]), key
         if k == 4:
             break
+
+
+def test_pair_lists_for_frame_skipping_and_flow_directories(tmp_path):
+    # vid.py:54-76: with dframe = 2 the flow lives in <seq>_02/, pairs are (i, i+2) forward and (i+2, i) backward, every
+    # second start frame is kept, first and last pair are duplicated
+    names = ['/data/DAVIS/JPEGImages/Full-Resolution/cat/%05d.jpg' % i for i in range(7)]
+    ds = vid.VidDataset(make_opts(batch_size=1), imglist=names, can_frame=3, dframe=2, init_frame=1)
+    assert ds.flowfwlist[0] == '/data/DAVIS/FlowFW/Full-Resolution/cat_02/flo-00000.pfm'
+    assert ds.flowbwlist[4] == '/data/DAVIS/FlowBW/Full-Resolution/cat_02/flo-00004.pfm'
+    assert ds.masklist[2] == '/data/DAVIS/Annotations/Full-Resolution/cat/00002.png'
+    assert ds.camlist[2] == '/data/DAVIS/Camera/Full-Resolution/cat/00002.txt'
+    unit = 6                                              # [1, 1, 3 | 3, 5, 5]: starts 1 and 3 forward, 3 and 5 backward
+    assert ds.baselist[:unit] == [1, 1, 3, 3, 5, 5] and ds.directlist[:unit] == [1, 1, 1, 0, 0, 0]
+    assert len(ds) == unit * (200 // unit)
+    sil = vid.VidDataset(make_opts(batch_size=1, sil_path='/masks'), imglist=names, dframe=1)
+    assert sil.masklist[1] == '/masks/cat/00001.png'
