@@ -119,3 +119,17 @@ def test_star_remesh_lands_on_the_surface():
     assert r.max() <= 1 + 1e-6 and r.min() > 0.97
     t = remesh.ray_mesh_outermost(np.zeros(3), np.array([[0., 0., 1.], [0., 0., -1.]]), v.astype(np.float64), f)
     assert np.allclose(t, 0.8, atol=1e-6)
+
+
+def test_star_remesh_survives_directions_that_miss_the_surface():
+    # an open surface (a hemisphere without its cap): rays through the opening miss; those vertices fall back to the mean hit
+    # radius instead of NaN
+    import numpy as np
+    from lasr_amd import synth
+    from lasr_amd.nnutils import remesh
+    v, f = synth.geodesic_sphere(5)
+    keep = (v[f][:, :, 2] > -0.2).all(1)
+    nv, nf = remesh.remesh_star(v, f[keep], 320)
+    assert np.isfinite(nv).all() and nf.shape == (320, 3)
+    r = np.linalg.norm(nv - nv.mean(0), axis=1)
+    assert r.min() > 0.3 and r.max() < 1.5
