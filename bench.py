@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- soft-rasteriser forward+backward throughput on MI355X (BASELINE.json metric #1).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B]      # N > 1: re-launches itself, one process per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          # the same thing, launched explicitly
+(the reference launches one process per GPU from its script line as well: scripts/template.sh:26, optimize.py:42-47)
 
 Workload (BASELINE configs[1]): mesh M2 (geodesic nu=11, V=1212, F=2420,
 the "~1.2k vert / 2.3k face" mesh), 256x256, LASR's raster modes (euclidean / softmax /
@@ -37,6 +38,7 @@ sys.path.insert(0, ROOT)
 from lasr_amd import _lib, parallel, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3       # dense fp32-input MFMA peak (same guide)
 IS = 256
 NU = 11                        # mesh M2
 N_FRAMES_CYCLE = 26            # yaw positions ("~26 frames" of BASELINE configs)
@@ -50,6 +52,7 @@ def parse():
     ap.add_argument('--frames', type=int, default=256, help='frames per GPU per step (SURVEY 8d batches: 1/16/64/256)')
     ap.add_argument('--image-size', type=int, default=256, help='256 = the headline metric; 512 = BASELINE configs[2] (camel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-lbs', action='store_true', help='skip the LBS (MFMA) micro-benchmark block')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
     return ap.parse_args()
 
@@ -111,21 +114,70 @@ def collect_kernel_times(h):
 
 
 def cpu_baseline(F):
-    """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload."""
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload: one warm-up pass,
+    then the median of 5 timed fwd+bwd passes with every host thread (forward parallel over pixels, backward over
+    (image, row band) tasks with per-band gradient slabs folded in band order), and the median of 3 passes of ONE frame
+    on one thread."""
     from oracle import sr_oracle
     cores = os.cpu_count() or 1
-    n = max(2, min(cores, 32))                      # one frame per core; fwd is pixel-parallel, bwd image-parallel
+    n = max(2, min(cores // 4, 64))                 # frames in the all-core sample (bounded: ~10-20 s of wall time in total)
+    bands = max(1, min(IS // 8, -(-2 * cores // n)))   # >= 2 backward tasks per thread
     fv, ft, near, far = synth.raster_batch(NU, N_FRAMES_CYCLE, count=n)
     kw = dict(synth.LASR_MODES, near=near, far=far)
     g = synth.upstream_grad(n, IS)
     sr_oracle.lib()
-    t0 = time.perf_counter()
-    ref = sr_oracle.forward(fv, ft, IS, **kw)
-    sr_oracle.backward(ref, g, IS, **kw)
-    dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d frames fwd+bwd of the same M2 256x256 workload, OpenMP threads=%d, %.1f s wall'
-                      % (n, cores, dt)}
+
+    def one_pass(fv_, ft_, g_, nb):
+        t0 = time.perf_counter()
+        ref = sr_oracle.forward(fv_, ft_, IS, **kw)
+        sr_oracle.backward_banded(ref, g_, nb, IS, **kw)
+        return time.perf_counter() - t0
+
+    threads = sr_oracle.set_threads(cores)
+    one_pass(fv, ft, g, bands)                      # warm-up (page faults, OpenMP pool)
+    t_all = sorted(one_pass(fv, ft, g, bands) for _ in range(5))
+    sr_oracle.set_threads(1)
+    one_pass(fv[:1], ft[:1], g[:1], 1)
+    t_one = sorted(one_pass(fv[:1], ft[:1], g[:1], 1) for _ in range(3))
+    sr_oracle.set_threads(cores)
+    busy = min(threads, n * bands)                  # tasks available to the backward; the forward has n*P >> threads
+    return {'value': n / t_all[2], 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'threads_busy_backward': busy, 'one_thread_frames_per_s': 1.0 / t_one[1],
+            'passes_s': [round(t, 4) for t in t_all],
+            'sample': '%d frames fwd+bwd of the same M2 %dx%d workload: 1 warm-up + median of 5 passes, %d OpenMP threads '
+                      '(backward: %d image x row-band tasks); 1-thread figure: median of 3 passes of 1 frame'
+                      % (n, IS, IS, threads, n * bands)}
+
+
+def lbs_leg(dev):
+    """The one MFMA user on the path (north_star): linear-blend skinning, `skin^T[V,K-1] x RT[K-1,12]` on
+    v_mfma_f32_16x16x4_f32.  us per call from HIP events at the S0 / dog15 sizes of SURVEY section 8 and a large batch;
+    flop count = 2*N*V*(K-1)*12 (blend contraction) + 2*N*V*12 (body transform)."""
+    from lasr_amd.nnutils import geom_utils
+    out = {'mfma_instruction': 'v_mfma_f32_16x16x4_f32', 'peak_tflops': MFMA_F32_PEAK_TF, 'sizes': {}}
+    for name, (N, V, K) in {'S0': (16, 642, 21), 'dog15': (6, 1282, 36), 'batch256': (256, 1212, 36)}.items():
+        gen = torch.Generator(device='cpu').manual_seed(0)
+        v = torch.randn(N, V, 3, generator=gen).to(dev)
+        R = torch.randn(N * K, 3, 3, generator=gen).to(dev)
+        T = torch.randn(N * K, 1, 3, generator=gen).to(dev)
+        sk = torch.softmax(torch.randn(N, K - 1, V, 1, generator=gen), 1).to(dev)
+        with torch.no_grad():
+            for _ in range(5):
+                geom_utils.obj_to_cam(v, R, T, K, 1, sk)
+            reps = 100
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                geom_utils.obj_to_cam(v, R, T, K, 1, sk)
+            e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        flops = 2 * N * V * (K - 1) * 12 + 2 * N * V * 12
+        mfma = N * -(-V // 16) * -(-(K - 1) // 4)        # one 16x16x4 instruction per 16 vertices x 4 bones (12 of 16 columns used)
+        out['sizes'][name] = {'N': N, 'V': V, 'K': K, 'us_per_call': round(us, 2), 'mfma_instructions': mfma,
+                              'achieved_tflops': flops / us / 1e6, 'frac_of_mfma_peak': flops / us / 1e6 / MFMA_F32_PEAK_TF,
+                              'achieved_GBs': N * (24 * V + 4 * V * (K - 1) + 48 * K) / us / 1e3}
+    return out
 
 
 def optimize_leg(dev, iters):
@@ -183,13 +235,25 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != a.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
-    if world == 1 and a.gpus > 1:
-        raise SystemExit('--gpus %d needs torch.distributed.run (one process per GPU)' % a.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no HIP device visible); there is no CPU fallback')
     backend = os.environ.get('LASR_BENCH_BACKEND', 'nccl')       # 'nccl' == RCCL on ROCm.  'gloo': functional check of the
     if backend != 'nccl':                                        # multi-rank path with all ranks sharing GPU 0 (1-GPU box)
         local = 0
+    elif a.gpus > torch.cuda.device_count():
+        raise SystemExit('--gpus %d but only %d HIP device(s) visible' % (a.gpus, torch.cuda.device_count()))
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # called as `python bench.py --gpus N`: launch one process per GPU ourselves (scripts/template.sh:26 does the same
+        # with torch.distributed.launch) and relay rank 0's JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
@@ -223,10 +287,15 @@ def main():
         one_step()
     barrier()
     dt = time.perf_counter() - t0
+    device_ids = [torch.cuda.current_device()]
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ids = [None] * world
+        dist.all_gather_object(ids, (rank, torch.cuda.current_device(), os.getpid()))
+        device_ids = [d for _, d, _ in sorted(ids)]
+        assert len({p for _, _, p in ids}) == world          # one process per rank
 
     # ---- roofline leg: per-kernel HIP-event timing inside the library (separate pass) ----
     h = job.h
@@ -250,6 +319,8 @@ def main():
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'world_size': world, 'backend': ('rccl (torch.distributed "nccl")' if backend == 'nccl' else backend) if world > 1 else None,
+            'rank_device_ids': device_ids,
             'config': {'workload': 'soft-rasteriser fwd+bwd, mesh M2 (V=1212,F=2420), %dx%d, LASR modes '
                                    '(euclidean/softmax/prod/vertex, sigma=1e-4, gamma=1e-2)' % (IS, IS),
                        'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
@@ -276,6 +347,8 @@ def main():
                 h.lasr_sr_set_forward_math(0)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(F)
+        if world == 1 and not a.no_lbs:
+            out['lbs'] = lbs_leg(dev)
         if world == 1 and a.lasr_iters > 0:
             out['optimize_py'] = optimize_leg(dev, a.lasr_iters)
         print(json.dumps(out), flush=True)

@@ -101,3 +101,36 @@ def backward(saved, grad_soft_colors, image_size=256, background_color=(0, 0, 0)
     if rc != 0:
         raise RuntimeError('oracle_sr_backward failed: %d' % rc)
     return gf, gt
+
+
+def set_threads(n):
+    """OpenMP thread count of the oracle (bench.py's cpu_baseline leg); returns the count now in force."""
+    lib().oracle_sr_set_threads(ctypes.c_int(int(n)))
+    return int(lib().oracle_sr_max_threads())
+
+
+def backward_banded(saved, grad_soft_colors, bands, image_size=256, background_color=(0, 0, 0), near=1, far=100,
+                    fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
+                    gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface'):
+    """fp32 backward with (image, row band) parallelism: per-band gradient slabs folded in band order (deterministic;
+    same arithmetic per pixel-face pair as backward()).  Used by bench.py's cpu_baseline leg so that the backward keeps
+    every host core busy, not one core per image."""
+    dt = np.dtype(np.float32)
+    fv, tx = saved['face_vertices'], saved['textures']
+    N, F = fv.shape[:2]
+    T = tx.shape[2]
+    IS = int(image_size)
+    g = np.ascontiguousarray(grad_soft_colors, dtype=dt)
+    assert g.shape == (N, 4, IS, IS)
+    gf = np.zeros((N, F, 3, 3), dt)
+    gt = np.zeros((N, F, T, 3), dt)
+    slabs = np.zeros((int(bands), gf.size + gt.size), dt)
+    rc = lib().oracle_sr_backward_banded_f32(
+        _ptr(fv), _ptr(tx), _ptr(saved['soft_colors']), _ptr(saved['faces_info']), _ptr(saved['aggrs_info']),
+        _ptr(gf), _ptr(gt), _ptr(g), _ptr(slabs), ctypes.c_int(int(bands)),
+        ctypes.c_int(N), ctypes.c_int(F), ctypes.c_int(T), ctypes.c_int(IS),
+        *_scalars(near, far, eps, sigma_val, dist_func, dist_eps, gamma_val, aggr_func_rgb,
+                  aggr_func_alpha, texture_type, fill_back))
+    if rc != 0:
+        raise RuntimeError('oracle_sr_backward_banded failed: %d' % rc)
+    return gf, gt

@@ -32,7 +32,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
 def test_no_compute_entry_points_without_gpu_but_metadata_calls_work():
     from lasr_amd import _lib
     h = _lib.lib()
-    assert h.lasr_abi_version() == 1
+    assert h.lasr_abi_version() >= 1
     assert h.lasr_strerror(0) == b'ok'
     assert b'workspace' in h.lasr_strerror(-3)
     n = h.lasr_sr_workspace_bytes(2, 100, 3, 64)

@@ -1,0 +1,46 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N` with no torchrun around it must launch one process per
+rank itself (the reference does so from its script line, scripts/template.sh:26 / optimize.py:42-47) and rank 0 must
+print ONE well-formed JSON line.  On a 1-GPU box the two ranks share GPU 0 and talk over gloo (LASR_BENCH_BACKEND);
+with >= 2 GPUs the same test runs the RCCL path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, cwd=ROOT, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_launch(cuda):
+    backend = 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+    out = run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--frames', '16'], {'LASR_BENCH_BACKEND': backend})
+    assert out['n_gpus'] == 2 and out['world_size'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
+    assert out['metric'].startswith('rasterizer fwd+bwd frames/sec at 256x256')
+    assert out['value'] > 0 and out['roofline']['frac'] > 0 and len(out['rank_device_ids']) == 2
+    assert ('rccl' in out['backend']) == (backend == 'nccl')
+    assert abs(out['value'] - 2 * 16 * 3 / (out['ms_per_step'] * 3e-3)) <= 1e-6 * out['value']
+
+
+def test_bench_single_gpu_line_has_every_block(cuda):
+    out = run_bench(['--steps', '3', '--warmup', '1', '--frames', '32', '--lasr-iters', '0'])
+    assert out['n_gpus'] == 1 and out['dtype'] == 'f32' and out['vs_baseline'] is None
+    r, c, l = out['roofline'], out['cpu_baseline'], out['lbs']
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['one_thread_frames_per_s'] > 0
+    assert l['mfma_instruction'] == 'v_mfma_f32_16x16x4_f32' and set(l['sizes']) == {'S0', 'dog15', 'batch256'}
+    assert all(v['us_per_call'] > 0 and v['mfma_instructions'] > 0 for v in l['sizes'].values())

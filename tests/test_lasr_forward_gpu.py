@@ -168,8 +168,11 @@ def test_graph_replay_matches_eager_forward(tmp_path, cuda):
 @pytest.mark.parametrize('name,over', [
     # BASELINE configs[2]/[3]: camel stages 3-4 -- 2 pairs per GPU, one hypothesis, 36 bones, 512x512
     ('camel', dict(img_size=512, subdivide=3, n_bones=36, n_hypo=1, batch_size=2, symmetric=False, only_mean_sym=False)),
-    # BASELINE configs[4]: dog15 stage 0 -- 3 pairs, 16 camera hypotheses, 21 bones (25-bone LBS comes with stage 1)
-    ('dog15', dict(img_size=128, subdivide=3, n_bones=26, n_hypo=16, batch_size=3, n_frames=15)),
+    # BASELINE configs[4]: dog15 at its real size (scripts/dog15.sh: 256x256, 3 pairs per GPU, 15 frames).
+    # stage 0: 16 camera hypotheses, 21 bones (96 renders per call); stage 1: best hypothesis, 26 bones = the 25-bone LBS
+    ('dog15-0', dict(img_size=256, subdivide=3, n_bones=21, n_hypo=16, batch_size=3, n_frames=15)),
+    ('dog15-1', dict(img_size=256, subdivide=3, n_bones=26, n_hypo=1, batch_size=3, n_frames=15, symmetric=False,
+                     only_mean_sym=False)),
 ])
 def test_other_baseline_configurations_step(tmp_path, cuda, name, over):
     tr = make_trainer(tmp_path, name=name, iters_per_epoch=2, **over)
