@@ -52,6 +52,7 @@ def parse():
     ap.add_argument('--frames', type=int, default=256, help='frames per GPU per step (SURVEY 8d batches: 1/16/64/256)')
     ap.add_argument('--image-size', type=int, default=256, help='256 = the headline metric; 512 = BASELINE configs[2] (camel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--forward-variant', type=int, default=None, help='A/B: 0 = one-phase forward kernel, 1 = two-phase (library default)')
     ap.add_argument('--no-lbs', action='store_true', help='skip the LBS (MFMA) micro-benchmark block')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
     return ap.parse_args()
@@ -265,6 +266,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if a.forward_variant is not None:
+        _lib.check(_lib.lib().lasr_sr_set_forward_variant(a.forward_variant), 'lasr_sr_set_forward_variant')
     B = a.frames
     # frames shard across ranks: rank r renders yaw positions r*B .. r*B+B-1 of the cycle (weak scaling)
     job = RasterStep(dev, B, first_frame=rank * B)

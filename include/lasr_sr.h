@@ -146,6 +146,13 @@ int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launch
 int lasr_sr_set_forward_math(int mode);
 
 /*
+ * Forward kernel used for LASR's mode combination, process-wide (no reference counterpart; an A/B switch for benchmarks
+ * and tests).  1 (default): the two-phase kernel (cheap pixel-major classification -> dense face-gathering batches ->
+ * per-pixel fold in face order, lasr_amd/csrc/sr_forward2.h).  0: the one-phase tile walk.  Both produce the same bits.
+ */
+int lasr_sr_set_forward_variant(int variant);
+
+/*
  * Test hook (no reference counterpart): adds to *mismatches the number of pairs for which the library's
  * exact division-by-reciprocal (sr_device.h) differs bitwise from the IEEE quotient a[i] / b[i].
  */

@@ -628,29 +628,50 @@ __global__ __launch_bounds__(256) void pmf_backward_point_kernel(const float* __
 // Perceptual-distance reduction, PerceptualSimilarity/util/util.py:71-83 + models/networks_basic.py:51-52:
 //   d[n] = 1 - mean_{pixels} sum_c a_hat[c] b_hat[c],   x_hat = x / (sqrt(sum_c x_c^2) + 1e-10)
 // fa [Na, C, P] (observed-image features; image n of fb pairs with fa[n / rep]), fb [N, C, P] (rendered-image features).
-// One thread per pixel walks the channels (plane stride P: coalesced across the wave); chunk partials, fixed-order fold.
+//
+// Shape: a block owns COS_TP = 32 consecutive pixels of one image and ALL channels; its 256 threads are 8 channel groups x
+// 32 pixels, thread (g, p) walks channels g, g+8, ...  A wave-load therefore touches two 128-B pixel rows, every thread has
+// C/8 independent (a, b) load pairs in flight instead of one serial chain over C, and the grid has N * ceil(P/32) blocks
+// (AlexNet layers 3-5, P = 225: 8 blocks per image instead of 1).  Channel partials meet in LDS and are folded in group
+// order (deterministic).  The backward keeps its C/8 (a, b) pairs in registers (CPT <= 48, i.e. C <= 384: every AlexNet
+// layer) so the features are read once; other channel counts take the generic two-pass instantiation.
+// Algorithmic bytes: forward 2*N*C*P*4 (the observed side is re-read per hypothesis, from L2), backward 3*N*C*P*4.
 // ===========================================================================
 constexpr float COS_EPS = 1e-10f;
-constexpr int COS_PX = 256;
+constexpr int COS_TP = 32;     // pixels per block
+constexpr int COS_CG = 8;      // channel groups per block
+
+__device__ __forceinline__ void cos_exchange(float (*red)[COS_CG][COS_TP], int cg, int pxl, float& dot, float& na, float& nb)
+{
+    red[0][cg][pxl] = dot; red[1][cg][pxl] = na; red[2][cg][pxl] = nb;
+    __syncthreads();
+    dot = na = nb = 0.f;
+#pragma unroll
+    for (int g = 0; g < COS_CG; g++) { dot += red[0][g][pxl]; na += red[1][g][pxl]; nb += red[2][g][pxl]; }
+}
 
 __global__ __launch_bounds__(256) void cosdist_forward_kernel(const float* __restrict__ fa, const float* __restrict__ fb,
                                                               float* __restrict__ part, int C, int P, int rep, int nch)
 {
-    __shared__ float red[4];
-    const int n = blockIdx.x, p = blockIdx.y * COS_PX + threadIdx.x;
-    float cosv = 0.f;
+    __shared__ float red[3][COS_CG][COS_TP];
+    const int n = blockIdx.x, pxl = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int p = blockIdx.y * COS_TP + pxl;
+    float dot = 0.f, na = 0.f, nb = 0.f;
     if (p < P) {
         const float* a = fa + (size_t)(n / rep) * C * P + p;
         const float* b = fb + (size_t)n * C * P + p;
-        float dot = 0.f, na = 0.f, nb = 0.f;
-        for (int c = 0; c < C; c++) {
+#pragma unroll 8
+        for (int c = cg; c < C; c += COS_CG) {
             const float x = a[(size_t)c * P], y = b[(size_t)c * P];
             dot += x * y; na += x * x; nb += y * y;
         }
-        cosv = dot / ((sqrtf(na) + COS_EPS) * (sqrtf(nb) + COS_EPS));
     }
-    cosv = block_sum(cosv, red);
-    if (threadIdx.x == 0) part[(size_t)n * nch + blockIdx.y] = cosv;
+    cos_exchange(red, cg, pxl, dot, na, nb);
+    if (cg != 0) return;                                     // lanes 0..31 of wave 0 finish the tile
+    float cosv = p < P ? dot / ((sqrtf(na) + COS_EPS) * (sqrtf(nb) + COS_EPS)) : 0.f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) cosv += __shfl_xor(cosv, o, 32);
+    if (pxl == 0) part[(size_t)n * nch + blockIdx.y] = cosv;
 }
 
 __global__ __launch_bounds__(256) void cosdist_fold_kernel(const float* __restrict__ part, float* __restrict__ d, int N, int nch, int P)
@@ -663,26 +684,50 @@ __global__ __launch_bounds__(256) void cosdist_fold_kernel(const float* __restri
 }
 
 // gradient w.r.t. fb only (the observed side is data): d cos / d b_c = a_c / (A B) - dot * b_c / (A * nb * B^2),
-// A = |a| + eps, B = |b| + eps, second term 0 where |b| = 0
+// A = |a| + eps, B = |b| + eps, second term 0 where |b| = 0.  CPT = channels per thread held in registers (0: re-read).
+template <int CPT>
 __global__ __launch_bounds__(256) void cosdist_backward_kernel(const float* __restrict__ fa, const float* __restrict__ fb,
                                                                const float* __restrict__ gd, float* __restrict__ gfb,
                                                                int C, int P, int rep)
 {
-    const int n = blockIdx.x, p = blockIdx.y * COS_PX + threadIdx.x;
-    if (p >= P) return;
-    const float* a = fa + (size_t)(n / rep) * C * P + p;
-    const float* b = fb + (size_t)n * C * P + p;
+    __shared__ float red[3][COS_CG][COS_TP];
+    const int n = blockIdx.x, pxl = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int p = blockIdx.y * COS_TP + pxl;
+    const bool in = p < P;
+    const float* a = fa + (size_t)(n / rep) * C * P + (in ? p : 0);
+    const float* b = fb + (size_t)n * C * P + (in ? p : 0);
     float* g = gfb + (size_t)n * C * P + p;
+    float xa[CPT > 0 ? CPT : 1], xb[CPT > 0 ? CPT : 1];
     float dot = 0.f, na = 0.f, nb = 0.f;
-    for (int c = 0; c < C; c++) {
-        const float x = a[(size_t)c * P], y = b[(size_t)c * P];
-        dot += x * y; na += x * x; nb += y * y;
+    if (CPT > 0) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg + COS_CG * i;
+            xa[i] = in ? a[(size_t)c * P] : 0.f;
+            xb[i] = in ? b[(size_t)c * P] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; i++) { dot += xa[i] * xb[i]; na += xa[i] * xa[i]; nb += xb[i] * xb[i]; }
+    } else if (in) {
+#pragma unroll 8
+        for (int c = cg; c < C; c += COS_CG) {
+            const float x = a[(size_t)c * P], y = b[(size_t)c * P];
+            dot += x * y; na += x * x; nb += y * y;
+        }
     }
+    cos_exchange(red, cg, pxl, dot, na, nb);
+    if (!in) return;
     const float A = sqrtf(na) + COS_EPS, nbr = sqrtf(nb), B = nbr + COS_EPS;
     const float k = -gd[n] / (float)P;                       // d = 1 - mean cos
     const float ka = k / (A * B);
     const float kb = nbr > 0.f ? k * dot / (A * nbr * B * B) : 0.f;
-    for (int c = 0; c < C; c++) g[(size_t)c * P] = ka * a[(size_t)c * P] - kb * b[(size_t)c * P];
+    if (CPT > 0) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) g[(size_t)(cg + COS_CG * i) * P] = ka * xa[i] - kb * xb[i];
+    } else {
+#pragma unroll 8
+        for (int c = cg; c < C; c += COS_CG) g[(size_t)c * P] = ka * a[(size_t)c * P] - kb * b[(size_t)c * P];
+    }
 }
 
 }  // namespace lasr
@@ -884,7 +929,7 @@ extern "C" int lasr_point_mesh_backward(const float* verts, const long long* fac
 extern "C" size_t lasr_cosdist_scratch_floats(int N, int P)
 {
     if (N < 0 || P < 0) return 0;
-    return (size_t)N * ((P + COS_PX - 1) / COS_PX) + 4;
+    return (size_t)N * ((P + COS_TP - 1) / COS_TP) + 4;
 }
 
 extern "C" int lasr_cosdist_forward(const float* feat_obs, const float* feat_rnd, float* dist, float* scratch, int N, int C,
@@ -894,7 +939,7 @@ extern "C" int lasr_cosdist_forward(const float* feat_obs, const float* feat_rnd
     if (N == 0) return LASR_OK;
     if (!feat_obs || !feat_rnd || !dist || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    const int nch = (P + COS_PX - 1) / COS_PX;
+    const int nch = (P + COS_TP - 1) / COS_TP;
     LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_forward_kernel, dim3(N, nch), dim3(256), 0, feat_obs, feat_rnd, scratch, C, P, rep, nch);
     int rc = launch_ok();
     if (rc) return rc;
@@ -909,7 +954,17 @@ extern "C" int lasr_cosdist_backward(const float* feat_obs, const float* feat_rn
     if (N == 0) return LASR_OK;
     if (!feat_obs || !feat_rnd || !grad_dist || !grad_rnd) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_COSDIST_BACKWARD, cosdist_backward_kernel, dim3(N, (P + COS_PX - 1) / COS_PX), dim3(256), 0, feat_obs, feat_rnd,
-                grad_dist, grad_rnd, C, P, rep);
+    const dim3 grid(N, (P + COS_TP - 1) / COS_TP);
+#define LASR_COS_BWD(CPT)                                                                                          \
+    LASR_LAUNCH(K_COSDIST_BACKWARD, (cosdist_backward_kernel<CPT>), grid, dim3(256), 0, feat_obs, feat_rnd, grad_dist, \
+                grad_rnd, C, P, rep)
+    switch (C % COS_CG == 0 ? C / COS_CG : 0) {         // AlexNet: 64, 192, 384, 256, 256 channels
+        case 8:  LASR_COS_BWD(8); break;
+        case 24: LASR_COS_BWD(24); break;
+        case 32: LASR_COS_BWD(32); break;
+        case 48: LASR_COS_BWD(48); break;
+        default: LASR_COS_BWD(0);
+    }
+#undef LASR_COS_BWD
     return launch_ok();
 }

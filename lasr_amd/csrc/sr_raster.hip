@@ -288,6 +288,10 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     }
 }
 
+}  // namespace lasr
+#include "sr_forward2.h"
+namespace lasr {
+
 // ---------------------------------------------------------------------------
 // Backward: one wave per (image, face); K.cu:486-668 evaluated face-major, in two stages.
 //   stage 1 (cheap, 64 bbox pixels per round): exact bbox test + barycentrics + the conservative
@@ -589,6 +593,7 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     return A;
 }
 
+static int g_forward_variant = 1;                            // 1 = two-phase kernel for LASR's modes (sr_forward2.h), 0 = one-phase
 static int g_forward_math = 0;                               // 0 = reference-faithful (default), 1 = relaxed, see forward_face
 static thread_local const float* g_near_far_dev = nullptr;   // set by the *_dev entry points around the call
 
@@ -624,7 +629,12 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     {
         ProfScope ps(K_SR_FORWARD, st);
         const bool rx = g_forward_math == 1 && is_lasr_fast(A.m);
-        if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        if (g_forward_variant == 1 && is_lasr_fast(A.m) && T == 3) {
+            if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward2_kernel<6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 6) hipLaunchKernelGGL((sr_forward2_kernel<6, false>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            else if (rx) hipLaunchKernelGGL((sr_forward2_kernel<3, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            else hipLaunchKernelGGL((sr_forward2_kernel<3, false>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        } else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (is_lasr_fast(A.m)) hipLaunchKernelGGL((sr_forward_kernel<true, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
@@ -794,6 +804,13 @@ extern "C" int lasr_selftest_div3(const float* a, const float* b, int* mismatche
     if (n == 0) return LASR_OK;
     hipLaunchKernelGGL(selftest_div3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, a, b, mismatches, n);
     return launch_ok();
+}
+
+extern "C" int lasr_sr_set_forward_variant(int variant)
+{
+    if (variant != 0 && variant != 1) return LASR_E_BADMODE;
+    g_forward_variant = variant;
+    return LASR_OK;
 }
 
 extern "C" int lasr_sr_set_forward_math(int mode)
