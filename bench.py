@@ -12,7 +12,7 @@ prod / vertex colours, sigma 1e-4, gamma 1e-2), B=256 synthetic yaw-rotated fram
 step, upstream gradient N(0,1)/P.  Inputs are resident in HBM before the timed region.
 
 One step = for the rank's B frames: fill soft_colors with the background, zero the gradient
-buffers, forward (setup + raster kernels), backward (setup + raster kernels) through the C ABI,
+buffers, forward (face setup + raster kernel), backward (raster kernel; it reuses the forward's face records) through the C ABI,
 scatter-add the face gradients to per-vertex mesh gradients; for N > 1 the [2,V,3] mesh
 gradient is then all-reduced over RCCL (frames are sharded data-parallel, weak scaling).
 Nothing inside the timed region touches the CPU oracle.
@@ -89,14 +89,17 @@ class RasterStep:
         self.colors.fill_(1.0)                       # background (1,1,1), alpha slot 1 (soft_rasterize.py:50-53)
         self.gf.zero_()
         self.gt.zero_()
-        rc = h.lasr_sr_forward(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
-                               self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                               B, F, 3, IS, *self.scalars, self.stream)
-        _lib.check(rc, 'lasr_sr_forward')
-        rc = h.lasr_sr_backward(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), None,
-                                self.aggrs.data_ptr(), self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(),
-                                self.ws.data_ptr(), self.ws.numel(), B, F, 3, IS, *self.scalars, self.stream)
-        _lib.check(rc, 'lasr_sr_backward')
+        near, far, tail = self.scalars[0], self.scalars[1], self.scalars[2:]
+        rc = h.lasr_sr_forward_ex(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
+                                  self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                  B, F, 3, 3, IS, near, far, None, *tail, _lib.SR_DEFAULT_FLAGS, self.stream)
+        _lib.check(rc, 'lasr_sr_forward_ex')
+        # the backward finds the forward's per-face records still in the workspace (what the autograd operator does)
+        rc = h.lasr_sr_backward_ex(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), self.aggrs.data_ptr(),
+                                   self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(), self.ws.data_ptr(),
+                                   self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail, _lib.SR_RECORDS_VALID,
+                                   self.stream)
+        _lib.check(rc, 'lasr_sr_backward_ex')
         # face -> vertex gradient scatter (autograd of face_vertices.py:4-22), summed over the rank's frames
         self.mesh_grad.zero_()
         self.mesh_grad[0].index_add_(0, self.scatter_idx, self.gf.sum(0).reshape(F * 3, 3))

@@ -125,6 +125,31 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
                           int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream);
 
 /*
+ * Supersets of the entry points above with every option as an argument (no reference counterpart).  channels = 3 or 6 (6 as
+ * for the *_attr variants); near_far_dev: NULL or a device pointer to {near, far} that overrides near / far.
+ * forward flags  : LASR_SR_RELAXED_MATH, LASR_SR_TWO_PHASE (the per-call forms of lasr_sr_set_forward_math / _variant below).
+ * backward flags : LASR_SR_RECORDS_VALID -- the caller vouches that `workspace` still holds the per-face records the forward
+ *                  pass of the SAME faces / N / F / IS / sigma_val / dist_eps left there (nothing else was run on that
+ *                  workspace in between); the backward then skips its own setup launch.  Without the flag every backward
+ *                  call rebuilds the records, so the plain entry points stay safe for callers that share one workspace.
+ */
+#define LASR_SR_DEFAULT_FLAGS (-1)   /* forward only: use the process-wide defaults of the two setters below */
+#define LASR_SR_RELAXED_MATH  1
+#define LASR_SR_TWO_PHASE     2
+#define LASR_SR_RECORDS_VALID 4
+int lasr_sr_forward_ex(const float* faces, const float* textures, float* faces_info, float* aggrs_info, float* soft_colors,
+                       void* workspace, size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near,
+                       float far, const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                       float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                       int flags, void* hip_stream);
+int lasr_sr_backward_ex(const float* faces, const float* textures, const float* soft_colors, const float* aggrs_info,
+                        float* grad_faces, float* grad_textures, const float* grad_soft_colors, void* workspace,
+                        size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near, float far,
+                        const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                        float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                        int flags, void* hip_stream);
+
+/*
  * Optional per-kernel timing for benchmarks (no reference counterpart: the
  * reference has no profiling hooks).  While enabled, every
  * kernel launch of this library is bracketed by hipEvents on its stream;
@@ -146,9 +171,9 @@ int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launch
 int lasr_sr_set_forward_math(int mode);
 
 /*
- * Forward kernel used for LASR's mode combination, process-wide (no reference counterpart; an A/B switch for benchmarks
- * and tests).  1 (default): the two-phase kernel (cheap pixel-major classification -> dense face-gathering batches ->
- * per-pixel fold in face order, lasr_amd/csrc/sr_forward2.h).  0: the one-phase tile walk.  Both produce the same bits.
+ * Forward kernel used for LASR's mode combination, process-wide default (no reference counterpart; an A/B switch for
+ * benchmarks and tests).  0 (default): the one-phase tile walk.  1: the two-phase kernel (cheap pixel-major classification -> dense face-gathering batches ->
+ * per-pixel fold in face order, lasr_amd/csrc/sr_forward2.h; measured slower, profiles/experiments/).  Same bits.
  */
 int lasr_sr_set_forward_variant(int variant);
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),
     'lasr_sr_backward_attr': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),
+    'lasr_sr_forward_ex': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
+    'lasr_sr_backward_ex': (_i, [_p] * 8 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
     'lasr_sr_set_forward_math': (_i, [_i]),
     'lasr_sr_set_forward_variant': (_i, [_i]),
     'lasr_selftest_div': (_i, [_p, _p, _p, _i, _p]),
@@ -68,6 +70,9 @@ SIGNATURES = {
     'lasr_prof_kernel_name': (ctypes.c_char_p, [_i]),
     'lasr_prof_collect': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
 }
+
+# flags of the *_ex entry points (include/lasr_sr.h)
+SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_TWO_PHASE, SR_RECORDS_VALID = -1, 1, 2, 4
 
 _lib = None
 

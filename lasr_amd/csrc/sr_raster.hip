@@ -44,14 +44,27 @@ struct RasterArgs {
 };
 
 // ---------------------------------------------------------------------------
+// One thread builds one face's record -- into LDS; the block then writes its 256 records (45 KB, contiguous in the
+// workspace) with coalesced stores.  Writing the 176-B records straight from the building threads is a 176-B-strided
+// scatter: the PMC pass of round 1 showed 2x the algorithmic write traffic for it (profiles/r01i_pmc.txt).
+constexpr int SETUP_STRIDE = REC + 1;      // odd LDS stride: the building threads' stores spread over the banks
 __global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__ faces, float* __restrict__ recs,
                                                        short4* __restrict__ rects, float* __restrict__ info27,
                                                        int total, float margin, int IS)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    build_record(faces + (size_t)i * 9, recs + (size_t)i * REC, rects + i, margin, IS,
-                 info27 ? info27 + (size_t)i * 27 : nullptr);
+    __shared__ float s_rec[256 * SETUP_STRIDE];
+    const int first = blockIdx.x * 256;
+    const int i = first + threadIdx.x;
+    if (i < total)
+        build_record(faces + (size_t)i * 9, s_rec + threadIdx.x * SETUP_STRIDE, rects + i, margin, IS,
+                     info27 ? info27 + (size_t)i * 27 : nullptr);
+    __syncthreads();
+    const int nflt = min(256, total - first) * REC;
+    float* __restrict__ out = recs + (size_t)first * REC;
+    for (int k = threadIdx.x; k < nflt; k += 256) {
+        const int r = k / REC;
+        out[k] = s_rec[r * SETUP_STRIDE + (k - r * REC)];
+    }
 }
 
 // Block -> (image, tile) with all tiles of an image kept on one XCD (block b runs
@@ -117,18 +130,20 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
             const float fmn = A.far - A.near;
             const float zn = RX ? (A.far - zp) * U.inv_fmn
                                 : (MK ? div_by_recip(A.far - zp, fmn, U.inv_fmn) : (A.far - zp) / fmn);
-            float rescale = 1.f;
-            if (zn > s.smax) {
-                rescale = RX ? __expf((s.smax - zn) * U.inv_gamma)
-                             : exp_1ulp(MK ? div_by_recip(s.smax - zn, A.gamma, U.inv_gamma) : (s.smax - zn) / A.gamma);
-                s.smax = zn;
-            }
-            const float ez = RX ? __expf((zn - s.smax) * U.inv_gamma)
-                                : exp_1ulp(MK ? div_by_recip(zn - s.smax, A.gamma, U.inv_gamma) : (zn - s.smax) / A.gamma);
-            s.ssum = rescale * s.ssum + ez * D;
+            // K.cu:428-446 evaluates two exponentials per fragment: exp((smax_old - zn)/gamma) rescales the history when zn is
+            // the new maximum (and the fragment's own weight is then exp(0) = 1 exactly), otherwise the history keeps weight 1
+            // and the fragment gets exp((zn - smax)/gamma).  One exponential of -|zn - smax|/gamma serves both cases with
+            // identical bits (exp_1ulp(0) == 1, x * 1 == x).
+            const bool up = zn > s.smax;
+            const float d = up ? s.smax - zn : zn - s.smax;
+            const float E = RX ? __expf(d * U.inv_gamma)
+                               : exp_1ulp(MK ? div_by_recip(d, A.gamma, U.inv_gamma) : d / A.gamma);
+            const float hist = up ? E : 1.f, wgt = up ? D : E * D;     // (rescale, ez * D) of the reference, branch-free
+            s.smax = up ? zn : s.smax;
+            s.ssum = hist * s.ssum + wgt;
 #pragma unroll
             for (int k = 0; k < NCH; k++)
-                s.c[k] = rescale * s.c[k] + ez * D * sample_colour(tex, c0, c1, c2, A.res, k, m.tex, lim, NCH);
+                s.c[k] = hist * s.c[k] + wgt * sample_colour(tex, c0, c1, c2, A.res, k, m.tex, lim, NCH);
         }
     }
 }
@@ -593,9 +608,11 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     return A;
 }
 
-static int g_forward_variant = 1;                            // 1 = two-phase kernel for LASR's modes (sr_forward2.h), 0 = one-phase
+// process-wide DEFAULTS of the two forward switches (lasr_sr_set_forward_math / _variant); the *_ex entry points take the
+// same choices per call in `flags`, and nothing else in this file is global state
+static int g_forward_variant = 0;                            // 0 = one-phase tile walk (default), 1 = two-phase (sr_forward2.h)
 static int g_forward_math = 0;                               // 0 = reference-faithful (default), 1 = relaxed, see forward_face
-static thread_local const float* g_near_far_dev = nullptr;   // set by the *_dev entry points around the call
+static int default_flags() { return (g_forward_math ? LASR_SR_RELAXED_MATH : 0) | (g_forward_variant ? LASR_SR_TWO_PHASE : 0); }
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -603,7 +620,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                         float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
                         float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps,
                         float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
-                        int double_side, void* hip_stream, int nch)
+                        int double_side, void* hip_stream, int nch, const float* near_far_dev, int flags)
 {
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
     if (rc) return rc;
@@ -614,7 +631,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     float* recs; short4* rects;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
                              gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
-    A.near_far_dev = g_near_far_dev;
+    A.near_far_dev = near_far_dev;
     const int total = N * F;
     if (total > 0) {
         {
@@ -628,8 +645,8 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const dim3 grid((unsigned)(N * tiles_x * tiles_x));
     {
         ProfScope ps(K_SR_FORWARD, st);
-        const bool rx = g_forward_math == 1 && is_lasr_fast(A.m);
-        if (g_forward_variant == 1 && is_lasr_fast(A.m) && T == 3) {
+        const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
+        if ((flags & LASR_SR_TWO_PHASE) && is_lasr_fast(A.m) && T == 3) {
             if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward2_kernel<6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
             else if (nch == 6) hipLaunchKernelGGL((sr_forward2_kernel<6, false>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
             else if (rx) hipLaunchKernelGGL((sr_forward2_kernel<3, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
@@ -648,7 +665,8 @@ static int backward_impl(const float* faces, const float* textures, const float*
                          float* grad_textures, const float* grad_soft_colors, void* workspace,
                          size_t workspace_bytes, int N, int F, int T, int IS, float near, float far, float eps,
                          float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
-                         int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream, int nch)
+                         int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream, int nch,
+                         const float* near_far_dev, int flags)
 {
     (void)faces_info;
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
@@ -661,14 +679,16 @@ static int backward_impl(const float* faces, const float* textures, const float*
     float* recs; short4* rects;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
                              gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
-    A.near_far_dev = g_near_far_dev;
+    A.near_far_dev = near_far_dev;
     const int total = N * F;
-    {
-        ProfScope ps(K_SR_SETUP, st);
-        hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, rects,
-                           (float*)nullptr, total, sqrtf(A.thr), IS);
+    if (!(flags & LASR_SR_RECORDS_VALID)) {      // the caller vouches that the forward's records are still in the workspace
+        {
+            ProfScope ps(K_SR_SETUP, st);
+            hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, rects,
+                               (float*)nullptr, total, sqrtf(A.thr), IS);
+        }
+        if ((rc = launch_ok())) return rc;
     }
-    if ((rc = launch_ok())) return rc;
     const dim3 grid((unsigned)((total + 3) / 4));   // 4 waves (faces) per 256-thread workgroup
     {
         ProfScope ps(K_SR_BACKWARD, st);
@@ -701,7 +721,7 @@ extern "C" int lasr_sr_forward(const float* faces, const float* textures, float*
 {
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
                         far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
-                        texture_sample_type, double_side, hip_stream, 3);
+                        texture_sample_type, double_side, hip_stream, 3, nullptr, default_flags());
 }
 
 extern "C" int lasr_sr_backward(const float* faces, const float* textures, const float* soft_colors,
@@ -713,7 +733,7 @@ extern "C" int lasr_sr_backward(const float* faces, const float* textures, const
 {
     return backward_impl(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces, grad_textures, grad_soft_colors,
                          workspace, workspace_bytes, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
-                         gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, hip_stream, 3);
+                         gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, hip_stream, 3, nullptr, 0);
 }
 
 // Multi-attribute variants: `channels` per-vertex attributes (3 or 6) interpolated and depth-blended in ONE pass over the
@@ -727,12 +747,9 @@ extern "C" int lasr_sr_forward_attr(const float* faces, const float* textures, f
 {
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, 3);
     if (rc) return rc;
-    g_near_far_dev = near_far_dev;
-    const int out = forward_impl(faces, textures, nullptr, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, 3, IS,
-                                 near, far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
-                                 texture_sample_type, double_side, hip_stream, channels);
-    g_near_far_dev = nullptr;
-    return out;
+    return forward_impl(faces, textures, nullptr, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, 3, IS,
+                        near, far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                        texture_sample_type, double_side, hip_stream, channels, near_far_dev, default_flags());
 }
 
 extern "C" int lasr_sr_backward_attr(const float* faces, const float* textures, const float* soft_colors,
@@ -744,13 +761,10 @@ extern "C" int lasr_sr_backward_attr(const float* faces, const float* textures, 
 {
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, 3);
     if (rc) return rc;
-    g_near_far_dev = near_far_dev;
-    const int out = backward_impl(faces, textures, soft_colors, nullptr, aggrs_info, grad_faces, grad_textures,
-                                  grad_soft_colors, workspace, workspace_bytes, N, F, 3, IS, near, far, eps, sigma_val,
-                                  func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha, texture_sample_type,
-                                  double_side, hip_stream, channels);
-    g_near_far_dev = nullptr;
-    return out;
+    return backward_impl(faces, textures, soft_colors, nullptr, aggrs_info, grad_faces, grad_textures,
+                         grad_soft_colors, workspace, workspace_bytes, N, F, 3, IS, near, far, eps, sigma_val,
+                         func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha, texture_sample_type,
+                         double_side, hip_stream, channels, near_far_dev, 0);
 }
 
 // near/far taken from device memory ({near, far} as two floats): LASR recomputes them from the projected
@@ -763,12 +777,9 @@ extern "C" int lasr_sr_forward_dev(const float* faces, const float* textures, fl
                                    int double_side, void* hip_stream)
 {
     if (!near_far_dev) return LASR_E_BADARG;
-    g_near_far_dev = near_far_dev;
-    const int rc = lasr_sr_forward(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T,
-                                   IS, 0.f, 0.f, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb,
-                                   func_id_alpha, texture_sample_type, double_side, hip_stream);
-    g_near_far_dev = nullptr;
-    return rc;
+    return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, 0.f,
+                        0.f, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                        texture_sample_type, double_side, hip_stream, 3, near_far_dev, default_flags());
 }
 
 extern "C" int lasr_sr_backward_dev(const float* faces, const float* textures, const float* soft_colors,
@@ -780,13 +791,43 @@ extern "C" int lasr_sr_backward_dev(const float* faces, const float* textures, c
                                     void* hip_stream)
 {
     if (!near_far_dev) return LASR_E_BADARG;
-    g_near_far_dev = near_far_dev;
-    const int rc = lasr_sr_backward(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces, grad_textures,
-                                    grad_soft_colors, workspace, workspace_bytes, N, F, T, IS, 0.f, 0.f, eps, sigma_val,
-                                    func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha, texture_sample_type,
-                                    double_side, hip_stream);
-    g_near_far_dev = nullptr;
-    return rc;
+    return backward_impl(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces, grad_textures, grad_soft_colors,
+                         workspace, workspace_bytes, N, F, T, IS, 0.f, 0.f, eps, sigma_val, func_id_dist, dist_eps,
+                         gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, hip_stream, 3,
+                         near_far_dev, 0);
+}
+
+// Supersets of the entry points above (include/lasr_sr.h): every option is an argument, nothing is read from process state.
+extern "C" int lasr_sr_forward_ex(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
+                                  float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T,
+                                  int channels, int IS, float near, float far, const float* near_far_dev, float eps,
+                                  float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                                  int func_id_alpha, int texture_sample_type, int double_side, int flags, void* hip_stream)
+{
+    if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
+    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_TWO_PHASE)) return LASR_E_BADARG;
+    const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
+    if (rc) return rc;
+    return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
+                        far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                        texture_sample_type, double_side, hip_stream, channels, near_far_dev, flags);
+}
+
+extern "C" int lasr_sr_backward_ex(const float* faces, const float* textures, const float* soft_colors,
+                                   const float* aggrs_info, float* grad_faces, float* grad_textures,
+                                   const float* grad_soft_colors, void* workspace, size_t workspace_bytes, int N, int F,
+                                   int T, int channels, int IS, float near, float far, const float* near_far_dev,
+                                   float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                                   int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side, int flags,
+                                   void* hip_stream)
+{
+    if (flags & ~LASR_SR_RECORDS_VALID) return LASR_E_BADARG;
+    const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
+    if (rc) return rc;
+    return backward_impl(faces, textures, soft_colors, nullptr, aggrs_info, grad_faces, grad_textures, grad_soft_colors,
+                         workspace, workspace_bytes, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
+                         gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, hip_stream, channels,
+                         near_far_dev, flags);
 }
 
 // Test hook: number of (a[i], b[i]) pairs for which div_by_recip(a, b, RN(1/b)) != a / b bitwise (added to *mismatches).

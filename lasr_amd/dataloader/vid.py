@@ -45,6 +45,11 @@ class VidDataset(base_data.BaseDataset):
         print('%d paris of images' % self.num_imgs)
 
 
+def config_path(opts, root='.'):
+    """configs/<dataname>.config under `root` (dataloader/vid.py:98 reads 'configs/%s.config' % opts.dataname)."""
+    return os.path.join(root, 'configs', '%s.config' % opts.dataname)
+
+
 def read_config(dataname, root='.'):
     config = configparser.RawConfigParser()
     path = os.path.join(root, 'configs', '%s.config' % dataname)

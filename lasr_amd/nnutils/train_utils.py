@@ -18,6 +18,11 @@ from . import loss_utils, mesh_net
 from .. import synth_data
 
 
+# --dataname values that select the in-memory synthetic sequence (lasr_amd/synth_data.py) when no configs/<name>.config exists;
+# 'fashion' is the reference's flag default (nnutils/mesh_net.py:69), which names no dataset shipped with it either
+SYNTHETIC_DATANAMES = {'synthetic', 'fashion'}
+
+
 def kmeans(x, k, iters=20):
     """Deterministic Lloyd k-means (farthest-point seeding).  x [n,3] -> (assignment [n], centres [k,3])."""
     c = [x[0]]
@@ -86,17 +91,27 @@ class LASRTrainer:
         synthetic sequence (there is no dataset on the benchmark machine)."""
         opts = self.opts
         self.sequence = None
-        try:
-            from ..dataloader import resident, vid
-            loader, self.n_frames_on_disk = vid.data_loader(opts, root=getattr(opts, 'data_root', '.'))
+        from ..dataloader import resident, vid
+        root = getattr(opts, 'data_root', '.')
+        cfg_path = vid.config_path(opts, root)
+        if os.path.exists(cfg_path):
+            # a sequence that HAS a config must load completely: a missing frame / mask / flow file is an error, not a
+            # reason to train on something else
+            loader, self.n_frames_on_disk = vid.data_loader(opts, root=root)
             if self.device.type == 'cuda':         # prepare every distinct pair once and keep it in HBM
                 one = LASRTrainer.__new__(LASRTrainer)
                 one.opts, one.device = SimpleNamespace(batch_size=1), torch.device('cpu')
                 loader = resident.ResidentLoader(loader, one._set_input_from_loader, self.device)
             self.dataloader = loader
+            if self.rank == 0:
+                print('[lasr_amd] data: sequence "%s" from %s (%d frames)' % (opts.dataname, cfg_path, self.n_frames_on_disk))
             return
-        except FileNotFoundError:
-            pass
+        if opts.dataname not in SYNTHETIC_DATANAMES:
+            raise FileNotFoundError('no %s for --dataname %s; the in-memory synthetic sequence is only used for --dataname %s'
+                                    % (cfg_path, opts.dataname, ' / '.join(sorted(SYNTHETIC_DATANAMES))))
+        if self.rank == 0:
+            print('[lasr_amd] data: in-memory SYNTHETIC sequence (--dataname %s, %d frames): no dataset is read'
+                  % (opts.dataname, opts.n_frames))
         self.sequence = synth_data.SyntheticSequence(self.device, opts.img_size, n_frames=opts.n_frames)
         npairs = len(self.sequence.pairs())
         # an epoch is padded to ~200 iterations per rank (dataloader/vid.py:78-80); pairs are dealt round-robin
@@ -241,22 +256,34 @@ class LASRTrainer:
         if getattr(self, 'manual_dp', False):              # mean of the ranks' gradients, one flat message over RCCL
             from .. import parallel
             parallel.allreduce_grads_([p.grad for p in m.parameters() if p.grad is not None], average=True)
-        cam_grad, finite = [], []
+        self.step_tail()
+        return total_loss.detach(), aux
+
+    def step_tail(self):
+        """What follows backward() in the reference loop (nnutils/train_utils.py:282-296): clip the mean-shape gradient to
+        norm 1 and the encoder / code-predictor gradients (jointly) to norm 10; if ANY gradient holds a NaN, zero every
+        gradient -- zero, not None: AdamW still runs, so the step applies weight decay and the decayed momentum exactly as
+        the reference's `optimizer.zero_grad()` (torch 1.7: in-place zeroing) followed by `optimizer.step()` does; then
+        AdamW and the OneCycle schedule.  The reference tests `isnan` per parameter tensor with a host sync each (~70 per
+        step); here one multi-tensor norm + one sync decides (an Inf gradient is treated like a NaN: it would turn into
+        NaN inside clip_grad_norm_ anyway)."""
+        m = self.module
+        cam_grad, grads = [], []
         for name, p in m.named_parameters():
             if p.grad is None:
                 continue
             if name == 'mean_v':
-                self.grad_meanv_norm = torch.nn.utils.clip_grad_norm_(p, 1.)
+                torch.nn.utils.clip_grad_norm_(p, 1.)
+                self.grad_meanv_norm = p.grad.view(-1).norm(2, -1)           # after clipping, as the reference logs it
             elif 'code_predictor' in name or 'encoder' in name:
                 cam_grad.append(p)
-            finite.append(p.grad)
+            grads.append(p.grad)
         self.grad_cam_norm = torch.nn.utils.clip_grad_norm_(cam_grad, 10.) if cam_grad else None
-        # a NaN/Inf anywhere makes its tensor's norm non-finite: one multi-tensor launch and one sync (reference: ~70)
-        if finite and not bool(torch.isfinite(torch.stack(torch._foreach_norm(finite)).sum())):
-            self.optimizer.zero_grad(set_to_none=not hasattr(self, '_graphs'))
+        self.skipped_nan = bool(grads) and not bool(torch.isfinite(torch.stack(torch._foreach_norm(grads)).sum()))
+        if self.skipped_nan:
+            torch._foreach_zero_(grads)
         self.optimizer.step()
         self.scheduler.step()
-        return total_loss.detach(), aux
 
     def reinit_bones(self):
         """Epoch-0 bone placement by k-means on the mean shape, rank 0 then broadcast (:243-256)."""
@@ -292,7 +319,11 @@ class LASRTrainer:
             for i, pair_ids in enumerate(self.dataloader):
                 m.iters, m.total_steps = i, total_steps
                 loss, aux = self.train_step(self.set_input(pair_ids))
-                self.epoch_nscore += aux['current_nscore'].detach()
+                # the score that ranks the camera hypotheses skips the first 100 iterations of an epoch (pose / scale noise
+                # is injected for 1 < i < 100 and the epoch starts with a transient), nnutils/train_utils.py:345-346.  An
+                # epoch is padded to >= 200 iterations in the reference; shorter epochs (tests, demos) score every iteration.
+                if i > 100 or len(self.dataloader) <= 101:
+                    self.epoch_nscore += aux['current_nscore'].detach()
                 total_steps += 1
             if self.distributed:                              # keep hypothesis selection identical on all ranks
                 dist.all_reduce(self.epoch_nscore)

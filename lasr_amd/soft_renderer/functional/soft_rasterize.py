@@ -20,6 +20,20 @@ _ALPHA = {'hard': 0, 'sum': 1, 'prod': 2}
 _TEX = {'surface': 0, 'vertex': 1}
 
 _workspaces = {}
+_forward_flags = _lib.SR_DEFAULT_FLAGS
+
+
+def set_forward_flags(flags):
+    """Forward-kernel flags the autograd operator passes per call: _lib.SR_DEFAULT_FLAGS (default: whatever
+    lasr_sr_set_forward_math / _variant set process-wide), or 0 / _lib.SR_RELAXED_MATH / _lib.SR_TWO_PHASE combinations
+    (include/lasr_sr.h).  Returns the previous value."""
+    global _forward_flags
+    old, _forward_flags = _forward_flags, int(flags)
+    return old
+
+
+def forward_flags():
+    return _forward_flags
 
 
 def _texels(textures):
@@ -96,21 +110,16 @@ class SoftRasterizeFunction(Function):
             soft_colors = const_tensor(bg, dev).view(1, C + 1, 1, 1).repeat(N, 1, IS, IS)
 
         h = _lib.lib()
+        # The per-face records (176 B per face) built by the forward stay in THIS call's workspace until its backward runs,
+        # which then skips its own setup pass (LASR_SR_RECORDS_VALID); a shared scratch buffer would be overwritten by the
+        # other renders of the step.  The caching allocator makes the per-call buffer free after the first iteration.
+        ws = torch.empty(max(h.lasr_sr_workspace_bytes(N, F, T, IS), 256), dtype=torch.uint8, device=dev)
+        ctx.ws = ws
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
-            if C == 6:
-                rc = h.lasr_sr_forward_attr(fv.data_ptr(), tx.data_ptr(), aggrs_info.data_ptr(), soft_colors.data_ptr(),
-                                            ws.data_ptr(), ws.numel(), N, F, C, IS, *ctx.near_far,
-                                            nf.data_ptr() if nf is not None else None, *tail, stream)
-            elif nf is not None:
-                rc = h.lasr_sr_forward_dev(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
-                                           soft_colors.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS,
-                                           nf.data_ptr(), *tail, stream)
-            else:
-                rc = h.lasr_sr_forward(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(),
-                                       soft_colors.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS,
-                                       *ctx.near_far, *tail, stream)
+            rc = h.lasr_sr_forward_ex(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(), soft_colors.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), N, F, T, C, IS, *ctx.near_far,
+                                      nf.data_ptr() if nf is not None else None, *tail, forward_flags(), stream)
         _lib.check(rc, 'lasr_sr_forward')
         ctx.save_for_backward(fv, tx, soft_colors, aggrs_info)
         ctx.mark_non_differentiable(aggrs_info)
@@ -126,24 +135,13 @@ class SoftRasterizeFunction(Function):
         grad_faces, grad_textures = grads[:N * F * 9].view(N, F, 9), grads[N * F * 9:].view(tx.shape)
         g = grad_soft_colors.contiguous().float()
         h = _lib.lib()
+        ws = ctx.ws
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
-            if C == 6:
-                rc = h.lasr_sr_backward_attr(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), aggrs_info.data_ptr(),
-                                             grad_faces.data_ptr(), grad_textures.data_ptr(), g.data_ptr(),
-                                             ws.data_ptr(), ws.numel(), N, F, C, IS, *ctx.near_far,
-                                             nf.data_ptr() if nf is not None else None, *tail, stream)
-            elif nf is not None:
-                rc = h.lasr_sr_backward_dev(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
-                                            aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
-                                            g.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS, nf.data_ptr(), *tail,
-                                            stream)
-            else:
-                rc = h.lasr_sr_backward(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), None,
-                                        aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(),
-                                        g.data_ptr(), ws.data_ptr(), ws.numel(), N, F, T, IS, *ctx.near_far, *tail,
-                                        stream)
+            rc = h.lasr_sr_backward_ex(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), aggrs_info.data_ptr(),
+                                       grad_faces.data_ptr(), grad_textures.data_ptr(), g.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), N, F, T, C, IS, *ctx.near_far,
+                                       nf.data_ptr() if nf is not None else None, *tail, _lib.SR_RECORDS_VALID, stream)
         _lib.check(rc, 'lasr_sr_backward')
         fshape, tshape = ctx.in_shapes
         return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),
