@@ -42,6 +42,7 @@ MFMA_F32_PEAK_TF = 157.3       # dense fp32-input MFMA peak (same guide)
 IS = 256
 NU = 11                        # mesh M2
 N_FRAMES_CYCLE = 26            # yaw positions ("~26 frames" of BASELINE configs)
+REBUILD_RECORDS = 1
 
 
 def parse():
@@ -52,7 +53,8 @@ def parse():
     ap.add_argument('--frames', type=int, default=256, help='frames per GPU per step (SURVEY 8d batches: 1/16/64/256)')
     ap.add_argument('--image-size', type=int, default=256, help='256 = the headline metric; 512 = BASELINE configs[2] (camel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--forward-variant', type=int, default=None, help='A/B: 0 = one-phase forward kernel, 1 = two-phase (library default)')
+    ap.add_argument('--rebuild-records', type=int, default=1, help='1: the backward rebuilds the per-face records (default), '
+                    '0: it reuses the forward\'s (LASR_SR_RECORDS_VALID)')
     ap.add_argument('--no-lbs', action='store_true', help='skip the LBS (MFMA) micro-benchmark block')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
     return ap.parse_args()
@@ -97,8 +99,8 @@ class RasterStep:
         # the backward finds the forward's per-face records still in the workspace (what the autograd operator does)
         rc = h.lasr_sr_backward_ex(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), self.aggrs.data_ptr(),
                                    self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(), self.ws.data_ptr(),
-                                   self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail, _lib.SR_RECORDS_VALID,
-                                   self.stream)
+                                   self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail,
+                                   0 if REBUILD_RECORDS else _lib.SR_RECORDS_VALID, self.stream)
         _lib.check(rc, 'lasr_sr_backward_ex')
         # face -> vertex gradient scatter (autograd of face_vertices.py:4-22), summed over the rank's frames
         self.mesh_grad.zero_()
@@ -117,19 +119,35 @@ def collect_kernel_times(h):
     return out
 
 
+def host_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread
+    host is often limited to a fraction of it; os.cpu_count() does not see that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota not in ('max', '-1'):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(F):
-    """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload: one warm-up pass,
-    then the median of 5 timed fwd+bwd passes with every host thread (forward parallel over pixels, backward over
-    (image, row band) tasks with per-band gradient slabs folded in band order), and the median of 3 passes of ONE frame
-    on one thread."""
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload.  The OpenMP thread count
+    is calibrated first (one short pass per candidate up to the usable CPUs; oversubscribing a quota-limited container is
+    several times slower than matching it), then one warm-up pass and the median of 5 timed fwd+bwd passes (forward parallel
+    over pixels, backward over (image, row band) tasks with per-band gradient slabs folded in band order), and the median of
+    3 passes of ONE frame on one thread."""
     from oracle import sr_oracle
-    cores = os.cpu_count() or 1
-    n = max(2, min(cores // 4, 64))                 # frames in the all-core sample (bounded: ~10-20 s of wall time in total)
-    bands = max(1, min(IS // 8, -(-2 * cores // n)))   # >= 2 backward tasks per thread
-    fv, ft, near, far = synth.raster_batch(NU, N_FRAMES_CYCLE, count=n)
-    kw = dict(synth.LASR_MODES, near=near, far=far)
-    g = synth.upstream_grad(n, IS)
+    usable = host_cpus()
     sr_oracle.lib()
+    kw = None
 
     def one_pass(fv_, ft_, g_, nb):
         t0 = time.perf_counter()
@@ -137,20 +155,40 @@ def cpu_baseline(F):
         sr_oracle.backward_banded(ref, g_, nb, IS, **kw)
         return time.perf_counter() - t0
 
-    threads = sr_oracle.set_threads(cores)
+    def sample(n):
+        fv, ft, near, far = synth.raster_batch(NU, N_FRAMES_CYCLE, count=n)
+        return fv, ft, synth.upstream_grad(n, IS), dict(synth.LASR_MODES, near=near, far=far)
+
+    # ---- calibration: 4 frames per candidate thread count
+    fv, ft, g, kw = sample(4)
+    cands = sorted({t for t in (4, 8, 16, 32, 64, 128, 256, usable) if t <= usable}) or [1]
+    calib = {}
+    for t in cands:
+        sr_oracle.set_threads(t)
+        one_pass(fv, ft, g, max(1, min(IS // 8, -(-2 * t // 4))))
+        calib[t] = 4 / one_pass(fv, ft, g, max(1, min(IS // 8, -(-2 * t // 4))))
+        if len(calib) > 1 and calib[t] < 0.8 * max(calib.values()):
+            break                                   # past the knee: more threads only get slower
+    threads = max(calib, key=calib.get)
+    # ---- timed passes
+    n = max(4, min(2 * threads, 64))                # bounded sample: a few seconds per pass at most
+    bands = max(1, min(IS // 8, -(-2 * threads // n)))
+    fv, ft, g, kw = sample(n)
+    threads = sr_oracle.set_threads(threads)
     one_pass(fv, ft, g, bands)                      # warm-up (page faults, OpenMP pool)
     t_all = sorted(one_pass(fv, ft, g, bands) for _ in range(5))
     sr_oracle.set_threads(1)
     one_pass(fv[:1], ft[:1], g[:1], 1)
     t_one = sorted(one_pass(fv[:1], ft[:1], g[:1], 1) for _ in range(3))
-    sr_oracle.set_threads(cores)
-    busy = min(threads, n * bands)                  # tasks available to the backward; the forward has n*P >> threads
+    sr_oracle.set_threads(threads)
     return {'value': n / t_all[2], 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'threads_busy_backward': busy, 'one_thread_frames_per_s': 1.0 / t_one[1],
+            'host_logical_cpus': os.cpu_count(), 'usable_cpus': usable,
+            'threads_busy_backward': min(threads, n * bands), 'one_thread_frames_per_s': 1.0 / t_one[1],
+            'thread_calibration_frames_per_s': {str(k): round(v, 2) for k, v in calib.items()},
             'passes_s': [round(t, 4) for t in t_all],
-            'sample': '%d frames fwd+bwd of the same M2 %dx%d workload: 1 warm-up + median of 5 passes, %d OpenMP threads '
-                      '(backward: %d image x row-band tasks); 1-thread figure: median of 3 passes of 1 frame'
-                      % (n, IS, IS, threads, n * bands)}
+            'sample': '%d frames fwd+bwd of the same M2 %dx%d workload: 1 warm-up + median of 5 passes with %d OpenMP threads '
+                      '(the fastest of the calibrated counts; backward: %d image x row-band tasks); 1-thread figure: median of '
+                      '3 passes of 1 frame' % (n, IS, IS, threads, n * bands)}
 
 
 def lbs_leg(dev):
@@ -231,9 +269,10 @@ def measured_traffic(kernel, frames_per_launch):
 
 
 def main():
-    global IS
+    global IS, REBUILD_RECORDS
     a = parse()
     IS = a.image_size
+    REBUILD_RECORDS = a.rebuild_records
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -269,8 +308,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if a.forward_variant is not None:
-        _lib.check(_lib.lib().lasr_sr_set_forward_variant(a.forward_variant), 'lasr_sr_set_forward_variant')
     B = a.frames
     # frames shard across ranks: rank r renders yaw positions r*B .. r*B+B-1 of the cycle (weak scaling)
     job = RasterStep(dev, B, first_frame=rank * B)

@@ -6,8 +6,10 @@ which also renders visualisations with pyrender / matplotlib -- not reproduced).
                       --nosymmetric --checkpoint_dir log/ --name spot3-1
 
 For frame i of the sequence it writes <checkpoint_dir>/<name>/pred<i>.obj (articulated shape in camera space, the frame
-the reference's scripts/eval_mesh.py evaluates: eval_mesh.py:106-109) and cam<i>.txt (3x3 root rotation, translation,
-focal scale, principal point).  The flags are optimize.py's; the model is rebuilt as that stage built it and the checkpoint
+the reference's scripts/eval_mesh.py evaluates: eval_mesh.py:106-109) and cam<i>.txt in the layout of the reference's
+extract.py:123-130: np.savetxt of the 4x4 array [[R | T] (3x4, root body-to-camera transform); [fx, fy, ppx, ppy]] with
+the intrinsics expressed in the uncropped image (nnutils/predictor.py:188-189).  The reference additionally writes bone /
+skinning-Gaussian .ply files and novel-view renders for its visualisation scripts; those are not produced.  The flags are optimize.py's; the model is rebuilt as that stage built it and the checkpoint
 is loaded as is (no re-meshing, no hypothesis selection beyond picking the best one for the export).
 """
 import os
@@ -40,11 +42,15 @@ def export(tr, out_dir):
             tr.model(bi)
             ids = bi['frameid'].view(-1, 2).t().reshape(-1)  # undo the pair interleave
             verts = m.verts_cam.view(len(ids), H, -1, 3)[:, best]
+            cam = {k: v.view(len(ids), H, *v.shape[1:])[:, best].cpu().numpy() for k, v in m.cam_export.items()}
             for k, fid in enumerate(int(v) for v in ids.tolist()):
                 if fid in done:
                     continue
                 path = os.path.join(out_dir, 'pred%d.obj' % fid)
                 save_obj(path, verts[k].cpu(), m.faces.cpu())
+                rtk = np.concatenate([np.concatenate([cam['R'][k], cam['T'][k][:, None]], 1),
+                                      np.concatenate([cam['focal'][k], cam['pp'][k]])[None]], 0)
+                np.savetxt(os.path.join(out_dir, 'cam%d.txt' % fid), rtk)
                 done[fid] = path
             if len(done) >= n_frames:
                 break

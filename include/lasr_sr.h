@@ -127,15 +127,14 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
 /*
  * Supersets of the entry points above with every option as an argument (no reference counterpart).  channels = 3 or 6 (6 as
  * for the *_attr variants); near_far_dev: NULL or a device pointer to {near, far} that overrides near / far.
- * forward flags  : LASR_SR_RELAXED_MATH, LASR_SR_TWO_PHASE (the per-call forms of lasr_sr_set_forward_math / _variant below).
+ * forward flags  : LASR_SR_RELAXED_MATH (the per-call form of lasr_sr_set_forward_math below), or LASR_SR_DEFAULT_FLAGS.
  * backward flags : LASR_SR_RECORDS_VALID -- the caller vouches that `workspace` still holds the per-face records the forward
  *                  pass of the SAME faces / N / F / IS / sigma_val / dist_eps left there (nothing else was run on that
  *                  workspace in between); the backward then skips its own setup launch.  Without the flag every backward
  *                  call rebuilds the records, so the plain entry points stay safe for callers that share one workspace.
  */
-#define LASR_SR_DEFAULT_FLAGS (-1)   /* forward only: use the process-wide defaults of the two setters below */
+#define LASR_SR_DEFAULT_FLAGS (-1)   /* forward only: use the process-wide default of lasr_sr_set_forward_math */
 #define LASR_SR_RELAXED_MATH  1
-#define LASR_SR_TWO_PHASE     2
 #define LASR_SR_RECORDS_VALID 4
 int lasr_sr_forward_ex(const float* faces, const float* textures, float* faces_info, float* aggrs_info, float* soft_colors,
                        void* workspace, size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near,
@@ -169,13 +168,6 @@ int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launch
  * within ~3e-5 of mode 0 (the north-star bar is 1e-4).  Other mode combinations and the backward pass are unaffected.
  */
 int lasr_sr_set_forward_math(int mode);
-
-/*
- * Forward kernel used for LASR's mode combination, process-wide default (no reference counterpart; an A/B switch for
- * benchmarks and tests).  0 (default): the one-phase tile walk.  1: the two-phase kernel (cheap pixel-major classification -> dense face-gathering batches ->
- * per-pixel fold in face order, lasr_amd/csrc/sr_forward2.h; measured slower, profiles/experiments/).  Same bits.
- */
-int lasr_sr_set_forward_variant(int variant);
 
 /*
  * Test hook (no reference counterpart): adds to *mismatches the number of pairs for which the library's

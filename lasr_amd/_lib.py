@@ -62,7 +62,6 @@ SIGNATURES = {
     'lasr_sr_forward_ex': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
     'lasr_sr_backward_ex': (_i, [_p] * 8 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
     'lasr_sr_set_forward_math': (_i, [_i]),
-    'lasr_sr_set_forward_variant': (_i, [_i]),
     'lasr_selftest_div': (_i, [_p, _p, _p, _i, _p]),
     'lasr_selftest_div3': (_i, [_p, _p, _p, _i, _p]),
     'lasr_prof_enable': (_i, [_i]),
@@ -72,7 +71,7 @@ SIGNATURES = {
 }
 
 # flags of the *_ex entry points (include/lasr_sr.h)
-SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_TWO_PHASE, SR_RECORDS_VALID = -1, 1, 2, 4
+SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_RECORDS_VALID = -1, 1, 4
 
 _lib = None
 

@@ -1,0 +1,249 @@
+// sr_backward.h -- the face-major backward raster kernel (template).  Two translation units instantiate it:
+//   sr_raster.hip        <false, 3>  every mode combination, compiled like the forward pass with -ffp-contract=off (the
+//                                    surface-texture path picks texels from (int)(w * res) and must see the forward's w);
+//   sr_backward_fast.hip <true, 3|6> LASR's mode combination (vertex attributes), compiled with -ffp-contract=fast: the
+//                                    reference's own backward is only defined up to float-atomic ordering (bar: 1e-3 of the
+//                                    largest gradient), so multiply-add pairs may fuse -- the kernel is VALU-issue bound and
+//                                    without contraction 672 M of its 1131 M VALU instructions per 256 frames are lone
+//                                    v_mul_f32 / v_add_f32 (profiles/r02c_v0_pmc.txt).
+#pragma once
+#include "sr_common.h"
+
+namespace lasr {
+
+// ---------------------------------------------------------------------------
+// Backward: one wave per (image, face); K.cu:486-668 evaluated face-major, in two stages.
+//   stage 1 (cheap, 64 bbox pixels per round): exact bbox test + barycentrics + the conservative
+//            line-distance reject; survivors are compacted (ballot + prefix) into a per-wave LDS ring.
+//   stage 2 (heavy, runs whenever 64 survivors are queued): full fragment + gradient math on dense lanes.
+// Roughly half of the bbox pixels of a face are farther than sqrt(threshold) from it; without the
+// compaction they would idle through the heavy code.  The heavy code uses v_rcp/v_exp based math
+// (FM = true): the reference backward is itself only defined up to float-atomic ordering.
+constexpr bool BWD_FM = true;
+constexpr int QCAP = 128;   // ring entries per wave (power of two, >= 2 * 64)
+
+template <bool LASR_FAST, int NCH>
+__global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
+                                                          const float* __restrict__ aggrs,
+                                                          const float* __restrict__ gcolors,
+                                                          float* __restrict__ gfaces, float* __restrict__ gtex)
+{
+    __shared__ unsigned int s_ring[4][QCAP];
+    constexpr bool FM = BWD_FM;
+    const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
+    if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
+    const int lane = threadIdx.x & 63;
+    unsigned int* ring = s_ring[threadIdx.x >> 6];
+    // blocks of one image stay on one XCD (block b runs on XCD b % 8): its 10 pixel planes (2.6 MB at 256x256) then
+    // live in a single 4 MB L2 instead of being fetched by all eight
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int gw = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
+    if (gw >= A.N * A.F) return;
+    const int bn = gw / A.F, fn = gw - bn * A.F;
+    const int IS = A.IS, P = IS * IS;
+    const cptr_t rec = as_const(A.recs + (size_t)gw * REC);
+    const cptr_t tex = as_const(A.textures + (size_t)gw * A.T * NCH);
+    const short4 rc4 = A.rects[gw];
+    const int flags = __float_as_int(rec[R_FLAGS]);
+
+    // exact pixel rectangle of the bbox test (columns x0..x1, rows r0..r1 from the top); empty when x0 > x1
+    const int x0 = rc4.x, x1 = rc4.y, r0 = rc4.z, r1 = rc4.w;
+    const int bw = x1 - x0 + 1, bh = r1 - r0 + 1;
+    const bool empty = !(bw > 0 && bh > 0);
+    const int npx = empty ? 0 : bw * bh;
+
+    float gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2)
+    float gt[18];                                // vertex attributes: [vertex j][channel k] at NCH*j + k (3*NCH used)
+#pragma unroll
+    for (int k = 0; k < 18; k++) gt[k] = 0.f;
+    const bool front = (flags & 8) != 0;
+    const bool vertex_tex = (m.tex == 1);
+    const int lim = (A.N * A.F - gw) * A.T;      // texels from this face to the end of the tensor
+    // cheap reject only for the soft distance modes and well-conditioned faces; 2 % slack on thr
+    const bool use_far = (m.dist == 2) && (flags & 16);
+    const float thr_pad = A.thr * 1.05f;
+    const float inv_is = 1.f / (float)IS;
+    const bool pow2 = (IS & (IS - 1)) == 0;      // then n * (1/IS) == n / IS exactly: skip the division per pixel
+
+    // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
+    int r = 0, c = 0;
+    const int dr = empty ? 0 : 64 / bw, dc = empty ? 0 : 64 - dr * bw;
+    if (!empty) { r = lane / bw; c = lane - r * bw; }
+
+    int head = 0, tail = 0, base = 0;            // wave-uniform ring state
+    while (true) {
+        if (base < npx) {
+            // ---------------- stage 1
+            const int xi = x0 + c, row = r0 + r;
+            const bool in_range = base + lane < npx;
+            c += dc; r += dr;
+            if (c >= bw) { c -= bw; r += 1; }
+            base += 64;
+            bool keep = in_range;                              // every pixel of the rect passes the bbox test
+            if (in_range && use_far) {
+                float w0, w1, w2;
+                barycentric(rec, pix_center_p2(xi, IS, inv_is, pow2), pix_center_p2(IS - 1 - row, IS, inv_is, pow2), w0, w1, w2);
+                keep = !certainly_far(rec, w0, w1, w2, thr_pad);
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (keep) ring[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (unsigned)xi | ((unsigned)row << 16);
+            tail += __popcll(mask);
+        }
+        const int avail = tail - head;
+        if (!(avail >= 64 || (base >= npx && avail > 0))) {
+            if (base >= npx) break;
+            continue;
+        }
+        // ---------------- stage 2 on up to 64 queued pixels
+        __builtin_amdgcn_wave_barrier();
+        const bool active = lane < avail;
+        const unsigned int packed = ring[(head + lane) & (QCAP - 1)];
+        head += min(avail, 64);
+        if (!active) continue;
+        const int xi = packed & 0xffff, row = packed >> 16;
+        const int pn = row * IS + xi;
+        const float xp = pix_center_p2(xi, IS, inv_is, pow2), yp = pix_center_p2(IS - 1 - row, IS, inv_is, pow2);
+
+        float w0, w1, w2;
+        Frag fr;
+        if (!fragment<FM>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+        const float D = fr.D;
+
+        // alpha path (K.cu:583-593); hard alpha: the reference still adds g_alpha into C
+        float Ca = gcolors[((size_t)bn * (NCH + 1) + NCH) * P + pn];
+        if (m.alpha == 1) Ca = div_<FM>(Ca, (float)A.F);
+        else if (m.alpha == 2) {
+            const float a_out = colors[((size_t)bn * (NCH + 1) + NCH) * P + pn];
+            Ca *= div_<FM>(1 - a_out, fmaxf(1 - D, 1e-6f));
+        }
+        float C = Ca;
+
+        const float u0 = w0, u1 = w1, u2 = w2;       // unclipped barycentrics (w0 of K.cu:596)
+        // surface sampling picks a texel from (int)(w * res): keep the exact division there
+        if (vertex_tex) clip_normalise<FM>(w0, w1, w2); else clip_normalise<false>(w0, w1, w2);
+        const float zp = depth_at<FM>(rec, w0, w1, w2);
+        {   // K.cu:599: no gradient at all for a fragment the forward pass depth-culled.  The fast-math depth decides unless it
+            // lies within 1e-4 relative of a plane; then the forward's own arithmetic is re-run so both passes agree.
+            float zc = zp;
+            const float tol = 1e-4f * fabsf(zp);
+            if (fabsf(zp - A.near) <= tol || fabsf(zp - A.far) <= tol) zc = depth_forward_exact(rec, xp, yp);
+            if (zc < A.near || zc > A.far) continue;
+        }
+
+        float gz0 = 0, gz1 = 0, gz2 = 0;
+        if (m.rgb == 0) {
+            if ((float)fn == aggrs[((size_t)bn * 2 + 1) * P + pn]) {       // K.cu:603
+                float g[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; k++) g[k] = gcolors[((size_t)bn * (NCH + 1) + k) * P + pn];
+                if (vertex_tex) {
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) {
+                        gt[k] += w0 * g[k]; gt[NCH + k] += w1 * g[k]; gt[2 * NCH + k] += w2 * g[k];
+                    }
+                } else {
+                    const int j = surface_texel(w0, w1, A.res);
+                    if (j >= 0 && j < A.T) {   // the reference only credits texels j < T (K.cu:605)
+                        float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
+                        atomicAdd(gtp + 0, g[0]); atomicAdd(gtp + 1, g[1]); atomicAdd(gtp + 2, g[2]);
+                    }
+                }
+            }
+        } else if (front || m.double_side) {                                 // K.cu:611-640
+            const float ssum = aggrs[((size_t)bn * 2 + 0) * P + pn];
+            const float smax = aggrs[((size_t)bn * 2 + 1) * P + pn];
+            const float zn = div_<FM>(A.far - zp, A.far - A.near);
+            const float sm = div_<FM>(D * exp_<FM>(div_<FM>(zn - smax, A.gamma)), ssum);
+            float g[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) g[k] = gcolors[((size_t)bn * (NCH + 1) + k) * P + pn];
+            if (vertex_tex) {
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+                    gt[k] += sm * (w0 * g[k]); gt[NCH + k] += sm * (w1 * g[k]); gt[2 * NCH + k] += sm * (w2 * g[k]);
+                }
+            } else {
+                const int j = surface_texel(w0, w1, A.res);
+                if (j >= 0 && j < A.T) {       // K.cu:620
+                    float* gtp = gtex + (size_t)gw * A.T * 3 + 3 * j;
+                    atomicAdd(gtp + 0, sm * g[0]); atomicAdd(gtp + 1, sm * g[1]); atomicAdd(gtp + 2, sm * g[2]);
+                }
+            }
+            float Crgb = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; k++)
+                Crgb += g[k] * (sample_colour(tex, w0, w1, w2, A.res, k, m.tex, lim, NCH) -
+                                colors[((size_t)bn * (NCH + 1) + k) * P + pn]);
+            Crgb *= sm;
+            C += div_<FM>(Crgb, D);
+            const float Cz = div_<FM>(div_<FM>(Crgb, A.gamma), A.near - A.far) * zp * zp;
+            const float iz0 = __builtin_amdgcn_rcpf(rec[2]), iz1 = __builtin_amdgcn_rcpf(rec[5]), iz2 = __builtin_amdgcn_rcpf(rec[8]);
+            gz0 = Cz * w0 * iz0 * iz0;
+            gz1 = Cz * w1 * iz1 * iz1;
+            gz2 = Cz * w2 * iz2 * iz2;
+        }
+
+        C *= div_<FM>(D * (1 - D), A.sigma);                                  // K.cu:644
+        float gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0, gx2 = 0, gy2 = 0;
+        if (m.dist == 1) {                                                    // K.cu:161-175
+            const float t0 = fr.t0, t1 = fr.t1, t2 = fr.t2;
+            const int p = t0 > t1 ? (t1 > t2 ? 2 : 1) : (t0 > t2 ? 2 : 0);
+            const float ipx = rec[R_INV + 3 * p + 0], ipy = rec[R_INV + 3 * p + 1];   // divergent gather: cold path
+            const float dis = fr.dis;
+            const float sc = 2.f * sqrtf(fabsf(dis));
+            float gxy[3][2];
+#pragma unroll
+            for (int l = 0; l < 2; l++) {
+                const float ipl = l == 0 ? ipx : ipy;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float acc = 0.f;
+                    acc += -ipl * rec[R_INV + 3 * k + 0] * xp;
+                    acc += -ipl * rec[R_INV + 3 * k + 1] * yp;
+                    acc += -ipl * rec[R_INV + 3 * k + 2] * 1.f;
+                    gxy[k][l] = acc * C * sc;
+                }
+            }
+            gx0 = gxy[0][0]; gy0 = gxy[0][1]; gx1 = gxy[1][0]; gy1 = gxy[1][1]; gx2 = gxy[2][0]; gy2 = gxy[2][1];
+        } else if (m.dist == 2) {                                             // K.cu:649-655
+            const float k2 = 2 * fr.sign * C;
+            gx0 = k2 * (fr.t0 + u0) * fr.dx; gy0 = k2 * (fr.t0 + u0) * fr.dy;
+            gx1 = k2 * (fr.t1 + u1) * fr.dx; gy1 = k2 * (fr.t1 + u1) * fr.dy;
+            gx2 = k2 * (fr.t2 + u2) * fr.dx; gy2 = k2 * (fr.t2 + u2) * fr.dy;
+        }
+        gv[0] += gx0; gv[1] += gy0; gv[2] += gz0;
+        gv[3] += gx1; gv[4] += gy1; gv[5] += gz1;
+        gv[6] += gx2; gv[7] += gy2; gv[8] += gz2;
+    }
+
+    // one wave reduction per face (sr_device.h: wave_reduce18), then a plain, non-atomic accumulate: this wave
+    // owns the face.  Lanes 15/31/47/63 each end up with the totals of up to five components.
+    float v18[18], red[5];
+    const int lane_row = lane >> 4;
+    const int sub = lane_row == 0 ? 0 : lane_row == 1 ? 2 : lane_row == 2 ? 1 : 3;   // component offset inside a register
+    float* gf = gfaces + (size_t)gw * 9;
+    float* gtp = gtex + (size_t)gw * 3 * NCH;
+    // pass 0: 9 face components + the first 9 attribute components; pass 1 (NCH = 6 only): attribute components 9..17
+#pragma unroll
+    for (int pass = 0; pass < (NCH == 6 ? 2 : 1); pass++) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            v18[k] = pass == 0 ? gv[k] : (vertex_tex ? gt[9 + k] : 0.f);
+            v18[9 + k] = pass == 0 ? (vertex_tex ? gt[k] : 0.f) : 0.f;
+        }
+        wave_reduce18(v18, red);
+        if ((lane & 15) == 15) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (i == 4 && (lane_row & 1)) continue;                          // register 4 only carries v[16], v[17]
+                const int comp = i == 4 ? 16 + (lane_row >> 1) : 4 * i + sub;
+                if (pass == 0) {
+                    if (comp < 9) gf[comp] += red[i];
+                    else if (vertex_tex) gtp[comp - 9] += red[i];
+                } else if (comp < 9 && vertex_tex) gtp[9 + comp] += red[i];
+            }
+        }
+    }
+}
+
+}  // namespace lasr

@@ -1,0 +1,28 @@
+// sr_common.h -- what the raster translation units share: the kernel argument block and the block -> work mapping.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sr_device.h"
+
+namespace lasr {
+
+struct RasterArgs {
+    const float* __restrict__ recs;      // [N*F, REC]
+    const short4* __restrict__ rects;    // [N*F] exact pixel rectangle (x0,x1,row0,row1) of the bbox test
+    const float* __restrict__ textures;  // [N,F,T,3]
+    int N, F, T, res, IS;
+    float near, far, eps, sigma, gamma, thr;
+    const float* __restrict__ near_far_dev;   // optional: {near, far} read on the device (no host sync)
+    Modes m;
+};
+
+// Block -> (image, tile) with all tiles of an image kept on one XCD (block b runs
+// on XCD b % 8; an image's records are then fetched into a single L2).
+__device__ __forceinline__ int xcd_remap(int b, int total)
+{
+    const int per = total >> 3;
+    if ((total & 7) == 0) return (b & 7) * per + (b >> 3);
+    return b;
+}
+
+}  // namespace lasr

@@ -271,6 +271,11 @@ template <int K, bool CLAMP, bool FM = false, bool MK = false, typename RP = cpt
 __device__ __forceinline__ void edge_project(RP rec, float w0, float w1, float w2,
                                              float& u0, float& u1, float& u2)
 {
+    // The reference's point-to-face distance is ill-conditioned on edge-on faces (a fused multiply-add in `num` moves the
+    // result by percents there), and the backward pass must re-derive the SAME distance the forward pass turned into D.  So
+    // this arithmetic is pinned to separate multiplies and adds in every translation unit; sr_backward_fast.hip
+    // (-ffp-contract=fast-honor-pragmas) fuses only the well-conditioned gradient arithmetic around it.
+#pragma clang fp contract(off)
     constexpr int B = (K + 1) % 3;
     const float e0 = rec[R_E + 3 * K + 0], e1 = rec[R_E + 3 * K + 1], e2 = rec[R_E + 3 * K + 2];
     const float eb = rec[R_E + 3 * K + B];
@@ -299,6 +304,7 @@ template <bool FM = false, bool MK = false, typename RP = cptr_t>
 __device__ __forceinline__ void euclid(RP rec, float xp, float yp,
                                        float w0, float w1, float w2, Frag& fr)
 {
+#pragma clang fp contract(off)   // see edge_project
     const float x0 = rec[0], y0 = rec[1], x1 = rec[3], y1 = rec[4], x2 = rec[6], y2 = rec[7];
     if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
         float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
@@ -344,6 +350,7 @@ __device__ __forceinline__ void euclid(RP rec, float xp, float yp,
 template <typename RP>
 __device__ __forceinline__ void barycentric(RP rec, float xp, float yp, float& w0, float& w1, float& w2)
 {
+#pragma clang fp contract(off)   // distance code: never fused, also in the contracted backward unit (see edge_project)
     w0 = rec[R_INV + 0] * xp + rec[R_INV + 1] * yp + rec[R_INV + 2];   // K.cu:24-29
     w1 = rec[R_INV + 3] * xp + rec[R_INV + 4] * yp + rec[R_INV + 5];
     w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
@@ -366,6 +373,7 @@ template <bool FM, bool MK, typename RP>
 __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float sigma,
                                            float xp, float yp, float w0, float w1, float w2, Frag& fr, float inv_sigma)
 {
+#pragma clang fp contract(off)   // see edge_project
     if (dist == 0) {
         if (!inside_closed(w0, w1, w2)) return false;
         fr.D = 1.f;
@@ -393,6 +401,25 @@ __device__ __forceinline__ float depth_at(RP rec, float c0, float c1, float c2)
         return 1.f / (div_by_recip(c0, rec[2], rec[R_IZ + 0]) + div_by_recip(c1, rec[5], rec[R_IZ + 1]) +
                       div_by_recip(c2, rec[8], rec[R_IZ + 2]));
     return div_<FM>(1.f, div_<FM>(c0, rec[2]) + div_<FM>(c1, rec[5]) + div_<FM>(c2, rec[8]));
+}
+
+// The forward pass's depth of a pixel on a face, bit for bit (barycentrics K.cu:24-29, clip/normalise :53-58, depth :423),
+// whatever contraction setting the including translation unit uses.  The backward pass evaluates it only for fragments whose
+// fast-math depth falls within rounding distance of the near / far planes, so that "this fragment was depth-culled in the
+// forward pass" (K.cu:424 / :599: no gradient at all) is decided from the same number in both passes.
+template <typename RP>
+__device__ __forceinline__ float depth_forward_exact(RP rec, float xp, float yp)
+{
+#pragma clang fp contract(off)
+    float w0 = rec[R_INV + 0] * xp + rec[R_INV + 1] * yp + rec[R_INV + 2];
+    float w1 = rec[R_INV + 3] * xp + rec[R_INV + 4] * yp + rec[R_INV + 5];
+    float w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
+    w0 = fmaxf(fminf(w0, 1.f), 0.f);
+    w1 = fmaxf(fminf(w1, 1.f), 0.f);
+    w2 = fmaxf(fminf(w2, 1.f), 0.f);
+    const float s = fmaxf(w0 + w1 + w2, 1e-5f);
+    w0 = w0 / s; w1 = w1 / s; w2 = w2 / s;                  // == div3_shared (bit-identical quotients, self-tested)
+    return 1.f / (w0 / rec[2] + w1 / rec[5] + w2 / rec[8]);  // == the reciprocal forms of depth_at (correctly rounded)
 }
 
 // texel index a surface sample lands in (K.cu:181-188 == 200-211).  A clipped barycentric

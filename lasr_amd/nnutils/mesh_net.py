@@ -130,6 +130,39 @@ class ResNetConv(nn.Module):
         return x
 
 
+def map_resnet_key(key):
+    """torchvision / reference names of the ResNet-18 trunk -> this module's names, or None if the key is not a trunk
+    tensor.  torchvision: 'layer2.0.downsample.1.weight'; reference checkpoints: 'encoder.resnet_conv.resnet.layer2...'
+    (net_blocks.py:291-313 wraps torchvision.models.resnet18 as `self.resnet`); here: 'layers.1.0.downsample.1.weight'."""
+    for prefix in ('encoder.resnet_conv.resnet.', 'resnet_conv.resnet.', 'resnet.', 'module.', ''):
+        if key.startswith(prefix):
+            k = key[len(prefix):]
+            break
+    head = k.split('.')[0]
+    if head in ('conv1', 'bn1'):
+        return k
+    if head.startswith('layer') and head[5:].isdigit() and 1 <= int(head[5:]) <= 4:
+        return 'layers.%d.%s' % (int(head[5:]) - 1, k.split('.', 1)[1])
+    return None                                            # fc.*, avgpool, anything else
+
+
+def load_resnet18_weights(trunk, path):
+    """Load a local torchvision resnet18 state_dict (or any checkpoint holding one, e.g. a reference LASR .pth) into a
+    ResNetConv.  Returns the number of tensors loaded; raises if the file holds none that fit."""
+    states = torch.load(path, map_location='cpu')
+    states = states.get('state_dict', states) if isinstance(states, dict) else states
+    own = trunk.state_dict()
+    picked = {}
+    for k, v in states.items():
+        m = map_resnet_key(k)
+        if m in own and torch.is_tensor(v) and own[m].shape == v.shape:
+            picked[m] = v
+    if not picked:
+        raise ValueError('%s holds no ResNet-18 trunk tensors' % path)
+    trunk.load_state_dict(picked, strict=False)
+    return len(picked)
+
+
 def _fc_stack(nc_in, nc_out, n):
     mods = []
     for _ in range(n):
@@ -241,6 +274,26 @@ class PerceptualDistance(nn.Module):
             p_.requires_grad_(False)
         self.register_buffer('shift', torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1))
         self.register_buffer('scale', torch.tensor([.458, .448, .450]).view(1, 3, 1, 1))
+
+    def load_weights(self, path):
+        """AlexNet convolution weights from a local state_dict: torchvision alexnet ('features.{0,3,6,8,10}.weight'), or the
+        LPIPS 'alex' network of third_party/PerceptualSimilarity ('net.slice{1..5}.{0,3,6,8,10}.weight').  The reference's
+        perceptual term is the unweighted cosine distance of these five feature maps (networks_basic.py:42-64)."""
+        states = torch.load(path, map_location='cpu')
+        states = states.get('state_dict', states) if isinstance(states, dict) else states
+        index = {'0': 0, '3': 1, '6': 2, '8': 3, '10': 4}
+        n = 0
+        for k, v in states.items():
+            parts = k.split('.')
+            if len(parts) >= 2 and parts[-1] in ('weight', 'bias') and parts[-2] in index and torch.is_tensor(v):
+                tgt = getattr(self.convs[index[parts[-2]]], parts[-1])
+                if tgt.shape == v.shape:
+                    tgt.data.copy_(v)
+                    n += 1
+        if n != 10:
+            raise ValueError('%s: expected the 5 AlexNet convolutions (10 tensors), found %d that fit' % (path, n))
+        self.pretrained = True
+        return n
 
     def _feats(self, x):
         x = (x - self.shift) / self.scale
@@ -501,6 +554,12 @@ class LASR(MeshNet):
         # ---- 1) flow rendering (:298-335)
         verts_cam = obj_to_cam(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
         self.verts_cam = verts_cam.detach()                                      # per-frame shape in camera space (export)
+        with torch.no_grad():                                                    # root camera per (image, hypothesis) (export):
+            half = IS / 2.                                                       # intrinsics back in the UNcropped image as
+            self.cam_export = dict(                                              # extract.py / nnutils/predictor.py:188-189
+                R=Rmat.reshape(n2 * H, K, 3, 3)[:, 0], T=Tmat.reshape(n2 * H, K, 3)[:, 0],
+                focal=(scale / self.cams[:, :1] * half)[:, :, None].repeat(1, 1, 2).reshape(n2 * H, 2),
+                pp=((ppoint + 1) * half / self.cams[:, :1] + self.pp)[:, None].repeat(1, H, 1).reshape(n2 * H, 2))
         verts_fl = torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1)
         # halves of the batch through unbind / chunk: one stack in the backward pass instead of zeros + copy per slice
         verts_pos0, verts_pos1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)

@@ -8,6 +8,7 @@ Differences, all behind the same calls:
   * k-means bone initialisation (:243-251, kmeans_pytorch) is a small Lloyd iteration with farthest-point seeding.
 """
 import os
+import sys
 from types import SimpleNamespace
 
 import torch
@@ -57,6 +58,13 @@ class LASRTrainer:
     def define_model(self):
         opts = self.opts
         self.model = mesh_net.LASR((opts.img_size, opts.img_size), opts, nz_feat=opts.nz_feat)
+        if getattr(opts, 'encoder_weights', ''):
+            n = mesh_net.load_resnet18_weights(self.model.encoder.resnet_conv, opts.encoder_weights)
+            if self.rank == 0:
+                print('[lasr_amd] encoder: %d ResNet-18 tensors from %s' % (n, opts.encoder_weights), file=sys.stderr)
+        elif self.rank == 0 and opts.model_path == '':
+            print('[lasr_amd] encoder: ResNet-18 trunk is RANDOMLY initialised (the reference starts from ImageNet weights; '
+                  'pass --encoder_weights <local resnet18 state_dict>)', file=sys.stderr)
         if opts.model_path != '':
             self.load_network(self.model, model_path=opts.model_path)
         self.model = nn.SyncBatchNorm.convert_sync_batchnorm(self.model).to(self.device)
@@ -84,6 +92,13 @@ class LASRTrainer:
         m.arap_loss_fn = loss_utils.ARAPLoss(mean_v[0].cpu(), faces[0].cpu()).to(self.device)
         m.flatten_loss = loss_utils.FlattenLoss(faces[0].cpu()).to(self.device)
         m.ptex_loss = mesh_net.PerceptualDistance().to(self.device) if self.opts.perceptual else None
+        if m.ptex_loss is not None:
+            if getattr(self.opts, 'alexnet_weights', ''):
+                m.ptex_loss.load_weights(self.opts.alexnet_weights)
+                m.ptex_loss.to(self.device)
+            elif self.rank == 0:
+                print('[lasr_amd] perceptual term: AlexNet features are RANDOM (frozen); the reference uses ImageNet weights -- '
+                      'pass --alexnet_weights <local alexnet state_dict> or --noperceptual', file=sys.stderr)
 
     # ---- data -------------------------------------------------------------------------------
     def init_dataset(self):
@@ -104,14 +119,15 @@ class LASRTrainer:
                 loader = resident.ResidentLoader(loader, one._set_input_from_loader, self.device)
             self.dataloader = loader
             if self.rank == 0:
-                print('[lasr_amd] data: sequence "%s" from %s (%d frames)' % (opts.dataname, cfg_path, self.n_frames_on_disk))
+                print('[lasr_amd] data: sequence "%s" from %s (%d frames)' % (opts.dataname, cfg_path, self.n_frames_on_disk),
+                      file=sys.stderr)
             return
         if opts.dataname not in SYNTHETIC_DATANAMES:
             raise FileNotFoundError('no %s for --dataname %s; the in-memory synthetic sequence is only used for --dataname %s'
                                     % (cfg_path, opts.dataname, ' / '.join(sorted(SYNTHETIC_DATANAMES))))
         if self.rank == 0:
             print('[lasr_amd] data: in-memory SYNTHETIC sequence (--dataname %s, %d frames): no dataset is read'
-                  % (opts.dataname, opts.n_frames))
+                  % (opts.dataname, opts.n_frames), file=sys.stderr)
         self.sequence = synth_data.SyntheticSequence(self.device, opts.img_size, n_frames=opts.n_frames)
         npairs = len(self.sequence.pairs())
         # an epoch is padded to ~200 iterations per rank (dataloader/vid.py:78-80); pairs are dealt round-robin
@@ -420,5 +436,10 @@ class LASRTrainer:
                 states['ctl_rs'] = network.ctl_rs.data.cpu()
                 states['log_ctl'] = network.log_ctl.data.cpu()
         own = network.state_dict()
+        for k in list(states):                                 # reference checkpoints name the trunk encoder.resnet_conv.resnet.layerN.*
+            if k.startswith('encoder.resnet_conv.') and k not in own:
+                mapped = mesh_net.map_resnet_key(k)
+                if mapped is not None:
+                    states['encoder.resnet_conv.' + mapped] = states.pop(k)
         network.load_state_dict({k: v for k, v in states.items()
                                  if k in own and torch.is_tensor(v) and own[k].shape == v.shape}, strict=False)

@@ -25,7 +25,7 @@ _forward_flags = _lib.SR_DEFAULT_FLAGS
 
 def set_forward_flags(flags):
     """Forward-kernel flags the autograd operator passes per call: _lib.SR_DEFAULT_FLAGS (default: whatever
-    lasr_sr_set_forward_math / _variant set process-wide), or 0 / _lib.SR_RELAXED_MATH / _lib.SR_TWO_PHASE combinations
+    lasr_sr_set_forward_math set process-wide), 0 or _lib.SR_RELAXED_MATH
     (include/lasr_sr.h).  Returns the previous value."""
     global _forward_flags
     old, _forward_flags = _forward_flags, int(flags)
@@ -110,13 +110,13 @@ class SoftRasterizeFunction(Function):
             soft_colors = const_tensor(bg, dev).view(1, C + 1, 1, 1).repeat(N, 1, IS, IS)
 
         h = _lib.lib()
-        # The per-face records (176 B per face) built by the forward stay in THIS call's workspace until its backward runs,
-        # which then skips its own setup pass (LASR_SR_RECORDS_VALID); a shared scratch buffer would be overwritten by the
-        # other renders of the step.  The caching allocator makes the per-call buffer free after the first iteration.
-        ws = torch.empty(max(h.lasr_sr_workspace_bytes(N, F, T, IS), 256), dtype=torch.uint8, device=dev)
-        ctx.ws = ws
+        # One scratch buffer per (device, stream) serves every call: the backward rebuilds the per-face records (29 us for
+        # 620k faces) instead of keeping them alive per call (LASR_SR_RECORDS_VALID) -- measured: the freshly written records
+        # are still in L2 / Infinity Cache when the face-major backward reads them, which saves more (0.06 ms per 256 frames)
+        # than the setup launch costs (0.03 ms); profiles/r02e_records_reuse.txt.
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
             rc = h.lasr_sr_forward_ex(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(), soft_colors.data_ptr(),
                                       ws.data_ptr(), ws.numel(), N, F, T, C, IS, *ctx.near_far,
                                       nf.data_ptr() if nf is not None else None, *tail, forward_flags(), stream)
@@ -135,13 +135,13 @@ class SoftRasterizeFunction(Function):
         grad_faces, grad_textures = grads[:N * F * 9].view(N, F, 9), grads[N * F * 9:].view(tx.shape)
         g = grad_soft_colors.contiguous().float()
         h = _lib.lib()
-        ws = ctx.ws
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
             rc = h.lasr_sr_backward_ex(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), aggrs_info.data_ptr(),
                                        grad_faces.data_ptr(), grad_textures.data_ptr(), g.data_ptr(), ws.data_ptr(),
                                        ws.numel(), N, F, T, C, IS, *ctx.near_far,
-                                       nf.data_ptr() if nf is not None else None, *tail, _lib.SR_RECORDS_VALID, stream)
+                                       nf.data_ptr() if nf is not None else None, *tail, 0, stream)
         _lib.check(rc, 'lasr_sr_backward')
         fshape, tshape = ctx.in_shapes
         return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),

@@ -31,7 +31,9 @@ DEFAULTS = dict(
     img_size=256, n_data_workers=1,                                               # dataloader/vid.py:34-35
     # additions of this build (not in the reference): synthetic data shape and the perceptual term switch
     # use_graph: replay forward + backward as one HIP graph (on by default on a GPU; --nouse_graph = eager as the reference)
-    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=True, data_root='.')
+    # encoder_weights / alexnet_weights: optional local state_dicts (torchvision resnet18 / alexnet, an LPIPS 'alex' net, or a
+    # reference LASR checkpoint) for the two networks the reference takes ImageNet-pretrained; '' = random init (no network here)
+    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=True, data_root='.', encoder_weights='', alexnet_weights='')
 
 
 def parse_flags(argv, defaults=DEFAULTS):

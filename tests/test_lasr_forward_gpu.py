@@ -228,6 +228,11 @@ def test_rendered_sequence_on_disk_trains(tmp_path, cuda):
              '--data_root', root, '--model_path', os.path.join(tr.save_dir, 'pred_net_latest.pth')]
     out = extract.main(flags)
     assert sorted(out) == [0, 1, 2] and all(os.path.exists(p) for p in out.values())
+    for fid in out:                                       # cam<i>.txt: [[R | T]; [fx fy ppx ppy]] (extract.py:123-130 of the reference)
+        rtk = np.loadtxt(os.path.join(str(tmp_path), 't', 'cam%d.txt' % fid))
+        assert rtk.shape == (4, 4) and np.isfinite(rtk).all()
+        np.testing.assert_allclose(rtk[:3, :3] @ rtk[:3, :3].T, np.eye(3), atol=1e-4)      # a rotation
+        assert rtk[2, 3] > 0 and rtk[3, 0] == rtk[3, 1] > 0                                # in front of the camera, fx == fy
     spec = importlib.util.spec_from_file_location('eval_mesh', os.path.join(ROOT, 'scripts', 'eval_mesh.py'))
     ev = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ev)

@@ -1,7 +1,8 @@
 """Graph-replay data parallelism (train_utils.define_model: gradients all-reduced as one flat message after the HIP-graph
 replay instead of through DDP's hooks).  Two ranks share the one GPU of the test box and talk over gloo; on a real node
-the same code runs one rank per GPU over RCCL.  After a few steps both ranks must hold identical parameters, and those
-must differ from a single-process run on rank 0's shard (i.e. the other rank's gradients really arrived)."""
+the same code runs one rank per GPU over RCCL.  After a few steps both ranks must hold identical parameters; those must
+equal a single-process run that evaluates BOTH ranks' shards each step and averages the two gradients (what the all-reduce
+computes), and must differ from a single-process run on rank 0's shard alone (the other rank's gradients really arrived)."""
 import os
 import socket
 import sys
@@ -79,4 +80,34 @@ def test_two_ranks_stay_in_lockstep(tmp_path, cuda, use_graph):
     assert all(map(lambda v: v == v, (l0, l1)))               # finite
     assert ids0 != ids1                                        # the ranks saw different pairs
     assert (f0 == f1).all()                                    # ... and still hold bit-identical parameters
+    if use_graph:
+        return                                                 # the single-process comparison below is done once
+    # ---- what the two ranks computed == mean of the two shards' gradients, step by step, in ONE process
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from lasr_amd.nnutils import train_utils
+
+    def single_process(shards):
+        torch.manual_seed(0)                                   # rank 0's initial weights (DDP broadcasts them)
+        tr = train_utils.LASRTrainer(make_opts(str(tmp_path / 'single'), use_graph=False)).init_training()
+        tr.model.train()
+        tr.reinit_bones()
+        for i in range(4):
+            tr.module.iters = i
+            tr.module.schedule_scalars()
+            tr.optimizer.zero_grad(set_to_none=True)
+            for ids in shards:
+                loss, _ = tr.model(tr.set_input([ids[i]]))
+                (loss / len(shards)).backward()
+            tr.step_tail()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for p in tr.module.parameters()]).double().cpu().numpy()
+    both = single_process([ids0, ids1])
+    alone = single_process([ids0])
+    scale = np.abs(both).max()
+    # not bit-equal: MIOpen may pick other convolution algorithms for the two call patterns, and torch's index_add
+    # gradients use float atomics; the parameters have moved by ~1e-2 after four steps
+    assert np.abs(f0 - both).max() <= 2e-4 * scale, (np.abs(f0 - both).max(), np.abs(f0 - alone).max(), scale)
+    assert np.abs(f0 - alone).max() >= 5 * np.abs(f0 - both).max() and np.abs(f0 - alone).max() > 1e-3 * scale, \
+        (np.abs(f0 - alone).max(), np.abs(f0 - both).max(), scale)
     # (use_graph=False is the reference's own arrangement: DistributedDataParallel + SyncBatchNorm kept in eval mode)

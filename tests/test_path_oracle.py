@@ -133,3 +133,24 @@ def test_star_remesh_survives_directions_that_miss_the_surface():
     assert np.isfinite(nv).all() and nf.shape == (320, 3)
     r = np.linalg.norm(nv - nv.mean(0), axis=1)
     assert r.min() > 0.3 and r.max() < 1.5
+
+
+def test_star_remesh_warns_when_the_surface_is_not_star_shaped():
+    # a dumbbell (two blobs joined along x, seen from the centroid of the first one) is crossed more than once by
+    # many rays; remesh_star keeps the outermost crossing and must say so.  Snapping --n_faces to 20 nu^2 is reported too.
+    import warnings
+    from lasr_amd import synth
+    from lasr_amd.nnutils import remesh
+    v, f = synth.geodesic_sphere(6)
+    v = v.astype(np.float64)
+    two = np.concatenate([v * 0.5, v * 0.5 + np.array([1.6, 0, 0])])      # disjoint second blob far off-centre
+    ff = np.concatenate([f, f + len(v)])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        remesh.remesh_star(two, ff, 1600)
+    msgs = ' | '.join(str(x.message) for x in w)
+    assert 'not star-shaped' in msgs and 'snapped to 1620' in msgs
+    with warnings.catch_warnings(record=True) as w:                        # a convex surface at an exact face count: silent
+        warnings.simplefilter('always')
+        remesh.remesh_star(v, f, 1620)
+    assert not w

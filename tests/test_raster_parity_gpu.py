@@ -333,32 +333,20 @@ def test_relaxed_forward_math_stays_inside_the_tolerance(oracle, cuda):
     print('relaxed forward: worst image max-abs error %.2e' % worst)
 
 
-@pytest.mark.parametrize('nu,IS,n', [(4, 64, 3), (11, 256, 2), (8, 100, 2)])
-def test_two_phase_forward_equals_one_phase_bit_for_bit(cuda, nu, IS, n):
-    # lasr_amd/csrc/sr_forward2.h: the two-phase kernel folds each pixel's fragments in face-index order with the same
-    # arithmetic as the one-phase walk, so images and aggregates must be IDENTICAL (3- and 6-channel passes, relaxed math too)
-    from lasr_amd import _lib
-    h = _lib.lib()
-    fv, ft, near, far = synth.raster_batch(nu, 5, count=n)
-    kw = dict(synth.LASR_MODES, near=near, far=far)
-    outs = {}
-    try:
-        for rx in (0, 1):
-            h.lasr_sr_set_forward_math(rx)
-            for variant in (0, 1):
-                h.lasr_sr_set_forward_variant(variant)
-                outs[rx, variant] = run_hip(cuda, fv, ft, IS, **kw)
-    finally:
-        h.lasr_sr_set_forward_variant(0)
-        h.lasr_sr_set_forward_math(0)
-    for rx in (0, 1):
-        assert np.array_equal(outs[rx, 0][0], outs[rx, 1][0]), 'image differs (relaxed=%d)' % rx
-        assert np.array_equal(outs[rx, 0][1], outs[rx, 1][1]), 'aggregates differ (relaxed=%d)' % rx
-    # near plane through the object: depth-culled fragments keep their alpha share in both kernels
-    kw2 = dict(kw, near=float(np.median(fv[..., 2])))
-    imgs = []
-    for variant in (0, 1):
-        h.lasr_sr_set_forward_variant(variant)
-        imgs.append(run_hip(cuda, fv, ft, IS, **kw2)[0])
-    h.lasr_sr_set_forward_variant(0)
-    assert np.array_equal(imgs[0], imgs[1])
+def test_faces_info_tensor_matches_the_reference_layout_bit_for_bit(oracle, cuda):
+    # the optional [N,F,27] `faces_info` output (K.cu:245-305: inverse matrix, vertex Gram matrix + 1, first-obtuse-corner
+    # flags, 6 unused slots) is written in the reference's layout for callers that still want it
+    for nu, n in ((4, 2), (11, 1)):
+        fv, ft, near, far = synth.raster_batch(nu, 7, count=n)
+        kw = dict(synth.LASR_MODES, near=near, far=far)
+        ref = oracle.forward(fv, ft, 32, **kw)
+        _, _, info = srf.soft_rasterize_raw(torch.from_numpy(fv).to(cuda), torch.from_numpy(ft).to(cuda), 32,
+                                            kw['background_color'], near, far, kw['fill_back'], kw['eps'], kw['sigma_val'],
+                                            kw['dist_func'], kw['dist_eps'], kw['gamma_val'], kw['aggr_func_rgb'],
+                                            kw['aggr_func_alpha'], kw['texture_type'], want_faces_info=True)
+        info = info.cpu().numpy()
+        assert info.shape == ref['faces_info'].shape == (n, fv.shape[1], 27)
+        assert np.array_equal(info[..., 0:9], ref['faces_info'][..., 0:9]), 'inverse matrix'
+        assert np.array_equal(info[..., 9:18], ref['faces_info'][..., 9:18]), 'Gram matrix'
+        assert np.array_equal(info[..., 18:21], ref['faces_info'][..., 18:21]), 'obtuse flags'
+        assert not info[..., 21:].any()
