@@ -674,13 +674,14 @@ __global__ __launch_bounds__(256) void cosdist_forward_kernel(const float* __res
     if (pxl == 0) part[(size_t)n * nch + blockIdx.y] = cosv;
 }
 
-__global__ __launch_bounds__(256) void cosdist_fold_kernel(const float* __restrict__ part, float* __restrict__ d, int N, int nch, int P)
+// one wave per image: lanes stride over the tile partials, fixed-order wave reduction
+__global__ __launch_bounds__(64) void cosdist_fold_kernel(const float* __restrict__ part, float* __restrict__ d, int N, int nch, int P)
 {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    const int n = blockIdx.x;
     float s = 0.f;
-    for (int k = 0; k < nch; k++) s += part[(size_t)n * nch + k];
-    d[n] = 1.f - s / (float)P;
+    for (int k = threadIdx.x; k < nch; k += 64) s += part[(size_t)n * nch + k];
+    s = wave_sum_to_lane63(s);
+    if (threadIdx.x == 63) d[n] = 1.f - s / (float)P;
 }
 
 // gradient w.r.t. fb only (the observed side is data): d cos / d b_c = a_c / (A B) - dot * b_c / (A * nb * B^2),
@@ -943,7 +944,7 @@ extern "C" int lasr_cosdist_forward(const float* feat_obs, const float* feat_rnd
     LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_forward_kernel, dim3(N, nch), dim3(256), 0, feat_obs, feat_rnd, scratch, C, P, rep, nch);
     int rc = launch_ok();
     if (rc) return rc;
-    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, scratch, dist, N, nch, P);
+    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_fold_kernel, dim3(N), dim3(64), 0, scratch, dist, N, nch, P);
     return launch_ok();
 }
 

@@ -57,6 +57,29 @@ def geodesic_distance(m1, m2):
     return torch.where(inside, angle, torch.where(cos > 0, torch.zeros_like(cos), torch.full_like(cos, math.pi)))
 
 
+def pose_noise_quat(n, t, device):
+    """n noise rotations as (x, y, z, w) quaternions with the reference's law (mesh_net.py:220-232): a rotation drawn
+    UNIFORMLY from SO(3) (Shoemake's construction, third_party/ext_utils/quatlib.py:22-27 `q_rnd_m`) pulled towards the
+    identity by spherical interpolation with factor t (quatlib.py:29-50 `q_scale_m`): its angle -- density proportional to
+    1 - cos(theta) on [0, pi] -- is multiplied by t, the axis stays uniform.  Runs on the device with torch's generator
+    (the reference draws on the host with numpy); t may be a 0-dim device tensor (graph capture)."""
+    u, v, w = torch.rand(3, n, device=device).unbind(0)
+    v, w = 2 * math.pi * v, 2 * math.pi * w
+    q = torch.stack([(1 - u).sqrt() * v.sin(), (1 - u).sqrt() * v.cos(), u.sqrt() * w.sin(), u.sqrt() * w.cos()], 1)   # wxyz
+    q = torch.where(q[:, :1] < 0, -q, q)                      # shorter arc to the identity (1, 0, 0, 0)
+    d = q[:, :1].clamp(max=1.0)
+    t0 = torch.acos(d)
+    tt = t0 * t
+    s1 = torch.sin(tt) / torch.sin(t0).clamp_min(1e-12)
+    s0 = torch.cos(tt) - d * s1
+    ident = torch.zeros_like(q)
+    ident[:, 0] = 1
+    slerp = s0 * ident + s1 * q
+    lin = ident + t * (q - ident)                              # d > 0.999: normalised linear interpolation (quatlib.py:38-41)
+    out = torch.where(d > 0.999, F.normalize(lin, dim=1), slerp)
+    return torch.cat([out[:, 1:], out[:, :1]], 1)              # -> xyzw for quaternion_to_rotation_matrix (mesh_net.py:231)
+
+
 def reg_decay(curr_steps, max_steps, min_wt, max_wt):
     """Exponential decay of a regulariser weight from max_wt to min_wt (mesh_net.py:106-113)."""
     if curr_steps > max_steps:
@@ -511,9 +534,7 @@ class LASR(MeshNet):
         quat = quat.view(-1, 9)
         if opts.noise and self.epoch > 0 and 1 < self.iters < 100:               # pose / scale noise (:220-235)
             decay = self.noise_decay                          # 0.2 * 1e-4 ** (iters / 100), device scalar (schedule_scalars)
-            axis = F.normalize(torch.randn(quat.shape[0], 3, device=quat.device), dim=1)
-            ang = torch.rand(quat.shape[0], 1, device=quat.device) * math.pi * decay
-            noise = torch.cat([axis * torch.sin(ang / 2), torch.cos(ang / 2)], 1)
+            noise = pose_noise_quat(quat.shape[0], decay, quat.device)
             quat = quat.view(-1, 3, 3).matmul(quaternion_to_rotation_matrix(noise)).view(-1, 9)
             scale = scale * (decay * torch.randn_like(scale) * opts.rscale).exp()
         depth = depth.view(n2, 1, K, 1).repeat(1, H, 1, 1).view(-1, 1)

@@ -154,3 +154,39 @@ def test_star_remesh_warns_when_the_surface_is_not_star_shaped():
         warnings.simplefilter('always')
         remesh.remesh_star(v, f, 1620)
     assert not w
+
+
+def test_pose_noise_follows_the_reference_law():
+    # mesh_net.py:220-232 draws a uniformly random rotation (quatlib.q_rnd_m) and slerps it towards the
+    # identity by the decay factor (quatlib.q_scale_m).  For t = 1 the angle theta has density (1 - cos theta) / pi on
+    # [0, pi] (mean pi/2 + 2/pi); for general t the angle is t * theta and the axis stays uniform on the sphere.
+    import math
+    import torch
+    from lasr_amd.nnutils.mesh_net import pose_noise_quat
+    torch.manual_seed(0)
+    n = 200000
+    for t in (1.0, 0.2, 0.02):
+        q = pose_noise_quat(n, t, torch.device('cpu'))
+        assert q.shape == (n, 4) and torch.allclose(q.norm(dim=1), torch.ones(n), atol=1e-5)
+        ang = 2 * torch.atan2(q[:, :3].norm(dim=1), q[:, 3].abs())
+        assert abs(float(ang.mean()) - t * (math.pi / 2 + 2 / math.pi)) < 0.01 * t * 3      # E[theta] = pi/2 + 2/pi
+        assert float(ang.max()) <= t * math.pi + 1e-4
+        # P(theta <= x) = (x - sin x) / pi for the unscaled angle
+        for x in (0.5, 1.5, 2.5):
+            emp = float((ang / t <= x).float().mean())
+            assert abs(emp - (x - math.sin(x)) / math.pi) < 5e-3, (t, x, emp)
+        axis = torch.nn.functional.normalize(q[:, :3], dim=1)
+        assert float(axis.mean(0).abs().max()) < 0.01                                        # uniform axis: zero mean ...
+        assert abs(float((axis[:, 2] ** 2).mean()) - 1 / 3) < 0.01                           # ... and isotropic second moment
+    # reference formulas, statement by statement (quatlib.py:29-50), on the same uniform draws
+    u, v, w = (x.numpy() for x in torch.rand(3, 1000, dtype=torch.float64).unbind(0))
+    q = np.stack([np.sqrt(1 - u) * np.sin(2 * np.pi * v), np.sqrt(1 - u) * np.cos(2 * np.pi * v),
+                  np.sqrt(u) * np.sin(2 * np.pi * w), np.sqrt(u) * np.cos(2 * np.pi * w)], 1)
+    q[q[:, 0] < 0] *= -1
+    d = q[:, 0].copy()
+    t0 = np.arccos(d)
+    tt = t0 * 0.3
+    s1 = np.sin(tt) / np.sin(t0)
+    ref = (np.cos(tt) - d * s1)[:, None] * np.array([1., 0, 0, 0]) + s1[:, None] * q
+    ang_ref = 2 * np.arccos(np.clip(ref[:, 0], -1, 1))
+    assert np.allclose(ang_ref, 0.3 * 2 * t0, atol=1e-9)       # slerp by t multiplies the rotation angle by t
