@@ -214,6 +214,17 @@ int lasr_cosdist_forward(const float* feat_obs, const float* feat_rnd, float* di
 int lasr_cosdist_backward(const float* feat_obs, const float* feat_rnd, const float* grad_dist, float* grad_rnd, int N,
                           int C, int P, int rep, void* hip_stream);
 
+/*
+ * Texture atlas -> per-face surface textures, replaces `soft_renderer.cuda.load_textures`
+ * (third_party/softras/soft_renderer/cuda/load_textures_cuda.cpp:10-28, kernel load_textures_cuda_kernel.cu:8-66; called
+ * from functional/load_obj.py when scripts/render_syn.py:71 loads its textured mesh).  image [H,W,3] (row 0 first, the caller
+ * flips as load_obj.py does), faces_uv [F,3,2] in [0,1], is_update [F] or NULL (NULL = all), textures [F,R*R,3] (only the
+ * faces with is_update != 0 are written).  Texel (w_x, w_y): barycentric ((w_x + 1/3)/R, (w_y + 1/3)/R, rest) for
+ * w_x + w_y < R, else the mirrored upper-triangle position; bilinear sample at uv * (size - 1).
+ */
+int lasr_load_textures(const float* image, const float* faces_uv, const int* is_update, float* textures, int F, int R, int H,
+                       int W, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,7 @@ SIGNATURES = {
     'lasr_cosdist_scratch_floats': (_sz, [_i, _i]),
     'lasr_cosdist_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_cosdist_backward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_load_textures': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),

@@ -731,6 +731,48 @@ __global__ __launch_bounds__(256) void cosdist_backward_kernel(const float* __re
     }
 }
 
+// ===========================================================================
+// Texture atlas -> per-face surface texels, third_party/softras/soft_renderer/cuda/load_textures_cuda_kernel.cu:8-66:
+// texel (w_x, w_y) of an R x R face texture sits at barycentric ((w_x + 1/3)/R, (w_y + 1/3)/R) of the lower triangle of
+// the texel grid (w_x + w_y < R), else at the mirrored position of the upper one; the atlas is sampled bilinearly at the
+// uv of that point, uv * (size - 1).  One thread per texel; 3 channels.  The reference reads row/column (int)(pos + 1)
+// unchecked (one past the image when uv == 1, with weight 0); the index is clamped here.
+// ===========================================================================
+__global__ __launch_bounds__(256) void load_textures_kernel(const float* __restrict__ image, const float* __restrict__ faces_uv,
+                                                            const int* __restrict__ is_update, float* __restrict__ textures,
+                                                            int F, int R, int H, int W)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F * R * R) return;
+    const int fn = i / (R * R), w_y = (i % (R * R)) / R, w_x = i % R;
+    if (is_update && is_update[fn] == 0) return;
+    float w0, w1;
+    if (w_x + w_y < R) {
+        w0 = (float)((w_x + 1. / 3.) / R);
+        w1 = (float)((w_y + 1. / 3.) / R);
+    } else {
+        w0 = (float)(((R - 1. - w_x) + 2. / 3.) / R);
+        w1 = (float)(((R - 1. - w_y) + 2. / 3.) / R);
+    }
+    const float w2 = (float)(1. - (double)w0 - (double)w1);
+    const float* uv = faces_uv + (size_t)fn * 6;
+    const float pos_x = (uv[0] * w0 + uv[2] * w1 + uv[4] * w2) * (float)(W - 1);
+    const float pos_y = (uv[1] * w0 + uv[3] * w1 + uv[5] * w2) * (float)(H - 1);
+    const int x0 = (int)pos_x, y0 = (int)pos_y;
+    const float wx1 = pos_x - (float)x0, wx0 = 1 - wx1, wy1 = pos_y - (float)y0, wy0 = 1 - wy1;
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+    const int ya = min(max(y0, 0), H - 1), yb = min(max((int)(pos_y + 1), 0), H - 1);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float c = 0;
+        c += image[((size_t)ya * W + xa) * 3 + k] * (wx0 * wy0);
+        c += image[((size_t)yb * W + xa) * 3 + k] * (wx0 * wy1);
+        c += image[((size_t)ya * W + xb) * 3 + k] * (wx1 * wy0);
+        c += image[((size_t)yb * W + xb) * 3 + k] * (wx1 * wy1);
+        textures[(size_t)i * 3 + k] = c;
+    }
+}
+
 }  // namespace lasr
 
 // ===========================================================================
@@ -967,5 +1009,18 @@ extern "C" int lasr_cosdist_backward(const float* feat_obs, const float* feat_rn
         default: LASR_COS_BWD(0);
     }
 #undef LASR_COS_BWD
+    return launch_ok();
+}
+
+extern "C" int lasr_load_textures(const float* image, const float* faces_uv, const int* is_update, float* textures, int F,
+                                  int R, int H, int W, void* hip_stream)
+{
+    if (F < 0 || R < 1 || H < 1 || W < 1) return LASR_E_BADARG;
+    if (F == 0) return LASR_OK;
+    if (!image || !faces_uv || !textures) return LASR_E_BADARG;
+    if ((long long)F * R * R > 0x7fffffffLL) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_LOAD_TEXTURES, load_textures_kernel, dim3((F * R * R + 255) / 256), dim3(256), 0, image, faces_uv, is_update,
+                textures, F, R, H, W);
     return launch_ok();
 }

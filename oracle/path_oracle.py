@@ -178,3 +178,37 @@ def chamfer_distance(a, b):
     """pytorch3d.loss.chamfer_distance()[0] semantics as used at nnutils/mesh_net.py:503 (parity unpinned)."""
     d = (a[:, :, None] - b[:, None]).pow(2).sum(-1)
     return (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
+
+
+def load_textures(image, faces_uv, R, is_update=None):
+    """third_party/softras/soft_renderer/cuda/load_textures_cuda_kernel.cu:8-66, numpy fp32 (bilinear branch).
+    image [H,W,3], faces_uv [F,3,2] -> [F,R*R,3].  Indices that the reference reads one past the image (uv == 1, weight 0)
+    are clamped."""
+    image = np.asarray(image, np.float32)
+    uv = np.asarray(faces_uv, np.float32)
+    H, W = image.shape[:2]
+    F = uv.shape[0]
+    out = np.zeros((F, R * R, 3), np.float32)
+    for i in range(R * R):
+        w_y, w_x = i // R, i % R
+        if w_x + w_y < R:
+            w0, w1 = np.float32((w_x + 1. / 3.) / R), np.float32((w_y + 1. / 3.) / R)
+        else:
+            w0, w1 = np.float32(((R - 1. - w_x) + 2. / 3.) / R), np.float32(((R - 1. - w_y) + 2. / 3.) / R)
+        w2 = np.float32(1. - np.float64(w0) - np.float64(w1))
+        px = (uv[:, 0, 0] * w0 + uv[:, 1, 0] * w1 + uv[:, 2, 0] * w2) * np.float32(W - 1)
+        py = (uv[:, 0, 1] * w0 + uv[:, 1, 1] * w1 + uv[:, 2, 1] * w2) * np.float32(H - 1)
+        x0, y0 = px.astype(np.int32), py.astype(np.int32)
+        wx1 = px - x0.astype(np.float32); wx0 = np.float32(1) - wx1
+        wy1 = py - y0.astype(np.float32); wy0 = np.float32(1) - wy1
+        xa, xb = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+        ya, yb = np.clip(y0, 0, H - 1), np.clip((py + np.float32(1)).astype(np.int32), 0, H - 1)
+        c = np.zeros((F, 3), np.float32)
+        c += image[ya, xa] * (wx0 * wy0)[:, None]
+        c += image[yb, xa] * (wx0 * wy1)[:, None]
+        c += image[ya, xb] * (wx1 * wy0)[:, None]
+        c += image[yb, xb] * (wx1 * wy1)[:, None]
+        out[:, i] = c
+    if is_update is not None:
+        out[np.asarray(is_update) == 0] = 0
+    return out

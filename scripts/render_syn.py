@@ -11,7 +11,8 @@ rendered with the hard rasteriser (lasr_sr_forward: hard distance / hard z-buffe
   .../FlowFW|FlowBW/.../flo-%05d.pfm  flow to the next / previous frame in pixels + validity; occ-%05d.pfm = -1
   <root>/configs/<outdir>.config      the [data] section optimize.py --dataname <outdir> reads
 The reference renders spot_triangulated.obj with its surface texture (not available offline); here the default object
-is this repository's blobby geodesic sphere with per-vertex colours, or any .obj given with --obj.
+is this repository's blobby geodesic sphere with per-vertex colours, or any .obj given with --obj; --surface_tex textures it
+from an atlas image through 5x5 per-face surface textures (lasr_load_textures) like the reference's textured models.
 """
 import argparse
 import math
@@ -74,6 +75,9 @@ def main(argv=None):
     ap.add_argument('--img_size', default=512, type=int)
     ap.add_argument('--root', default='.')
     ap.add_argument('--seed', default=0, type=int)
+    ap.add_argument('--surface_tex', action='store_true',
+                    help='texture the object from an atlas image through per-face 5x5 surface textures, the way the '
+                         'reference renders its textured .obj (render_syn.py:71: texture_res=5, texture_type=surface)')
     args = ap.parse_args(argv)
     dev = torch.device('cuda', 0)
     size, dframe, focal, depth = args.img_size, 1, 10.0, 10.0
@@ -87,6 +91,17 @@ def main(argv=None):
         overts = torch.from_numpy(v).to(dev)[None].float()
         faces = torch.from_numpy(np.asarray(f, np.int64)).to(dev)[None]
         colors = torch.from_numpy(tex).to(dev)[None].float()
+
+    tex_type = 'vertex'
+    if args.surface_tex:
+        # a procedural atlas (smooth colour field + checker) and spherical uv per face corner stand in for the .mtl image of
+        # the reference's models; sampled into [F, 5*5, 3] surface texels by lasr_load_textures (load_textures_cuda_kernel.cu)
+        yy, xx = np.mgrid[:128, :128] / 127.0
+        atlas = np.stack([0.5 + 0.5 * np.sin(6.28 * xx), 0.5 + 0.5 * np.cos(9.42 * yy), 0.25 + 0.5 * ((np.floor(8 * xx) + np.floor(8 * yy)) % 2)], -1)
+        d = torch.nn.functional.normalize(overts[0], dim=1)
+        uv = torch.stack([torch.atan2(d[:, 0], d[:, 2]) / (2 * math.pi) + 0.5, torch.acos(d[:, 1].clamp(-1, 1)) / math.pi], 1)
+        colors = sr.functional.load_textures(torch.from_numpy(atlas.astype(np.float32)).to(dev), uv[faces[0]], 5)[None]
+        tex_type = 'surface'
 
     base = os.path.join(args.root, 'database', 'DAVIS')
     sub = {k: os.path.join(base, k, 'Full-Resolution', args.outdir) for k in
@@ -115,7 +130,7 @@ def main(argv=None):
         verts_list.append(verts)
         pre = (verts - eye) * verts.new_tensor([1, -1, 1])
         with torch.no_grad():
-            out = renderer.render_mesh(sr.Mesh(pre, faces, textures=colors, texture_type='vertex'))
+            out = renderer.render_mesh(sr.Mesh(pre, faces, textures=colors, texture_type=tex_type))
         mask = out[0, -1].cpu().numpy() > 0.5
         img = out[0, :3].permute(1, 2, 0).cpu().numpy() * 255
         if bgcolor is None:

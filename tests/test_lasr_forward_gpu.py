@@ -291,3 +291,25 @@ def test_graph_replay_covers_the_pose_noise_iterations(tmp_path, cuda):
     # (eager and captured runs may pick different convolution algorithms: percent-level agreement; stale gradients of the
     # other graph would differ completely)
     assert float((g_graph - g_eager).abs().max()) <= 0.05 * float(g_eager.abs().max())
+
+
+def test_render_syn_with_surface_textures(tmp_path, cuda):
+    # scripts/render_syn.py --surface_tex = atlas image -> 5x5 per-face surface texels
+    # (lasr_load_textures) -> hard rasteriser in surface-texture mode, the path the reference's render_syn.py:71 takes
+    import importlib.util
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location('render_syn', os.path.join(ROOT, 'scripts', 'render_syn.py'))
+    render_syn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(render_syn)
+    imgs = {}
+    for tag, extra in (('v', []), ('s', ['--surface_tex'])):
+        root = str(tmp_path / tag)
+        render_syn.main(['--outdir', 'syn', '--nframes', '2', '--img_size', '96', '--root', root] + extra)
+        d = os.path.join(root, 'database', 'DAVIS')
+        imgs[tag] = np.asarray(Image.open(os.path.join(d, 'JPEGImages', 'Full-Resolution', 'syn', '00000.jpg')), np.float32)
+        mask = np.asarray(Image.open(os.path.join(d, 'Annotations', 'Full-Resolution', 'syn', '00000.png'))) > 0
+        assert 0.05 < mask.mean() < 0.9
+        assert os.path.exists(os.path.join(d, 'FlowFW', 'Full-Resolution', 'syn', 'flo-00000.pfm'))
+    fg = imgs['s'][mask]
+    assert fg.std(0).min() > 5                                  # the atlas pattern shows on the object
+    assert np.abs(imgs['s'][mask] - imgs['v'][mask]).mean() > 5  # and differs from the vertex-coloured render

@@ -380,3 +380,22 @@ def test_perceptual_cosine_reduction_matches_reference_formula(cuda, N, C, h, re
     assert torch.isnan(gr[0, :, 0, 0]).all() and torch.isfinite(gd).all()         # autograd: sqrt'(0); kernel: term dropped
     dead = torch.isnan(gr)                                         # every all-zero channel vector of fb (few channels: several)
     assert float((gd - gr)[~dead].abs().max()) <= 1e-5 * float(gr[~dead].abs().max())
+
+
+def test_load_textures_kernel_matches_restatement(cuda):
+    # texture atlas -> per-face surface texels (soft_renderer.cuda.load_textures), then rendered
+    # through the surface-texture mode of the rasteriser
+    from lasr_amd.soft_renderer import functional as srf
+    rng = np.random.default_rng(3)
+    for (H, W, F, R) in ((9, 17, 5, 3), (64, 48, 300, 5), (7, 7, 2, 1)):
+        img = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+        uv = rng.uniform(0, 1, (F, 3, 2)).astype(np.float32)
+        uv[0] = [[0, 0], [1, 0], [1, 1]]                                  # corners of the atlas, incl. uv == 1
+        upd = (rng.uniform(0, 1, F) > 0.2).astype(np.int32)
+        upd[0] = 1
+        ref = po.load_textures(img, uv, R, upd)
+        got = srf.load_textures(torch.from_numpy(img).to(cuda), torch.from_numpy(uv).to(cuda), R, torch.from_numpy(upd)).cpu().numpy()
+        assert got.shape == (F, R * R, 3)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    with pytest.raises(TypeError):
+        srf.load_textures(torch.from_numpy(img), torch.from_numpy(uv), R)

@@ -190,3 +190,29 @@ def test_pose_noise_follows_the_reference_law():
     ref = (np.cos(tt) - d * s1)[:, None] * np.array([1., 0, 0, 0]) + s1[:, None] * q
     ang_ref = 2 * np.arccos(np.clip(ref[:, 0], -1, 1))
     assert np.allclose(ang_ref, 0.3 * 2 * t0, atol=1e-9)       # slerp by t multiplies the rotation angle by t
+
+
+def test_load_textures_restatement_on_analytic_atlases():
+    # load_textures_cuda_kernel.cu:8-66: a constant atlas gives constant texels; on an atlas that is linear in (x, y) the
+    # bilinear sample equals the atlas function at uv * (size - 1), i.e. at the texel's barycentric point of the face's uv
+    import numpy as np
+    from oracle import path_oracle as po
+    H, W, R = 9, 17, 3
+    yy, xx = np.mgrid[:H, :W].astype(np.float32)
+    lin = np.stack([2 * xx + 1, 3 * yy - 2, xx + yy], -1).astype(np.float32)
+    uv = np.array([[[0.1, 0.2], [0.9, 0.3], [0.4, 0.8]], [[0, 0], [1, 0], [0, 1]]], np.float32)
+    t = po.load_textures(lin, uv, R)
+    assert t.shape == (2, R * R, 3)
+    for i in range(R * R):
+        w_y, w_x = i // R, i % R
+        if w_x + w_y < R:
+            w0, w1 = (w_x + 1 / 3) / R, (w_y + 1 / 3) / R
+        else:
+            w0, w1 = ((R - 1 - w_x) + 2 / 3) / R, ((R - 1 - w_y) + 2 / 3) / R
+        p = (uv[:, 0] * w0 + uv[:, 1] * w1 + uv[:, 2] * (1 - w0 - w1)) * np.array([W - 1, H - 1])
+        np.testing.assert_allclose(t[:, i, 0], 2 * p[:, 0] + 1, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(t[:, i, 1], 3 * p[:, 1] - 2, rtol=1e-5, atol=1e-5)
+    const = po.load_textures(np.full((H, W, 3), 0.25, np.float32), uv, R)
+    np.testing.assert_allclose(const, 0.25, atol=1e-7)
+    skipped = po.load_textures(lin, uv, R, is_update=[1, 0])
+    assert np.array_equal(skipped[0], t[0]) and not skipped[1].any()
