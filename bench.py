@@ -268,6 +268,26 @@ def measured_traffic(kernel, frames_per_launch):
     return k['bytes'] * frames_per_launch / d['frames_per_launch'], os.path.basename(files[-1])
 
 
+def valu_issue(kernel, frames_per_launch, launch_ms):
+    """What actually bounds the raster kernels: VALU issue.  Instruction mix of one launch from the committed SQ counter passes
+    (profiles/*_valu.json, built by tools/valu_json.py from rocprofv3 --pmc SQ_INSTS_VALU*), priced with the per-instruction
+    issue costs measured by tools/ubench/ and compared with this run's launch time."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_valu.json')))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    k = d.get('kernels', {}).get(kernel)
+    if not k:
+        return None
+    scale = frames_per_launch / d['frames_per_launch']
+    return {'source': os.path.basename(files[-1]), 'valu_wave_instructions_per_launch': k['valu_wave_instructions'] * scale,
+            'live_lane_fraction': k['live_lane_fraction'], 'modelled_issue_ms': k['modelled_issue_ms'] * scale,
+            'frac_of_launch_time': k['modelled_issue_ms'] * scale / launch_ms,
+            'note': 'sum over instruction kinds of count x measured issue cycles / (1024 SIMDs x 2.4 GHz); packed fp32 and '
+                    'MFMA do not apply to this arithmetic (DESIGN.md section 4)'}
+
+
 def main():
     global IS, REBUILD_RECORDS
     a = parse()
@@ -371,7 +391,8 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ktimes[dom][0],
-                         'all_kernels_avg_ms': {k: v[0] for k, v in ktimes.items()}},
+                         'all_kernels_avg_ms': {k: v[0] for k, v in ktimes.items()},
+                         'valu_issue': valu_issue(dom, B, ktimes[dom][0]) if IS == 256 else None},
         }
         if world == 1:
             # informational: the opt-in relaxed forward arithmetic (lasr_sr_set_forward_math(1), image within ~1e-5 of the

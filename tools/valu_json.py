@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""profiles/rNN_pmc_sq.txt (SQ instruction counters per dispatch, tools/pmc_summary.py) -> rNN_valu.json: per raster kernel the
+VALU wave-instruction mix of one launch and the issue time it implies under the per-instruction costs measured by
+tools/ubench/ (profiles/r02_valu_issue.txt).  bench.py attaches it to the JSON line as `valu_issue`.
+usage: valu_json.py <pmc_sq.txt> <frames_per_launch>"""
+import json
+import re
+import sys
+
+COST = {'fp32_vgpr': 2.5, 'fp32_sgpr_operand': 4.15, 'f64': 4.3, 'transcendental': 8.3, 'other': 4.1}   # cycles @ 2.4 GHz per wave64
+SGPR_SHARE = {'sr_forward_kernel': 0.28, 'sr_backward_kernel': 0.45}     # static share of fp32 mul/add/fma with an SGPR source (ISA)
+SIMDS, GHZ = 1024, 2.4
+
+txt, frames = sys.argv[1], int(sys.argv[2])
+k = {}
+for line in open(txt):
+    m = re.match(r'\s*\S*(sr_\w+?_kernel)\S*\s+(SQ_\w+)\s+(\d+)', line)
+    if not m or 'ILb1ELi3ELb1' in line or 'setup' in line:
+        continue
+    k.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
+out = {'frames_per_launch': frames, 'cycles_per_wave_instruction': COST, 'simds': SIMDS, 'clock_ghz': GHZ, 'kernels': {}}
+for name, c in k.items():
+    fp32 = c['SQ_INSTS_VALU_MUL_F32'] + c['SQ_INSTS_VALU_FMA_F32'] + c['SQ_INSTS_VALU_ADD_F32']
+    f64 = c['SQ_INSTS_VALU_MUL_F64'] + c['SQ_INSTS_VALU_FMA_F64'] + c['SQ_INSTS_VALU_ADD_F64']
+    tr = c['SQ_INSTS_VALU_TRANS_F32']
+    other = c['SQ_INSTS_VALU'] - fp32 - f64 - tr
+    s = SGPR_SHARE.get(name, 0.3)
+    cyc = (fp32 * (1 - s) * COST['fp32_vgpr'] + fp32 * s * COST['fp32_sgpr_operand'] + f64 * COST['f64'] +
+           tr * COST['transcendental'] + other * COST['other'])
+    out['kernels'][name] = {
+        'valu_wave_instructions': c['SQ_INSTS_VALU'], 'fp32_mul_add_fma': fp32, 'f64': f64, 'transcendental': tr, 'other': other,
+        'salu': c['SQ_INSTS_SALU'], 'smem': c['SQ_INSTS_SMEM'],
+        'live_lane_fraction': c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU']),
+        'wait_any_fraction_of_wave_cycles': c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'],
+        'modelled_issue_ms': cyc / SIMDS / (GHZ * 1e6)}
+print(json.dumps(out, indent=1))
