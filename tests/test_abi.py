@@ -53,6 +53,22 @@ def test_argument_validation_happens_before_any_launch():
     assert h.lasr_sr_forward(*args, 0, 1, 3, 8, 1., 2., 1e-3, 1e-4, 2, 9.2, 1e-2, 1, 2, 1, 1, None) == 0    # empty batch
 
 
+def test_ex_entry_points_validate_flags_and_channels_on_the_host():
+    from lasr_amd import _lib
+    h = _lib.lib()
+    tail = (1e-3, 1e-4, 2, 9.2, 1e-2, 1, 2, 1, 1)
+    fwd = lambda channels, flags, dist=2: h.lasr_sr_forward_ex(None, None, None, None, None, None, 0, 0, 1, 3, channels, 8, 1., 2., None,
+                                                               tail[0], tail[1], dist, *tail[3:], flags, None)
+    assert fwd(3, 0) == 0 and fwd(3, _lib.SR_RELAXED_MATH) == 0 and fwd(3, _lib.SR_DEFAULT_FLAGS) == 0        # empty batch: ok
+    assert fwd(3, _lib.SR_RECORDS_VALID) == -1 and fwd(3, 64) == -1                                            # not forward flags
+    assert fwd(6, 0) == 0 and fwd(5, 0) == -2 and fwd(6, 0, dist=1) == -2                                      # 6 channels: LASR modes only
+    bwd = lambda flags: h.lasr_sr_backward_ex(None, None, None, None, None, None, None, None, 0, 0, 1, 3, 3, 8, 1., 2., None,
+                                              *tail, flags, None)
+    assert bwd(0) == 0 and bwd(_lib.SR_RECORDS_VALID) == 0 and bwd(_lib.SR_RELAXED_MATH) == -1
+    assert h.lasr_load_textures(None, None, None, None, 0, 5, 4, 4, None) == 0                                 # no faces
+    assert h.lasr_load_textures(None, None, None, None, 3, 5, 4, 4, None) == -1 and h.lasr_load_textures(None, None, None, None, 3, 0, 4, 4, None) == -1
+
+
 def test_product_package_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'lasr_amd')):

@@ -180,3 +180,37 @@ def test_pair_lists_for_frame_skipping_and_flow_directories(tmp_path):
     assert len(ds) == unit * (200 // unit)
     sil = vid.VidDataset(make_opts(batch_size=1, sil_path='/masks'), imglist=names, dframe=1)
     assert sil.masklist[1] == '/masks/cat/00001.png'
+
+
+def test_image_ops_on_analytic_cases_of_the_opencv_definitions():
+    # OpenCV is not installed, so the restatements of cv2.resize / cv2.remap in ext_utils/image.py are
+    # pinned to cases whose OpenCV result follows from the documented sampling rule (INTER_LINEAR: src = (dst + 0.5) * scale - 0.5
+    # with the border replicated; INTER_NEAREST: src = floor(dst * scale); remap with integer maps: a copy with constant border).
+    # 2x2 -> 4x4 bilinear upsample: separable, weights (1, .75, .25, 0) along each axis
+    src = np.array([[0., 10.], [20., 30.]])
+    w = np.array([1., .75, .25, 0.])
+    exp = (np.outer(w, w) * 0 + np.outer(w, 1 - w) * 10 + np.outer(1 - w, w) * 20 + np.outer(1 - w, 1 - w) * 30)
+    assert np.allclose(iu.resize_linear(src, 4, 4), exp)
+    # a linear ramp is reproduced exactly away from the clamped border, for a non-integer scale too
+    ramp = np.arange(10.)[None].repeat(3, 0)
+    out = iu.resize_linear(ramp, 7, 3)
+    pos = (np.arange(7) + 0.5) * (10 / 7) - 0.5
+    assert np.allclose(out[1], np.clip(pos, 0, 9))
+    # 3 channels resize like three planes; an identity resize is the identity
+    rgb = np.random.default_rng(0).uniform(0, 1, (5, 6, 3))
+    assert np.allclose(iu.resize_linear(rgb, 6, 5), rgb)
+    assert np.allclose(iu.resize_linear(rgb, 9, 4)[..., 1], iu.resize_linear(rgb[..., 1], 9, 4))
+    # nearest: floor(i * scale), never rounds up (7 -> 3: indices 0, 2, 4), upsampling repeats
+    assert np.array_equal(iu.resize_nearest(np.arange(7)[None], 3, 1), [[0, 2, 4]])
+    assert np.array_equal(iu.resize_nearest(np.arange(3)[None], 6, 1), [[0, 0, 1, 1, 2, 2]])
+    # remap with integer maps = crop with constant padding, any side
+    img = np.arange(20.).reshape(4, 5)
+    assert np.array_equal(iu.crop_pad(img, 3, 2, 3, border=-1.), [[13., 14., -1.], [18., 19., -1.], [-1., -1., -1.]])
+    assert np.array_equal(iu.crop_pad(img, -2, -1, 3, border=0.), [[0., 0., 0.], [0., 0., 0.], [0., 0., 5.]])
+    assert np.array_equal(iu.crop_pad(img, 10, 10, 2, border=7.), np.full((2, 2), 7.))         # entirely outside
+    # distance transforms: a single foreground pixel gives Euclidean distances; the barrier is a sigmoid of the signed distance
+    m = np.zeros((9, 9)); m[4, 4] = 1
+    dt = iu.compute_dt(m, iters=0) * 9
+    assert abs(dt[4, 7] - 3) < 1e-9 and abs(dt[1, 0] - 5) < 1e-9 and dt[4, 4] == 0
+    b = iu.compute_dt_barrier(m, k=50)
+    assert b[4, 4] < 0.5 < b[4, 5] and abs(b[0, 0] - 1 / (1 + np.exp(-50 * np.hypot(4, 4) / 9))) < 1e-9

@@ -350,3 +350,32 @@ def test_faces_info_tensor_matches_the_reference_layout_bit_for_bit(oracle, cuda
         assert np.array_equal(info[..., 9:18], ref['faces_info'][..., 9:18]), 'Gram matrix'
         assert np.array_equal(info[..., 18:21], ref['faces_info'][..., 18:21]), 'obtuse flags'
         assert not info[..., 21:].any()
+
+
+def test_backward_on_the_forwards_records_equals_a_rebuild(cuda):
+    # LASR_SR_RECORDS_VALID: the backward may skip its face setup when the forward's workspace is untouched -- same bits
+    from lasr_amd import _lib
+    import math
+    h = _lib.lib()
+    fv, ft, near, far = synth.raster_batch(8, 5, count=3)
+    N, F, IS = fv.shape[0], fv.shape[1], 96
+    m = synth.LASR_MODES
+    tail = (float(m['eps']), float(m['sigma_val']), 2, float(math.log(1. / m['dist_eps'] - 1.)), float(m['gamma_val']), 1, 2, 1, 1)
+    tfv = torch.from_numpy(fv).to(cuda).reshape(N, F, 9).contiguous()
+    tft = torch.from_numpy(ft).to(cuda).reshape(N, F, 9).contiguous()
+    g = torch.from_numpy(synth.upstream_grad(N, IS, 5)).to(cuda)
+    colors = torch.ones(N, 4, IS, IS, device=cuda)
+    aggrs = torch.empty(N, 2, IS, IS, device=cuda)
+    ws = torch.empty(h.lasr_sr_workspace_bytes(N, F, 3, IS), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(h.lasr_sr_forward_ex(tfv.data_ptr(), tft.data_ptr(), None, aggrs.data_ptr(), colors.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), N, F, 3, 3, IS, float(near), float(far), None, *tail, 0, st), 'forward_ex')
+    out = []
+    for flags in (_lib.SR_RECORDS_VALID, 0):
+        gf, gt = torch.zeros(N, F, 9, device=cuda), torch.zeros(N, F, 9, device=cuda)
+        _lib.check(h.lasr_sr_backward_ex(tfv.data_ptr(), tft.data_ptr(), colors.data_ptr(), aggrs.data_ptr(), gf.data_ptr(),
+                                         gt.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), N, F, 3, 3, IS, float(near),
+                                         float(far), None, *tail, flags, st), 'backward_ex')
+        out.append((gf.cpu().numpy(), gt.cpu().numpy()))
+    assert np.abs(out[0][0]).max() > 0
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
