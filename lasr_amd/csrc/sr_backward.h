@@ -21,14 +21,15 @@ namespace lasr {
 // (FM = true): the reference backward is itself only defined up to float-atomic ordering.
 constexpr bool BWD_FM = true;
 constexpr int QCAP = 128;   // ring entries per wave (power of two, >= 2 * 64)
+constexpr int BWD_THREADS = 64;   // one wave per workgroup (see backward_impl)
 
 template <bool LASR_FAST, int NCH>
-__global__ __launch_bounds__(256) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
+__global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
                                                           const float* __restrict__ aggrs,
                                                           const float* __restrict__ gcolors,
                                                           float* __restrict__ gfaces, float* __restrict__ gtex)
 {
-    __shared__ unsigned int s_ring[4][QCAP];
+    __shared__ unsigned int s_ring[BWD_THREADS / 64][QCAP];
     constexpr bool FM = BWD_FM;
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }

@@ -12,9 +12,9 @@ void launch_backward_fast(int nch, dim3 grid, hipStream_t st, const RasterArgs& 
                           const float* gcolors, float* gfaces, float* gtex)
 {
     if (nch == 6)
-        hipLaunchKernelGGL((sr_backward_kernel<true, 6>), grid, dim3(256), 0, st, A, colors, aggrs, gcolors, gfaces, gtex);
+        hipLaunchKernelGGL((sr_backward_kernel<true, 6>), grid, dim3(BWD_THREADS), 0, st, A, colors, aggrs, gcolors, gfaces, gtex);
     else
-        hipLaunchKernelGGL((sr_backward_kernel<true, 3>), grid, dim3(256), 0, st, A, colors, aggrs, gcolors, gfaces, gtex);
+        hipLaunchKernelGGL((sr_backward_kernel<true, 3>), grid, dim3(BWD_THREADS), 0, st, A, colors, aggrs, gcolors, gfaces, gtex);
 }
 
 }  // namespace lasr
