@@ -105,9 +105,15 @@ def test_two_ranks_stay_in_lockstep(tmp_path, cuda, use_graph):
     both = single_process([ids0, ids1])
     alone = single_process([ids0])
     scale = np.abs(both).max()
-    # not bit-equal: MIOpen may pick other convolution algorithms for the two call patterns, and torch's index_add
-    # gradients use float atomics; the parameters have moved by ~1e-2 after four steps
-    assert np.abs(f0 - both).max() <= 2e-4 * scale, (np.abs(f0 - both).max(), np.abs(f0 - alone).max(), scale)
-    assert np.abs(f0 - alone).max() >= 5 * np.abs(f0 - both).max() and np.abs(f0 - alone).max() > 1e-3 * scale, \
-        (np.abs(f0 - alone).max(), np.abs(f0 - both).max(), scale)
+    d_both, d_alone = np.abs(f0 - both), np.abs(f0 - alone)
+    stats = dict(max_both=d_both.max(), p999_both=np.quantile(d_both, 0.999), l2_both=np.linalg.norm(d_both),
+                 max_alone=d_alone.max(), l2_alone=np.linalg.norm(d_alone), scale=scale)
+    print('dp-equivalence', stats)
+    # not bit-equal: MIOpen may pick other convolution algorithms for the two call patterns, torch's index_add
+    # gradients use float atomics, and Adam's first steps move a parameter by lr*sign(g) -- a gradient entry that is
+    # rounding noise around zero can land a full 2*lr apart. So: all but a handful of entries agree tightly, the
+    # handful stay within a few lr, and the whole vector is far closer to the two-shard mean than to one shard alone.
+    assert stats['p999_both'] <= 2e-5 * scale, stats
+    assert stats['max_both'] <= 5e-4 * scale, stats
+    assert stats['l2_alone'] >= 10 * stats['l2_both'] and stats['max_alone'] > 1e-3 * scale, stats
     # (use_graph=False is the reference's own arrangement: DistributedDataParallel + SyncBatchNorm kept in eval mode)
