@@ -78,6 +78,7 @@ def main(argv):
     import torch.distributed as dist
     if torch.cuda.is_available():
         torch.cuda.set_device(opts.local_rank)
+        torch.backends.cudnn.benchmark = True               # optimize.py:30-31 (on ROCm: MIOpen's find mode; 122.6 -> 124.3 it/s)
     world = int(os.environ.get('WORLD_SIZE', opts.ngpu))
     if world > 1 or 'RANK' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
