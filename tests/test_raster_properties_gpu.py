@@ -1,0 +1,118 @@
+"""Size-independent properties of the HIP soft-rasteriser at the FULL bench workload (BASELINE.json configs[1]: 256 frames of
+256x256, M2 mesh V=1212 / F=2420), where the CPU oracle is too slow to check every frame:
+
+  * frames of a batch are independent: frame k of the 256-frame launch is bit-identical (image, aggregates, gradients) to frame k
+    rendered alone -- tile binning, XCD remapping and the face-major backward never mix images;
+  * a sample of the frames still goes through the oracle (image <= 1e-4, gradients <= 1e-3 of the largest entry);
+  * the backward is linear in the upstream gradient (K.cu:482-640 multiplies every term by one grad_soft_colors entry);
+  * the colour channels are convex combinations of texture / background values, alpha lies in [0, 1]
+    (K.cu:430-468: softmax weights sum to one, alpha = 1 - prod(1 - D)).
+
+Everything runs through the C ABI exactly as bench.py's timed step does (bench.RasterStep).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FRAMES = 256
+SAMPLE = (0, 97, 255)
+
+
+@pytest.fixture(scope='module')
+def full(cuda):
+    import bench
+    rs = bench.RasterStep(cuda, FRAMES, 0)
+    rs.step()
+    torch.cuda.synchronize()
+    return bench, rs, dict(img=rs.colors.clone(), aggr=rs.aggrs.clone(), gf=rs.gf.clone(), gt=rs.gt.clone(),
+                           mesh_grad=rs.mesh_grad.clone())
+
+
+def test_frames_of_a_batch_are_independent(full, cuda):
+    bench, rs, out = full
+    for k in SAMPLE:
+        one = bench.RasterStep(cuda, 1, k)
+        assert torch.equal(one.fv[0], rs.fv[k])                  # same synthetic frame
+        one.g.copy_(rs.g[k:k + 1])
+        one.step()
+        torch.cuda.synchronize()
+        assert torch.equal(one.colors[0], out['img'][k]), 'image of frame %d depends on its batch' % k
+        assert torch.equal(one.aggrs[0], out['aggr'][k])
+        assert torch.equal(one.gf[0], out['gf'][k]), 'vertex gradient of frame %d depends on its batch' % k
+        assert torch.equal(one.gt[0], out['gt'][k])
+
+
+def test_sampled_frames_of_the_full_batch_match_the_oracle(full, oracle):
+    bench, rs, out = full
+    from lasr_amd import synth
+    m = synth.LASR_MODES
+    kw = dict(background_color=[1., 1., 1.], near=float(rs.near), far=float(rs.far), fill_back=True, eps=m['eps'],
+              sigma_val=m['sigma_val'], dist_func='euclidean', dist_eps=m['dist_eps'], gamma_val=m['gamma_val'],
+              aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='vertex')
+    idx = list(SAMPLE)
+    fv = rs.fv[idx].cpu().numpy().reshape(len(idx), rs.F, 3, 3)
+    ft = rs.ft[idx].cpu().numpy().reshape(len(idx), rs.F, 3, 3)
+    g = rs.g[idx].cpu().numpy()
+    ref = oracle.forward(fv, ft, bench.IS, **kw)
+    err = np.abs(out['img'][idx].cpu().numpy() - ref['soft_colors']).max()
+    assert err <= 1e-4, 'image max-abs %.3e' % err
+    gf_ref, gt_ref = oracle.backward(ref, g, bench.IS, **kw)
+    for name, a, b in (('grad_faces', out['gf'][idx], gf_ref), ('grad_textures', out['gt'][idx], gt_ref)):
+        a = a.cpu().numpy().reshape(b.shape)
+        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max(), name
+
+
+def test_backward_is_linear_in_the_upstream_gradient(full, cuda):
+    bench, rs, out = full
+    g0 = rs.g.clone()
+    try:
+        rs.g.copy_(g0 * 2)                                        # a power of two: every product and sum scales exactly
+        rs.step()
+        assert torch.equal(rs.gf, out['gf'] * 2) and torch.equal(rs.gt, out['gt'] * 2)
+        gen = torch.Generator(device=cuda).manual_seed(5)
+        g1 = torch.randn(g0.shape, device=cuda, generator=gen)
+        rs.g.copy_(g1)
+        rs.step()
+        gf1, gt1 = rs.gf.clone(), rs.gt.clone()
+        rs.g.copy_(g0 + g1)
+        rs.step()
+        for name, both, a, b in (('grad_faces', rs.gf, out['gf'], gf1), ('grad_textures', rs.gt, out['gt'], gt1)):
+            d = (both - (a + b)).abs().max().item()
+            assert d <= 1e-5 * max(a.abs().max().item(), b.abs().max().item()), (name, d)
+        rs.g.zero_()
+        rs.step()
+        assert not rs.gf.any() and not rs.gt.any() and not rs.mesh_grad.any()
+    finally:
+        rs.g.copy_(g0)
+
+
+def test_colours_are_convex_combinations_and_alpha_is_a_probability(full):
+    bench, rs, out = full
+    img = out['img']
+    assert torch.isfinite(img).all()
+    lo = min(float(rs.ft.min()), 1.0)
+    hi = max(float(rs.ft.max()), 1.0)
+    assert float(img[:, :3].min()) >= lo - 1e-5 and float(img[:, :3].max()) <= hi + 1e-5
+    assert float(img[:, 3].min()) >= 0.0 and float(img[:, 3].max()) <= 1.0
+    covered = (img[:, 3] > 0.5).float().mean().item()
+    assert 0.05 < covered < 0.9                                   # the mesh is in view in every frame, and is not the whole image
+    assert (img[:, 3].flatten(1).max(1).values > 0.99).all()
+
+
+def test_vertex_scatter_equals_the_sum_over_incident_faces(full):
+    bench, rs, out = full
+    F = rs.F
+    faces = rs.faces_idx.cpu().numpy().reshape(-1)
+    for slot, per_face in ((0, out['gf']), (1, out['gt'])):
+        acc = np.zeros((rs.V, 3), np.float64)
+        np.add.at(acc, faces, per_face.double().sum(0).cpu().numpy().reshape(F * 3, 3))
+        got = out['mesh_grad'][slot].double().cpu().numpy()
+        assert np.abs(got - acc).max() <= 1e-4 * np.abs(acc).max()
