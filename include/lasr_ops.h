@@ -225,6 +225,70 @@ int lasr_cosdist_backward(const float* feat_obs, const float* feat_rnd, const fl
 int lasr_load_textures(const float* image, const float* faces_uv, const int* is_update, float* textures, int F, int R, int H,
                        int W, void* hip_stream);
 
+/*
+ * ---- small-tensor glue of LASR.forward as single kernels (lasr_amd/csrc/glue.hip) -----------------------------------
+ *
+ * Rotation distance, third_party/ext_utils/util_rot.py:27-37 (called at nnutils/mesh_net.py:508 / :516): m1, m2 [n,3,3]
+ * row-major -> angle [n] = acos((trace(m1 m2^T) - 1) / 2); where |cos| >= 1 the angle is 0 / pi with zero gradient (the
+ * reference's acos(min(cos, 1)) back-propagates NaN there and its trainer skips the step).
+ */
+int lasr_geodesic_forward(const float* m1, const float* m2, float* angle, int n, void* hip_stream);
+int lasr_geodesic_backward(const float* m1, const float* m2, const float* grad_angle, float* grad_m1, float* grad_m2, int n,
+                           void* hip_stream);
+
+/*
+ * total = sum_t weights[t] * mean(terms[t]) -- the reference's chain `total_loss += w * x.mean()` at
+ * nnutils/mesh_net.py:374-530.  terms: HOST array of n_terms device pointers (each a contiguous fp32 tensor of numels[t]
+ * elements), weights / groups: host arrays; out [n_groups + 1] (device): out[g] = sum of the weighted means of group g (the
+ * per-loss scalars LASR logs: mask_loss, flow_rd_loss, ...), out[n_groups] = total, both accumulated in term order.
+ * Backward: coef[t] = grad_total * weights[t] / numels[t] (the gradient of every element of term t).
+ */
+#define LASR_MEANS_MAX_TERMS 24
+int lasr_weighted_means_forward(const float* const* terms, const int* numels, const float* weights, const int* groups,
+                                int n_terms, int n_groups, float* out, void* hip_stream);
+int lasr_weighted_means_backward(const int* numels, const float* weights, int n_terms, const float* grad_total, float* coef,
+                                 void* hip_stream);
+
+/*
+ * Intrinsics bookkeeping of the image pair, nnutils/mesh_net.py:204-217.  cams [2B, cam_stride] (column 0 = crop scale; rows
+ * 0..B-1 frames t, B..2B-1 frames t'), pp [2B,2], predicted scale [2B,H], depth [2B,K], ppoint [2B,2], half_size = img_size/2:
+ *   scale_out = cams0 * scale;  depth_out = depth with column 0 multiplied by cams0;
+ *   ppoint_out[:B] = ppoint[:B];  ppoint_out[B+i] = (ppoint[i] + cams0_i pp_i / half + 1) * (cams0_{B+i} / cams0_i)
+ *                                                   - cams0_{B+i} pp_{B+i} / half - 1
+ * Backward: gradients w.r.t. scale, depth, ppoint (rows B.. of ppoint receive 0: the reference discards that prediction).
+ */
+int lasr_intrinsics_forward(const float* cams, int cam_stride, const float* pp, const float* scale, const float* depth,
+                            const float* ppoint, float* scale_out, float* depth_out, float* ppoint_out, int B, int H, int K,
+                            float half_size, void* hip_stream);
+int lasr_intrinsics_backward(const float* cams, int cam_stride, const float* grad_scale_out, const float* grad_depth_out,
+                             const float* grad_ppoint_out, float* grad_scale, float* grad_depth, float* grad_ppoint, int B, int H,
+                             int K, void* hip_stream);
+
+/*
+ * Bone-transform fix-up, nnutils/mesh_net.py:259-283.  quat [M,K,9]: the 3x3 Q the pose head
+ * predicts per (image-hypothesis m = image * H + h, bone k); trans [M*K,2], depth [M*K]; rest_ts [H,K-1,3] joint centres.
+ *   root k = 0:  rmat = Q^T, tmat = (trans, depth)
+ *   bone k >= 1: rmat = Q,   tmat = -Q^T c + (trans, depth) + c,  c = rest_ts[h, k-1]      (rotation about the joint)
+ * rmat [M*K,3,3], tmat [M*K,3].  Backward: gradients of quat, trans, depth and rest_ts (summed over the images, in image
+ * order: deterministic).  rest_ts / grad_rest may be NULL when K == 1.
+ */
+int lasr_bone_fixup_forward(const float* quat, const float* trans, const float* depth, const float* rest_ts, float* rmat,
+                            float* tmat, int M, int H, int K, void* hip_stream);
+int lasr_bone_fixup_backward(const float* quat, const float* rest_ts, const float* grad_rmat, const float* grad_tmat,
+                             float* grad_quat, float* grad_trans, float* grad_depth, float* grad_rest, int M, int H, int K,
+                             void* hip_stream);
+
+/*
+ * Symmetric squared Chamfer distance of small point sets -- pytorch3d.loss.chamfer_distance()[0] as used on the bones' control
+ * points at nnutils/mesh_net.py:500-503: a [N,P,3], b [N,Q,3] -> out[n] = mean_i min_j |a_i - b_j|^2 + mean_j min_i |b_j - a_i|^2
+ * (the caller averages over n); nn_ab [N,P] / nn_ba [N,Q] int32 receive the nearest indices (first minimum) for the backward,
+ * which writes grad_a [N,P,3] and grad_b [N,Q,3] for an upstream grad_out [N] by gathers (no atomics).
+ */
+int lasr_chamfer_forward(const float* a, const float* b, float* out, int* nn_ab, int* nn_ba, int N, int P, int Q,
+                         void* hip_stream);
+int lasr_chamfer_backward(const float* a, const float* b, const int* nn_ab, const int* nn_ba, const float* grad_out, float* grad_a,
+                          float* grad_b, int N, int P, int Q, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

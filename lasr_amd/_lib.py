@@ -56,6 +56,17 @@ SIGNATURES = {
     'lasr_cosdist_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_cosdist_backward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_load_textures': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    # lasr_amd/csrc/glue.hip
+    'lasr_geodesic_forward': (_i, [_p, _p, _p, _i, _p]),
+    'lasr_geodesic_backward': (_i, [_p, _p, _p, _p, _p, _i, _p]),
+    'lasr_weighted_means_forward': (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
+    'lasr_weighted_means_backward': (_i, [_p, _p, _i, _p, _p, _p]),
+    'lasr_intrinsics_forward': (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    'lasr_intrinsics_backward': (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_bone_fixup_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_bone_fixup_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_chamfer_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_chamfer_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),

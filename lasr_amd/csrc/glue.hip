@@ -1,0 +1,427 @@
+// glue.hip -- the small-tensor arithmetic of LASR.forward between its big operators, as single kernels.
+//
+// In the reference these are runs of eager elementwise / slice / cat / mean ops on tensors of a few hundred floats
+// (nnutils/mesh_net.py:204-217 intrinsics bookkeeping, :259-283 bone-transform fix-up, :506-522 rotation distance,
+// :374-530 the weighted sum of loss means): ~150 launches of 2-4 us per optimisation step and as many autograd nodes.
+// Each kernel here is one workgroup (the data fits a few wavefronts); the point is launch count, not bandwidth.
+#include <hip/hip_runtime.h>
+
+#include "../../include/lasr_ops.h"
+#include "ops_common.h"
+
+namespace lasr {
+
+// ---- rotation distance (third_party/ext_utils/util_rot.py:27-37) ------------------------------------------------------
+// cos = (trace(m1 m2^T) - 1) / 2, angle = acos(cos) where |cos| < 1, else 0 (cos >= 1) or pi (cos <= -1).
+__device__ __forceinline__ float geodesic_cos(const float* a, const float* b)
+{
+    const float r0 = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];      // (m1 m2^T)[0,0]
+    const float r1 = a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+    const float r2 = a[6] * b[6] + a[7] * b[7] + a[8] * b[8];
+    return (r0 + r1 + r2 - 1.f) / 2.f;
+}
+
+__global__ __launch_bounds__(256) void geodesic_forward_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
+                                                               float* __restrict__ angle, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float c = geodesic_cos(m1 + 9 * (size_t)i, m2 + 9 * (size_t)i);
+    angle[i] = fabsf(c) < 1.f ? acosf(c) : (c > 0.f ? 0.f : 3.14159265358979323846f);
+}
+
+__global__ __launch_bounds__(256) void geodesic_backward_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                const float* __restrict__ gangle, float* __restrict__ g1,
+                                                                float* __restrict__ g2, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* a = m1 + 9 * (size_t)i;
+    const float* b = m2 + 9 * (size_t)i;
+    const float c = geodesic_cos(a, b);
+    // d acos / d cos = -1 / sqrt(1 - cos^2); outside (-1, 1) the angle is a constant (zero gradient)
+    const float gc = fabsf(c) < 1.f ? -gangle[i] / sqrtf(1.f - c * c) * 0.5f : 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        g1[9 * (size_t)i + k] = gc * b[k];
+        g2[9 * (size_t)i + k] = gc * a[k];
+    }
+}
+
+// ---- total = sum_i w_i * mean(x_i), with per-group partial totals ----------------------------------------------------
+struct MeansArgs {
+    const float* x[LASR_MEANS_MAX_TERMS];
+    int n[LASR_MEANS_MAX_TERMS];
+    float w[LASR_MEANS_MAX_TERMS];
+    int g[LASR_MEANS_MAX_TERMS];
+    int terms, groups;
+};
+
+// One workgroup of 1024 threads walks the terms in order; out[0..groups) = group totals, out[groups] = total,
+// accumulated in term order by one thread (deterministic).
+__global__ __launch_bounds__(1024) void weighted_means_kernel(MeansArgs A, float* __restrict__ out)
+{
+    __shared__ float red[16];
+    __shared__ float acc[LASR_MEANS_MAX_TERMS + 1];
+    const int tid = threadIdx.x;
+    if (tid <= A.groups) acc[tid] = 0.f;
+    for (int t = 0; t < A.terms; t++) {
+        const float* __restrict__ x = A.x[t];
+        float s = 0.f;
+        for (int i = tid; i < A.n[t]; i += 1024) s += x[i];
+        s = wave_sum_to_lane63(s);
+        __syncthreads();
+        if ((tid & 63) == 63) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) tot += red[k];
+            const float v = A.w[t] * (A.n[t] > 0 ? tot / (float)A.n[t] : 0.f);
+            acc[A.g[t]] += v;
+            acc[A.groups] += v;
+        }
+    }
+    __syncthreads();
+    if (tid <= A.groups) out[tid] = acc[tid];
+}
+
+struct MeansCoef { float c[LASR_MEANS_MAX_TERMS]; int terms; };
+__global__ __launch_bounds__(64) void weighted_means_backward_kernel(MeansCoef C, const float* __restrict__ gtotal,
+                                                                     float* __restrict__ coef)
+{
+    const int t = threadIdx.x;
+    if (t < C.terms) coef[t] = gtotal[0] * C.c[t];
+}
+
+// ---- intrinsics bookkeeping (nnutils/mesh_net.py:204-217) ------------------------------------------------------------
+// cams[:, 0] = crop scale a of each image (rows 0..B-1: frames t, rows B..2B-1: frames t'), pp = crop centre offsets.
+//   scale_out = a * scale;   depth_out[:, 0] = a * depth[:, 0], other columns unchanged
+//   ppoint_out[:B] = ppoint[:B];   ppoint_out[B + i] = (ppoint[i] + a_i pp_i / h + 1) * (a'_i / a_i) - a'_i pp'_i / h - 1
+__global__ __launch_bounds__(256) void intrinsics_forward_kernel(const float* __restrict__ cams, int cam_stride,
+                                                                 const float* __restrict__ pp, const float* __restrict__ scale,
+                                                                 const float* __restrict__ depth,
+                                                                 const float* __restrict__ ppoint, float* __restrict__ scale_out,
+                                                                 float* __restrict__ depth_out, float* __restrict__ ppoint_out,
+                                                                 int B, int H, int K, float half)
+{
+    const int n2 = 2 * B;
+    for (int i = threadIdx.x; i < n2 * H; i += 256) scale_out[i] = cams[(i / H) * cam_stride] * scale[i];
+    for (int i = threadIdx.x; i < n2 * K; i += 256) {
+        const float d = depth[i];
+        depth_out[i] = (i % K == 0) ? cams[(i / K) * cam_stride] * d : d;
+    }
+    for (int i = threadIdx.x; i < n2 * 2; i += 256) {
+        const int r = i >> 1, c = i & 1;
+        if (r < B) { ppoint_out[i] = ppoint[i]; continue; }
+        const int r0 = r - B;
+        const float a0 = cams[r0 * cam_stride], a1 = cams[r * cam_stride];
+        const float ppb1 = a0 * pp[2 * r0 + c] / half, ppb2 = a1 * pp[2 * r + c] / half;
+        const float ppa1 = ppoint[2 * r0 + c] + ppb1 + 1.f;
+        ppoint_out[i] = ppa1 * (a1 / a0) - ppb2 - 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void intrinsics_backward_kernel(const float* __restrict__ cams, int cam_stride,
+                                                                  const float* __restrict__ gscale_out,
+                                                                  const float* __restrict__ gdepth_out,
+                                                                  const float* __restrict__ gppoint_out, float* __restrict__ gscale,
+                                                                  float* __restrict__ gdepth, float* __restrict__ gppoint, int B,
+                                                                  int H, int K)
+{
+    const int n2 = 2 * B;
+    for (int i = threadIdx.x; i < n2 * H; i += 256) gscale[i] = cams[(i / H) * cam_stride] * gscale_out[i];
+    for (int i = threadIdx.x; i < n2 * K; i += 256) {
+        const float g = gdepth_out[i];
+        gdepth[i] = (i % K == 0) ? cams[(i / K) * cam_stride] * g : g;
+    }
+    for (int i = threadIdx.x; i < n2 * 2; i += 256) {
+        const int r = i >> 1, c = i & 1;
+        if (r >= B) { gppoint[i] = 0.f; continue; }                  // the predicted principal point of frame t' is not used
+        const float a0 = cams[r * cam_stride], a1 = cams[(r + B) * cam_stride];
+        gppoint[i] = gppoint_out[i] + gppoint_out[2 * (r + B) + c] * (a1 / a0);
+    }
+}
+
+// ---- bone-transform fix-up (nnutils/mesh_net.py:259-283) --------------------------------------------------------------
+// Per (image-hypothesis m, bone k): Q = the 3x3 the pose head predicts (row-major), t = (trans_x, trans_y, depth).
+//   root (k = 0):   R' = Q^T,  T' = t
+//   bones (k >= 1): R' = Q,    T' = t + c - Q^T c     with c = rest_ts[h, k-1] (rotate about the joint)
+// (the reference transposes every Q, applies -R c + T + c with R = Q^T, then transposes the bones back.)
+__global__ __launch_bounds__(256) void bone_fixup_forward_kernel(const float* __restrict__ quat, const float* __restrict__ trans,
+                                                                 const float* __restrict__ depth, const float* __restrict__ rest,
+                                                                 float* __restrict__ Rout, float* __restrict__ Tout, int M, int H,
+                                                                 int K)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;                    // i = (m * K + k),  m = image * H + h
+    if (i >= M * K) return;
+    const int k = i % K, h = (i / K) % H;
+    const float* q = quat + 9 * (size_t)i;
+    float* R = Rout + 9 * (size_t)i;
+    float tx = trans[2 * (size_t)i], ty = trans[2 * (size_t)i + 1], tz = depth[i];
+    if (k == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) R[3 * r + c] = q[3 * c + r];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 9; j++) R[j] = q[j];
+        const float* c = rest + 3 * ((size_t)h * (K - 1) + (k - 1));
+        // (Q^T c)_r = sum_j Q[j][r] c_j ; summed j = 0,1,2 like the reference's matmul row
+        const float r0 = q[0] * c[0] + q[3] * c[1] + q[6] * c[2];
+        const float r1 = q[1] * c[0] + q[4] * c[1] + q[7] * c[2];
+        const float r2 = q[2] * c[0] + q[5] * c[1] + q[8] * c[2];
+        tx = -r0 + tx + c[0]; ty = -r1 + ty + c[1]; tz = -r2 + tz + c[2];
+    }
+    Tout[3 * (size_t)i] = tx; Tout[3 * (size_t)i + 1] = ty; Tout[3 * (size_t)i + 2] = tz;
+}
+
+// grad_quat / grad_trans / grad_depth per (m, k); grad_rest[h, k-1] = sum over the images of (g - Q g) in image order.
+__global__ __launch_bounds__(256) void bone_fixup_backward_kernel(const float* __restrict__ quat, const float* __restrict__ rest,
+                                                                  const float* __restrict__ gR, const float* __restrict__ gT,
+                                                                  float* __restrict__ gquat, float* __restrict__ gtrans,
+                                                                  float* __restrict__ gdepth, float* __restrict__ grest, int M,
+                                                                  int H, int K)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = M * K;
+    if (i < total) {
+        const int k = i % K, h = (i / K) % H;
+        const float* g = gR + 9 * (size_t)i;
+        const float* t = gT + 3 * (size_t)i;
+        float* gq = gquat + 9 * (size_t)i;
+        gtrans[2 * (size_t)i] = t[0]; gtrans[2 * (size_t)i + 1] = t[1]; gdepth[i] = t[2];
+        if (k == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) gq[3 * c + r] = g[3 * r + c];
+        } else {
+            const float* c = rest + 3 * ((size_t)h * (K - 1) + (k - 1));
+            // T'_r = t_r + c_r - sum_j Q[j][r] c_j   =>   dT'_r / dQ[j][r] = -c_j
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int r = 0; r < 3; r++) gq[3 * j + r] = g[3 * j + r] - c[j] * t[r];
+        }
+    }
+    // rest_ts: one thread per (h, k-1, component) sums its images in order
+    const int nrest = H * (K - 1) * 3;
+    if (i < nrest) {
+        const int comp = i % 3, kb = (i / 3) % (K - 1), h = i / (3 * (K - 1));
+        const int images = M / H;
+        float s = 0.f;
+        for (int im = 0; im < images; im++) {
+            const size_t e = ((size_t)(im * H + h)) * K + (kb + 1);
+            const float* q = quat + 9 * e;
+            const float* t = gT + 3 * e;
+            // dT'_r / dc_j = delta_rj - Q[j][r]
+            s += t[comp] - (q[3 * comp + 0] * t[0] + q[3 * comp + 1] * t[1] + q[3 * comp + 2] * t[2]);
+        }
+        grest[i] = s;
+    }
+}
+
+// ---- symmetric Chamfer distance of two small point sets (pytorch3d.loss.chamfer_distance as used at nnutils/mesh_net.py:503) --
+// a [N,P,3], b [N,Q,3] -> out[n] = mean_i min_j |a_i - b_j|^2 + mean_j min_i |b_j - a_i|^2, nearest indices kept for the
+// backward.  One workgroup per batch item (the control-point sets hold <= 35 points; larger sets loop).
+__global__ __launch_bounds__(256) void chamfer_forward_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ out, int* __restrict__ nn_ab,
+                                                              int* __restrict__ nn_ba, int P, int Q)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float* A = a + (size_t)n * P * 3;
+    const float* Bp = b + (size_t)n * Q * 3;
+    float sa = 0.f, sb = 0.f;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const float x = A[3 * i], y = A[3 * i + 1], z = A[3 * i + 2];
+        float best = 3.4e38f; int arg = 0;
+        for (int j = 0; j < Q; j++) {
+            const float dx = x - Bp[3 * j], dy = y - Bp[3 * j + 1], dz = z - Bp[3 * j + 2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; arg = j; }                    // first minimum, like min(dim)
+        }
+        nn_ab[(size_t)n * P + i] = arg;
+        sa += best;
+    }
+    for (int j = threadIdx.x; j < Q; j += 256) {
+        const float x = Bp[3 * j], y = Bp[3 * j + 1], z = Bp[3 * j + 2];
+        float best = 3.4e38f; int arg = 0;
+        for (int i = 0; i < P; i++) {
+            const float dx = x - A[3 * i], dy = y - A[3 * i + 1], dz = z - A[3 * i + 2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; arg = i; }
+        }
+        nn_ba[(size_t)n * Q + j] = arg;
+        sb += best;
+    }
+    sa = block_sum(sa, red);
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0) out[n] = sa / (float)P + sb / (float)Q;
+}
+
+// grad_a[n,i] = g[n] * (2/P (a_i - b_nn(i)) + 2/Q sum_{j: nn'(j) = i} (a_i - b_j)), grad_b likewise (gather form: deterministic)
+__global__ __launch_bounds__(256) void chamfer_backward_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               const int* __restrict__ nn_ab, const int* __restrict__ nn_ba,
+                                                               const float* __restrict__ g, float* __restrict__ ga,
+                                                               float* __restrict__ gb, int P, int Q)
+{
+    const int n = blockIdx.x;
+    const float* A = a + (size_t)n * P * 3;
+    const float* Bp = b + (size_t)n * Q * 3;
+    const int* ab = nn_ab + (size_t)n * P;
+    const int* ba = nn_ba + (size_t)n * Q;
+    const float wp = g[n] * 2.f / (float)P, wq = g[n] * 2.f / (float)Q;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const float x = A[3 * i], y = A[3 * i + 1], z = A[3 * i + 2];
+        const int j0 = ab[i];
+        float gx = wp * (x - Bp[3 * j0]), gy = wp * (y - Bp[3 * j0 + 1]), gz = wp * (z - Bp[3 * j0 + 2]);
+        for (int j = 0; j < Q; j++)
+            if (ba[j] == i) { gx += wq * (x - Bp[3 * j]); gy += wq * (y - Bp[3 * j + 1]); gz += wq * (z - Bp[3 * j + 2]); }
+        float* o = ga + ((size_t)n * P + i) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+    for (int j = threadIdx.x; j < Q; j += 256) {
+        const float x = Bp[3 * j], y = Bp[3 * j + 1], z = Bp[3 * j + 2];
+        const int i0 = ba[j];
+        float gx = wq * (x - A[3 * i0]), gy = wq * (y - A[3 * i0 + 1]), gz = wq * (z - A[3 * i0 + 2]);
+        for (int i = 0; i < P; i++)
+            if (ab[i] == j) { gx += wp * (x - A[3 * i]); gy += wp * (y - A[3 * i + 1]); gz += wp * (z - A[3 * i + 2]); }
+        float* o = gb + ((size_t)n * Q + j) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+}
+
+}  // namespace lasr
+
+using namespace lasr;
+
+extern "C" int lasr_geodesic_forward(const float* m1, const float* m2, float* angle, int n, void* hip_stream)
+{
+    if (n < 0) return LASR_E_BADARG;
+    if (n == 0) return LASR_OK;
+    if (!m1 || !m2 || !angle) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_GEODESIC_FORWARD, geodesic_forward_kernel, dim3((n + 255) / 256), dim3(256), 0, m1, m2, angle, n);
+    return launch_ok();
+}
+
+extern "C" int lasr_geodesic_backward(const float* m1, const float* m2, const float* grad_angle, float* grad_m1, float* grad_m2,
+                                      int n, void* hip_stream)
+{
+    if (n < 0) return LASR_E_BADARG;
+    if (n == 0) return LASR_OK;
+    if (!m1 || !m2 || !grad_angle || !grad_m1 || !grad_m2) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_GEODESIC_BACKWARD, geodesic_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, m1, m2, grad_angle, grad_m1,
+                grad_m2, n);
+    return launch_ok();
+}
+
+extern "C" int lasr_weighted_means_forward(const float* const* terms, const int* numels, const float* weights, const int* groups,
+                                           int n_terms, int n_groups, float* out, void* hip_stream)
+{
+    if (n_terms < 0 || n_terms > LASR_MEANS_MAX_TERMS || n_groups < 1 || n_groups > LASR_MEANS_MAX_TERMS) return LASR_E_BADARG;
+    if (!out || (n_terms > 0 && (!terms || !numels || !weights || !groups))) return LASR_E_BADARG;
+    MeansArgs A;
+    A.terms = n_terms; A.groups = n_groups;
+    for (int t = 0; t < n_terms; t++) {
+        if (numels[t] < 0 || groups[t] < 0 || groups[t] >= n_groups || (numels[t] > 0 && !terms[t])) return LASR_E_BADARG;
+        A.x[t] = terms[t]; A.n[t] = numels[t]; A.w[t] = weights[t]; A.g[t] = groups[t];
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_WEIGHTED_MEANS, weighted_means_kernel, dim3(1), dim3(1024), 0, A, out);
+    return launch_ok();
+}
+
+extern "C" int lasr_weighted_means_backward(const int* numels, const float* weights, int n_terms, const float* grad_total,
+                                            float* coef, void* hip_stream)
+{
+    if (n_terms < 0 || n_terms > LASR_MEANS_MAX_TERMS) return LASR_E_BADARG;
+    if (n_terms == 0) return LASR_OK;
+    if (!numels || !weights || !grad_total || !coef) return LASR_E_BADARG;
+    MeansCoef C;
+    C.terms = n_terms;
+    for (int t = 0; t < n_terms; t++) C.c[t] = numels[t] > 0 ? weights[t] / (float)numels[t] : 0.f;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_WEIGHTED_MEANS, weighted_means_backward_kernel, dim3(1), dim3(64), 0, C, grad_total, coef);
+    return launch_ok();
+}
+
+extern "C" int lasr_intrinsics_forward(const float* cams, int cam_stride, const float* pp, const float* scale, const float* depth,
+                                       const float* ppoint, float* scale_out, float* depth_out, float* ppoint_out, int B, int H,
+                                       int K, float half_size, void* hip_stream)
+{
+    if (B < 0 || H < 1 || K < 1 || cam_stride < 1 || !(half_size > 0.f)) return LASR_E_BADARG;
+    if (B == 0) return LASR_OK;
+    if (!cams || !pp || !scale || !depth || !ppoint || !scale_out || !depth_out || !ppoint_out) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_INTRINSICS, intrinsics_forward_kernel, dim3(1), dim3(256), 0, cams, cam_stride, pp, scale, depth, ppoint,
+                scale_out, depth_out, ppoint_out, B, H, K, half_size);
+    return launch_ok();
+}
+
+extern "C" int lasr_intrinsics_backward(const float* cams, int cam_stride, const float* grad_scale_out,
+                                        const float* grad_depth_out, const float* grad_ppoint_out, float* grad_scale,
+                                        float* grad_depth, float* grad_ppoint, int B, int H, int K, void* hip_stream)
+{
+    if (B < 0 || H < 1 || K < 1 || cam_stride < 1) return LASR_E_BADARG;
+    if (B == 0) return LASR_OK;
+    if (!cams || !grad_scale_out || !grad_depth_out || !grad_ppoint_out || !grad_scale || !grad_depth || !grad_ppoint)
+        return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_INTRINSICS, intrinsics_backward_kernel, dim3(1), dim3(256), 0, cams, cam_stride, grad_scale_out, grad_depth_out,
+                grad_ppoint_out, grad_scale, grad_depth, grad_ppoint, B, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_bone_fixup_forward(const float* quat, const float* trans, const float* depth, const float* rest_ts,
+                                       float* rmat, float* tmat, int M, int H, int K, void* hip_stream)
+{
+    if (M < 0 || H < 1 || K < 1 || M % H != 0) return LASR_E_BADARG;
+    if (M == 0) return LASR_OK;
+    if (!quat || !trans || !depth || !rmat || !tmat || (K > 1 && !rest_ts)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_BONE_FIXUP, bone_fixup_forward_kernel, dim3((M * K + 255) / 256), dim3(256), 0, quat, trans, depth, rest_ts,
+                rmat, tmat, M, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_bone_fixup_backward(const float* quat, const float* rest_ts, const float* grad_rmat, const float* grad_tmat,
+                                        float* grad_quat, float* grad_trans, float* grad_depth, float* grad_rest, int M, int H,
+                                        int K, void* hip_stream)
+{
+    if (M < 0 || H < 1 || K < 1 || M % H != 0) return LASR_E_BADARG;
+    if (M == 0) return LASR_OK;
+    if (!quat || !grad_rmat || !grad_tmat || !grad_quat || !grad_trans || !grad_depth || (K > 1 && (!rest_ts || !grad_rest)))
+        return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int work = M * K > H * (K - 1) * 3 ? M * K : H * (K - 1) * 3;
+    LASR_LAUNCH(K_BONE_FIXUP, bone_fixup_backward_kernel, dim3((work + 255) / 256), dim3(256), 0, quat, rest_ts, grad_rmat,
+                grad_tmat, grad_quat, grad_trans, grad_depth, grad_rest, M, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_chamfer_forward(const float* a, const float* b, float* out, int* nn_ab, int* nn_ba, int N, int P, int Q,
+                                    void* hip_stream)
+{
+    if (N < 0 || P < 1 || Q < 1) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!a || !b || !out || !nn_ab || !nn_ba) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_CHAMFER, chamfer_forward_kernel, dim3(N), dim3(256), 0, a, b, out, nn_ab, nn_ba, P, Q);
+    return launch_ok();
+}
+
+extern "C" int lasr_chamfer_backward(const float* a, const float* b, const int* nn_ab, const int* nn_ba, const float* grad_out,
+                                     float* grad_a, float* grad_b, int N, int P, int Q, void* hip_stream)
+{
+    if (N < 0 || P < 1 || Q < 1) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!a || !b || !nn_ab || !nn_ba || !grad_out || !grad_a || !grad_b) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_CHAMFER, chamfer_backward_kernel, dim3(N), dim3(256), 0, a, b, nn_ab, nn_ba, grad_out, grad_a, grad_b, P, Q);
+    return launch_ok();
+}

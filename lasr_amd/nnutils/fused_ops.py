@@ -261,3 +261,202 @@ def cosine_distance(feat_obs, feat_rnd, repeat=1):
     util/util.py:71-83, models/networks_basic.py:51-52): feat_obs [N/repeat,C,h,w] (no gradient), feat_rnd [N,C,h,w]
     -> [N]."""
     return _CosDist.apply(feat_obs, feat_rnd, repeat)
+
+
+# ---- small-tensor glue of LASR.forward (lasr_amd/csrc/glue.hip): one launch where the reference runs a chain of tiny ops --------
+class _Geodesic(Function):
+    @staticmethod
+    def forward(ctx, m1, m2):
+        _lib.need_cuda(m1, m2)
+        m1, m2 = m1.contiguous().float(), m2.contiguous().float()
+        n = m1.numel() // 9
+        angle = torch.empty(n, dtype=torch.float32, device=m1.device)
+        guard, st = _lib.stream_of(m1)
+        with guard:
+            rc = _lib.lib().lasr_geodesic_forward(m1.data_ptr(), m2.data_ptr(), angle.data_ptr(), n, st)
+        _lib.check(rc, 'lasr_geodesic_forward')
+        ctx.save_for_backward(m1, m2)
+        return angle
+
+    @staticmethod
+    def backward(ctx, g):
+        m1, m2 = ctx.saved_tensors
+        g = g.contiguous().float()
+        g1, g2 = torch.empty_like(m1), torch.empty_like(m2)
+        guard, st = _lib.stream_of(m1)
+        with guard:
+            rc = _lib.lib().lasr_geodesic_backward(m1.data_ptr(), m2.data_ptr(), g.data_ptr(), g1.data_ptr(), g2.data_ptr(),
+                                                   m1.numel() // 9, st)
+        _lib.check(rc, 'lasr_geodesic_backward')
+        return g1, g2
+
+
+def geodesic_distance(m1, m2):
+    """Rotation angle between two batches of 3x3 matrices [n,3,3] -> [n] (/root/reference/third_party/ext_utils/util_rot.py:27-37)."""
+    return _Geodesic.apply(m1, m2)
+
+
+class _WeightedMeans(Function):
+    @staticmethod
+    def forward(ctx, weights, groups, n_groups, *xs):
+        import ctypes
+        _lib.need_cuda(*xs)
+        xs = [x.contiguous().float() for x in xs]
+        n = len(xs)
+        ctx.numels = (ctypes.c_int * n)(*[x.numel() for x in xs])
+        ctx.weights = (ctypes.c_float * n)(*[float(w) for w in weights])
+        ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+        grp = (ctypes.c_int * n)(*[int(g) for g in groups])
+        out = torch.empty(n_groups + 1, dtype=torch.float32, device=xs[0].device)
+        guard, st = _lib.stream_of(xs[0])
+        with guard:
+            rc = _lib.lib().lasr_weighted_means_forward(ptrs, ctx.numels, ctx.weights, grp, n, n_groups, out.data_ptr(), st)
+        _lib.check(rc, 'lasr_weighted_means_forward')
+        ctx.shapes = [x.shape for x in xs]
+        ctx.device = xs[0].device
+        total, sums = out[n_groups], out[:n_groups]
+        ctx.mark_non_differentiable(sums)
+        return total, sums
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        n = len(ctx.shapes)
+        g = g.contiguous().float()
+        coef = torch.empty(n, dtype=torch.float32, device=ctx.device)
+        guard, st = _lib.stream_of(coef)
+        with guard:
+            rc = _lib.lib().lasr_weighted_means_backward(ctx.numels, ctx.weights, n, g.data_ptr(), coef.data_ptr(), st)
+        _lib.check(rc, 'lasr_weighted_means_backward')
+        return (None, None, None) + tuple(coef[t].expand(ctx.shapes[t]) for t in range(n))
+
+
+def weighted_mean_sum(terms, n_groups=None):
+    """terms: [(tensor, weight, group)] -> (total, group totals [n_groups]) with total = sum_t weight_t * tensor_t.mean()
+    accumulated in list order -- the reference's `total_loss += w * x.mean()` chain (nnutils/mesh_net.py:374-530) in one launch.
+    The group totals (the per-loss scalars LASR logs) carry no gradient."""
+    xs = [t[0] for t in terms]
+    groups = [t[2] for t in terms]
+    n_groups = max(groups) + 1 if n_groups is None else n_groups
+    return _WeightedMeans.apply(tuple(float(t[1]) for t in terms), tuple(groups), n_groups, *xs)
+
+
+class _Intrinsics(Function):
+    @staticmethod
+    def forward(ctx, cams, pp, scale, depth, ppoint, half):
+        _lib.need_cuda(cams, pp, scale, depth, ppoint)
+        cams, pp = cams.contiguous().float(), pp.contiguous().float()
+        scale, depth, ppoint = scale.contiguous().float(), depth.contiguous().float(), ppoint.contiguous().float()
+        n2, H, K = scale.shape[0], scale.shape[1], depth.shape[1]
+        so, do, po = torch.empty_like(scale), torch.empty_like(depth), torch.empty_like(ppoint)
+        guard, st = _lib.stream_of(scale)
+        with guard:
+            rc = _lib.lib().lasr_intrinsics_forward(cams.data_ptr(), cams.shape[1], pp.data_ptr(), scale.data_ptr(), depth.data_ptr(),
+                                                    ppoint.data_ptr(), so.data_ptr(), do.data_ptr(), po.data_ptr(), n2 // 2, H, K,
+                                                    float(half), st)
+        _lib.check(rc, 'lasr_intrinsics_forward')
+        ctx.save_for_backward(cams)
+        ctx.dims = (n2 // 2, H, K)
+        return so, do, po
+
+    @staticmethod
+    def backward(ctx, gs, gd, gp):
+        cams, = ctx.saved_tensors
+        B, H, K = ctx.dims
+        gs, gd, gp = gs.contiguous().float(), gd.contiguous().float(), gp.contiguous().float()
+        a, b, c = torch.empty_like(gs), torch.empty_like(gd), torch.empty_like(gp)
+        guard, st = _lib.stream_of(gs)
+        with guard:
+            rc = _lib.lib().lasr_intrinsics_backward(cams.data_ptr(), cams.shape[1], gs.data_ptr(), gd.data_ptr(), gp.data_ptr(),
+                                                     a.data_ptr(), b.data_ptr(), c.data_ptr(), B, H, K, st)
+        _lib.check(rc, 'lasr_intrinsics_backward')
+        return None, None, a, b, c, None
+
+
+def intrinsics(cams, pp, scale, depth, ppoint, img_size):
+    """Crop-aware intrinsics of an image pair (/root/reference/nnutils/mesh_net.py:204-217): cams [2B,>=1] (column 0 = crop
+    scale), pp [2B,2], predicted scale [2B,H], depth [2B,K], ppoint [2B,2] -> (scale [2B,H], depth [2B,K], ppoint [2B,2])."""
+    return _Intrinsics.apply(cams, pp, scale, depth, ppoint, img_size / 2.)
+
+
+class _BoneFixup(Function):
+    @staticmethod
+    def forward(ctx, quat, trans, depth, rest_ts, H, K):
+        _lib.need_cuda(quat, trans, depth, rest_ts)
+        quat, trans, depth = quat.contiguous().float(), trans.contiguous().float(), depth.contiguous().float()
+        rest = rest_ts.contiguous().float() if rest_ts is not None else None
+        MK = quat.numel() // 9
+        M = MK // K
+        rmat = torch.empty(MK, 3, 3, dtype=torch.float32, device=quat.device)
+        tmat = torch.empty(MK, 3, dtype=torch.float32, device=quat.device)
+        guard, st = _lib.stream_of(quat)
+        with guard:
+            rc = _lib.lib().lasr_bone_fixup_forward(quat.data_ptr(), trans.data_ptr(), depth.data_ptr(),
+                                                    rest.data_ptr() if rest is not None else None, rmat.data_ptr(), tmat.data_ptr(),
+                                                    M, H, K, st)
+        _lib.check(rc, 'lasr_bone_fixup_forward')
+        ctx.save_for_backward(quat, rest)
+        ctx.dims = (M, H, K)
+        ctx.in_shapes = (quat.shape, trans.shape, depth.shape, None if rest is None else rest_ts.shape)
+        return rmat, tmat
+
+    @staticmethod
+    def backward(ctx, gR, gT):
+        quat, rest = ctx.saved_tensors
+        M, H, K = ctx.dims
+        gR, gT = gR.contiguous().float(), gT.contiguous().float()
+        dev = quat.device
+        gq = torch.empty(M * K, 9, dtype=torch.float32, device=dev)
+        gt = torch.empty(M * K, 2, dtype=torch.float32, device=dev)
+        gd = torch.empty(M * K, dtype=torch.float32, device=dev)
+        gr = torch.empty(H, K - 1, 3, dtype=torch.float32, device=dev) if rest is not None else None
+        guard, st = _lib.stream_of(quat)
+        with guard:
+            rc = _lib.lib().lasr_bone_fixup_backward(quat.data_ptr(), rest.data_ptr() if rest is not None else None, gR.data_ptr(),
+                                                     gT.data_ptr(), gq.data_ptr(), gt.data_ptr(), gd.data_ptr(),
+                                                     gr.data_ptr() if gr is not None else None, M, H, K, st)
+        _lib.check(rc, 'lasr_bone_fixup_backward')
+        qs, ts, ds, rs = ctx.in_shapes
+        return gq.view(qs), gt.view(ts), gd.view(ds), (gr.view(rs) if gr is not None else None), None, None
+
+
+def bone_fixup(quat, trans, depth, rest_ts, H, K):
+    """Bone-transform fix-up (/root/reference/nnutils/mesh_net.py:259-283): quat [M*K,9] (or [M*K,3,3]) predicted matrices,
+    trans [M*K,2], depth [M*K,1], rest_ts [H,(K-1)*3] joint centres (None for K == 1) -> (Rmat [M*K,3,3], Tmat [M*K,3]):
+    root = transposed prediction; bones rotate about their joint: T' = -Q^T c + T + c, R' = Q."""
+    return _BoneFixup.apply(quat, trans, depth, rest_ts if K > 1 else None, H, K)
+
+
+class _Chamfer(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _lib.need_cuda(a, b)
+        a, b = a.contiguous().float(), b.contiguous().float()
+        N, P, Q = a.shape[0], a.shape[1], b.shape[1]
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+        nn = torch.empty(N * (P + Q), dtype=torch.int32, device=a.device)
+        guard, st = _lib.stream_of(a)
+        with guard:
+            rc = _lib.lib().lasr_chamfer_forward(a.data_ptr(), b.data_ptr(), out.data_ptr(), nn.data_ptr(),
+                                                 nn.data_ptr() + 4 * N * P, N, P, Q, st)
+        _lib.check(rc, 'lasr_chamfer_forward')
+        ctx.save_for_backward(a, b, nn)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, nn = ctx.saved_tensors
+        N, P, Q = a.shape[0], a.shape[1], b.shape[1]
+        g = g.contiguous().float()
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        guard, st = _lib.stream_of(a)
+        with guard:
+            rc = _lib.lib().lasr_chamfer_backward(a.data_ptr(), b.data_ptr(), nn.data_ptr(), nn.data_ptr() + 4 * N * P, g.data_ptr(),
+                                                  ga.data_ptr(), gb.data_ptr(), N, P, Q, st)
+        _lib.check(rc, 'lasr_chamfer_backward')
+        return ga, gb
+
+
+def chamfer(a, b):
+    """Symmetric squared Chamfer distance per batch item, a [N,P,3], b [N,Q,3] -> [N]
+    (pytorch3d.loss.chamfer_distance as used at /root/reference/nnutils/mesh_net.py:500-503; the caller takes the batch mean)."""
+    return _Chamfer.apply(a, b)

@@ -50,6 +50,8 @@ def geodesic_distance(m1, m2):
     """Rotation angle between two batches of 3x3 matrices (ext_utils/util_rot.py:27-37).  Same values; where the two
     rotations coincide (cos rounds to +-1) the reference's acos(min(cos, 1)) back-propagates 0 * inf = NaN and its trainer
     skips the step -- here that element simply has zero gradient."""
+    if m1.is_cuda:
+        return fused_ops.geodesic_distance(m1, m2)                             # one kernel (lasr_geodesic_forward/backward)
     m = torch.bmm(m1, m2.transpose(1, 2))
     cos = (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1) / 2
     inside = cos.abs() < 1
@@ -90,11 +92,8 @@ def reg_decay(curr_steps, max_steps, min_wt, max_wt):
 def chamfer_distance(a, b):
     """Symmetric squared Chamfer distance averaged over the batch (pytorch3d.loss.chamfer_distance()[0] as used
     at mesh_net.py:503); the point sets here are the <= 35 control points."""
-    if a.is_cuda:                                     # nearest neighbours from one kernel; gradient through the gather
-        ib, ia = fused_ops.nearest_point(a, b)[1], fused_ops.nearest_point(b, a)[1]
-        da = (a - torch.gather(b, 1, ib[..., None].expand(-1, -1, 3))).pow(2).sum(-1)
-        db = (b - torch.gather(a, 1, ia[..., None].expand(-1, -1, 3))).pow(2).sum(-1)
-        return (da.mean(1) + db.mean(1)).mean()
+    if a.is_cuda:                                     # one kernel each way (lasr_chamfer_forward / backward)
+        return fused_ops.chamfer(a, b).mean()
     d = (a[:, :, None] - b[:, None]).pow(2).sum(-1)
     return (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
 
@@ -432,20 +431,27 @@ class MeshNet(nn.Module):
         mean_v = self.symmetrize(self.mean_v)
         tex = self.symmetrize_color(self.tex)
         n2 = 2 * local_batch_size
-        faces = self.faces[None].repeat(n2, 1, 1)
+        key = (n2, self.faces.data_ptr(), tuple(self.faces.shape))
+        if getattr(self, '_faces_key', None) != key:                         # connectivity is fixed: repeat it once, not per step
+            self._faces_key, self._faces_n2, self._faces_rep = key, self.faces[None].repeat(n2, 1, 1), None
+        faces = self._faces_n2
         mean_v = mean_v[None].repeat(n2, 1, 1, 1).view(n2 * mean_v.shape[0], -1, 3)
         tex = tex.sigmoid()[None].repeat(n2, 1, 1, 1).view(n2 * tex.shape[0], -1, 3)      # sigmoid once per hypothesis
         return mean_v, tex, faces
 
 
 # ----------------------------------------------------------------------------------------------
-def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0, pp1, proj_cam0, proj_cam1):
+def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0, pp1, proj_cam0, proj_cam1, verts_pre=None):
     """Render the camera-space positions of frame t and t' as vertex colours on frame-t geometry and reproject both
-    (mesh_net.py:75-104).  Returns flow [B*H,IS,IS,2], bgmask (bool), fgmask."""
-    n_hypo = verts.shape[0] // faces.shape[0]
-    faces = faces[:, None].repeat(1, n_hypo, 1, 1).view(-1, faces.shape[1], 3)
-    eye = sr.functional.const_tensor(renderer_soft.transform.transformer._eye, verts.device)[None, None]
-    verts_pre = (verts[:, :, :3] + eye) * sr.functional.const_tensor([1, -1, 1], verts.device)
+    (mesh_net.py:75-104).  Returns flow [B*H,IS,IS,2], bgmask (bool), fgmask.  `faces` may already be repeated per
+    hypothesis; `verts_pre` (the pre-transformed vertices, (verts + eye) * (1,-1,1)) may be passed when the caller has
+    them already -- LASR.forward computes them once for its three render calls."""
+    if faces.shape[0] != verts.shape[0]:
+        n_hypo = verts.shape[0] // faces.shape[0]
+        faces = faces[:, None].repeat(1, n_hypo, 1, 1).view(-1, faces.shape[1], 3)
+    if verts_pre is None:
+        eye = sr.functional.const_tensor(renderer_soft.transform.transformer._eye, verts.device)[None, None]
+        verts_pre = (verts[:, :, :3] + eye) * sr.functional.const_tensor([1, -1, 1], verts.device)
     # The reference renders the batch [verts_pre; verts_pre] with textures [pos0; pos1]: the same geometry twice.
     # One pass with 6 attribute channels gives the same two images (and the same alpha) for half the raster work.
     px = renderer_soft.render_mesh(sr.Mesh(verts_pre, faces,
@@ -503,6 +509,17 @@ class LASR(MeshNet):
         dis = self.log_ctl.exp().view(H, -1, 1, 3) * dis.pow(2)
         return (-10 * dis.sum(3)).softmax(1)[:, :, :, None]                        # H,J,V,1
 
+    @property
+    def cam_export(self):
+        """Root camera per (image, hypothesis) of the last training-mode forward: R, T and the intrinsics back in the UNcropped
+        image, as extract.py / nnutils/predictor.py:188-189 of the reference write them."""
+        Rmat, Tmat, scale, ppoint, cams, pp, n2, H, K, IS = self._cam_src
+        half = IS / 2.
+        with torch.no_grad():
+            return dict(R=Rmat.reshape(n2 * H, K, 3, 3)[:, 0], T=Tmat.reshape(n2 * H, K, 3)[:, 0],
+                        focal=(scale / cams[:, :1] * half)[:, :, None].repeat(1, 1, 2).reshape(n2 * H, 2),
+                        pp=((ppoint + 1) * half / cams[:, :1] + pp)[:, None].repeat(1, H, 1).reshape(n2 * H, 2))
+
     def forward(self, batch_input):
         opts = self.opts
         if not self.training:
@@ -522,14 +539,9 @@ class LASR(MeshNet):
                 m.eval()
         scale, trans, quat, depth, ppoint = self.code_predictor(self.encoder(self.input_imgs))
 
-        # intrinsics bookkeeping (:204-217)
-        scale = self.cams[:, :1] * scale
-        depth = torch.cat([self.cams[:, :1] * depth[:, :1], depth[:, 1:]], 1).reshape(-1, 1)
-        ppb1 = self.cams[:B, :1] * self.pp[:B] / (IS / 2.)
-        ppb2 = self.cams[B:, :1] * self.pp[B:] / (IS / 2.)
-        ppa1 = ppoint[:B] + ppb1 + 1
-        ppa2 = ppa1 * (self.cams[B:, :1] / self.cams[:B, :1])
-        ppoint = torch.cat([ppoint[:B], ppa2 - ppb2 - 1], 0)
+        # intrinsics bookkeeping (:204-217): crop scale into focal length / root depth, frame t' shares frame t's principal point
+        scale, depth, ppoint = fused_ops.intrinsics(self.cams, self.pp, scale, depth, ppoint, IS)
+        depth = depth.reshape(-1, 1)
 
         quat = quat.view(-1, 9)
         if opts.noise and self.epoch > 0 and 1 < self.iters < 100:               # pose / scale noise (:220-235)
@@ -550,66 +562,65 @@ class LASR(MeshNet):
             halforisize = 0.5 * IS / self.cams[:, :1]
             ppoint = (0.5 * self.oriimg_shape - self.pp[:]) / halforisize - 1
 
-        # ---- rigid + articulated transforms (:259-289)
-        Rmat = quat.view(-1, 3, 3).permute(0, 2, 1)
-        Tmat = torch.cat([trans, depth], 1)
+        # ---- rigid + articulated transforms (:259-289): Rmat = predicted matrix transposed, Tmat = (trans, depth); bones
+        # k >= 1 rotate about their joint (T' = -R c + T + c with c = rest_ts) and are transposed back -- one kernel (row a3)
+        Rmat, Tmat = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K)
         skin = None
         if K > 1:
             skin_h = self._skinning(pred_v, n2)
             skin = skin_h.repeat(n2, 1, 1, 1)
-            rest_ts = self.rest_ts[:, None, :, None].repeat(n2, 1, 1, 1).view(-1, K - 1, 3, 1)
-            ctl_ts = self.ctl_ts[:, None, :, None].repeat(n2, 1, 1, 1).view(-1, K - 1, 3, 1)
-            Rm = Rmat.reshape(-1, K, 3, 3)
-            Tm = Tmat.view(-1, K, 3, 1)
-            Tm = torch.cat([Tm[:, :1], -Rm[:, 1:].matmul(rest_ts) + Tm[:, 1:] + rest_ts], 1)   # rotate about the joint
-            Rm = torch.cat([Rm[:, :1], Rm[:, 1:].permute(0, 1, 3, 2)], 1)
-            Rmat, Tmat = Rm.reshape(-1, 3, 3), Tm.reshape(-1, 3)
-            eye = torch.eye(K - 1, device=Rmat.device)[None, :, :, None]
-            # joints / control points through the same transforms; only rest_ts / ctl_ts receive gradient (:285-288)
-            jp = obj_to_cam(rest_ts[:, :, :, 0], Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
-            self.joints_proj = pinhole_cam(torch.cat([jp, torch.ones_like(jp[:, :, :1])], -1), ppoint.detach(), scale.detach())
-            cp = obj_to_cam(ctl_ts[:, :, :, 0], Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
-            self.ctl_proj = pinhole_cam(torch.cat([cp, torch.ones_like(cp[:, :, :1])], -1), ppoint.detach(), scale.detach())
+            eye = getattr(self, '_eye_bones', None)                              # identity "skin" of joints + control points
+            if eye is None or eye.device != Rmat.device or eye.shape[1] != K - 1:
+                eye = torch.eye(K - 1, device=Rmat.device)[None, :, :, None]
+                eye = self._eye_bones = torch.cat([eye, eye], 2)                 # [1, K-1, 2(K-1), 1]
+            # joints and control points through the same transforms, in one call (the reference makes two, :285-288); only
+            # rest_ts / ctl_ts receive gradient
+            pts = torch.cat([self.rest_ts.view(H, K - 1, 3), self.ctl_ts.view(H, K - 1, 3)], 1).repeat(n2, 1, 1)
+            jc = obj_to_cam(pts, Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
+            proj = pinhole_cam(torch.cat([jc, torch.ones_like(jc[:, :, :1])], -1), ppoint.detach(), scale.detach())
+            self.joints_proj, self.ctl_proj = proj.split([K - 1, K - 1], 1)
         self.deform_v = obj_to_cam(pred_v, Rmat.reshape(-1, 3, 3), Tmat[:, None, :], K, H, skin, tocam=False)
 
         # ---- 1) flow rendering (:298-335)
         verts_cam = obj_to_cam(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
         self.verts_cam = verts_cam.detach()                                      # per-frame shape in camera space (export)
-        with torch.no_grad():                                                    # root camera per (image, hypothesis) (export):
-            half = IS / 2.                                                       # intrinsics back in the UNcropped image as
-            self.cam_export = dict(                                              # extract.py / nnutils/predictor.py:188-189
-                R=Rmat.reshape(n2 * H, K, 3, 3)[:, 0], T=Tmat.reshape(n2 * H, K, 3)[:, 0],
-                focal=(scale / self.cams[:, :1] * half)[:, :, None].repeat(1, 1, 2).reshape(n2 * H, 2),
-                pp=((ppoint + 1) * half / self.cams[:, :1] + self.pp)[:, None].repeat(1, H, 1).reshape(n2 * H, 2))
+        # what cam_export needs (views, no kernels: the export arithmetic runs only when extract.py asks for it)
+        self._cam_src = (Rmat.detach(), Tmat.detach(), scale.detach(), ppoint.detach(), self.cams, self.pp, n2, H, K, IS)
         verts_fl = torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1)
         # halves of the batch through unbind / chunk: one stack in the backward pass instead of zeros + copy per slice
         verts_pos0, verts_pos1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)
         verts_fl = pinhole_cam(verts_fl, ppoint, scale)
         with torch.no_grad():                                                    # near/far stay on the device (:304-311)
-            dmax, dmin = verts_fl[:, :, 2].max(), verts_fl[:, :, 2].min()
-            near, far = dmin - (dmax - dmin) / 2, dmax + (dmax - dmin) / 2
+            dmin, dmax = torch.aminmax(verts_fl[:, :, 2])                        # one reduction for both
+            half_range = (dmax - dmin) / 2
+            near, far = dmin - half_range, dmax + half_range
         for r in (self.renderer_softflf, self.renderer_softflb, self.renderer_softtex):
             r.rasterizer.near, r.rasterizer.far = near, far
             if opts.sigval != 1e-4:
                 r.rasterizer.sigma_val = opts.sigval
         if opts.sigval != 1e-4:
             self.renderer_soft.rasterizer.sigma_val = opts.sigval
+        # the three render calls share their geometry: pre-transformed vertices (look_at eye, y flip) and the per-hypothesis
+        # face table are built once (the face table only when the batch shape changes: it is the template's connectivity)
+        eye3 = sr.functional.const_tensor(self.renderer_softtex.transform.transformer._eye, verts_fl.device)[None, None]
+        verts_pre = (verts_fl[:, :, :3] + eye3) * sr.functional.const_tensor([1, -1, 1], verts_fl.device)
+        vp0, vp1 = verts_pre.reshape(2, B * H, -1, 3).unbind(0)
+        faces_rep = self._faces_rep                                             # reset by get_mean_shape when the key changes
+        if faces_rep is None:
+            faces_rep = self._faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
         vf0, vf1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)
         pp0, pp1 = ppoint[:, None].repeat(1, H, 1).view(2, B * H, 2).unbind(0)
         sc0, sc1 = scale.reshape(2, B * H, 1).unbind(0)
         self.flow_fw, self.bgmask_fw, self.fgmask_flowf = render_flow_soft_2(
-            self.renderer_softflf, vf0, faces[:B], verts_pos0, verts_pos1, pp0, pp1, sc0, sc1)
+            self.renderer_softflf, vf0, faces_rep[:B * H], verts_pos0, verts_pos1, pp0, pp1, sc0, sc1, verts_pre=vp0)
         self.flow_bw, self.bgmask_bw, self.fgmask_flowb = render_flow_soft_2(
-            self.renderer_softflb, vf1, faces[B:], verts_pos1, verts_pos0, pp1, pp0, sc1, sc0)
+            self.renderer_softflb, vf1, faces_rep[B * H:], verts_pos1, verts_pos0, pp1, pp0, sc1, sc0, verts_pre=vp1)
         self.bgmask = torch.cat([self.bgmask_fw, self.bgmask_bw], 0)
         self.flow_rd = torch.cat([self.flow_fw, self.flow_bw], 0)
 
         # ---- 3) texture + silhouette rendering (:348-363).  The reference recomputes LBS + projection here from
         # a clone of the same Rmat (verts_tex == verts_fl) and once more for a never-rendered verts_mask: reused.
-        eye3 = sr.functional.const_tensor(self.renderer_softtex.transform.transformer._eye, verts_fl.device)[None, None]
-        verts_pre = (verts_fl[:, :, :3] + eye3) * sr.functional.const_tensor([1, -1, 1], verts_fl.device)
         self.renderer_softtex.rasterizer.background_color = [1, 1, 1]
-        faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
         tex_img = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=tex, texture_type='vertex'))
         self.texture_render, alpha = tex_img.split([3, 1], 1)
         self.mask_pred = alpha.squeeze(1)
@@ -624,16 +635,19 @@ class LASR(MeshNet):
                     sr.Mesh(verts_pre.view(n2, H, -1, 3)[:1, self.optim_idx].detach(), faces[:1],
                             textures=skin_colors[None], texture_type='vertex'))[:, :3]
 
-        # ---- losses.  1) silhouette (:374-390)
+        # ---- losses (:374-530).  The reference accumulates `total_loss += w * x.mean()` term by term; here every term is
+        # queued as (tensor, weight, group) and ONE kernel forms the weighted means, the per-loss scalars LASR logs (group
+        # totals) and the total in the same order (fused_ops.weighted_mean_sum).
+        G_MASK, G_FLOW, G_TEX, G_TRI, G_SYM, G_LMOTION, G_ARAP, G_BONESYM, G_CAM, G_AUX = range(10)
+        terms = []
+        # 1) silhouette (:374-390)
         self.mask_loss_sub = image_losses.mask_loss_table(self.mask_pred.view(n2, H, IS, IS), self.masks, self.occ)
-        self.mask_loss = self.mask_loss_sub.mean()
-        total = self.mask_loss.clone()
+        terms.append((self.mask_loss_sub, 1., G_MASK))
         # 2) flow (:393-416)
         self.flow_rd_loss_sub, self.flow_rd_map = image_losses.flow_loss_table(
             self.flow_rd.view(n2, H, IS, IS, 2), self.flow, self.bgmask.view(n2, H, IS, IS), self.occ, self.masks)
         self.vis_mask = (~self.bgmask).view(n2, H, IS, IS) & ((self.occ != 0) & (self.masks > 0))[:, None]
-        self.flow_rd_loss = self.flow_rd_loss_sub.mean()
-        total = total + self.flow_rd_loss
+        terms.append((self.flow_rd_loss_sub, 1., G_FLOW))
         # 3) texture (:419-447)
         tr = self.texture_render.view(n2, H, 3, IS, IS)
         tmp = image_losses.tex_loss_table(img_obs, img_white, tr, self.mask_pred.view(n2, H, IS, IS), self.occ,
@@ -648,61 +662,59 @@ class LASR(MeshNet):
             percept = self.ptex_loss.forward_pair(obspair, 2 * rndpair - 1, repeat=H)
             tmp = tmp + 0.005 * percept.view(2, -1).sum(0).view(n2, H)
         self.texture_loss_sub = 0.25 * tmp
-        self.texture_loss = self.texture_loss_sub.mean()
-        total = total + self.texture_loss
+        terms.append((self.texture_loss_sub, 1., G_TEX))
 
         # 4) shape smoothness (:449-459)
         # a device scalar the trainer refreshes (schedule_scalars), so that one captured graph serves every epoch
         factor = 1 if H > 1 else self.reg_factor
-        tri = factor * 0.005 * self.triangle_loss_fn_sr(pred_v) * (4 ** opts.subdivide) / 64.
-        tri = tri + factor * 5e-4 * self.flatten_loss(pred_v) * (2 ** opts.subdivide / 8.0)
+        tri = self.triangle_loss_fn_sr(pred_v) * (factor * (0.005 * (4 ** opts.subdivide) / 64.))
+        tri = tri + self.flatten_loss(pred_v) * (factor * (5e-4 * (2 ** opts.subdivide / 8.0)))
         self.triangle_loss_sub = tri.view(n2, H)
-        self.triangle_loss = self.triangle_loss_sub.mean()
-        total = total + self.triangle_loss
+        terms.append((self.triangle_loss_sub, 1., G_TRI))
         if (not opts.symmetric) and opts.symmetric_loss:                          # symmetry (:461-478)
             pa = pred_v.view(n2, H, -1, 3)[0]
             pb = pa * sr.functional.const_tensor([-1, 1, 1], pa.device)
-            total = total + point_mesh_face_distance(pa, self.faces, pb) + point_mesh_face_distance(pb, self.faces, pa)
+            terms.append((point_mesh_face_distance(pa, self.faces, pb).view(1), 1., G_SYM))
+            terms.append((point_mesh_face_distance(pb, self.faces, pa).view(1), 1., G_SYM))
             if opts.opt_tex == 'yes':
                 p1 = pred_v[:1].detach()
                 idx1 = nearest_index(p1, p1 * sr.functional.const_tensor([-1, 1, 1], p1.device))
-                total = total + (self.tex[0][idx1[0]].detach() - self.tex[0]).abs().mean() * 1e-3
+                terms.append(((self.tex[0][idx1[0]].detach() - self.tex[0]).abs(), 1e-3, G_SYM))
         # 5) deformation (:481-497)
         if K > 1:
             self.lmotion_loss_sub = factor * (self.deform_v - pred_v).norm(2, -1).mean(-1).view(n2, H)
-            self.lmotion_loss = self.lmotion_loss_sub.mean()
-            total = total + self.lmotion_loss
+            terms.append((self.lmotion_loss_sub, 1., G_LMOTION))
             dv0, dv1 = self.deform_v.reshape(2, B * H, -1, 3).unbind(0)
-            self.arap_loss = self.arap_loss_fn(dv0, dv1).mean() * (4 ** opts.subdivide) / 64.
-            total = total + self.arap_loss
+            terms.append((self.arap_loss_fn(dv0, dv1), (4 ** opts.subdivide) / 64., G_ARAP))
             if opts.symmetric_loss:                                              # bone symmetry (:500-503)
                 ca = self.ctl_ts.view(H, -1, 3)
-                total = total + 0.1 * chamfer_distance(ca, ca * sr.functional.const_tensor([-1, 1, 1], ca.device))
+                terms.append((fused_ops.chamfer(ca, ca * sr.functional.const_tensor([-1, 1, 1], ca.device)), 0.1, G_BONESYM))
         # 7) camera (:506-522)
         if opts.use_gtpose:
-            cam = geodesic_distance(quat.view(-1, 3, 3), quat_pred.view(-1, 3, 3)).mean()
-            cam = cam + (scale_pred - scale).abs().mean() + (trans_pred - trans).abs().mean()
-            cam = cam + (depth_pred - depth).abs().mean() + (ppoint_pred - ppoint).abs().mean()
-            self.cam_loss = 0.2 * cam
+            terms.append((geodesic_distance(quat.view(-1, 3, 3), quat_pred.view(-1, 3, 3)), 0.2, G_CAM))
+            for pred, gt in ((scale_pred, scale), (trans_pred, trans), (depth_pred, depth), (ppoint_pred, ppoint)):
+                terms.append(((pred - gt).abs(), 0.2, G_CAM))
         else:
             q0, q1 = quat.view(2, -1, 3, 3).unbind(0)
-            self.cam_loss = 0.001 * geodesic_distance(q0, q1).mean()
+            terms.append((geodesic_distance(q0, q1), 0.001, G_CAM))
             if K > 1:
                 t0, t1 = trans.view(2, B * H, K, 2).unbind(0)
                 d0, d1 = depth.view(2, B * H, K, 1).unbind(0)
-                self.cam_loss = self.cam_loss + 0.01 * (t0 - t1)[:, 1:].abs().mean()
-                self.cam_loss = self.cam_loss + 0.01 * (d0 - d1)[:, 1:].abs().mean()
-        total = total + self.cam_loss
-        # 8) aux (:524-530)
-        total = total + 0.02 * F.relu(2 - Tmat.view(-1, 1, K, 3)[:, :, :1, -1]).mean()
+                terms.append(((t0 - t1)[:, 1:].abs(), 0.01, G_CAM))
+                terms.append(((d0 - d1)[:, 1:].abs(), 0.01, G_CAM))
+        # 8) aux (:524-530): keep the root in front of the camera; joints and control points inside the silhouette
+        terms.append((F.relu(2 - Tmat.view(-1, 1, K, 3)[:, :, :1, -1]), 0.02, G_AUX))
         if K > 1:
             barrier = self.ddts_barrier.repeat(1, H, 1, 1).view(-1, 1, IS, IS)
-            bl = F.grid_sample(barrier, self.joints_proj[:, :, :2].reshape(-1, K - 1, 1, 2), padding_mode='border',
-                               align_corners=False).mean()
-            cl = F.grid_sample(barrier, self.ctl_proj[:, :, :2].reshape(-1, K - 1, 1, 2), padding_mode='border',
-                               align_corners=False).mean()
-            total = total + 100 * (0.1 * bl + 0.1 * cl)
+            # 100 * (0.1 * mean(joints) + 0.1 * mean(control points)) = 20 * mean over both sets (equal sizes), one sampling call
+            both = F.grid_sample(barrier, proj[:, :, :2].reshape(-1, 2 * (K - 1), 1, 2), padding_mode='border', align_corners=False)
+            terms.append((both, 20., G_AUX))
+        total, sums = fused_ops.weighted_mean_sum(terms, 10)
         self.total_loss = total
+        self.mask_loss, self.flow_rd_loss, self.texture_loss = sums[G_MASK], sums[G_FLOW], sums[G_TEX]
+        self.triangle_loss, self.cam_loss = sums[G_TRI], sums[G_CAM]
+        if K > 1:
+            self.lmotion_loss, self.arap_loss = sums[G_LMOTION], sums[G_ARAP]
 
         aux = dict(flow_rd_map=self.flow_rd_map, flow_rd=self.flow_rd, vis_mask=self.vis_mask, mask_pred=self.mask_pred,
                    total_loss=self.total_loss, mask_loss=self.mask_loss, texture_loss=self.texture_loss,
@@ -710,9 +722,10 @@ class LASR(MeshNet):
         if K > 1:
             aux['lmotion_loss'] = self.lmotion_loss
             aux['ctl_proj'] = self.ctl_proj
-        aux['current_nscore'] = self.texture_loss_sub.mean(0) + self.flow_rd_loss_sub.mean(0) + self.mask_loss_sub.mean(0)
+        # per-hypothesis scores (:532-541): mean over the images of each table, and their sum (texture + flow + mask)
+        per_hypo = torch.stack([self.mask_loss_sub, self.flow_rd_loss_sub, self.texture_loss_sub], 0).detach().mean(1)   # [3,H]
+        aux['current_nscore'] = per_hypo.sum(0)
         if H > 1:
-            per_hypo = torch.stack([self.mask_loss_sub, self.flow_rd_loss_sub, self.texture_loss_sub], 0).detach().mean(1)
             for h in range(H):                                                   # views of one [3,H] table
                 aux['mask_hypo_%d' % h] = per_hypo[0, h]
                 aux['flow_hypo_%d' % h] = per_hypo[1, h]

@@ -212,3 +212,50 @@ def load_textures(image, faces_uv, R, is_update=None):
     if is_update is not None:
         out[np.asarray(is_update) == 0] = 0
     return out
+
+
+def geodesic_distance(m1, m2):
+    """third_party/ext_utils/util_rot.py:27-37: rotation angle between [n,3,3] batches (cos clamped to [-1, 1])."""
+    m = torch.bmm(m1, m2.transpose(1, 2))
+    cos = (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1) / 2
+    cos = torch.min(cos, torch.ones_like(cos))
+    cos = torch.max(cos, -torch.ones_like(cos))
+    return torch.acos(cos)
+
+
+def intrinsics(cams, pp, scale, depth, ppoint, img_size):
+    """nnutils/mesh_net.py:204-217, line by line: -> (scale [2B,H], depth [2B,K], ppoint [2B,2])."""
+    B = cams.shape[0] // 2
+    scale = cams[:, :1] * scale
+    depth = torch.cat([cams[:, :1] * depth[:, :1], depth[:, 1:]], 1)
+    ppb1 = cams[:B, :1] * pp[:B] / (img_size / 2.)
+    ppb2 = cams[B:, :1] * pp[B:] / (img_size / 2.)
+    ppa1 = ppoint[:B] + ppb1 + 1
+    ppa2 = ppa1 * (cams[B:, :1] / cams[:B, :1])
+    ppoint = torch.cat([ppoint[:B], ppa2 - ppb2 - 1], 0)
+    return scale, depth, ppoint
+
+
+def bone_fixup(quat, trans, depth, rest_ts, n_images, H, K):
+    """nnutils/mesh_net.py:259-283, line by line: quat [M*K,9], trans [M*K,2], depth [M*K,1], rest_ts [H,(K-1)*3]
+    (M = n_images * H) -> (Rmat [M*K,3,3], Tmat [M*K,3])."""
+    Rmat = quat.view(-1, 3, 3).permute(0, 2, 1)
+    Tmat = torch.cat([trans, depth], 1)
+    if K > 1:
+        rest = rest_ts[:, None, :, None].repeat(n_images, 1, 1, 1).view(-1, K - 1, 3, 1)
+        Rmat = Rmat.reshape(-1, K, 3, 3)
+        Tmat = Tmat.view(-1, K, 3, 1)
+        Tmat = torch.cat([Tmat[:, :1], -Rmat[:, 1:].matmul(rest) + Tmat[:, 1:] + rest], 1)
+        Rmat = torch.cat([Rmat[:, :1], Rmat[:, 1:].permute(0, 1, 3, 2)], 1)
+    return Rmat.reshape(-1, 3, 3), Tmat.reshape(-1, 3)
+
+
+def weighted_mean_sum(terms):
+    """total_loss += w * x.mean(), term by term (nnutils/mesh_net.py:374-530): terms = [(tensor, weight, group)]
+    -> (total, [group totals])."""
+    total, groups = 0., {}
+    for x, w, g in terms:
+        v = w * x.mean()
+        total = total + v
+        groups[g] = groups.get(g, 0.) + v
+    return total, [groups[g] for g in sorted(groups)]

@@ -399,3 +399,130 @@ def test_load_textures_kernel_matches_restatement(cuda):
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
     with pytest.raises(TypeError):
         srf.load_textures(torch.from_numpy(img), torch.from_numpy(uv), R)
+
+
+# ---- small-tensor glue kernels (lasr_amd/csrc/glue.hip) vs the line-by-line torch restatements ------------------------------
+def _grads(outs, cots, leaves):
+    return torch.autograd.grad([o for o in outs], leaves, [c for c in cots], allow_unused=True)
+
+
+def test_geodesic_distance_values_and_gradients(cuda):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(3)
+    q1, q2 = torch.randn(300, 4, generator=g), torch.randn(300, 4, generator=g)
+    m1 = po.quaternion_to_rotation_matrix(q1).reshape(-1, 3, 3)
+    m2 = po.quaternion_to_rotation_matrix(q2).reshape(-1, 3, 3)
+    m2[:4] = m1[:4]                                                     # coincident rotations: angle 0, gradient 0 (not NaN)
+    a, b = m1.clone().requires_grad_(), m2.clone().requires_grad_()
+    ref = po.geodesic_distance(a.double(), b.double())
+    cot = torch.randn(300, generator=g)
+    cot[:4] = 1.0
+    ga_ref, gb_ref = _grads([ref[4:]], [cot[4:].double()], [a, b])      # the reference's gradient is NaN on the coincident rows
+    A, B_ = m1.to(cuda).requires_grad_(), m2.to(cuda).requires_grad_()
+    out = fused_ops.geodesic_distance(A, B_)
+    assert out.shape == (300,)
+    # acos is ill-conditioned at the ends: an fp32 rounding of cos (6e-8) moves the angle by 6e-8 / sin(angle)
+    sin = ref.detach().sin().abs().clamp_min(1e-3).numpy()
+    assert (np.abs(out.cpu().detach().numpy() - ref.detach().numpy())[4:] <= 2e-6 + 5e-7 / sin[4:]).all()
+    assert float(out[:4].abs().max()) <= 2e-3                           # acos(1 - a few ulp) = sqrt(2 * 2.4e-7) = 7e-4
+    gA, gB = _grads([out], [cot.to(cuda)], [A, B_])
+    assert torch.isfinite(gA).all() and torch.isfinite(gB).all()
+    mid = torch.from_numpy(sin > 0.1)                                   # d acos / d cos = -1 / sin: compare away from the poles
+    mid[:4] = False
+    np.testing.assert_allclose(gA[mid].cpu().numpy(), ga_ref[mid].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gB[mid].cpu().numpy(), gb_ref[mid].numpy(), rtol=1e-4, atol=1e-5)
+    assert int(mid.sum()) > 250
+    # opposite rotations (cos = -1 exactly): pi, zero gradient
+    flip = torch.diag(torch.tensor([1., -1., -1.]))[None].to(cuda).requires_grad_()
+    eye = torch.eye(3)[None].to(cuda)
+    ang = fused_ops.geodesic_distance(flip, eye)
+    assert abs(float(ang) - np.pi) < 1e-6 and float(_grads([ang], [torch.ones(1, device=cuda)], [flip])[0].abs().max()) == 0
+
+
+@pytest.mark.parametrize('B,H,K', [(1, 8, 21), (2, 1, 1), (3, 16, 26)])
+def test_intrinsics_kernel_matches_the_reference_lines(cuda, B, H, K):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(B * 100 + H)
+    cams = torch.rand(2 * B, 7, generator=g) + 0.5
+    pp = torch.randn(2 * B, 2, generator=g) * 20
+    scale, depth, ppoint = torch.rand(2 * B, H, generator=g) + 1, torch.randn(2 * B, K, generator=g), torch.randn(2 * B, 2, generator=g) * 0.1
+    leaves = [t.clone().requires_grad_() for t in (scale, depth, ppoint)]
+    ref = po.intrinsics(cams, pp, *leaves, 256)
+    cots = [torch.randn(r.shape, generator=g) for r in ref]
+    gref = _grads(ref, cots, leaves)
+    dl = [t.clone().to(cuda).requires_grad_() for t in (scale, depth, ppoint)]
+    out = fused_ops.intrinsics(cams.to(cuda), pp.to(cuda), *dl, 256)
+    for o, r in zip(out, ref):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), r.detach().numpy(), rtol=1e-6, atol=1e-6)
+    gout = _grads(out, [c.to(cuda) for c in cots], dl)
+    for a, b in zip(gout, gref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-6, atol=1e-6)
+    assert float(gout[2][B:].abs().max()) == 0                          # frame t' principal point prediction is discarded
+
+
+@pytest.mark.parametrize('n_images,H,K', [(2, 8, 21), (4, 1, 1), (6, 16, 26), (2, 2, 5)])
+def test_bone_fixup_kernel_matches_the_reference_lines(cuda, n_images, H, K):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(n_images * 10 + K)
+    M = n_images * H
+    quat = po.quaternion_to_rotation_matrix(torch.randn(M * K, 4, generator=g)).reshape(-1, 9) + 0.01 * torch.randn(M * K, 9, generator=g)
+    trans, depth = torch.randn(M * K, 2, generator=g), torch.randn(M * K, 1, generator=g) + 5
+    rest = torch.randn(H, max(K - 1, 0) * 3, generator=g)
+    leaves = [t.clone().requires_grad_() for t in (quat, trans, depth, rest)]
+    R, T = po.bone_fixup(*leaves, n_images, H, K)
+    cR, cT = torch.randn(R.shape, generator=g), torch.randn(T.shape, generator=g)
+    gref = _grads([R, T], [cR, cT], leaves)
+    dl = [t.clone().to(cuda).requires_grad_() for t in (quat, trans, depth, rest)]
+    Rd, Td = fused_ops.bone_fixup(*dl, H, K)
+    assert Rd.shape == R.shape and Td.shape == T.shape
+    assert torch.equal(Rd.cpu(), R.detach())                            # pure data movement
+    np.testing.assert_allclose(Td.detach().cpu().numpy(), T.detach().numpy(), rtol=1e-6, atol=2e-6)
+    gout = _grads([Rd, Td], [cR.to(cuda), cT.to(cuda)], dl)
+    for k, (a, b) in enumerate(zip(gout, gref)):
+        if K == 1 and k == 3:
+            assert a is None or not a.any()
+            continue
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_weighted_mean_sum_matches_the_reference_chain(cuda):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(9)
+    shapes = [(2, 8), (2, 8), (16, 642), (1,), (168,), (16, 20, 1, 1), (5000,), (3, 3)]
+    weights = [1.0, 1.0, 0.25, 0.1, 0.001, 10.0, 0.02, 5.0]
+    groups = [0, 1, 2, 2, 3, 4, 4, 5]
+    xs = [torch.randn(s, generator=g) for s in shapes]
+    leaves = [x.clone().double().requires_grad_() for x in xs]
+    total, sums = po.weighted_mean_sum(list(zip(leaves, weights, groups)))
+    gref = torch.autograd.grad(total * 3.0, leaves)
+    dl = [x.clone().to(cuda).requires_grad_() for x in xs]
+    dl_in = list(dl)
+    dl_in[2] = dl[2].t().contiguous().t()                               # a non-contiguous term is accepted (copied)
+    tot, sm = fused_ops.weighted_mean_sum(list(zip(dl_in, weights, groups)))
+    assert sm.shape == (6,) and not sm.requires_grad
+    np.testing.assert_allclose(float(tot), float(total), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(sm.cpu().numpy(), np.array([float(s) for s in sums]), rtol=2e-6, atol=1e-7)
+    gout = torch.autograd.grad(tot * 3.0, dl)
+    for a, b in zip(gout, gref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-6, atol=1e-12)
+    with pytest.raises(TypeError):
+        fused_ops.weighted_mean_sum([(xs[0], 1.0, 0)])                  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize('N,P,Q', [(8, 20, 20), (2, 300, 421), (1, 1, 5)])
+def test_chamfer_kernel_values_indices_and_gradients(cuda, N, P, Q):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(N * 7 + P)
+    a, b = torch.randn(N, P, 3, generator=g), torch.randn(N, Q, 3, generator=g)
+    x, y = a.clone().double().requires_grad_(), b.clone().double().requires_grad_()
+    d = (x[:, :, None] - y[:, None]).pow(2).sum(-1)
+    ref = d.min(2)[0].mean(1) + d.min(1)[0].mean(1)                     # per batch item; po.chamfer_distance is its mean
+    cot = torch.randn(N, generator=g)
+    gx, gy = torch.autograd.grad(ref, [x, y], cot.double())
+    u, v = a.clone().to(cuda).requires_grad_(), b.clone().to(cuda).requires_grad_()
+    out = fused_ops.chamfer(u, v)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    gu, gv = torch.autograd.grad(out, [u, v], cot.to(cuda))
+    np.testing.assert_allclose(gu.cpu().numpy(), gx.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gv.cpu().numpy(), gy.numpy(), rtol=1e-4, atol=1e-6)
+    assert abs(float(out.mean()) - float(po.chamfer_distance(a, b))) <= 1e-5 * float(ref.mean().abs()) + 1e-6
