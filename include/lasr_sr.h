@@ -106,9 +106,9 @@ int lasr_sr_backward_dev(const float* faces, const float* textures, const float*
 /*
  * Multi-attribute rasterisation.  LASR's flow renders rasterise the SAME geometry twice
  * in one call, once per 3-channel vertex attribute (camera-space positions of frame t and t', nnutils/mesh_net.py:85-87).
- * These entry points interpolate and depth-blend `channels` (3 or 6) per-vertex attributes in one pass: the per-channel
- * arithmetic is that of the 3-channel kernels, so channels [0,3) and [3,6) equal two separate renders and the face
- * gradient equals the sum of theirs.  Only LASR's mode combination (2,1,2,1, double sided) is accepted for 6 channels.
+ * These entry points interpolate and depth-blend `channels` (3, 6 or 9) per-vertex attributes in one pass: the per-channel
+ * arithmetic is that of the 3-channel kernels, so channels [0,3), [3,6) and [6,9) equal separate renders and the face
+ * gradient equals the sum of theirs.  Only LASR's mode combination (2,1,2,1, double sided) is accepted for 6 / 9 channels.
  *   textures [N,F,3,channels]   soft_colors / grad_soft_colors [N,channels+1,IS,IS] (alpha is the LAST plane)
  *   grad_textures [N,F,3,channels]   near_far_dev: optional {near, far} on the device (else the two floats are used)
  */
@@ -125,7 +125,7 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
                           int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream);
 
 /*
- * Supersets of the entry points above with every option as an argument (no reference counterpart).  channels = 3 or 6 (6 as
+ * Supersets of the entry points above with every option as an argument (no reference counterpart).  channels = 3, 6 or 9 (6 and 9 as
  * for the *_attr variants); near_far_dev: NULL or a device pointer to {near, far} that overrides near / far.
  * forward flags  : LASR_SR_RELAXED_MATH (the per-call form of lasr_sr_set_forward_math below), or LASR_SR_DEFAULT_FLAGS.
  * backward flags : LASR_SR_RECORDS_VALID -- the caller vouches that `workspace` still holds the per-face records the forward

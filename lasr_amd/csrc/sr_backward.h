@@ -1,7 +1,7 @@
 // sr_backward.h -- the face-major backward raster kernel (template).  Two translation units instantiate it:
 //   sr_raster.hip        <false, 3>  every mode combination, compiled like the forward pass with -ffp-contract=off (the
 //                                    surface-texture path picks texels from (int)(w * res) and must see the forward's w);
-//   sr_backward_fast.hip <true, 3|6> LASR's mode combination (vertex attributes), compiled with -ffp-contract=fast: the
+//   sr_backward_fast.hip <true, 3|6|9> LASR's mode combination (vertex attributes), compiled with -ffp-contract=fast: the
 //                                    reference's own backward is only defined up to float-atomic ordering (bar: 1e-3 of the
 //                                    largest gradient), so multiply-add pairs may fuse -- the kernel is VALU-issue bound and
 //                                    without contraction 672 M of its 1131 M VALU instructions per 256 frames are lone
@@ -54,9 +54,11 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     const int npx = empty ? 0 : bw * bh;
 
     float gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2)
-    float gt[18];                                // vertex attributes: [vertex j][channel k] at NCH*j + k (3*NCH used)
+    constexpr int NGT = 3 * NCH < 18 ? 18 : 3 * NCH;
+    constexpr int THIRD = NCH == 9 ? 18 : 0;     // start of the third group of nine attribute components (NCH = 9 only)
+    float gt[NGT];                               // vertex attributes: [vertex j][channel k] at NCH*j + k (3*NCH used)
 #pragma unroll
-    for (int k = 0; k < 18; k++) gt[k] = 0.f;
+    for (int k = 0; k < NGT; k++) gt[k] = 0.f;
     const bool front = (flags & 8) != 0;
     const bool vertex_tex = (m.tex == 1);
     const int lim = (A.N * A.F - gw) * A.T;      // texels from this face to the end of the tensor
@@ -224,13 +226,14 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     const int sub = lane_row == 0 ? 0 : lane_row == 1 ? 2 : lane_row == 2 ? 1 : 3;   // component offset inside a register
     float* gf = gfaces + (size_t)gw * 9;
     float* gtp = gtex + (size_t)gw * 3 * NCH;
-    // pass 0: 9 face components + the first 9 attribute components; pass 1 (NCH = 6 only): attribute components 9..17
+    // pass 0: 9 face components + the first 9 attribute components; pass 1 (NCH = 6, 9): attribute components 9..17 and,
+    // for NCH = 9, 18..26 in the second half of the 18-wide reduction
 #pragma unroll
-    for (int pass = 0; pass < (NCH == 6 ? 2 : 1); pass++) {
+    for (int pass = 0; pass < (NCH > 3 ? 2 : 1); pass++) {
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             v18[k] = pass == 0 ? gv[k] : (vertex_tex ? gt[9 + k] : 0.f);
-            v18[9 + k] = pass == 0 ? (vertex_tex ? gt[k] : 0.f) : 0.f;
+            v18[9 + k] = pass == 0 ? (vertex_tex ? gt[k] : 0.f) : (NCH == 9 && vertex_tex ? gt[THIRD + k] : 0.f);
         }
         wave_reduce18(v18, red);
         if ((lane & 15) == 15) {
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
                 if (pass == 0) {
                     if (comp < 9) gf[comp] += red[i];
                     else if (vertex_tex) gtp[comp - 9] += red[i];
-                } else if (comp < 9 && vertex_tex) gtp[9 + comp] += red[i];
+                } else if ((comp < 9 || NCH == 9) && vertex_tex) gtp[9 + comp] += red[i];
             }
         }
     }

@@ -130,9 +130,10 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
     }
 }
 
-// NCH = attribute channels per vertex: 3 (RGB, every mode) or 6 (two attribute triples rendered in ONE pass over the
+// NCH = attribute channels per vertex: 3 (RGB, every mode), 6 (two attribute triples rendered in ONE pass over the
 // geometry -- LASR's flow renders, nnutils/mesh_net.py:85-87, rasterise the same mesh twice with two different
-// per-vertex attributes; channels are independent, so the result equals the two separate renders).
+// per-vertex attributes; channels are independent, so the result equals the two separate renders) or 9 (the flow
+// attributes plus the texture colours: the texture render of a LASR step, mesh_net.py:348-363, has the same geometry).
 template <bool LASR_FAST, int NCH, bool RX = false>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
@@ -403,7 +404,9 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     {
         ProfScope ps(K_SR_FORWARD, st);
         const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
-        if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (is_lasr_fast(A.m)) hipLaunchKernelGGL((sr_forward_kernel<true, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
@@ -446,7 +449,7 @@ static int backward_impl(const float* faces, const float* textures, const float*
     const dim3 grid((unsigned)total);
     {
         ProfScope ps(K_SR_BACKWARD, st);
-        if (nch == 6 || is_lasr_fast(A.m))
+        if (nch > 3 || is_lasr_fast(A.m))
             launch_backward_fast(nch, grid, st, A, soft_colors, aggrs_info, grad_soft_colors, grad_faces, grad_textures);
         else
             hipLaunchKernelGGL((sr_backward_kernel<false, 3>), grid, dim3(BWD_THREADS), 0, st, A, soft_colors, aggrs_info,
@@ -458,8 +461,9 @@ static int backward_impl(const float* faces, const float* textures, const float*
 static int check_nch(int channels, int dist, int rgb, int alpha, int tex, int double_side, int T)
 {
     if (channels == 3) return LASR_OK;
-    // the 6-channel pass exists for LASR's flow renders only: euclidean / softmax / prod / vertex attributes, double sided
-    if (channels != 6 || T != 3 || !(dist == 2 && rgb == 1 && alpha == 2 && tex == 1 && double_side)) return LASR_E_BADMODE;
+    // the 6- and 9-channel passes exist for LASR's renders only (two flow attribute triples; + the texture colours when the
+    // three renders of a step share their geometry): euclidean / softmax / prod / vertex attributes, double sided
+    if ((channels != 6 && channels != 9) || T != 3 || !(dist == 2 && rgb == 1 && alpha == 2 && tex == 1 && double_side)) return LASR_E_BADMODE;
     return LASR_OK;
 }
 

@@ -69,8 +69,9 @@ def _near_far_dev(near, far, dev):
 class SoftRasterizeFunction(Function):
     """face_vertices [N,F,3,3], textures [N,F,T,3] (T = 3 vertex colours or R*R surface texels) -> [N,4,IS,IS].
 
-    Extension over the reference: vertex textures may carry 6 channels, [N,F,3,6] -> [N,7,IS,IS] (alpha last): two
-    attribute triples depth-blended in ONE pass over the geometry (lasr_sr_*_attr), equal to two 3-channel renders.
+    Extension over the reference: vertex textures may carry 6 or 9 channels, [N,F,3,6] -> [N,7,IS,IS] (alpha last): two
+    or three attribute triples depth-blended in ONE pass over the geometry (lasr_sr_*_attr), equal to separate 3-channel
+    renders; `background_color` may then hold one value per channel.
     """
 
     @staticmethod
@@ -89,11 +90,11 @@ class SoftRasterizeFunction(Function):
         if C == 3:
             T = _texels(textures)
             tx = textures.detach().reshape(N, F, T, 3).contiguous()
-        elif C == 6 and texture_type == 'vertex' and textures.shape[2] == 3:
+        elif C in (6, 9) and texture_type == 'vertex' and textures.shape[2] == 3:
             T = 3
             tx = textures.detach().contiguous()
         else:
-            raise ValueError('textures must be [N,F,T,3], or [N,F,3,6] vertex attributes')
+            raise ValueError('textures must be [N,F,T,3], or [N,F,3,6] / [N,F,3,9] vertex attributes')
         IS = int(image_size)
         nf = _near_far_dev(near, far, dev)
         tail = (float(eps), float(sigma_val), _DIST[dist_func], float(math.log(1. / dist_eps - 1.)), float(gamma_val),
@@ -103,7 +104,9 @@ class SoftRasterizeFunction(Function):
         ctx.in_shapes = (face_vertices.shape, textures.shape)
 
         aggrs_info = torch.empty(N, 2, IS, IS, dtype=torch.float32, device=dev)
-        bg = [float(background_color[k % 3]) for k in range(C)] + [1.0]              # alpha plane starts at 1
+        # background per channel: 3 values repeat for every attribute triple, or one value per channel; alpha plane starts at 1
+        nb = len(background_color)
+        bg = [float(background_color[k if nb == C else k % 3]) for k in range(C)] + [1.0]
         if all(v == bg[0] for v in bg):
             soft_colors = torch.full((N, C + 1, IS, IS), bg[0], dtype=torch.float32, device=dev)
         else:

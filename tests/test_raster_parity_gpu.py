@@ -269,6 +269,40 @@ def test_six_channel_pass_equals_two_three_channel_renders(oracle, cuda):
         srf.soft_rasterize(tfv, t6, IS, **dict(kw, aggr_func_rgb='hard'))
 
 
+def test_nine_channel_pass_equals_three_three_channel_renders(oracle, cuda):
+    # the three renders of a LASR step (texture, flow t->t', flow t'->t attributes) share their geometry: one pass, per-channel
+    # background (white for the texture triple, black for the positions)
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    rng = np.random.default_rng(11)
+    ft2 = rng.uniform(-2, 2, ft.shape).astype(np.float32)
+    ft3 = rng.uniform(-2, 2, ft.shape).astype(np.float32)
+    IS = 64
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    bgs = ([1., 1., 1.], [0., 0., 0.], [0.25, 0.5, 0.75])
+    g = np.concatenate([synth.upstream_grad(2, IS, 2)[:, :3], synth.upstream_grad(2, IS, 3)[:, :3], synth.upstream_grad(2, IS, 4)], 1)
+    assert g.shape == (2, 10, IS, IS)
+    tfv = torch.from_numpy(fv).to(cuda).requires_grad_(True)
+    t9 = torch.from_numpy(np.concatenate([ft, ft2, ft3], -1)).to(cuda).requires_grad_(True)
+    img9 = srf.soft_rasterize(tfv, t9, IS, **dict(kw, background_color=bgs[0] + bgs[1] + bgs[2]))
+    assert img9.shape == (2, 10, IS, IS)
+    img9.backward(torch.from_numpy(g).to(cuda))
+    out = img9.detach().cpu().numpy()
+    gf_sum, zero_a = 0, np.zeros_like(g[:, 9:10])
+    for k, (tex, bg) in enumerate(zip((ft, ft2, ft3), bgs)):
+        gk = np.concatenate([g[:, 3 * k:3 * k + 3], g[:, 9:10] if k == 0 else zero_a], 1)      # the alpha gradient counted once
+        ik, gfk, gtk = run_hip(cuda, fv, tex, IS, g=gk, **dict(kw, background_color=bg))
+        assert np.array_equal(out[:, 3 * k:3 * k + 3], ik[:, :3]), 'triple %d' % k
+        assert np.array_equal(out[:, 9], ik[:, 3])
+        gt9 = t9.grad.cpu().numpy()[..., 3 * k:3 * k + 3]
+        assert np.abs(gt9 - gtk).max() <= 1e-5 * np.abs(gtk).max()
+        gf_sum = gf_sum + gfk
+    assert np.abs(tfv.grad.cpu().numpy() - gf_sum).max() <= 1e-5 * np.abs(gf_sum).max()
+    ref = oracle.forward(fv, ft3, IS, **dict(kw, background_color=bgs[2]))
+    assert np.abs(out[:, 6:9] - ref['soft_colors'][:, :3]).max() <= IMG_TOL
+    with pytest.raises(Exception):          # 9 channels exist for LASR's mode combination only
+        srf.soft_rasterize(tfv, t9, IS, **dict(kw, aggr_func_rgb='hard'))
+
+
 def test_integration_stub_binds_like_the_reference_extension(oracle, cuda):
     # INTEGRATION.md "Option B": the ctypes module a reference maintainer would drop in for
     # soft_renderer.cuda.soft_rasterize -- same two entry points, same argument order as the pybind functions
