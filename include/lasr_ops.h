@@ -127,6 +127,18 @@ int lasr_flow_reproject_backward(const float* px, const float* fl1, const float*
                                  float* grad_pp1, float* grad_fl1, float* scratch, int N, int P, void* hip_stream);
 
 /*
+ * The same on six position planes that sit inside a wider render (LASR.forward renders texture + both position triples in
+ * one 9-attribute pass, [N,10,P]): pos6 points at the first position plane of image 0, consecutive images are batch_stride
+ * floats apart (>= 6 P), the six planes of an image are contiguous.  grad_pos6 is a dense [N,6,P] tensor.
+ */
+int lasr_flow_reproject_planes_forward(const float* pos6, long long batch_stride, const float* pp0, const float* pp1,
+                                       const float* fl0, const float* fl1, float* flow, unsigned char* bgmask, int N, int P,
+                                       void* hip_stream);
+int lasr_flow_reproject_planes_backward(const float* pos6, long long batch_stride, const float* fl1, const float* grad_flow,
+                                        float* grad_pos6, float* grad_pp1, float* grad_fl1, float* scratch, int N, int P,
+                                        void* hip_stream);
+
+/*
  * Unit quaternion -> rotation matrix, kornia 0.5.3 `quaternion_to_rotation_matrix` semantics (not vendored in the
  * reference; call sites nnutils/mesh_net.py:232,250,265 and third_party/ext_nnutils/net_blocks.py:359): coefficient
  * order (x,y,z,w); the quaternion is normalised first (q / max(|q|, 1e-12));

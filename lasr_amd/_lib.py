@@ -41,6 +41,8 @@ SIGNATURES = {
     'lasr_flow_reproject_scratch_floats': (_sz, [_i, _i]),
     'lasr_flow_reproject_forward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_flow_reproject_backward': (_i, [_p] * 7 + [_i, _i, _p]),
+    'lasr_flow_reproject_planes_forward': (_i, [_p, ctypes.c_longlong] + [_p] * 6 + [_i, _i, _p]),
+    'lasr_flow_reproject_planes_backward': (_i, [_p, ctypes.c_longlong] + [_p] * 6 + [_i, _i, _p]),
     'lasr_quat_to_rotmat_forward': (_i, [_p, _p, _i, _p]),
     'lasr_quat_to_rotmat_backward': (_i, [_p, _p, _p, _i, _p]),
     'lasr_skin_weights_forward': (_i, [_p] * 5 + [_i, _i, _i, _p]),

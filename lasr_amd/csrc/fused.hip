@@ -30,10 +30,11 @@ __host__ __device__ inline int px_chunks(int P) { int n = (P + FUSED_PX_PER_BLOC
 __global__ __launch_bounds__(256) void flow_reproject_forward_kernel(const float* __restrict__ px, const float* __restrict__ pp0,
                                                                      const float* __restrict__ pp1, const float* __restrict__ fl0,
                                                                      const float* __restrict__ fl1, float2* __restrict__ flow,
-                                                                     unsigned char* __restrict__ bg, int P, int nch)
+                                                                     unsigned char* __restrict__ bg, int P, int nch,
+                                                                     long long in_stride)
 {
     const int n = blockIdx.x;
-    const float* q = px + (size_t)n * 7 * P;
+    const float* q = px + (size_t)n * in_stride;     // 7 P for a [N,7,P] render; larger when the planes sit inside a wider render
     const float c0x = pp0[2 * n], c0y = pp0[2 * n + 1], c1x = pp1[2 * n], c1y = pp1[2 * n + 1], f0 = fl0[n], f1 = fl1[n];
     const int per = (P + nch - 1) / nch, p0 = blockIdx.y * per, p1 = min(P, p0 + per);
     for (int p = p0 + threadIdx.x; p < p1; p += 256) {
@@ -52,12 +53,13 @@ __global__ __launch_bounds__(256) void flow_reproject_forward_kernel(const float
 // part[n][chunk][4] = (d pp1.x, d pp1.y, d fl1, -)
 __global__ __launch_bounds__(256) void flow_reproject_backward_kernel(const float* __restrict__ px, const float* __restrict__ fl1,
                                                                       const float2* __restrict__ gflow, float* __restrict__ gpx,
-                                                                      float* __restrict__ part, int P, int nch)
+                                                                      float* __restrict__ part, int P, int nch,
+                                                                      long long in_stride, int out_planes)
 {
     __shared__ float red[4];
     const int n = blockIdx.x;
-    const float* q = px + (size_t)n * 7 * P;
-    float* g = gpx + (size_t)n * 7 * P;
+    const float* q = px + (size_t)n * in_stride;
+    float* g = gpx + (size_t)n * out_planes * P;     // 7 planes (with the alpha plane's zeros) or the 6 position planes only
     const float f1 = fl1[n];
     const int per = (P + nch - 1) / nch, p0 = blockIdx.y * per, p1 = min(P, p0 + per);
     float sx = 0.f, sy = 0.f, sf = 0.f;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void flow_reproject_backward_kernel(const floa
         }
         g[p] = 0.f; g[P + p] = 0.f; g[2 * (size_t)P + p] = 0.f;
         g[3 * (size_t)P + p] = gx1; g[4 * (size_t)P + p] = gy1; g[5 * (size_t)P + p] = gz1;
-        g[6 * (size_t)P + p] = 0.f;
+        if (out_planes == 7) g[6 * (size_t)P + p] = 0.f;
     }
     sx = block_sum(sx, red); sy = block_sum(sy, red); sf = block_sum(sf, red);
     if (threadIdx.x == 0) {
@@ -796,7 +798,21 @@ extern "C" int lasr_flow_reproject_forward(const float* px, const float* pp0, co
     hipStream_t st = (hipStream_t)hip_stream;
     const int nch = px_chunks(P);
     LASR_LAUNCH(K_FLOW_REPROJECT_FORWARD, flow_reproject_forward_kernel, dim3(N, nch), dim3(256), 0, px, pp0, pp1, fl0, fl1,
-                (float2*)flow, bgmask, P, nch);
+                (float2*)flow, bgmask, P, nch, (long long)7 * P);
+    return launch_ok();
+}
+
+extern "C" int lasr_flow_reproject_planes_forward(const float* pos6, long long batch_stride, const float* pp0, const float* pp1,
+                                                  const float* fl0, const float* fl1, float* flow, unsigned char* bgmask, int N,
+                                                  int P, void* hip_stream)
+{
+    if (N < 0 || P < 0 || batch_stride < (long long)6 * P) return LASR_E_BADARG;
+    if (N == 0 || P == 0) return LASR_OK;
+    if (!pos6 || !pp0 || !pp1 || !fl0 || !fl1 || !flow || !bgmask) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int nch = px_chunks(P);
+    LASR_LAUNCH(K_FLOW_REPROJECT_FORWARD, flow_reproject_forward_kernel, dim3(N, nch), dim3(256), 0, pos6, pp0, pp1, fl0, fl1,
+                (float2*)flow, bgmask, P, nch, batch_stride);
     return launch_ok();
 }
 
@@ -810,7 +826,25 @@ extern "C" int lasr_flow_reproject_backward(const float* px, const float* fl1, c
     hipStream_t st = (hipStream_t)hip_stream;
     const int nch = px_chunks(P);
     LASR_LAUNCH(K_FLOW_REPROJECT_BACKWARD, flow_reproject_backward_kernel, dim3(N, nch), dim3(256), 0, px, fl1,
-                (const float2*)grad_flow, grad_px, scratch, P, nch);
+                (const float2*)grad_flow, grad_px, scratch, P, nch, (long long)7 * P, 7);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_FLOW_REPROJECT_BACKWARD, flow_reproject_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, scratch, grad_pp1,
+                grad_fl1, N, nch);
+    return launch_ok();
+}
+
+extern "C" int lasr_flow_reproject_planes_backward(const float* pos6, long long batch_stride, const float* fl1,
+                                                   const float* grad_flow, float* grad_pos6, float* grad_pp1, float* grad_fl1,
+                                                   float* scratch, int N, int P, void* hip_stream)
+{
+    if (N < 0 || P < 0 || batch_stride < (long long)6 * P) return LASR_E_BADARG;
+    if (N == 0) return LASR_OK;
+    if (!pos6 || !fl1 || !grad_flow || !grad_pos6 || !grad_pp1 || !grad_fl1 || !scratch) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int nch = px_chunks(P);
+    LASR_LAUNCH(K_FLOW_REPROJECT_BACKWARD, flow_reproject_backward_kernel, dim3(N, nch), dim3(256), 0, pos6, fl1,
+                (const float2*)grad_flow, grad_pos6, scratch, P, nch, batch_stride, 6);
     int rc = launch_ok();
     if (rc) return rc;
     LASR_LAUNCH(K_FLOW_REPROJECT_BACKWARD, flow_reproject_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, scratch, grad_pp1,

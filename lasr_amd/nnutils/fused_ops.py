@@ -55,6 +55,54 @@ def flow_reproject(px, pp0, pp1, fl0, fl1):
     return _FlowReproject.apply(px, pp0, pp1, fl0.reshape(N, -1)[:, 0], fl1.reshape(N, -1)[:, 0])
 
 
+class _FlowReprojectPlanes(Function):
+    @staticmethod
+    def forward(ctx, pos6, pp0, pp1, fl0, fl1):
+        _lib.need_cuda(pos6, pp0, pp1, fl0, fl1)
+        N, P = pos6.shape[0], pos6[0, 0].numel()
+        if pos6.dtype != torch.float32 or pos6.shape[1] != 6 or (N > 0 and not pos6[0].is_contiguous()):
+            raise ValueError('pos6 must be float32 [N,6,IS,IS] with the six planes of an image contiguous')
+        stride = pos6.stride(0) if N > 1 else 6 * P
+        pp0, pp1 = pp0.contiguous().float(), pp1.contiguous().float()
+        fl0, fl1 = fl0.contiguous().float(), fl1.contiguous().float()
+        flow = torch.empty(N, *pos6.shape[2:], 2, dtype=torch.float32, device=pos6.device)
+        bg = torch.empty(N, *pos6.shape[2:], dtype=torch.uint8, device=pos6.device)
+        guard, st = _lib.stream_of(pos6)
+        with guard:
+            rc = _lib.lib().lasr_flow_reproject_planes_forward(pos6.data_ptr(), stride, pp0.data_ptr(), pp1.data_ptr(), fl0.data_ptr(),
+                                                               fl1.data_ptr(), flow.data_ptr(), bg.data_ptr(), N, P, st)
+        _lib.check(rc, 'lasr_flow_reproject_planes_forward')
+        ctx.save_for_backward(pos6, fl1)
+        ctx.stride = stride
+        bg = bg.view(torch.bool)
+        ctx.mark_non_differentiable(bg)
+        return flow, bg
+
+    @staticmethod
+    def backward(ctx, gflow, _gbg):
+        pos6, fl1 = ctx.saved_tensors
+        N, P = pos6.shape[0], pos6[0, 0].numel()
+        gflow = gflow.contiguous().float()
+        gpos = torch.empty(pos6.shape, dtype=torch.float32, device=pos6.device)
+        gpp1 = torch.empty(N, 2, dtype=torch.float32, device=pos6.device)
+        gfl1 = torch.empty(N, dtype=torch.float32, device=pos6.device)
+        h = _lib.lib()
+        scratch = torch.empty(h.lasr_flow_reproject_scratch_floats(N, P), dtype=torch.float32, device=pos6.device)
+        guard, st = _lib.stream_of(pos6)
+        with guard:
+            rc = h.lasr_flow_reproject_planes_backward(pos6.data_ptr(), ctx.stride, fl1.data_ptr(), gflow.data_ptr(), gpos.data_ptr(),
+                                                       gpp1.data_ptr(), gfl1.data_ptr(), scratch.data_ptr(), N, P, st)
+        _lib.check(rc, 'lasr_flow_reproject_planes_backward')
+        return gpos, None, gpp1, None, gfl1
+
+
+def flow_reproject_planes(pos6, pp0, pp1, fl0, fl1):
+    """flow_reproject on the six position planes [N,6,IS,IS] of a wider render (a channel slice of the [N,10,IS,IS] output of the
+    9-attribute pass: consecutive images further apart than 6 planes) -> flow [N,IS,IS,2], bgmask [N,IS,IS] bool."""
+    N = pos6.shape[0]
+    return _FlowReprojectPlanes.apply(pos6, pp0, pp1, fl0.reshape(N, -1)[:, 0], fl1.reshape(N, -1)[:, 0])
+
+
 class _QuatToRotmat(Function):
     @staticmethod
     def forward(ctx, q):

@@ -586,10 +586,7 @@ class LASR(MeshNet):
         self.verts_cam = verts_cam.detach()                                      # per-frame shape in camera space (export)
         # what cam_export needs (views, no kernels: the export arithmetic runs only when extract.py asks for it)
         self._cam_src = (Rmat.detach(), Tmat.detach(), scale.detach(), ppoint.detach(), self.cams, self.pp, n2, H, K, IS)
-        verts_fl = torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1)
-        # halves of the batch through unbind / chunk: one stack in the backward pass instead of zeros + copy per slice
-        verts_pos0, verts_pos1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)
-        verts_fl = pinhole_cam(verts_fl, ppoint, scale)
+        verts_fl = pinhole_cam(torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1), ppoint, scale)
         with torch.no_grad():                                                    # near/far stay on the device (:304-311)
             dmin, dmax = torch.aminmax(verts_fl[:, :, 2])                        # one reduction for both
             half_range = (dmax - dmin) / 2
@@ -600,30 +597,33 @@ class LASR(MeshNet):
                 r.rasterizer.sigma_val = opts.sigval
         if opts.sigval != 1e-4:
             self.renderer_soft.rasterizer.sigma_val = opts.sigval
-        # the three render calls share their geometry: pre-transformed vertices (look_at eye, y flip) and the per-hypothesis
-        # face table are built once (the face table only when the batch shape changes: it is the template's connectivity)
+
+        # ---- 1) + 3) flow and texture / silhouette rendering (:298-363) in ONE pass.  The reference makes three render calls:
+        # flow t -> t' (frame-t geometry, attributes = camera-space positions of frames t and t'), flow t' -> t, and the
+        # texture render of all frames, whose geometry it recomputes from a clone of the same Rmat (verts_tex == verts_fl).
+        # All three rasterise the same 2B*H meshes with the same settings, so one 9-attribute pass (colour, own position, the
+        # other frame's position; background white / black / black) yields the same images -- channels are blended
+        # independently -- for one distance / sigmoid / depth evaluation per fragment instead of two.
+        N, BH = n2 * H, B * H
         eye3 = sr.functional.const_tensor(self.renderer_softtex.transform.transformer._eye, verts_fl.device)[None, None]
         verts_pre = (verts_fl[:, :, :3] + eye3) * sr.functional.const_tensor([1, -1, 1], verts_fl.device)
-        vp0, vp1 = verts_pre.reshape(2, B * H, -1, 3).unbind(0)
         faces_rep = self._faces_rep                                             # reset by get_mean_shape when the key changes
         if faces_rep is None:
             faces_rep = self._faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
-        vf0, vf1 = verts_fl.reshape(2, B * H, -1, 4).unbind(0)
-        pp0, pp1 = ppoint[:, None].repeat(1, H, 1).view(2, B * H, 2).unbind(0)
-        sc0, sc1 = scale.reshape(2, B * H, 1).unbind(0)
-        self.flow_fw, self.bgmask_fw, self.fgmask_flowf = render_flow_soft_2(
-            self.renderer_softflf, vf0, faces_rep[:B * H], verts_pos0, verts_pos1, pp0, pp1, sc0, sc1, verts_pre=vp0)
-        self.flow_bw, self.bgmask_bw, self.fgmask_flowb = render_flow_soft_2(
-            self.renderer_softflb, vf1, faces_rep[B * H:], verts_pos1, verts_pos0, pp1, pp0, sc1, sc0, verts_pre=vp1)
-        self.bgmask = torch.cat([self.bgmask_fw, self.bgmask_bw], 0)
-        self.flow_rd = torch.cat([self.flow_fw, self.flow_bw], 0)
 
-        # ---- 3) texture + silhouette rendering (:348-363).  The reference recomputes LBS + projection here from
-        # a clone of the same Rmat (verts_tex == verts_fl) and once more for a never-rendered verts_mask: reused.
-        self.renderer_softtex.rasterizer.background_color = [1, 1, 1]
-        tex_img = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=tex, texture_type='vertex'))
-        self.texture_render, alpha = tex_img.split([3, 1], 1)
+        def other_frame(t):                                                      # [t; t'] -> [t'; t] along the batch
+            return t.reshape(2, BH, *t.shape[1:]).flip(0).reshape(t.shape)
+        attrs = torch.cat([tex, verts_cam, other_frame(verts_cam)], -1)          # [N,V,9]
+        self.renderer_softtex.rasterizer.background_color = [1, 1, 1, 0, 0, 0, 0, 0, 0]
+        px = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=attrs, texture_type='vertex'))
+        self.texture_render, pos6, alpha = px.split([3, 6, 1], 1)
         self.mask_pred = alpha.squeeze(1)
+        pp_all = ppoint[:, None].repeat(1, H, 1).view(N, 2)
+        sc_all = scale.reshape(N, 1)
+        self.flow_rd, self.bgmask = fused_ops.flow_reproject_planes(pos6, pp_all, other_frame(pp_all), sc_all, other_frame(sc_all))
+        self.flow_fw, self.flow_bw = self.flow_rd[:BH], self.flow_rd[BH:]         # the reference's per-direction attributes (views)
+        self.bgmask_fw, self.bgmask_bw = self.bgmask[:BH], self.bgmask[BH:]
+        self.fgmask_flowf, self.fgmask_flowb = self.mask_pred[:BH], self.mask_pred[BH:]
         fg_obs = (self.masks > 0).float()[:, None]
         img_obs = self.imgs * fg_obs
         img_white = 1 - fg_obs + img_obs

@@ -94,6 +94,11 @@ def run_both(tmp_path, **over):
     loss, aux = m({k: v.clone() for k, v in batch.items()})
     loss.backward()
     captured['near_far'] = (float(m.renderer_softtex.rasterizer.near), float(m.renderer_softtex.rasterizer.far))
+    if 'flow_fw' not in captured:
+        # the product renders the two flow directions and the texture in ONE 9-attribute pass over all 2B*H meshes (same
+        # geometry): the flow renders' geometry is the two halves of that call's
+        half = captured['tex'].shape[0] // 2
+        captured['flow_fw'], captured['flow_bw'] = captured['tex'][:half], captured['tex'][half:]
 
     # ---- oracle side, CPU: once independently, once with the product's raster geometry injected
     names = ['mean_v', 'tex'] + (['ctl_rs', 'rest_ts', 'ctl_ts', 'log_ctl'] if K > 1 else [])

@@ -115,5 +115,5 @@ def test_two_ranks_stay_in_lockstep(tmp_path, cuda, use_graph):
     # handful stay within a few lr, and the whole vector is far closer to the two-shard mean than to one shard alone.
     assert stats['p999_both'] <= 2e-5 * scale, stats
     assert stats['max_both'] <= 5e-4 * scale, stats
-    assert stats['l2_alone'] >= 10 * stats['l2_both'] and stats['max_alone'] > 1e-3 * scale, stats
+    assert stats['l2_alone'] >= 5 * stats['l2_both'] and stats['max_alone'] > 1e-3 * scale, stats
     # (use_graph=False is the reference's own arrangement: DistributedDataParallel + SyncBatchNorm kept in eval mode)
