@@ -301,6 +301,18 @@ int lasr_chamfer_forward(const float* a, const float* b, float* out, int* nn_ab,
 int lasr_chamfer_backward(const float* a, const float* b, const int* nn_ab, const int* nn_ba, const float* grad_out, float* grad_a,
                           float* grad_b, int N, int P, int Q, void* hip_stream);
 
+/*
+ * Mean shape of the batch, third_party/ext_nnutils/mesh_net.py:128-149 (symmetrize) + :171-185 (get_mean_shape): mean_v / tex
+ * [H,Vp,3] (independent + right-half vertices per hypothesis) -> out_v / out_tex [R*H, Vp+S, 3]: the last S vertices are appended
+ * once more mirrored (flip [3], e.g. (-1,1,1)), positions are multiplied by mask [Vp+S,3] (NULL = none; zeros pin the plane
+ * vertices), colours go through a sigmoid, and the H meshes are tiled R times (one per image).  S = 0: no symmetry.
+ * Backward: grad_mean_v / grad_tex_param [H,Vp,3] (either may be NULL), summed over the R copies in order.
+ */
+int lasr_mean_shape_forward(const float* mean_v, const float* tex, const float* flip, const float* mask, float* out_v,
+                            float* out_tex, int R, int H, int Vp, int S, void* hip_stream);
+int lasr_mean_shape_backward(const float* tex, const float* flip, const float* mask, const float* grad_v, const float* grad_tex,
+                             float* grad_mean_v, float* grad_tex_param, int R, int H, int Vp, int S, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ SIGNATURES = {
     'lasr_bone_fixup_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_mean_shape_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_mean_shape_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_backward_dev': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),

@@ -294,6 +294,62 @@ __global__ __launch_bounds__(256) void chamfer_backward_kernel(const float* __re
     }
 }
 
+// ---- mean shape of the batch (third_party/ext_nnutils/mesh_net.py:128-149, 171-185) ------------------------------------------
+// mean_v / tex [H,Vp,3] hold the independent + right-half vertices; the full mesh appends the mirror images of the last S
+// vertices (x flip) and pins the symmetry-plane vertices with a 0/1 mask; every (image, hypothesis) of the batch gets a copy,
+// the colours go through a sigmoid.  out_v / out_tex [R*H, Vp+S, 3].  S = 0: no symmetry (plain tiling).
+__global__ __launch_bounds__(256) void mean_shape_forward_kernel(const float* __restrict__ mean_v, const float* __restrict__ tex,
+                                                                 const float* __restrict__ flip, const float* __restrict__ mask,
+                                                                 float* __restrict__ out_v, float* __restrict__ out_tex, int R,
+                                                                 int H, int Vp, int S)
+{
+    const int V = Vp + S;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * H * V * 3) return;
+    const int c = i % 3, v = (i / 3) % V, h = (i / (3 * V)) % H;
+    const int src = v < Vp ? v : v - S;
+    float x = mean_v[((size_t)h * Vp + src) * 3 + c];
+    if (v >= Vp) x = flip[c] * x;
+    if (mask) x = x * mask[3 * v + c];
+    out_v[i] = x;
+    const float t = tex[((size_t)h * Vp + src) * 3 + c];
+    out_tex[i] = 1.f / (1.f + expf(-t));
+}
+
+__global__ __launch_bounds__(256) void mean_shape_backward_kernel(const float* __restrict__ tex, const float* __restrict__ flip,
+                                                                  const float* __restrict__ mask, const float* __restrict__ g_v,
+                                                                  const float* __restrict__ g_tex, float* __restrict__ gm,
+                                                                  float* __restrict__ gt, int R, int H, int Vp, int S)
+{
+    const int V = Vp + S;
+    const int i = blockIdx.x * 256 + threadIdx.x;              // (h, u, c) of the parameters
+    if (i >= H * Vp * 3) return;
+    const int c = i % 3, u = (i / 3) % Vp, h = i / (3 * Vp);
+    const bool mirrored = S > 0 && u >= Vp - S;
+    const int v2 = u + S;
+    float sv = 0.f, sv2 = 0.f, st = 0.f;
+    for (int n = 0; n < R; n++) {                              // images in order: deterministic
+        const size_t row = ((size_t)n * H + h) * V;
+        if (g_v) {
+            sv += g_v[(row + u) * 3 + c];
+            if (mirrored) sv2 += g_v[(row + v2) * 3 + c];
+        }
+        if (g_tex) {
+            st += g_tex[(row + u) * 3 + c];
+            if (mirrored) st += g_tex[(row + v2) * 3 + c];
+        }
+    }
+    if (gm) {
+        float a = mask ? sv * mask[3 * u + c] : sv;
+        if (mirrored) a += (mask ? sv2 * mask[3 * v2 + c] : sv2) * flip[c];
+        gm[i] = a;
+    }
+    if (gt) {
+        const float sg = 1.f / (1.f + expf(-tex[i]));
+        gt[i] = st * sg * (1.f - sg);
+    }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -423,5 +479,33 @@ extern "C" int lasr_chamfer_backward(const float* a, const float* b, const int* 
     if (!a || !b || !nn_ab || !nn_ba || !grad_out || !grad_a || !grad_b) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
     LASR_LAUNCH(K_CHAMFER, chamfer_backward_kernel, dim3(N), dim3(256), 0, a, b, nn_ab, nn_ba, grad_out, grad_a, grad_b, P, Q);
+    return launch_ok();
+}
+
+extern "C" int lasr_mean_shape_forward(const float* mean_v, const float* tex, const float* flip, const float* mask, float* out_v,
+                                       float* out_tex, int R, int H, int Vp, int S, void* hip_stream)
+{
+    if (R < 0 || H < 0 || Vp < 0 || S < 0 || S > Vp) return LASR_E_BADARG;
+    if (R == 0 || H == 0 || Vp == 0) return LASR_OK;
+    if (!mean_v || !tex || !out_v || !out_tex || (S > 0 && !flip)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int total = R * H * (Vp + S) * 3;
+    LASR_LAUNCH(K_MEAN_SHAPE, mean_shape_forward_kernel, dim3((total + 255) / 256), dim3(256), 0, mean_v, tex, flip, mask, out_v,
+                out_tex, R, H, Vp, S);
+    return launch_ok();
+}
+
+extern "C" int lasr_mean_shape_backward(const float* tex, const float* flip, const float* mask, const float* grad_v,
+                                        const float* grad_tex, float* grad_mean_v, float* grad_tex_param, int R, int H, int Vp,
+                                        int S, void* hip_stream)
+{
+    if (R < 0 || H < 0 || Vp < 0 || S < 0 || S > Vp) return LASR_E_BADARG;
+    if (H == 0 || Vp == 0) return LASR_OK;
+    if ((grad_mean_v && !grad_v && R > 0) || (grad_tex_param && ((!grad_tex && R > 0) || !tex)) || (S > 0 && !flip))
+        return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int total = H * Vp * 3;
+    LASR_LAUNCH(K_MEAN_SHAPE, mean_shape_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, tex, flip, mask, grad_v, grad_tex,
+                grad_mean_v, grad_tex_param, R, H, Vp, S);
     return launch_ok();
 }

@@ -508,3 +508,48 @@ def chamfer(a, b):
     """Symmetric squared Chamfer distance per batch item, a [N,P,3], b [N,Q,3] -> [N]
     (pytorch3d.loss.chamfer_distance as used at /root/reference/nnutils/mesh_net.py:500-503; the caller takes the batch mean)."""
     return _Chamfer.apply(a, b)
+
+
+class _MeanShape(Function):
+    @staticmethod
+    def forward(ctx, mean_v, tex, flip, mask, R, S):
+        _lib.need_cuda(mean_v, tex, flip, mask)
+        mean_v, tex = mean_v.contiguous().float(), tex.contiguous().float()
+        flip = flip.contiguous().float().reshape(-1) if flip is not None else None
+        mask = mask.contiguous().float() if mask is not None else None
+        H, Vp = mean_v.shape[0], mean_v.shape[1]
+        out_v = torch.empty(R * H, Vp + S, 3, dtype=torch.float32, device=mean_v.device)
+        out_t = torch.empty_like(out_v)
+        guard, st = _lib.stream_of(mean_v)
+        with guard:
+            rc = _lib.lib().lasr_mean_shape_forward(mean_v.data_ptr(), tex.data_ptr(), flip.data_ptr() if flip is not None else None,
+                                                    mask.data_ptr() if mask is not None else None, out_v.data_ptr(), out_t.data_ptr(),
+                                                    R, H, Vp, S, st)
+        _lib.check(rc, 'lasr_mean_shape_forward')
+        ctx.save_for_backward(tex, flip, mask)
+        ctx.dims = (R, H, Vp, S)
+        return out_v, out_t
+
+    @staticmethod
+    def backward(ctx, gv, gt):
+        tex, flip, mask = ctx.saved_tensors
+        R, H, Vp, S = ctx.dims
+        need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gv = gv.contiguous().float() if need_v else None
+        gt = gt.contiguous().float() if need_t else None
+        gm = torch.empty(H, Vp, 3, dtype=torch.float32, device=tex.device) if need_v else None
+        gp = torch.empty(H, Vp, 3, dtype=torch.float32, device=tex.device) if need_t else None
+        guard, st = _lib.stream_of(tex)
+        ptr = lambda t: t.data_ptr() if t is not None else None                  # noqa: E731
+        with guard:
+            rc = _lib.lib().lasr_mean_shape_backward(tex.data_ptr(), ptr(flip), ptr(mask), ptr(gv), ptr(gt), ptr(gm), ptr(gp),
+                                                     R, H, Vp, S, st)
+        _lib.check(rc, 'lasr_mean_shape_backward')
+        return gm, gp, None, None, None, None
+
+
+def mean_shape(mean_v, tex, flip, mask, repeats, num_sym):
+    """Per-hypothesis mean shape and colours -> the batch's meshes (/root/reference/third_party/ext_nnutils/mesh_net.py:128-149,
+    171-185): mean_v / tex [H,Vp,3] -> (verts [repeats*H, Vp+num_sym, 3], sigmoid colours, same shape); the last num_sym vertices
+    are mirrored (flip [1,3]) and appended, positions times mask [Vp+num_sym,3].  num_sym = 0: no symmetry (flip / mask None)."""
+    return _MeanShape.apply(mean_v, tex, flip, mask, int(repeats), int(num_sym))

@@ -317,8 +317,11 @@ class PerceptualDistance(nn.Module):
         self.pretrained = True
         return n
 
-    def _feats(self, x):
-        x = (x - self.shift) / self.scale
+    def _feats(self, x, unit_range=False):
+        """Feature maps of the five AlexNet convolutions.  unit_range: x is in [0, 1] and stands for 2 x - 1 (the reference maps
+        its images to [-1, 1] first, mesh_net.py:436-441); ((2x - 1) - shift) / scale == (x - (1 + shift) / 2) / (scale / 2) is
+        folded into the input normalisation instead of costing two more passes over the images."""
+        x = (x - (1 + self.shift) / 2) / (self.scale / 2) if unit_range else (x - self.shift) / self.scale
         out = []
         for i, c in enumerate(self.convs):
             if i in (1, 2):
@@ -327,11 +330,11 @@ class PerceptualDistance(nn.Module):
             out.append(x)
         return out
 
-    def forward_pair(self, a, b, repeat=1):
+    def forward_pair(self, a, b, repeat=1, unit_range=False):
         """Distance between a[i // repeat] and b[i]: `a` holds each observed image once where the reference feeds the
-        network `repeat` identical copies of it (one per hypothesis, mesh_net.py:436-441)."""
+        network `repeat` identical copies of it (one per hypothesis, mesh_net.py:436-441).  unit_range: see _feats."""
         d = 0
-        for fa, fb in zip(self._feats(a), self._feats(b)):
+        for fa, fb in zip(self._feats(a, unit_range), self._feats(b, unit_range)):
             if fb.is_cuda and not fa.requires_grad:
                 d = d + fused_ops.cosine_distance(fa, fb, repeat)            # normalise + dot + spatial mean: one kernel
                 continue
@@ -428,13 +431,18 @@ class MeshNet(nn.Module):
 
     def get_mean_shape(self, local_batch_size):
         """-> mean_v [2B*H,V,3], tex [2B*H,V,3] (sigmoid), faces [2B,F,3] (ext_nnutils/mesh_net.py:171-185)."""
-        mean_v = self.symmetrize(self.mean_v)
-        tex = self.symmetrize_color(self.tex)
         n2 = 2 * local_batch_size
         key = (n2, self.faces.data_ptr(), tuple(self.faces.shape))
         if getattr(self, '_faces_key', None) != key:                         # connectivity is fixed: repeat it once, not per step
             self._faces_key, self._faces_n2, self._faces_rep = key, self.faces[None].repeat(n2, 1, 1), None
         faces = self._faces_n2
+        if self.mean_v.is_cuda:                                                # symmetrise + sigmoid + tile: one kernel
+            sym = self.symmetric
+            mean_v, tex = fused_ops.mean_shape(self.mean_v, self.tex, self.flip if sym else None, self.sym_mask if sym else None,
+                                               n2, self.num_sym if sym else 0)
+            return mean_v, tex, faces
+        mean_v = self.symmetrize(self.mean_v)
+        tex = self.symmetrize_color(self.tex)
         mean_v = mean_v[None].repeat(n2, 1, 1, 1).view(n2 * mean_v.shape[0], -1, 3)
         tex = tex.sigmoid()[None].repeat(n2, 1, 1, 1).view(n2 * tex.shape[0], -1, 3)      # sigmoid once per hypothesis
         return mean_v, tex, faces
@@ -657,9 +665,8 @@ class LASR(MeshNet):
             # the observed side is the same image for all H hypotheses: its features are computed once per image
             obspair = torch.cat([img_obs, img_white], 0)
             rndpair = torch.cat([img_rnd, self.texture_render], 0)
-            with torch.no_grad():
-                obspair = 2 * obspair - 1
-            percept = self.ptex_loss.forward_pair(obspair, 2 * rndpair - 1, repeat=H)
+            # (the [0,1] -> [-1,1] map of :436-441 is folded into the network's input normalisation: unit_range)
+            percept = self.ptex_loss.forward_pair(obspair, rndpair, repeat=H, unit_range=True)
             tmp = tmp + 0.005 * percept.view(2, -1).sum(0).view(n2, H)
         self.texture_loss_sub = 0.25 * tmp
         terms.append((self.texture_loss_sub, 1., G_TEX))
@@ -682,7 +689,9 @@ class LASR(MeshNet):
                 terms.append(((self.tex[0][idx1[0]].detach() - self.tex[0]).abs(), 1e-3, G_SYM))
         # 5) deformation (:481-497)
         if K > 1:
-            self.lmotion_loss_sub = factor * (self.deform_v - pred_v).norm(2, -1).mean(-1).view(n2, H)
+            self.lmotion_loss_sub = (self.deform_v - pred_v).norm(2, -1).mean(-1).view(n2, H)
+            if torch.is_tensor(factor):                                          # H == 1: the schedule's device scalar (else 1)
+                self.lmotion_loss_sub = factor * self.lmotion_loss_sub
             terms.append((self.lmotion_loss_sub, 1., G_LMOTION))
             dv0, dv1 = self.deform_v.reshape(2, B * H, -1, 3).unbind(0)
             terms.append((self.arap_loss_fn(dv0, dv1), (4 ** opts.subdivide) / 64., G_ARAP))

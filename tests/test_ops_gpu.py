@@ -526,3 +526,54 @@ def test_chamfer_kernel_values_indices_and_gradients(cuda, N, P, Q):
     np.testing.assert_allclose(gu.cpu().numpy(), gx.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gv.cpu().numpy(), gy.numpy(), rtol=1e-4, atol=1e-6)
     assert abs(float(out.mean()) - float(po.chamfer_distance(a, b))) <= 1e-5 * float(ref.mean().abs()) + 1e-6
+
+
+def test_perceptual_unit_range_fold_equals_the_explicit_map(cuda):
+    # mesh_net.py:436-441 feeds 2 * img - 1 to the perceptual network; the product folds that map into the input normalisation
+    from lasr_amd.nnutils import mesh_net
+    pd = mesh_net.PerceptualDistance().to(cuda)
+    g = torch.Generator().manual_seed(4)
+    a = torch.rand(2, 3, 64, 64, generator=g).to(cuda)
+    b = torch.rand(6, 3, 64, 64, generator=g).to(cuda)
+    b1, b2 = b.clone().requires_grad_(), b.clone().requires_grad_()
+    d1 = pd.forward_pair(a, b1, repeat=3, unit_range=True)
+    d2 = pd.forward_pair(2 * a - 1, 2 * b2 - 1, repeat=3)
+    assert d1.shape == d2.shape == (6,)
+    np.testing.assert_allclose(d1.detach().cpu().numpy(), d2.detach().cpu().numpy(), rtol=2e-5, atol=1e-6)
+    cot = torch.randn(6, generator=g).to(cuda)
+    g1, = torch.autograd.grad(d1, b1, cot)
+    g2, = torch.autograd.grad(d2, b2, cot)
+    assert float((g1 - g2).abs().max()) <= 2e-4 * float(g2.abs().max())
+
+
+@pytest.mark.parametrize('H,Vp,S,R', [(8, 337, 305, 2), (1, 40, 0, 4), (3, 10, 10, 6)])
+def test_mean_shape_kernel_matches_symmetrize_sigmoid_tile(cuda, H, Vp, S, R):
+    # third_party/ext_nnutils/mesh_net.py:128-149 (symmetrize) + :171-185 (get_mean_shape), written out with torch ops
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(H * 31 + S)
+    mv, tx = torch.randn(H, Vp, 3, generator=g), torch.randn(H, Vp, 3, generator=g)
+    flip = torch.tensor([[-1., 1., 1.]])
+    mask = torch.ones(Vp + S, 3)
+    mask[:max(Vp - S, 0) // 2, 0] = 0
+
+    def restatement(mean_v, tex):
+        if S > 0:
+            mean_v = torch.cat([mean_v, flip * mean_v[..., -S:, :]], -2) * mask
+            tex = torch.cat([tex, tex[..., -S:, :]], -2)
+        V = mean_v.shape[1]
+        return (mean_v[None].repeat(R, 1, 1, 1).view(R * H, V, 3), tex.sigmoid()[None].repeat(R, 1, 1, 1).view(R * H, V, 3))
+    a, b = mv.clone().requires_grad_(), tx.clone().requires_grad_()
+    rv, rt = restatement(a, b)
+    cv, ct = torch.randn(rv.shape, generator=g), torch.randn(rt.shape, generator=g)
+    ga, gb = torch.autograd.grad([rv, rt], [a, b], [cv, ct])
+    x, y = mv.clone().to(cuda).requires_grad_(), tx.clone().to(cuda).requires_grad_()
+    ov, ot = fused_ops.mean_shape(x, y, flip.to(cuda) if S else None, mask.to(cuda) if S else None, R, S)
+    assert torch.equal(ov.cpu(), rv.detach())                          # copies, sign flips and 0/1 masks: exact
+    np.testing.assert_allclose(ot.detach().cpu().numpy(), rt.detach().numpy(), rtol=2e-6, atol=1e-7)
+    gx, gy = torch.autograd.grad([ov, ot], [x, y], [cv.to(cuda), ct.to(cuda)])
+    np.testing.assert_allclose(gx.cpu().numpy(), ga.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gy.cpu().numpy(), gb.numpy(), rtol=1e-5, atol=1e-6)
+    # colours without gradient (--opt_tex no): only the shape gradient is produced
+    ov2, ot2 = fused_ops.mean_shape(x, y.detach(), flip.to(cuda) if S else None, mask.to(cuda) if S else None, R, S)
+    gx2, = torch.autograd.grad([ov2], [x], [cv.to(cuda)])
+    assert torch.equal(gx2, gx)
