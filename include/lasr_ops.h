@@ -76,6 +76,10 @@ int lasr_flow_loss_forward(const float* flow_rd, const float* flow_obs, const un
 int lasr_flow_loss_backward(const float* flow_rd, const float* flow_obs, const unsigned char* bg, const float* occ,
                             const float* masks, const float* scratch, const float* grad_loss, float* grad_flow_rd,
                             int I, int H, int P, int obs_image_stride, void* hip_stream);
+/* The same, also writing sel as vis_mask [I,H,P] uint8 (the `vis_mask` LASR.forward returns, nnutils/mesh_net.py:405). */
+int lasr_flow_loss_forward_vis(const float* flow_rd, const float* flow_obs, const unsigned char* bg, const float* occ,
+                               const float* masks, float* loss, float* flow_rd_map, unsigned char* vis_mask, float* scratch,
+                               int I, int H, int P, int obs_image_stride, void* hip_stream);
 
 /*
  * L1 texture loss table, nnutils/mesh_net.py:425-441 (without the perceptual term):
@@ -312,6 +316,12 @@ int lasr_mean_shape_forward(const float* mean_v, const float* tex, const float* 
                             float* out_tex, int R, int H, int Vp, int S, void* hip_stream);
 int lasr_mean_shape_backward(const float* tex, const float* flip, const float* mask, const float* grad_v, const float* grad_tex,
                              float* grad_mean_v, float* grad_tex_param, int R, int H, int Vp, int S, void* hip_stream);
+
+/*
+ * Observed images of the texture losses, nnutils/mesh_net.py:364-366: fg = masks > 0; out[:n] = imgs * fg (object on black),
+ * out[n:] = 1 - fg + imgs * fg (object on white).  imgs [n,3,P], masks [n,P] -> out [2n,3,P]; data only, no gradient.
+ */
+int lasr_obs_pair(const float* imgs, const float* masks, float* out, int n, int P, void* hip_stream);
 
 #ifdef __cplusplus
 }

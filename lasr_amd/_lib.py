@@ -32,6 +32,7 @@ SIGNATURES = {
     'lasr_mask_loss_backward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_flow_loss_forward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),
     'lasr_flow_loss_backward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),
+    'lasr_flow_loss_forward_vis': (_i, [_p] * 9 + [_i, _i, _i, _i, _p]),
     'lasr_tex_loss_forward': (_i, [_p] * 7 + [_f, _i, _i, _i, _p]),
     'lasr_tex_loss_backward': (_i, [_p] * 9 + [_f, _i, _i, _i, _p]),
     'lasr_arap_forward': (_i, [_p] * 5 + [_i, _i, _p]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     'lasr_bone_fixup_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_obs_pair': (_i, [_p, _p, _p, _i, _i, _p]),
     'lasr_mean_shape_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_mean_shape_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_dev': (_i, [_p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS_DEV),

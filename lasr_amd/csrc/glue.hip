@@ -350,6 +350,22 @@ __global__ __launch_bounds__(256) void mean_shape_backward_kernel(const float* _
     }
 }
 
+// ---- observed images for the texture losses (nnutils/mesh_net.py:364-366, 436) ------------------------------------------------
+// fg = masks > 0;  out[i] = imgs[i] * fg (object on black),  out[n + i] = 1 - fg + imgs[i] * fg (object on white);
+// imgs [n,3,P], masks [n,P] -> out [2n,3,P] (the pair the perceptual network sees, and the two L1 targets).
+__global__ __launch_bounds__(256) void obs_pair_kernel(const float* __restrict__ imgs, const float* __restrict__ masks,
+                                                       float* __restrict__ out, int n, int P)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)n * 3 * P;
+    if (i >= total) return;
+    const size_t im = i / ((size_t)3 * P), p = i % P;
+    const float fg = masks[im * P + p] > 0.f ? 1.f : 0.f;
+    const float obs = imgs[i] * fg;
+    out[i] = obs;
+    out[total + i] = 1.f - fg + obs;
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -507,5 +523,16 @@ extern "C" int lasr_mean_shape_backward(const float* tex, const float* flip, con
     const int total = H * Vp * 3;
     LASR_LAUNCH(K_MEAN_SHAPE, mean_shape_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, tex, flip, mask, grad_v, grad_tex,
                 grad_mean_v, grad_tex_param, R, H, Vp, S);
+    return launch_ok();
+}
+
+extern "C" int lasr_obs_pair(const float* imgs, const float* masks, float* out, int n, int P, void* hip_stream)
+{
+    if (n < 0 || P < 0) return LASR_E_BADARG;
+    if (n == 0 || P == 0) return LASR_OK;
+    if (!imgs || !masks || !out) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t total = (size_t)n * 3 * P;
+    LASR_LAUNCH(K_OBS_PAIR, obs_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, imgs, masks, out, n, P);
     return launch_ok();
 }

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void flow_loss_forward_kernel(const float2* __
                                                                 const unsigned char* __restrict__ bg, const float* __restrict__ occ,
                                                                 const float* __restrict__ masks, const float* __restrict__ img,
                                                                 float* __restrict__ part, float* __restrict__ fmap,
-                                                                int H, int P, int obs_stride, int nch)
+                                                                int H, int P, int obs_stride, int nch,
+                                                                unsigned char* __restrict__ vis)
 {
     __shared__ float red[4];
     const int ij = blockIdx.x, i = ij / H, ch = blockIdx.y;
@@ -358,7 +359,9 @@ __global__ __launch_bounds__(256) void flow_loss_forward_kernel(const float2* __
         const float dx = f.x - ox[p], dy = f.y - oy[p];
         const float e = sqrtf(dx * dx + dy * dy) * (sigmoid_f(-oc[p]) / wmean);
         fmap[(size_t)ij * P + p] = e;
-        if (!bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f) { s += e; c += 1.f; }
+        const bool sel = !bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f;
+        if (vis) vis[(size_t)ij * P + p] = sel ? 1 : 0;             // the vis_mask LASR logs (mesh_net.py:405), for free
+        if (sel) { s += e; c += 1.f; }
     }
     s = block_sum(s, red); c = block_sum(c, red);
     if (threadIdx.x == 0) { float* q = part + ((size_t)ij * nch + ch) * 4; q[0] = s; q[1] = 0.f; q[2] = c; q[3] = 0.f; }
@@ -670,6 +673,15 @@ extern "C" int lasr_flow_loss_forward(const float* flow_rd, const float* flow_ob
                                       const float* occ, const float* masks, float* loss, float* flow_rd_map,
                                       float* scratch, int I, int H, int P, int obs_image_stride, void* hip_stream)
 {
+    return lasr_flow_loss_forward_vis(flow_rd, flow_obs, bg, occ, masks, loss, flow_rd_map, nullptr, scratch, I, H, P,
+                                      obs_image_stride, hip_stream);
+}
+
+extern "C" int lasr_flow_loss_forward_vis(const float* flow_rd, const float* flow_obs, const unsigned char* bg,
+                                          const float* occ, const float* masks, float* loss, float* flow_rd_map,
+                                          unsigned char* vis_mask, float* scratch, int I, int H, int P, int obs_image_stride,
+                                          void* hip_stream)
+{
     if (check_ihp(I, H, P)) return LASR_E_BADARG;
     if (I * H == 0) return LASR_OK;
     if (!flow_rd || !flow_obs || !bg || !occ || !masks || !loss || !flow_rd_map || !scratch) return LASR_E_BADARG;
@@ -682,7 +694,7 @@ extern "C" int lasr_flow_loss_forward(const float* flow_rd, const float* flow_ob
     LASR_LAUNCH(K_LOSS_FINALIZE, flow_loss_stats_fold_kernel, dim3((I + 255) / 256), dim3(256), 0, sc.ipart, sc.img, I, H * nch);
     if ((rc = launch_ok())) return rc;
     LASR_LAUNCH(K_FLOW_LOSS_FORWARD, flow_loss_forward_kernel, dim3(I * H, nch), dim3(256), 0, (const float2*)flow_rd,
-                flow_obs, bg, occ, masks, sc.img, sc.part, flow_rd_map, H, P, obs_image_stride, nch);
+                flow_obs, bg, occ, masks, sc.img, sc.part, flow_rd_map, H, P, obs_image_stride, nch, vis_mask);
     if ((rc = launch_ok())) return rc;
     LASR_LAUNCH(K_LOSS_FINALIZE, loss_finalize_kernel<1>, dim3((I * H + 255) / 256), dim3(256), 0, sc.part, sc.tot, loss,
                 I * H, nch, 1.f);

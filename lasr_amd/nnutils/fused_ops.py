@@ -553,3 +553,17 @@ def mean_shape(mean_v, tex, flip, mask, repeats, num_sym):
     171-185): mean_v / tex [H,Vp,3] -> (verts [repeats*H, Vp+num_sym, 3], sigmoid colours, same shape); the last num_sym vertices
     are mirrored (flip [1,3]) and appended, positions times mask [Vp+num_sym,3].  num_sym = 0: no symmetry (flip / mask None)."""
     return _MeanShape.apply(mean_v, tex, flip, mask, int(repeats), int(num_sym))
+
+
+def obs_pair(imgs, masks):
+    """Observed image on black and on white for the texture losses (/root/reference/nnutils/mesh_net.py:364-366):
+    imgs [n,3,IS,IS], masks [n,IS,IS] -> [2n,3,IS,IS] = cat(imgs * fg, 1 - fg + imgs * fg), fg = masks > 0.  Data, no gradient."""
+    _lib.need_cuda(imgs, masks)
+    imgs, masks = imgs.detach().contiguous().float(), masks.detach().contiguous().float()
+    n, P = imgs.shape[0], masks[0].numel()
+    out = torch.empty(2 * n, *imgs.shape[1:], dtype=torch.float32, device=imgs.device)
+    guard, st = _lib.stream_of(imgs)
+    with guard:
+        rc = _lib.lib().lasr_obs_pair(imgs.data_ptr(), masks.data_ptr(), out.data_ptr(), n, P, st)
+    _lib.check(rc, 'lasr_obs_pair')
+    return out

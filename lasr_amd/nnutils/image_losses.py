@@ -63,19 +63,21 @@ class _FlowLoss(Function):
         occ, masks = occ.contiguous().float(), masks.contiguous().float()
         loss = torch.empty(I, H, dtype=torch.float32, device=flow_rd.device)
         fmap = torch.empty(flow_rd.shape[:-1], dtype=torch.float32, device=flow_rd.device)
+        vis = torch.empty(flow_rd.shape[:-1], dtype=torch.uint8, device=flow_rd.device)
         scratch = _scratch(flow_rd.device, I, H, P)
         guard, st = _lib.stream_of(flow_rd)
         with guard:
-            rc = _lib.lib().lasr_flow_loss_forward(flow_rd.data_ptr(), flow_obs.data_ptr(), bg8.data_ptr(), occ.data_ptr(),
-                                                   masks.data_ptr(), loss.data_ptr(), fmap.data_ptr(), scratch.data_ptr(),
-                                                   I, H, P, stride, st)
-        _lib.check(rc, 'lasr_flow_loss_forward')
+            rc = _lib.lib().lasr_flow_loss_forward_vis(flow_rd.data_ptr(), flow_obs.data_ptr(), bg8.data_ptr(), occ.data_ptr(),
+                                                       masks.data_ptr(), loss.data_ptr(), fmap.data_ptr(), vis.data_ptr(),
+                                                       scratch.data_ptr(), I, H, P, stride, st)
+        _lib.check(rc, 'lasr_flow_loss_forward_vis')
         ctx.save_for_backward(flow_rd, flow_obs, bg8, occ, masks, scratch)
-        ctx.mark_non_differentiable(fmap)
-        return loss, fmap
+        vis = vis.view(torch.bool)
+        ctx.mark_non_differentiable(fmap, vis)
+        return loss, fmap, vis
 
     @staticmethod
-    def backward(ctx, g, _gmap):
+    def backward(ctx, g, _gmap, _gvis=None):
         flow_rd, flow_obs, bg8, occ, masks, scratch = ctx.saved_tensors
         I, H = flow_rd.shape[:2]
         P = occ[0].numel()
@@ -90,10 +92,12 @@ class _FlowLoss(Function):
         return gf, None, None, None, None
 
 
-def flow_loss_table(flow_rd, flow_obs, bgmask, occ, masks):
+def flow_loss_table(flow_rd, flow_obs, bgmask, occ, masks, with_vis=False):
     """flow_rd [2B,H,IS,IS,2], flow_obs [2B,>=2,IS,IS], bgmask [2B,H,IS,IS] bool, occ/masks [2B,IS,IS]
-    -> (loss [2B,H], weighted error map [2B,H,IS,IS])   (mesh_net.py:393-413)."""
-    return _FlowLoss.apply(flow_rd, flow_obs, bgmask, occ, masks)
+    -> (loss [2B,H], weighted error map [2B,H,IS,IS])   (mesh_net.py:393-413).  with_vis: also the selection mask
+    (~bgmask & (occ != 0) & (masks > 0), the reference's `vis_mask`) the kernel evaluates anyway."""
+    loss, fmap, vis = _FlowLoss.apply(flow_rd, flow_obs, bgmask, occ, masks)
+    return (loss, fmap, vis) if with_vis else (loss, fmap)
 
 
 class _TexLoss(Function):

@@ -632,9 +632,8 @@ class LASR(MeshNet):
         self.flow_fw, self.flow_bw = self.flow_rd[:BH], self.flow_rd[BH:]         # the reference's per-direction attributes (views)
         self.bgmask_fw, self.bgmask_bw = self.bgmask[:BH], self.bgmask[BH:]
         self.fgmask_flowf, self.fgmask_flowb = self.mask_pred[:BH], self.mask_pred[BH:]
-        fg_obs = (self.masks > 0).float()[:, None]
-        img_obs = self.imgs * fg_obs
-        img_white = 1 - fg_obs + img_obs
+        obspair = fused_ops.obs_pair(self.imgs, self.masks)                     # observed object on black | on white (:364-366)
+        img_obs, img_white = obspair[:n2], obspair[n2:]
         if K > 1 and self.iters == 0:                                            # part rendering, logging only (:368-370)
             with torch.no_grad():
                 cmap = torch.tensor(synth.label_palette(K - 1), dtype=torch.float32, device=tex.device)
@@ -652,9 +651,8 @@ class LASR(MeshNet):
         self.mask_loss_sub = image_losses.mask_loss_table(self.mask_pred.view(n2, H, IS, IS), self.masks, self.occ)
         terms.append((self.mask_loss_sub, 1., G_MASK))
         # 2) flow (:393-416)
-        self.flow_rd_loss_sub, self.flow_rd_map = image_losses.flow_loss_table(
-            self.flow_rd.view(n2, H, IS, IS, 2), self.flow, self.bgmask.view(n2, H, IS, IS), self.occ, self.masks)
-        self.vis_mask = (~self.bgmask).view(n2, H, IS, IS) & ((self.occ != 0) & (self.masks > 0))[:, None]
+        self.flow_rd_loss_sub, self.flow_rd_map, self.vis_mask = image_losses.flow_loss_table(
+            self.flow_rd.view(n2, H, IS, IS, 2), self.flow, self.bgmask.view(n2, H, IS, IS), self.occ, self.masks, with_vis=True)
         terms.append((self.flow_rd_loss_sub, 1., G_FLOW))
         # 3) texture (:419-447)
         tr = self.texture_render.view(n2, H, 3, IS, IS)
@@ -663,11 +661,10 @@ class LASR(MeshNet):
         if self.ptex_loss is not None:
             img_rnd = self.texture_render * self.mask_pred[:, None]
             # the observed side is the same image for all H hypotheses: its features are computed once per image
-            obspair = torch.cat([img_obs, img_white], 0)
             rndpair = torch.cat([img_rnd, self.texture_render], 0)
             # (the [0,1] -> [-1,1] map of :436-441 is folded into the network's input normalisation: unit_range)
             percept = self.ptex_loss.forward_pair(obspair, rndpair, repeat=H, unit_range=True)
-            tmp = tmp + 0.005 * percept.view(2, -1).sum(0).view(n2, H)
+            tmp = torch.add(tmp, percept.view(2, -1).sum(0).view(n2, H), alpha=0.005)
         self.texture_loss_sub = 0.25 * tmp
         terms.append((self.texture_loss_sub, 1., G_TEX))
 

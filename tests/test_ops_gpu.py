@@ -166,6 +166,11 @@ def test_flow_loss_table(cuda, I, H, S):
     close(fmap, ref_map, 1e-5, 'flow map')
     (out * dev_t(w, cuda)).sum().backward()
     close(b.grad, a.grad, 1e-5, 'flow loss grad')
+    # the selection mask the kernel evaluates anyway == the reference's vis_mask (mesh_net.py:405)
+    out2, fmap2, vis = image_losses.flow_loss_table(b.detach(), dev_t(obs, cuda), dev_t(bg, cuda), dev_t(occ, cuda),
+                                                    dev_t(masks, cuda), with_vis=True)
+    want = ~torch.from_numpy(bg) & ((torch.from_numpy(occ) != 0) & (torch.from_numpy(masks) > 0))[:, None]
+    assert vis.dtype == torch.bool and torch.equal(vis.cpu(), want) and torch.equal(out2, out.detach())
 
 
 @pytest.mark.parametrize('I,H,S', [(2, 8, 32), (4, 1, 17), (2, 2, 256)])
@@ -577,3 +582,13 @@ def test_mean_shape_kernel_matches_symmetrize_sigmoid_tile(cuda, H, Vp, S, R):
     ov2, ot2 = fused_ops.mean_shape(x, y.detach(), flip.to(cuda) if S else None, mask.to(cuda) if S else None, R, S)
     gx2, = torch.autograd.grad([ov2], [x], [cv.to(cuda)])
     assert torch.equal(gx2, gx)
+
+
+def test_obs_pair_kernel(cuda):
+    from lasr_amd.nnutils import fused_ops
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.rand(3, 3, 20, 20, generator=g)
+    masks = (torch.rand(3, 20, 20, generator=g) > 0.4).float() * torch.rand(3, 20, 20, generator=g)
+    fg = (masks > 0).float()[:, None]
+    out = fused_ops.obs_pair(imgs.to(cuda), masks.to(cuda)).cpu()
+    assert torch.equal(out[:3], imgs * fg) and torch.equal(out[3:], 1 - fg + imgs * fg)
