@@ -296,6 +296,9 @@ class PerceptualDistance(nn.Module):
             p_.requires_grad_(False)
         self.register_buffer('shift', torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1))
         self.register_buffer('scale', torch.tensor([.458, .448, .450]).view(1, 3, 1, 1))
+        # the same normalisation for inputs given in [0, 1] that stand for 2 x - 1: ((2x - 1) - shift) / scale = x * gain + bias
+        self.register_buffer('unit_gain', 2. / self.scale, persistent=False)
+        self.register_buffer('unit_bias', -(1. + self.shift) / self.scale, persistent=False)
 
     def load_weights(self, path):
         """AlexNet convolution weights from a local state_dict: torchvision alexnet ('features.{0,3,6,8,10}.weight'), or the
@@ -319,9 +322,12 @@ class PerceptualDistance(nn.Module):
 
     def _feats(self, x, unit_range=False):
         """Feature maps of the five AlexNet convolutions.  unit_range: x is in [0, 1] and stands for 2 x - 1 (the reference maps
-        its images to [-1, 1] first, mesh_net.py:436-441); ((2x - 1) - shift) / scale == (x - (1 + shift) / 2) / (scale / 2) is
+        its images to [-1, 1] first, mesh_net.py:436-441); ((2x - 1) - shift) / scale == x * (2 / scale) - (1 + shift) / scale is
         folded into the input normalisation instead of costing two more passes over the images."""
-        x = (x - (1 + self.shift) / 2) / (self.scale / 2) if unit_range else (x - self.shift) / self.scale
+        if unit_range:                                         # x * (2 / scale) - (1 + shift) / scale, one pass
+            x = torch.addcmul(self.unit_bias, x, self.unit_gain)
+        else:
+            x = (x - self.shift) / self.scale
         out = []
         for i, c in enumerate(self.convs):
             if i in (1, 2):
