@@ -323,6 +323,28 @@ int lasr_mean_shape_backward(const float* tex, const float* flip, const float* m
  */
 int lasr_obs_pair(const float* imgs, const float* masks, float* out, int n, int P, void* hip_stream);
 
+/*
+ * The optimisation-step tail, nnutils/train_utils.py:282-296: clip the mean-shape gradient to
+ * norm max_norm_shape (1) and the encoder + code-predictor gradients jointly to max_norm_cam (10) with
+ * torch.nn.utils.clip_grad_norm_'s coefficient min(1, max / (norm + 1e-6)); if ANY gradient element is NaN / Inf every gradient
+ * becomes zero (the reference's zero_grad()) and the update still runs; then AdamW (decoupled weight decay, torch.optim.AdamW
+ * arithmetic: p -= lr wd p; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)) on
+ * every tensor, and each tensor's step counter += 1.  Three launches over all tensors, no host synchronisation.
+ *   table   device array, one row of 8 x 64 bit per tensor: {param, grad, exp_avg, exp_avg_sq, step (float*, may be 0), numel,
+ *           group index, clip class (0 none, 1 mean shape, 2 camera networks)}
+ *   chunks  device int32 [n_chunks, 2] = (table row, element offset), one per lasr_tail_chunk_elems() elements of a tensor
+ *   partials device float [n_chunks] scratch; ctl device float [8]: out {clip coefficient shape, cam, all-finite flag,
+ *           shape gradient norm after clipping, camera-network gradient norm before clipping, norm of all gradients}
+ *   lr .. weight_decay: HOST arrays per parameter group (n_groups <= LASR_TAIL_MAX_GROUPS); bias_correction1/2 = 1 - beta^t of
+ *           the step being taken, evaluated by the caller in double.
+ */
+#define LASR_TAIL_MAX_GROUPS 16
+int lasr_tail_chunk_elems(void);
+int lasr_tail_step(const void* table, const int* chunks, int n_chunks, float* partials, float* ctl, float max_norm_shape,
+                   float max_norm_cam, const float* lr, const float* beta1, const float* beta2, const float* eps,
+                   const float* weight_decay, const double* bias_correction1, const double* bias_correction2, int n_groups,
+                   void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

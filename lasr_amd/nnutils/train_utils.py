@@ -16,7 +16,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import loss_utils, mesh_net
-from .. import synth_data
+from .. import _lib, synth_data
 
 
 # --dataname values that select the in-memory synthetic sequence (lasr_amd/synth_data.py) when no configs/<name>.config exists;
@@ -283,6 +283,8 @@ class LASRTrainer:
         AdamW and the OneCycle schedule.  The reference tests `isnan` per parameter tensor with a host sync each (~70 per
         step); here one multi-tensor norm + one sync decides (an Inf gradient is treated like a NaN: it would turn into
         NaN inside clip_grad_norm_ anyway)."""
+        if self._tail_table() is not None:
+            return self._step_tail_hip()
         m = self.module
         cam_grad, grads = [], []
         for name, p in m.named_parameters():
@@ -299,6 +301,85 @@ class LASRTrainer:
         if self.skipped_nan:
             torch._foreach_zero_(grads)
         self.optimizer.step()
+        self.scheduler.step()
+
+    # ---- the same tail as three multi-tensor HIP launches (lasr_tail_step, lasr_amd/csrc/tail.hip) ------------------------
+    # Used on a GPU from the second step on: the first step goes through torch.optim.AdamW, which creates the optimizer state
+    # (exp_avg, exp_avg_sq, step) that the kernels then update in place -- state_dict() / load_state_dict() keep working.
+    @property
+    def skipped_nan(self):
+        v = getattr(self, '_skipped_nan', False)
+        return bool(v() if callable(v) else v)
+
+    @skipped_nan.setter
+    def skipped_nan(self, v):
+        self._skipped_nan = v
+
+    def _tail_table(self):
+        """Device table of (param, grad, exp_avg, exp_avg_sq, step, numel, group, clip class) rows, rebuilt when an address
+        changes; None when the fused tail does not apply (CPU, --nofused_tail, optimizer state not created yet, ...)."""
+        if self.device.type != 'cuda' or not getattr(self.opts, 'fused_tail', True):
+            return None
+        opt = self.optimizer
+        names = {id(p): n for n, p in self.module.named_parameters()}
+        rows, key = [], []
+        for gi, group in enumerate(opt.param_groups):
+            if group.get('amsgrad') or group.get('maximize'):
+                return None
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = opt.state.get(p)
+                if not st or 'exp_avg' not in st or not torch.is_tensor(st.get('step')) or not st['step'].is_cuda:
+                    return None
+                g = p.grad
+                if p.dtype != torch.float32 or g.dtype != torch.float32 or not (p.is_contiguous() and g.is_contiguous()):
+                    return None
+                name = names.get(id(p), '')
+                clip = 1 if name == 'mean_v' else (2 if ('code_predictor' in name or 'encoder' in name) else 0)
+                rows.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
+                             st['step'].data_ptr(), p.numel(), gi, clip))
+                key.append(st['step'])
+        if not rows or len(opt.param_groups) > 16:
+            return None
+        cached = getattr(self, '_tail_cache', None)
+        if cached is not None and cached['rows'] == rows:
+            return cached
+        steps = torch.stack([t.reshape(()) for t in key]).cpu()                 # one sync per (re)build
+        if float(steps.min()) != float(steps.max()):
+            return None                                                          # tensors at different step counts: torch path
+        h = _lib.lib()
+        ch = h.lasr_tail_chunk_elems()
+        chunks = [(i, off) for i, r in enumerate(rows) for off in range(0, r[5], ch)]
+        dev = self.device
+        self._tail_cache = cached = dict(
+            rows=rows, t=int(steps[0]), n_chunks=len(chunks),
+            table=torch.tensor(rows, dtype=torch.int64).to(dev), chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
+            partials=torch.empty(len(chunks), dtype=torch.float32, device=dev), ctl=torch.zeros(8, dtype=torch.float32, device=dev))
+        return cached
+
+    def _step_tail_hip(self):
+        import ctypes
+        c = self._tail_cache
+        groups = self.optimizer.param_groups
+        n = len(groups)
+        t = c['t'] + 1
+
+        def arr(kind, vals):
+            return (kind * n)(*vals)
+        b1, b2 = [g['betas'][0] for g in groups], [g['betas'][1] for g in groups]
+        guard, st = _lib.stream_of(c['ctl'])
+        with guard:
+            rc = _lib.lib().lasr_tail_step(
+                c['table'].data_ptr(), c['chunks'].data_ptr(), c['n_chunks'], c['partials'].data_ptr(), c['ctl'].data_ptr(), 1., 10.,
+                arr(ctypes.c_float, [g['lr'] for g in groups]), arr(ctypes.c_float, b1), arr(ctypes.c_float, b2),
+                arr(ctypes.c_float, [g['eps'] for g in groups]), arr(ctypes.c_float, [g['weight_decay'] for g in groups]),
+                arr(ctypes.c_double, [1. - b ** t for b in b1]), arr(ctypes.c_double, [1. - b ** t for b in b2]), n, st)
+        _lib.check(rc, 'lasr_tail_step')
+        c['t'] = t
+        ctl = c['ctl']
+        self.grad_meanv_norm, self.grad_cam_norm = ctl[3], ctl[4]                # device scalars, read when logged
+        self._skipped_nan = lambda: float(ctl[2]) == 0.                          # host sync only if somebody asks
         self.scheduler.step()
 
     def reinit_bones(self):

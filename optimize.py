@@ -33,7 +33,9 @@ DEFAULTS = dict(
     # use_graph: replay forward + backward as one HIP graph (on by default on a GPU; --nouse_graph = eager as the reference)
     # encoder_weights / alexnet_weights: optional local state_dicts (torchvision resnet18 / alexnet, an LPIPS 'alex' net, or a
     # reference LASR checkpoint) for the two networks the reference takes ImageNet-pretrained; '' = random init (no network here)
-    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=True, data_root='.', encoder_weights='', alexnet_weights='')
+    # fused_tail: clipping + NaN guard + AdamW as three multi-tensor HIP launches (--nofused_tail = torch.optim.AdamW every step)
+    n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=True, data_root='.', encoder_weights='', alexnet_weights='',
+    fused_tail=True)
 
 
 def parse_flags(argv, defaults=DEFAULTS):
