@@ -225,7 +225,8 @@ def lbs_leg(dev):
 def optimize_leg(dev, iters):
     """BASELINE.json's second figure: optimize.py iterations/s on the spot3 stage-0 configuration
     (scripts/spot3.sh:24: B=1 pair, 8 hypotheses, 21 bones, icosphere-3, 256x256), synthetic 3-frame sequence,
-    full step = encoder + LBS + 3 render calls fwd/bwd + loss tables + regularisers + AdamW."""
+    full step = encoder + LBS + the render (one nine-attribute pass for the reference's three calls) fwd/bwd + loss tables +
+    regularisers + clipping / NaN guard / AdamW."""
     import optimize
     from lasr_amd.nnutils import train_utils
     opts = optimize.parse_flags(['--name', 'bench', '--checkpoint_dir', '', '--only_mean_sym', '--nouse_gtpose',
@@ -247,10 +248,11 @@ def optimize_leg(dev, iters):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {'iters_per_s': iters / dt, 'ms_per_iter': dt / iters * 1e3, 'iters': iters, 'final_loss': float(loss),
-            'config': 'spot3 stage 0: batch 1 pair, n_hypo 8, n_bones 21, V=642/F=1280, 256x256; per iteration 2 x 8 '
-                      'six-attribute flow renders + 16 texture renders fwd+bwd (the reference rasterises the same 48 '
-                      'images as 3-channel renders), random-init encoder + perceptual net; forward+backward replayed '
-                      'as one HIP graph (--use_graph), fused AdamW eager'}
+            'config': 'spot3 stage 0: batch 1 pair, n_hypo 8, n_bones 21, V=642/F=1280, 256x256; per iteration ONE nine-attribute '
+                      'render of the 16 (image, hypothesis) meshes fwd+bwd (texture colours + both flow position triples; the '
+                      'reference rasterises the same geometry as 48 three-channel images), random-init encoder + perceptual '
+                      'net; forward+backward replayed as one HIP graph (--use_graph), clipping + NaN guard + AdamW as three '
+                      'multi-tensor HIP launches'}
 
 
 def measured_traffic(kernel, frames_per_launch):
