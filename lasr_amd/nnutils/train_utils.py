@@ -344,10 +344,11 @@ class LASRTrainer:
             return None
         cached = getattr(self, '_tail_cache', None)
         if cached is not None and cached['rows'] == rows:
-            return cached
+            return cached if cached.get('table') is not None else None
         steps = torch.stack([t.reshape(()) for t in key]).cpu()                 # one sync per (re)build
-        if float(steps.min()) != float(steps.max()):
-            return None                                                          # tensors at different step counts: torch path
+        if float(steps.min()) != float(steps.max()):                             # tensors at different step counts (a parameter
+            self._tail_cache = dict(rows=rows, table=None)                       # joined later): torch path, decided once
+            return None
         h = _lib.lib()
         ch = h.lasr_tail_chunk_elems()
         chunks = [(i, off) for i, r in enumerate(rows) for off in range(0, r[5], ch)]

@@ -107,3 +107,20 @@ def test_fused_tail_against_the_reference_loop_body(tmp_path, cuda):
         assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max())), name
     np.testing.assert_allclose(float(torch.cat([p.grad.view(-1) for n, p in tr.module.named_parameters()
                                                 if 'encoder' in n or 'code_predictor' in n]).norm()), 10.0, rtol=1e-4)
+
+
+def test_fused_tail_steps_aside_when_step_counts_differ(tmp_path, cuda):
+    # a tensor whose optimizer state is at another step count (e.g. a parameter that joined later) needs its own bias
+    # correction: the trainer then keeps torch.optim.AdamW for every step, decided once (no per-step host sync)
+    tr = make(tmp_path, cuda, fused=True)
+    set_grads(tr, 1, 1.0)
+    tr.step_tail()
+    assert tr._tail_table() is not None
+    tr.optimizer.state[tr.module.mean_v]['step'] += 3
+    tr._tail_cache = None
+    set_grads(tr, 2, 1.0)
+    before = tr.module.tex.detach().clone()
+    tr.step_tail()
+    assert tr._tail_table() is None and tr._tail_cache['table'] is None
+    assert float((tr.module.tex - before).abs().max()) > 0           # the torch path stepped
+    assert float(tr.optimizer.state[tr.module.tex]['step']) == 2 and float(tr.optimizer.state[tr.module.mean_v]['step']) == 5
