@@ -1,8 +1,10 @@
 """oracle/path_oracle.py (torch restatements of the Python path pieces) against fixtures captured from the
 imported reference, plus hand-computable cases for the loss tables that cannot be captured."""
+import math
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import path_oracle as po
@@ -216,3 +218,64 @@ def test_load_textures_restatement_on_analytic_atlases():
     np.testing.assert_allclose(const, 0.25, atol=1e-7)
     skipped = po.load_textures(lin, uv, R, is_update=[1, 0])
     assert np.array_equal(skipped[0], t[0]) and not skipped[1].any()
+
+
+# ---- restatements behind the glue kernels (lasr_amd/csrc/glue.hip): hand-checkable cases -----------------------------------
+def test_intrinsics_restatement_hand_case():
+    # uncropped pair (crop scale 1, centre offset 0): focal length and depth pass through, frame t' gets frame t's principal point
+    B, H, K = 2, 3, 4
+    cams = torch.ones(2 * B, 7)
+    pp = torch.zeros(2 * B, 2)
+    scale, depth, ppoint = torch.rand(2 * B, H), torch.rand(2 * B, K), torch.rand(2 * B, 2)
+    s, d, p = po.intrinsics(cams, pp, scale, depth, ppoint, 256)
+    assert torch.equal(s, scale) and torch.equal(d, depth)
+    assert torch.allclose(p[B:], ppoint[:B], atol=1e-6) and torch.equal(p[:B], ppoint[:B])
+    # a frame t' cropped twice as tightly (scale 2) with a shifted crop centre
+    cams[B:, 0] = 2.
+    pp[B:] = torch.tensor([12.8, -25.6])
+    s, d, p = po.intrinsics(cams, pp, scale, depth, ppoint, 256)
+    assert torch.allclose(s[B:], 2 * scale[B:]) and torch.allclose(d[B:, 0], 2 * depth[B:, 0]) and torch.equal(d[:, 1:], depth[:, 1:])
+    want = (ppoint[:B] + 1) * 2 - 2 * torch.tensor([12.8, -25.6]) / 128 - 1
+    assert torch.allclose(p[B:], want, atol=1e-6)
+
+
+def test_bone_fixup_restatement_hand_case():
+    # one image, one hypothesis, root + one bone; the bone turns 90 degrees about z around the joint c = (1, 0, 0)
+    Rz = torch.tensor([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]])
+    quat = torch.stack([torch.eye(3), Rz.t()]).reshape(2, 9)            # the head predicts the TRANSPOSE of the applied rotation
+    trans, depth = torch.tensor([[0.1, 0.2], [0., 0.]]), torch.tensor([[5.], [0.]])
+    rest = torch.tensor([[1., 0., 0.]])
+    R, T = po.bone_fixup(quat, trans, depth, rest, 1, 1, 2)
+    assert torch.equal(R[0], torch.eye(3)) and torch.equal(T[0], torch.tensor([0.1, 0.2, 5.]))
+    assert torch.equal(R[1], Rz.t())                                     # bones are transposed back (mesh_net.py:281)
+    assert torch.allclose(T[1], rest[0] - Rz @ rest[0])                  # x -> R (x - c) + c: the joint stays where it is
+    assert torch.allclose(Rz @ rest[0] + T[1], rest[0])
+
+
+def test_geodesic_chamfer_and_loss_sum_restatements_hand_cases():
+    th = 0.7
+    Rz = torch.tensor([[math.cos(th), -math.sin(th), 0.], [math.sin(th), math.cos(th), 0.], [0., 0., 1.]])
+    ang = po.geodesic_distance(torch.stack([torch.eye(3), Rz]), torch.stack([torch.eye(3), torch.eye(3)]))
+    assert abs(float(ang[0])) < 1e-3 and abs(float(ang[1]) - th) < 1e-6
+    a = torch.tensor([[[0., 0., 0.], [1., 0., 0.]]])
+    b = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [5., 0., 0.]]])
+    # a -> b: (1 + 0) / 2; b -> a: (1 + 0 + 16) / 3
+    assert abs(float(po.chamfer_distance(a, b)) - (0.5 + 17. / 3)) < 1e-6
+    total, groups = po.weighted_mean_sum([(torch.tensor([1., 3.]), 2., 0), (torch.tensor([[4.]]), 0.5, 1), (torch.tensor([2., 2., 2.]), 1., 0)])
+    assert float(total) == 2 * 2 + 0.5 * 4 + 2 and [float(g) for g in groups] == [6., 2.]
+
+
+def test_glue_kernels_reject_cpu_tensors():
+    from lasr_amd.nnutils import fused_ops
+    z = torch.zeros
+    calls = [lambda: fused_ops.intrinsics(z(2, 7), z(2, 2), z(2, 1), z(2, 1), z(2, 2), 64),
+             lambda: fused_ops.bone_fixup(z(2, 9), z(2, 2), z(2, 1), None, 1, 1),
+             lambda: fused_ops.geodesic_distance(z(2, 3, 3), z(2, 3, 3)),
+             lambda: fused_ops.chamfer(z(1, 2, 3), z(1, 2, 3)),
+             lambda: fused_ops.mean_shape(z(1, 4, 3), z(1, 4, 3), None, None, 2, 0),
+             lambda: fused_ops.obs_pair(z(1, 3, 4, 4), z(1, 4, 4)),
+             lambda: fused_ops.weighted_mean_sum([(z(3), 1., 0)]),
+             lambda: fused_ops.flow_reproject_planes(z(1, 6, 4, 4), z(1, 2), z(1, 2), z(1, 1), z(1, 1))]
+    for call in calls:
+        with pytest.raises(TypeError):                                   # no CPU fallback behind the HIP operators
+            call()
