@@ -184,3 +184,10 @@ def test_whole_forward_rigid(tmp_path, cuda):
     # n_bones = 1: no skinning, no fix-up, no deformation losses
     out = run_both(tmp_path, n_bones=1, n_hypo=2, batch_size=1)
     check(*out, K=1)
+
+
+def test_whole_forward_ground_truth_cameras(tmp_path, cuda):
+    # scripts/spot3-gtcam.sh: --use_gtpose with one rigid hypothesis -- the render uses the data's cameras, the predicted code
+    # only enters through the camera loss (:506-514)
+    out = run_both(tmp_path, n_bones=1, n_hypo=1, batch_size=1, use_gtpose=True, symmetric=False, only_mean_sym=False)
+    check(*out, K=1)
