@@ -29,6 +29,11 @@ def allreduce_grads_(tensors, average=True, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return tensors
+    if len(tensors) == 1 and tensors[0].is_contiguous():                     # already one flat message: reduce it in place
+        dist.all_reduce(tensors[0], group=group)
+        if average:
+            tensors[0] /= world
+        return tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, group=group)
     if average:
