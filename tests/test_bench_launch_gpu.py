@@ -44,3 +44,39 @@ def test_bench_single_gpu_line_has_every_block(cuda):
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['one_thread_frames_per_s'] > 0
     assert l['mfma_instruction'] == 'v_mfma_f32_16x16x4_f32' and set(l['sizes']) == {'S0', 'dog15', 'batch256'}
     assert all(v['us_per_call'] > 0 and v['mfma_instructions'] > 0 for v in l['sizes'].values())
+
+
+def test_rccl_executes_on_this_box(cuda):
+    # One rank, backend 'nccl' (= RCCL on ROCm): communicator creation, an all-reduce of the mesh-gradient message, a barrier and
+    # the object gather bench.py uses -- the calls of the N > 1 path, on the one GPU this box has (RCCL refuses two ranks on one
+    # device, so the two-rank test above runs over gloo here and over RCCL wherever there are two GPUs).
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from lasr_amd import parallel
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(%d), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', device_id=dev)
+assert dist.get_backend() == 'nccl'
+g = torch.arange(2 * 1212 * 3, dtype=torch.float32, device=dev).reshape(2, 1212, 3)
+want = g.clone()
+dist.all_reduce(g)                      # goes through RCCL even with one rank
+parallel.allreduce_grads_([g], average=False)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(g, want)
+ids = [None]
+dist.all_gather_object(ids, (0, torch.cuda.current_device(), os.getpid()))
+assert ids[0][2] == os.getpid()
+dist.destroy_process_group()
+print('rccl ok', torch.cuda.nccl.version())
+'''
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    p = subprocess.run([sys.executable, '-c', code % (ROOT, port)], cwd=ROOT, timeout=300, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and 'rccl ok' in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
