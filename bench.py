@@ -374,7 +374,7 @@ def main():
     if rank == 0:
         F, P = job.F, IS * IS
         alg = {'sr_forward_kernel': (72 * F + 24 * P) * B, 'sr_backward_kernel': (144 * F + 40 * P) * B,
-               'sr_setup_kernel': (36 + 160) * F * B}
+               'sr_setup_kernel': (36 + 192 + 8) * F * B}
         dom = max((k for k in ktimes if k != 'sr_setup_kernel'), key=lambda k: ktimes[k][0])
         achieved = alg[dom] / (ktimes[dom][0] * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dom, B) if IS == 256 else (None, None)   # PMC passes were taken at 256x256

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
             Crgb *= sm;
             C += div_<FM>(Crgb, D);
             const float Cz = div_<FM>(div_<FM>(Crgb, A.gamma), A.near - A.far) * zp * zp;
-            const float iz0 = __builtin_amdgcn_rcpf(rec[2]), iz1 = __builtin_amdgcn_rcpf(rec[5]), iz2 = __builtin_amdgcn_rcpf(rec[8]);
+            const float iz0 = __builtin_amdgcn_rcpf(rec[R_FACE + 2]), iz1 = __builtin_amdgcn_rcpf(rec[R_FACE + 5]), iz2 = __builtin_amdgcn_rcpf(rec[R_FACE + 8]);
             gz0 = Cz * w0 * iz0 * iz0;
             gz1 = Cz * w1 * iz1 * iz1;
             gz2 = Cz * w2 * iz2 * iz2;

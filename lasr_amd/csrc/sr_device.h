@@ -6,7 +6,7 @@
 // -ffp-contract=off, the geometry (barycentrics, edge projections, depth) is
 // bit-identical to an un-contracted fp32 evaluation of the reference; only
 // exp() may differ by an ulp from a host libm.  What is NOT taken from the
-// reference is the execution shape: per-face constants live in a 44-float
+// reference is the execution shape: per-face constants live in a 48-float
 // record that a wave reads through the scalar cache (the face index is
 // wave-uniform), the bbox reject becomes an exact integer pixel rectangle, divisions by
 // per-face constants go through correctly rounded reciprocals, and runtime-indexed arrays
@@ -17,22 +17,24 @@
 namespace lasr {
 
 // ---- per-face record -------------------------------------------------------
-// [0..8]   x0 y0 z0 x1 y1 z1 x2 y2 z2
-// [9..17]  inv  : rows of adj([x y 1])/det                         (K.cu:274-286)
-// [18..26] e    : e[k][j] = sym[3k+j] - sym[3((k+1)%3)+j]           (K.cu:81-83,132-134, hoisted)
-// [27..29] den  : den[k]  = e[k][k] - e[k][(k+1)%3]                 (K.cu:85,136, hoisted)
-// [30]     flags: bit0..2 first obtuse corner (K.cu:296-304), bit3 front-facing (K.cu:41-44),
-//                 bit4 well-conditioned (the cheap line-distance reject below may be used),
-//                 bit5 reciprocals usable
-// [31..33] hk2  : squared height of vertex k over its opposite edge (own addition: w_k * h_k is the
-//                 signed distance of a pixel to that edge's line, a lower bound of the true distance)
-// [34..35] rect : the pixels that pass the bbox test of K.cu:33-38, as EXACT integer bounds (own addition):
-//                 [34] = x0 | x1 << 16 (columns), [35] = r0 | r1 << 16 (rows from the top); empty = x0 > x1
-// [36..38] iden : RN(1/den[k])   } correctly rounded reciprocals for the exact-division-by-reciprocal below;
-// [39..41] iz   : RN(1/z_k)      } flags bit5 says they are usable (finite, denominators in a safe range)
-// [42..43] pad to 176 B (16-B multiple so records start on a dwordx4 boundary)
-constexpr int REC = 44;
-constexpr int R_FACE = 0, R_INV = 9, R_E = 18, R_DEN = 27, R_FLAGS = 30, R_HK2 = 31, R_BB = 34, R_IDEN = 36, R_IZ = 39;
+// 48 floats = 192 B on 64-B boundaries, fields grouped by the cache line the raster walks need them in (a record is
+// fetched through the scalar cache with dependent loads: three aligned lines instead of the 3-4 a packed 176-B record
+// straddles; measured -1.8 % on the backward kernel, which starts every wave with this fetch).
+// line 0  [0..1]   rect : the pixels that pass the bbox test of K.cu:33-38, as EXACT integer bounds (own addition):
+//                         [0] = x0 | x1 << 16 (columns), [1] = r0 | r1 << 16 (rows from the top); empty = x0 > x1
+//         [2]      flags: bit0..2 first obtuse corner (K.cu:296-304), bit3 front-facing (K.cu:41-44),
+//                         bit4 well-conditioned (the cheap line-distance reject below may be used), bit5 reciprocals usable
+//         [3..11]  inv  : rows of adj([x y 1])/det                         (K.cu:274-286)
+//         [12..14] hk2  : squared height of vertex k over its opposite edge (own addition: w_k * h_k is the
+//                         signed distance of a pixel to that edge's line, a lower bound of the true distance)
+// line 1  [16..24] x0 y0 z0 x1 y1 z1 x2 y2 z2
+//         [25..27] den  : den[k]  = e[k][k] - e[k][(k+1)%3]                 (K.cu:85,136, hoisted)
+//         [28..30] iden : RN(1/den[k])   } correctly rounded reciprocals for the exact-division-by-reciprocal below;
+// line 2  [32..40] e    : e[k][j] = sym[3k+j] - sym[3((k+1)%3)+j]           (K.cu:81-83,132-134, hoisted)
+//         [41..43] iz   : RN(1/z_k)      } flags bit5 says they are usable (finite, denominators in a safe range)
+//         [15], [31], [44..47] padding
+constexpr int REC = 48;
+constexpr int R_BB = 0, R_FLAGS = 2, R_INV = 3, R_HK2 = 12, R_FACE = 16, R_DEN = 25, R_IDEN = 28, R_E = 32, R_IZ = 41;
 
 // Read-only buffers written by an EARLIER kernel are viewed through the constant address
 // space: with a wave-uniform index the compiler then emits s_load (scalar cache -> SGPRs)
@@ -181,7 +183,9 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
             ok = ok && recip_safe(d) && recip_safe(z);
         }
         if (ok) rec[R_FLAGS] = __int_as_float(__float_as_int(rec[R_FLAGS]) | 32);
-        rec[R_IZ + 3] = 0.f; rec[R_IZ + 4] = 0.f;
+        rec[15] = 0.f; rec[31] = 0.f;                               // padding: defined bytes in the workspace
+#pragma unroll
+        for (int k = 44; k < REC; k++) rec[k] = 0.f;
     }
     if (info27) {   // reference layout, for callers that still want the tensor
 #pragma unroll
@@ -305,7 +309,7 @@ __device__ __forceinline__ void euclid(RP rec, float xp, float yp,
                                        float w0, float w1, float w2, Frag& fr)
 {
 #pragma clang fp contract(off)   // see edge_project
-    const float x0 = rec[0], y0 = rec[1], x1 = rec[3], y1 = rec[4], x2 = rec[6], y2 = rec[7];
+    const float x0 = rec[R_FACE + 0], y0 = rec[R_FACE + 1], x1 = rec[R_FACE + 3], y1 = rec[R_FACE + 4], x2 = rec[R_FACE + 6], y2 = rec[R_FACE + 7];
     if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
         float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
         float u0, u1, u2;
@@ -398,9 +402,9 @@ template <bool FM = false, bool MK = false, typename RP = cptr_t>
 __device__ __forceinline__ float depth_at(RP rec, float c0, float c1, float c2)
 {
     if (MK)
-        return 1.f / (div_by_recip(c0, rec[2], rec[R_IZ + 0]) + div_by_recip(c1, rec[5], rec[R_IZ + 1]) +
-                      div_by_recip(c2, rec[8], rec[R_IZ + 2]));
-    return div_<FM>(1.f, div_<FM>(c0, rec[2]) + div_<FM>(c1, rec[5]) + div_<FM>(c2, rec[8]));
+        return 1.f / (div_by_recip(c0, rec[R_FACE + 2], rec[R_IZ + 0]) + div_by_recip(c1, rec[R_FACE + 5], rec[R_IZ + 1]) +
+                      div_by_recip(c2, rec[R_FACE + 8], rec[R_IZ + 2]));
+    return div_<FM>(1.f, div_<FM>(c0, rec[R_FACE + 2]) + div_<FM>(c1, rec[R_FACE + 5]) + div_<FM>(c2, rec[R_FACE + 8]));
 }
 
 // The forward pass's depth of a pixel on a face, bit for bit (barycentrics K.cu:24-29, clip/normalise :53-58, depth :423),
@@ -419,7 +423,7 @@ __device__ __forceinline__ float depth_forward_exact(RP rec, float xp, float yp)
     w2 = fmaxf(fminf(w2, 1.f), 0.f);
     const float s = fmaxf(w0 + w1 + w2, 1e-5f);
     w0 = w0 / s; w1 = w1 / s; w2 = w2 / s;                  // == div3_shared (bit-identical quotients, self-tested)
-    return 1.f / (w0 / rec[2] + w1 / rec[5] + w2 / rec[8]);  // == the reciprocal forms of depth_at (correctly rounded)
+    return 1.f / (w0 / rec[R_FACE + 2] + w1 / rec[R_FACE + 5] + w2 / rec[R_FACE + 8]);  // == the reciprocal forms of depth_at (correctly rounded)
 }
 
 // texel index a surface sample lands in (K.cu:181-188 == 200-211).  A clipped barycentric

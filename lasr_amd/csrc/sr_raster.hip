@@ -3,7 +3,7 @@
 // Replaces the three reference kernels (soft_rasterize_cuda_kernel.cu "K.cu":245-305, 308-483, 486-668) with a
 // different execution shape:
 //
-//   setup    1 thread / face : 44-float record (geometry, hoisted edge vectors, correctly rounded reciprocals, flags)
+//   setup    1 thread / face : 48-float record (geometry, hoisted edge vectors, correctly rounded reciprocals, flags)
 //            + the EXACT integer pixel rectangle of the reference's float bbox test (sr_device.h).
 //   forward  1 workgroup / 16x16 px tile, 1 wave / 8x8 quadrant, 1 lane / pixel.
 //            level 1: the workgroup scans the image's pixel rects (coalesced 8-B loads) and compacts, IN FACE-INDEX
@@ -35,8 +35,8 @@ constexpr int TILE = 16;        // pixels per tile side (4 waves of 8x8)
 constexpr int LIST_CAP = 2048;  // faces scanned per round == capacity of each LDS list (u16 ids; 5 lists = 20 KB)
 
 // ---------------------------------------------------------------------------
-// One thread builds one face's record -- into LDS; the block then writes its 256 records (45 KB, contiguous in the
-// workspace) with coalesced stores.  Writing the 176-B records straight from the building threads is a 176-B-strided
+// One thread builds one face's record -- into LDS; the block then writes its 256 records (48 KB, contiguous in the
+// workspace) with coalesced stores.  Writing the 192-B records straight from the building threads is a 192-B-strided
 // scatter: the PMC pass of round 1 showed 2x the algorithmic write traffic for it (profiles/r01i_pmc.txt).
 constexpr int SETUP_STRIDE = REC + 1;      // odd LDS stride: the building threads' stores spread over the banks
 __global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__ faces, float* __restrict__ recs,
