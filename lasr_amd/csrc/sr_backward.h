@@ -44,11 +44,12 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     const int IS = A.IS, P = IS * IS;
     const cptr_t rec = as_const(A.recs + (size_t)gw * REC);
     const cptr_t tex = as_const(A.textures + (size_t)gw * A.T * NCH);
-    const short4 rc4 = A.rects[gw];
     const int flags = __float_as_int(rec[R_FLAGS]);
 
-    // exact pixel rectangle of the bbox test (columns x0..x1, rows r0..r1 from the top); empty when x0 > x1
-    const int x0 = rc4.x, x1 = rc4.y, r0 = rc4.z, r1 = rc4.w;
+    // exact pixel rectangle of the bbox test (columns x0..x1, rows r0..r1 from the top); empty when x0 > x1.  Read from the
+    // record's first cache line (the flags sit there too) rather than from the separate rect array the forward's binning scans
+    const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
+    const int x0 = (int)(short)(rx & 0xffff), x1 = rx >> 16, r0 = (int)(short)(ry & 0xffff), r1 = ry >> 16;
     const int bw = x1 - x0 + 1, bh = r1 - r0 + 1;
     const bool empty = !(bw > 0 && bh > 0);
     const int npx = empty ? 0 : bw * bh;
