@@ -303,6 +303,34 @@ def test_nine_channel_pass_equals_three_three_channel_renders(oracle, cuda):
         srf.soft_rasterize(tfv, t9, IS, **dict(kw, aggr_func_rgb='hard'))
 
 
+def test_nine_channel_pass_vs_oracle_at_lasr_size(oracle, cuda):
+    # the render LASR.forward issues (spot3 stage-0 sized mesh, 256x256, nine attributes) straight against the oracle: each
+    # attribute triple is an oracle render of its own; the face gradient is the sum of the three oracle gradients
+    fv, ft, near, far = synth.raster_batch(8, 3, count=2)
+    rng = np.random.default_rng(21)
+    tex = [ft, rng.uniform(-1, 3, ft.shape).astype(np.float32), rng.uniform(-1, 3, ft.shape).astype(np.float32)]
+    bgs = ([1., 1., 1.], [0., 0., 0.], [0., 0., 0.])
+    IS = 256
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    g = np.concatenate([synth.upstream_grad(2, IS, 5)[:, :3], synth.upstream_grad(2, IS, 6)[:, :3], synth.upstream_grad(2, IS, 7)], 1)
+    tfv = torch.from_numpy(fv).to(cuda).requires_grad_(True)
+    t9 = torch.from_numpy(np.concatenate(tex, -1)).to(cuda).requires_grad_(True)
+    img = srf.soft_rasterize(tfv, t9, IS, **dict(kw, background_color=bgs[0] + bgs[1] + bgs[2]))
+    img.backward(torch.from_numpy(g).to(cuda))
+    out, gf_ref = img.detach().cpu().numpy(), 0
+    for k in range(3):
+        okw = dict(kw, background_color=bgs[k])
+        ref = oracle.forward(fv, tex[k], IS, **okw)
+        assert np.abs(out[:, 3 * k:3 * k + 3] - ref['soft_colors'][:, :3]).max() <= IMG_TOL
+        assert np.abs(out[:, 9] - ref['soft_colors'][:, 3]).max() <= IMG_TOL
+        gk = np.concatenate([g[:, 3 * k:3 * k + 3], g[:, 9:10] if k == 0 else np.zeros_like(g[:, 9:10])], 1)
+        gf_k, gt_k = oracle.backward(ref, gk, IS, **okw)
+        gf_ref = gf_ref + gf_k
+        gt9 = t9.grad.cpu().numpy()[..., 3 * k:3 * k + 3]
+        assert np.abs(gt9 - gt_k).max() <= GRAD_REL * np.abs(gt_k).max(), 'attribute gradient of triple %d' % k
+    assert np.abs(tfv.grad.cpu().numpy() - gf_ref).max() <= GRAD_REL * np.abs(gf_ref).max()
+
+
 def test_integration_stub_binds_like_the_reference_extension(oracle, cuda):
     # INTEGRATION.md "Option B": the ctypes module a reference maintainer would drop in for
     # soft_renderer.cuda.soft_rasterize -- same two entry points, same argument order as the pybind functions
