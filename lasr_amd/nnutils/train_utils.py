@@ -340,7 +340,7 @@ class LASRTrainer:
                 rows.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
                              st['step'].data_ptr(), p.numel(), gi, clip))
                 key.append(st['step'])
-        if not rows or len(opt.param_groups) > 16:
+        if not rows or len(opt.param_groups) > _lib.TAIL_MAX_GROUPS:
             return None
         cached = getattr(self, '_tail_cache', None)
         if cached is not None and cached['rows'] == rows:

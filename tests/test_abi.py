@@ -98,3 +98,20 @@ def test_fused_operator_argument_validation():
     assert h.lasr_cosdist_forward(None, None, None, None, 2, 8, 16, 0, None) == -1                        # rep must be >= 1
     assert h.lasr_cosdist_scratch_floats(4, 1000) >= 16
     assert h.lasr_sr_set_forward_math(0) == 0 and h.lasr_sr_set_forward_math(7) == -2
+
+
+def test_header_constants_match_the_python_mirror():
+    import re
+    from lasr_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ops = open(os.path.join(root, 'include', 'lasr_ops.h')).read()
+    sr = open(os.path.join(root, 'include', 'lasr_sr.h')).read()
+
+    def define(text, name):
+        m = re.search(r'#define\s+%s\s+\(?(-?\d+)\)?' % name, text)
+        assert m, name
+        return int(m.group(1))
+    assert define(ops, 'LASR_MEANS_MAX_TERMS') == _lib.MEANS_MAX_TERMS
+    assert define(ops, 'LASR_TAIL_MAX_GROUPS') == _lib.TAIL_MAX_GROUPS
+    assert define(sr, 'LASR_SR_RELAXED_MATH') == _lib.SR_RELAXED_MATH
+    assert define(sr, 'LASR_SR_RECORDS_VALID') == _lib.SR_RECORDS_VALID
