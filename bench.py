@@ -11,8 +11,8 @@ the "~1.2k vert / 2.3k face" mesh), 256x256, LASR's raster modes (euclidean / so
 prod / vertex colours, sigma 1e-4, gamma 1e-2), B=256 synthetic yaw-rotated frames per GPU per
 step, upstream gradient N(0,1)/P.  Inputs are resident in HBM before the timed region.
 
-One step = for the rank's B frames: fill soft_colors with the background, zero the gradient
-buffers, forward (face setup + raster kernel), backward (raster kernel; it reuses the forward's face records) through the C ABI,
+One step = for the rank's B frames: fill soft_colors with the background, forward (face setup + raster kernel), backward
+(face setup + raster kernel; it stores every gradient element, so the buffers need no zero fill) through the C ABI,
 scatter-add the face gradients to per-vertex mesh gradients; for N > 1 the [2,V,3] mesh
 gradient is then all-reduced over RCCL (frames are sharded data-parallel, weak scaling).
 Nothing inside the timed region touches the CPU oracle.
@@ -89,8 +89,7 @@ class RasterStep:
     def step(self):
         B, F, h = self.B, self.F, self.h
         self.colors.fill_(1.0)                       # background (1,1,1), alpha slot 1 (soft_rasterize.py:50-53)
-        self.gf.zero_()
-        self.gt.zero_()
+        # (the gradient buffers are not zeroed: LASR_SR_GRADS_OVERWRITE -- every element is stored by the wave that owns its face)
         near, far, tail = self.scalars[0], self.scalars[1], self.scalars[2:]
         rc = h.lasr_sr_forward_ex(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
                                   self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
@@ -100,7 +99,7 @@ class RasterStep:
         rc = h.lasr_sr_backward_ex(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), self.aggrs.data_ptr(),
                                    self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(), self.ws.data_ptr(),
                                    self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail,
-                                   0 if REBUILD_RECORDS else _lib.SR_RECORDS_VALID, self.stream)
+                                   _lib.SR_GRADS_OVERWRITE | (0 if REBUILD_RECORDS else _lib.SR_RECORDS_VALID), self.stream)
         _lib.check(rc, 'lasr_sr_backward_ex')
         # face -> vertex gradient scatter (autograd of face_vertices.py:4-22), summed over the rank's frames
         self.mesh_grad.zero_()

@@ -132,10 +132,14 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
  *                  pass of the SAME faces / N / F / IS / sigma_val / dist_eps left there (nothing else was run on that
  *                  workspace in between); the backward then skips its own setup launch.  Without the flag every backward
  *                  call rebuilds the records, so the plain entry points stay safe for callers that share one workspace.
+ *                  LASR_SR_GRADS_OVERWRITE -- vertex textures only: every element of grad_faces / grad_textures is written (each
+ *                  face is owned by one wavefront), so the caller may pass uninitialised buffers instead of zeroed ones (the
+ *                  reference accumulates with atomics into zeroed tensors, soft_rasterize.py:88-89); ignored for surface textures.
  */
 #define LASR_SR_DEFAULT_FLAGS (-1)   /* forward only: use the process-wide default of lasr_sr_set_forward_math */
 #define LASR_SR_RELAXED_MATH  1
 #define LASR_SR_RECORDS_VALID 4
+#define LASR_SR_GRADS_OVERWRITE 8   /* backward, vertex textures: grad_faces / grad_textures need not be zeroed by the caller */
 int lasr_sr_forward_ex(const float* faces, const float* textures, float* faces_info, float* aggrs_info, float* soft_colors,
                        void* workspace, size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near,
                        float far, const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,

@@ -242,10 +242,13 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
             for (int i = 0; i < 5; i++) {
                 if (i == 4 && (lane_row & 1)) continue;                          // register 4 only carries v[16], v[17]
                 const int comp = i == 4 ? 16 + (lane_row >> 1) : 4 * i + sub;
+                // this wave owns the face: a plain read-modify-write, or a plain store when the caller did not zero the buffers
+                // (LASR_SR_GRADS_OVERWRITE; vertex attributes only -- surface texels are credited with atomics above)
+                const bool ow = A.overwrite_grads && vertex_tex;
                 if (pass == 0) {
-                    if (comp < 9) gf[comp] += red[i];
-                    else if (vertex_tex) gtp[comp - 9] += red[i];
-                } else if ((comp < 9 || NCH == 9) && vertex_tex) gtp[9 + comp] += red[i];
+                    if (comp < 9) gf[comp] = ow ? red[i] : gf[comp] + red[i];
+                    else if (vertex_tex) gtp[comp - 9] = ow ? red[i] : gtp[comp - 9] + red[i];
+                } else if ((comp < 9 || NCH == 9) && vertex_tex) gtp[9 + comp] = ow ? red[i] : gtp[9 + comp] + red[i];
             }
         }
     }

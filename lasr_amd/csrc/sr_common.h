@@ -14,6 +14,7 @@ struct RasterArgs {
     float near, far, eps, sigma, gamma, thr;
     const float* __restrict__ near_far_dev;   // optional: {near, far} read on the device (no host sync)
     Modes m;
+    int overwrite_grads;                      // backward, vertex attributes: store the face's gradients instead of adding to them
 };
 
 // Block -> (image, tile) with all tiles of an image kept on one XCD (block b runs

@@ -364,6 +364,7 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     A.near = near; A.far = far; A.near_far_dev = nullptr; A.eps = eps; A.sigma = sigma; A.gamma = gamma;
     A.thr = dist_eps * sigma;                                              // K.cu:352 (float product)
     A.m = Modes{dist, rgb, alpha, tex, double_side ? 1 : 0};
+    A.overwrite_grads = 0;
     return A;
 }
 
@@ -435,6 +436,7 @@ static int backward_impl(const float* faces, const float* textures, const float*
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
                              gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
     A.near_far_dev = near_far_dev;
+    A.overwrite_grads = (flags & LASR_SR_GRADS_OVERWRITE) && texture_sample_type == 1;
     const int total = N * F;
     if (!(flags & LASR_SR_RECORDS_VALID)) {      // the caller vouches that the forward's records are still in the workspace
         {
@@ -575,7 +577,7 @@ extern "C" int lasr_sr_backward_ex(const float* faces, const float* textures, co
                                    int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side, int flags,
                                    void* hip_stream)
 {
-    if (flags & ~LASR_SR_RECORDS_VALID) return LASR_E_BADARG;
+    if (flags & ~(LASR_SR_RECORDS_VALID | LASR_SR_GRADS_OVERWRITE)) return LASR_E_BADARG;
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
     if (rc) return rc;
     return backward_impl(faces, textures, soft_colors, nullptr, aggrs_info, grad_faces, grad_textures, grad_soft_colors,

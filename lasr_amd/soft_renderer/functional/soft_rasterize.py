@@ -134,8 +134,13 @@ class SoftRasterizeFunction(Function):
         N, F, T, IS = ctx.geom
         C, nf, tail = ctx.C, ctx.nf, ctx.tail
         dev = fv.device
-        grads = torch.zeros(N * F * 9 + tx.numel(), dtype=torch.float32, device=dev)        # one fill for both
+        # vertex attributes: every gradient element is stored by the wavefront that owns its face (LASR_SR_GRADS_OVERWRITE), no
+        # zero fill needed; surface texels are credited with atomics and need zeroed buffers like the reference's (:88-89)
+        vertex = tail[7] == _TEX['vertex']
+        grads = (torch.empty if vertex else torch.zeros)(N * F * 9 + tx.numel(), dtype=torch.float32, device=dev)
         grad_faces, grad_textures = grads[:N * F * 9].view(N, F, 9), grads[N * F * 9:].view(tx.shape)
+        if vertex and (N == 0 or F == 0 or IS == 0):
+            grads.zero_()                                                   # nothing is launched for an empty problem
         g = grad_soft_colors.contiguous().float()
         h = _lib.lib()
         with torch.cuda.device(dev):
@@ -144,7 +149,8 @@ class SoftRasterizeFunction(Function):
             rc = h.lasr_sr_backward_ex(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), aggrs_info.data_ptr(),
                                        grad_faces.data_ptr(), grad_textures.data_ptr(), g.data_ptr(), ws.data_ptr(),
                                        ws.numel(), N, F, T, C, IS, *ctx.near_far,
-                                       nf.data_ptr() if nf is not None else None, *tail, 0, stream)
+                                       nf.data_ptr() if nf is not None else None, *tail,
+                                       _lib.SR_GRADS_OVERWRITE if vertex else 0, stream)
         _lib.check(rc, 'lasr_sr_backward')
         fshape, tshape = ctx.in_shapes
         return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),

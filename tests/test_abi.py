@@ -65,6 +65,7 @@ def test_ex_entry_points_validate_flags_and_channels_on_the_host():
     bwd = lambda flags: h.lasr_sr_backward_ex(None, None, None, None, None, None, None, None, 0, 0, 1, 3, 3, 8, 1., 2., None,
                                               *tail, flags, None)
     assert bwd(0) == 0 and bwd(_lib.SR_RECORDS_VALID) == 0 and bwd(_lib.SR_RELAXED_MATH) == -1
+    assert bwd(_lib.SR_GRADS_OVERWRITE) == 0 and bwd(_lib.SR_GRADS_OVERWRITE | _lib.SR_RECORDS_VALID) == 0 and bwd(16) == -1
     assert h.lasr_load_textures(None, None, None, None, 0, 5, 4, 4, None) == 0                                 # no faces
     assert h.lasr_load_textures(None, None, None, None, 3, 5, 4, 4, None) == -1 and h.lasr_load_textures(None, None, None, None, 3, 0, 4, 4, None) == -1
 
@@ -115,3 +116,4 @@ def test_header_constants_match_the_python_mirror():
     assert define(ops, 'LASR_TAIL_MAX_GROUPS') == _lib.TAIL_MAX_GROUPS
     assert define(sr, 'LASR_SR_RELAXED_MATH') == _lib.SR_RELAXED_MATH
     assert define(sr, 'LASR_SR_RECORDS_VALID') == _lib.SR_RECORDS_VALID
+    assert define(sr, 'LASR_SR_GRADS_OVERWRITE') == _lib.SR_GRADS_OVERWRITE

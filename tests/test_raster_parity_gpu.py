@@ -441,3 +441,38 @@ def test_backward_on_the_forwards_records_equals_a_rebuild(cuda):
         out.append((gf.cpu().numpy(), gt.cpu().numpy()))
     assert np.abs(out[0][0]).max() > 0
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('channels', [3, 6, 9])
+def test_backward_may_overwrite_uninitialised_gradient_buffers(cuda, channels):
+    # LASR_SR_GRADS_OVERWRITE (vertex textures): every gradient element is stored by the wavefront that owns its face, so the
+    # caller need not zero the buffers -- same bits as accumulating into zeros, including faces that receive no gradient at all
+    from lasr_amd import _lib
+    import math
+    h = _lib.lib()
+    fv, ft, near, far = synth.raster_batch(8, 5, count=3)
+    fv[1, :40] += 50.                                       # a block of faces far outside the view: empty rects, zero gradient
+    N, F, IS, C = fv.shape[0], fv.shape[1], 96, channels
+    rng = np.random.default_rng(C)
+    attrs = rng.uniform(0, 1, (N, F, 3, C)).astype(np.float32)
+    m = synth.LASR_MODES
+    tail = (float(m['eps']), float(m['sigma_val']), 2, float(math.log(1. / m['dist_eps'] - 1.)), float(m['gamma_val']), 1, 2, 1, 1)
+    tfv = torch.from_numpy(fv).to(cuda).reshape(N, F, 9).contiguous()
+    tft = torch.from_numpy(attrs).to(cuda).contiguous()
+    g = torch.from_numpy(rng.standard_normal((N, C + 1, IS, IS)).astype(np.float32) / (IS * IS)).to(cuda)
+    colors = torch.ones(N, C + 1, IS, IS, device=cuda)
+    aggrs = torch.empty(N, 2, IS, IS, device=cuda)
+    ws = torch.empty(h.lasr_sr_workspace_bytes(N, F, 3, IS), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(h.lasr_sr_forward_ex(tfv.data_ptr(), tft.data_ptr(), None, aggrs.data_ptr(), colors.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), N, F, 3, C, IS, float(near), float(far), None, *tail, 0, st), 'forward_ex')
+    out = []
+    for flags, init in ((0, 0.0), (_lib.SR_GRADS_OVERWRITE, float('nan'))):
+        gf = torch.full((N, F, 9), init, device=cuda)
+        gt = torch.full((N, F, 3, C), init, device=cuda)
+        _lib.check(h.lasr_sr_backward_ex(tfv.data_ptr(), tft.data_ptr(), colors.data_ptr(), aggrs.data_ptr(), gf.data_ptr(),
+                                         gt.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), N, F, 3, C, IS, float(near),
+                                         float(far), None, *tail, flags, st), 'backward_ex')
+        out.append((gf.cpu().numpy(), gt.cpu().numpy()))
+    assert np.abs(out[0][0]).max() > 0 and not out[0][0][1, :40].any()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
