@@ -345,6 +345,15 @@ int lasr_tail_step(const void* table, const int* chunks, int n_chunks, float* pa
                    const float* weight_decay, const double* bias_correction1, const double* bias_correction2, int n_groups,
                    void* hip_stream);
 
+/*
+ * Plumbing around the raster calls.
+ * lasr_fill_planes: dst [N, n_values, plane_elems], plane c of every image := values[c] (host array) -- the background fill the
+ *   reference does before its forward kernel (third_party/softras/soft_renderer/functional/soft_rasterize.py:50-53: colour planes =
+ *   background, alpha plane = 1).
+ */
+#define LASR_FILL_MAX_PLANES 16
+int lasr_fill_planes(float* dst, const float* values, int n_values, int N, long long plane_elems, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

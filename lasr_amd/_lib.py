@@ -70,6 +70,7 @@ SIGNATURES = {
     'lasr_bone_fixup_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_fill_planes': (_i, [_p, _p, _i, _i, ctypes.c_longlong, _p]),
     'lasr_tail_chunk_elems': (_i, []),
     'lasr_tail_step': (_i, [_p, _p, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'lasr_obs_pair': (_i, [_p, _p, _p, _i, _i, _p]),

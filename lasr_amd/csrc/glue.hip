@@ -366,6 +366,26 @@ __global__ __launch_bounds__(256) void obs_pair_kernel(const float* __restrict__
     out[total + i] = 1.f - fg + obs;
 }
 
+// ---- plumbing around the raster calls -------------------------------------------------------------------------------------------
+// Background fill: dst [N, C, P], plane c of every image = values[c] (soft_rasterize.py:50-53 fills soft_colors with the background
+// colour and alpha slot 1 before the forward kernel); 16-B stores, one workgroup per 4096 floats of a plane.
+struct PlaneValues { float v[LASR_FILL_MAX_PLANES]; };
+__global__ __launch_bounds__(256) void fill_planes_kernel(float* __restrict__ dst, PlaneValues V, int C, long long P)
+{
+    const long long plane = blockIdx.y;                      // n * C + c
+    const float val = V.v[plane % C];
+    float* __restrict__ d = dst + plane * P;
+    const long long base = (long long)blockIdx.x * 4096;     // this workgroup's 4096 floats: 4 rounds of 256 lanes x 16 B
+    if (base + 4096 <= P && (((size_t)(d + base)) & 15) == 0) {
+        const float4 q = make_float4(val, val, val, val);
+        float4* o = (float4*)(d + base);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j * 256 + threadIdx.x] = q;          // consecutive lanes, consecutive 16 B: coalesced
+    } else {
+        for (long long i = base + threadIdx.x; i < base + 4096 && i < P; i += 256) d[i] = val;
+    }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -534,5 +554,18 @@ extern "C" int lasr_obs_pair(const float* imgs, const float* masks, float* out, 
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t total = (size_t)n * 3 * P;
     LASR_LAUNCH(K_OBS_PAIR, obs_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, imgs, masks, out, n, P);
+    return launch_ok();
+}
+
+extern "C" int lasr_fill_planes(float* dst, const float* values, int n_values, int N, long long plane_elems, void* hip_stream)
+{
+    if (N < 0 || plane_elems < 0 || n_values < 1 || n_values > LASR_FILL_MAX_PLANES) return LASR_E_BADARG;
+    if (N == 0 || plane_elems == 0) return LASR_OK;
+    if (!dst || !values) return LASR_E_BADARG;
+    PlaneValues V;
+    for (int k = 0; k < n_values; k++) V.v[k] = values[k];
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_FILL_PLANES, fill_planes_kernel, dim3((unsigned)((plane_elems + 4095) / 4096), (unsigned)(N * n_values)), dim3(256),
+                0, dst, V, n_values, plane_elems);
     return launch_ok();
 }

@@ -567,3 +567,21 @@ def obs_pair(imgs, masks):
         rc = _lib.lib().lasr_obs_pair(imgs.data_ptr(), masks.data_ptr(), out.data_ptr(), n, P, st)
     _lib.check(rc, 'lasr_obs_pair')
     return out
+
+
+# ---- plumbing around the raster calls ------------------------------------------------------------------------------------------
+def fill_planes(dst, values):
+    """dst [N, C, ...] (contiguous fp32, on the GPU): channel plane c of every image := values[c], in place -- the background fill
+    in front of the forward raster kernel (/root/reference/third_party/softras/soft_renderer/functional/soft_rasterize.py:50-53)."""
+    import ctypes
+    _lib.need_cuda(dst)
+    C = dst.shape[1]
+    if len(values) != C or dst.dtype != torch.float32 or not dst.is_contiguous():
+        raise ValueError('fill_planes: dst must be contiguous fp32 [N, %d, ...]' % len(values))
+    N = dst.shape[0]
+    P = dst[0, 0].numel() if N else 0
+    guard, st = _lib.stream_of(dst)
+    with guard:
+        rc = _lib.lib().lasr_fill_planes(dst.data_ptr(), (ctypes.c_float * C)(*[float(v) for v in values]), C, N, P, st)
+    _lib.check(rc, 'lasr_fill_planes')
+    return dst

@@ -6,6 +6,7 @@ Mirror of the reference operator
 tensors) with the native call going through the C ABI of include/lasr_sr.h
 instead of the `soft_renderer.cuda.soft_rasterize` pybind module.
 """
+import ctypes
 import math
 
 import torch
@@ -107,10 +108,12 @@ class SoftRasterizeFunction(Function):
         # background per channel: 3 values repeat for every attribute triple, or one value per channel; alpha plane starts at 1
         nb = len(background_color)
         bg = [float(background_color[k if nb == C else k % 3]) for k in range(C)] + [1.0]
-        if all(v == bg[0] for v in bg):
-            soft_colors = torch.full((N, C + 1, IS, IS), bg[0], dtype=torch.float32, device=dev)
-        else:
-            soft_colors = const_tensor(bg, dev).view(1, C + 1, 1, 1).repeat(N, 1, IS, IS)
+        soft_colors = torch.empty(N, C + 1, IS, IS, dtype=torch.float32, device=dev)
+        if soft_colors.numel():
+            with torch.cuda.device(dev):                                        # one launch, per-plane values (lasr_fill_planes)
+                rc = _lib.lib().lasr_fill_planes(soft_colors.data_ptr(), (ctypes.c_float * (C + 1))(*bg), C + 1, N, IS * IS,
+                                                 torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(rc, 'lasr_fill_planes')
 
         h = _lib.lib()
         # One scratch buffer per (device, stream) serves every call: the backward rebuilds the per-face records (29 us for

@@ -592,3 +592,13 @@ def test_obs_pair_kernel(cuda):
     fg = (masks > 0).float()[:, None]
     out = fused_ops.obs_pair(imgs.to(cuda), masks.to(cuda)).cpu()
     assert torch.equal(out[:3], imgs * fg) and torch.equal(out[3:], 1 - fg + imgs * fg)
+
+
+def test_fill_planes(cuda):
+    from lasr_amd.nnutils import fused_ops
+    for shape, vals in (((3, 4, 16, 16), (1., 1., 1., 1.)), ((2, 10, 7, 5), tuple(float(k) / 4 for k in range(10))), ((1, 2, 1, 1), (3., -2.)),
+                        ((2, 4, 256, 256), (0.25, 0.5, 0.75, 1.))):
+        t = torch.full(shape, float('nan'), device=cuda)
+        fused_ops.fill_planes(t, vals)
+        want = torch.tensor(vals).view(1, -1, 1, 1).expand(shape)
+        assert torch.equal(t.cpu(), want)
