@@ -11,8 +11,8 @@ the "~1.2k vert / 2.3k face" mesh), 256x256, LASR's raster modes (euclidean / so
 prod / vertex colours, sigma 1e-4, gamma 1e-2), B=256 synthetic yaw-rotated frames per GPU per
 step, upstream gradient N(0,1)/P.  Inputs are resident in HBM before the timed region.
 
-One step = for the rank's B frames: fill soft_colors with the background, forward (face setup + raster kernel), backward
-(face setup + raster kernel; it stores every gradient element, so the buffers need no zero fill) through the C ABI,
+One step = for the rank's B frames: forward (face setup + raster kernel; the background colour is an argument, every element of
+soft_colors is written), backward (face setup + raster kernel; it stores every gradient element) through the C ABI,
 scatter-add the face gradients to per-vertex mesh gradients; for N > 1 the [2,V,3] mesh
 gradient is then all-reduced over RCCL (frames are sharded data-parallel, weak scaling).
 Nothing inside the timed region touches the CPU oracle.
@@ -85,16 +85,18 @@ class RasterStep:
         self.scalars = (float(self.near), float(self.far), float(m['eps']), float(m['sigma_val']), 2,
                         float(math.log(1. / m['dist_eps'] - 1.)), float(m['gamma_val']), 1, 2, 1, 1)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
+        self.white = (ctypes.c_float * 3)(1., 1., 1.)
 
     def step(self):
         B, F, h = self.B, self.F, self.h
-        self.colors.fill_(1.0)                       # background (1,1,1), alpha slot 1 (soft_rasterize.py:50-53)
-        # (the gradient buffers are not zeroed: LASR_SR_GRADS_OVERWRITE -- every element is stored by the wave that owns its face)
+        # No background fill and no gradient zeroing passes: the background colour (1,1,1) is an argument of lasr_sr_forward_bg,
+        # which writes every element of soft_colors (the reference pre-fills and re-reads it, soft_rasterize.py:50-53), and the
+        # backward stores every gradient element (LASR_SR_GRADS_OVERWRITE).
         near, far, tail = self.scalars[0], self.scalars[1], self.scalars[2:]
-        rc = h.lasr_sr_forward_ex(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
+        rc = h.lasr_sr_forward_bg(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
                                   self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                                  B, F, 3, 3, IS, near, far, None, *tail, _lib.SR_DEFAULT_FLAGS, self.stream)
-        _lib.check(rc, 'lasr_sr_forward_ex')
+                                  B, F, 3, 3, IS, near, far, None, *tail, self.white, _lib.SR_DEFAULT_FLAGS, self.stream)
+        _lib.check(rc, 'lasr_sr_forward_bg')
         # the backward finds the forward's per-face records still in the workspace (what the autograd operator does)
         rc = h.lasr_sr_backward_ex(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), self.aggrs.data_ptr(),
                                    self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(), self.ws.data_ptr(),

@@ -145,6 +145,14 @@ int lasr_sr_forward_ex(const float* faces, const float* textures, float* faces_i
                        float far, const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,
                        float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
                        int flags, void* hip_stream);
+/* lasr_sr_forward_ex with the background colour as an argument (`background`: HOST array of `channels` floats): soft_colors
+ * need not be pre-filled -- every element is written, colour planes and alpha -- which saves the caller's fill pass
+ * (soft_rasterize.py:50-53) and the kernel's read of it. */
+int lasr_sr_forward_bg(const float* faces, const float* textures, float* faces_info, float* aggrs_info, float* soft_colors,
+                       void* workspace, size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near,
+                       float far, const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                       float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                       const float* background, int flags, void* hip_stream);
 int lasr_sr_backward_ex(const float* faces, const float* textures, const float* soft_colors, const float* aggrs_info,
                         float* grad_faces, float* grad_textures, const float* grad_soft_colors, void* workspace,
                         size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near, float far,

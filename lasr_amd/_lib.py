@@ -81,6 +81,7 @@ SIGNATURES = {
     'lasr_sr_forward_attr': (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),
     'lasr_sr_backward_attr': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_ex': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
+    'lasr_sr_forward_bg': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p, _i, _p]),
     'lasr_sr_backward_ex': (_i, [_p] * 8 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
     'lasr_sr_set_forward_math': (_i, [_i]),
     'lasr_selftest_div': (_i, [_p, _p, _p, _i, _p]),

@@ -15,6 +15,8 @@ struct RasterArgs {
     const float* __restrict__ near_far_dev;   // optional: {near, far} read on the device (no host sync)
     Modes m;
     int overwrite_grads;                      // backward, vertex attributes: store the face's gradients instead of adding to them
+    int use_bg;                               // forward: the background colour comes from bg[] instead of the pre-filled soft_colors
+    float bg[9];
 };
 
 // Block -> (image, tile) with all tiles of an image kept on one XCD (block b runs

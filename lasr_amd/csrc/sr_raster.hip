@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     else { s.ssum = expf(A.eps / A.gamma); s.smax = A.eps; }
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
-        const float bg = valid ? colors[((size_t)bn * (NCH + 1) + k) * P + pn] : 1.f;
+        // the reference's caller pre-fills soft_colors with the background (soft_rasterize.py:50-53) and the kernel reads it back;
+        // lasr_sr_forward_bg passes the colour itself, which saves the fill and this read
+        const float bg = A.use_bg ? A.bg[k] : (valid ? colors[((size_t)bn * (NCH + 1) + k) * P + pn] : 1.f);
         s.c[k] = m.rgb == 0 ? bg : bg * s.ssum;
     }
 
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     else a_out = (float)(1. - (double)s.a);
     colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = a_out;
     if (m.rgb == 0) {
-        if (s.fbest != -1) {
+        if (s.fbest != -1 || A.use_bg) {             // no face: the pre-filled background stays -- or is written now
 #pragma unroll
             for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k];
         }
@@ -365,6 +367,7 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     A.thr = dist_eps * sigma;                                              // K.cu:352 (float product)
     A.m = Modes{dist, rgb, alpha, tex, double_side ? 1 : 0};
     A.overwrite_grads = 0;
+    A.use_bg = 0;
     return A;
 }
 
@@ -379,7 +382,8 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                         float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
                         float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps,
                         float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
-                        int double_side, void* hip_stream, int nch, const float* near_far_dev, int flags)
+                        int double_side, void* hip_stream, int nch, const float* near_far_dev, int flags,
+                        const float* background = nullptr)
 {
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
     if (rc) return rc;
@@ -391,6 +395,10 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
                              gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
     A.near_far_dev = near_far_dev;
+    if (background) {
+        A.use_bg = 1;
+        for (int k = 0; k < nch; k++) A.bg[k] = background[k];
+    }
     const int total = N * F;
     if (total > 0) {
         {
@@ -567,6 +575,23 @@ extern "C" int lasr_sr_forward_ex(const float* faces, const float* textures, flo
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
                         far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
                         texture_sample_type, double_side, hip_stream, channels, near_far_dev, flags);
+}
+
+extern "C" int lasr_sr_forward_bg(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
+                                  float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T,
+                                  int channels, int IS, float near, float far, const float* near_far_dev, float eps,
+                                  float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                                  int func_id_alpha, int texture_sample_type, int double_side, const float* background, int flags,
+                                  void* hip_stream)
+{
+    if (!background) return LASR_E_BADARG;
+    if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
+    if (flags & ~LASR_SR_RELAXED_MATH) return LASR_E_BADARG;
+    const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
+    if (rc) return rc;
+    return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
+                        far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                        texture_sample_type, double_side, hip_stream, channels, near_far_dev, flags, background);
 }
 
 extern "C" int lasr_sr_backward_ex(const float* faces, const float* textures, const float* soft_colors,

@@ -108,12 +108,8 @@ class SoftRasterizeFunction(Function):
         # background per channel: 3 values repeat for every attribute triple, or one value per channel; alpha plane starts at 1
         nb = len(background_color)
         bg = [float(background_color[k if nb == C else k % 3]) for k in range(C)] + [1.0]
+        # no pre-fill: lasr_sr_forward_bg takes the background as an argument and writes every element of soft_colors
         soft_colors = torch.empty(N, C + 1, IS, IS, dtype=torch.float32, device=dev)
-        if soft_colors.numel():
-            with torch.cuda.device(dev):                                        # one launch, per-plane values (lasr_fill_planes)
-                rc = _lib.lib().lasr_fill_planes(soft_colors.data_ptr(), (ctypes.c_float * (C + 1))(*bg), C + 1, N, IS * IS,
-                                                 torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(rc, 'lasr_fill_planes')
 
         h = _lib.lib()
         # One scratch buffer per (device, stream) serves every call: the backward rebuilds the per-face records (29 us for
@@ -123,9 +119,10 @@ class SoftRasterizeFunction(Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
-            rc = h.lasr_sr_forward_ex(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(), soft_colors.data_ptr(),
+            rc = h.lasr_sr_forward_bg(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(), soft_colors.data_ptr(),
                                       ws.data_ptr(), ws.numel(), N, F, T, C, IS, *ctx.near_far,
-                                      nf.data_ptr() if nf is not None else None, *tail, forward_flags(), stream)
+                                      nf.data_ptr() if nf is not None else None, *tail, (ctypes.c_float * C)(*bg[:C]),
+                                      forward_flags(), stream)
         _lib.check(rc, 'lasr_sr_forward')
         ctx.save_for_backward(fv, tx, soft_colors, aggrs_info)
         ctx.mark_non_differentiable(aggrs_info)

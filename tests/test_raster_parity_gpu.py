@@ -476,3 +476,34 @@ def test_backward_may_overwrite_uninitialised_gradient_buffers(cuda, channels):
         out.append((gf.cpu().numpy(), gt.cpu().numpy()))
     assert np.abs(out[0][0]).max() > 0 and not out[0][0][1, :40].any()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('rgb,alpha,channels', [(1, 2, 3), (1, 2, 9), (0, 2, 3), (0, 0, 3), (1, 1, 3)])
+def test_forward_with_the_background_as_an_argument(cuda, rgb, alpha, channels):
+    # lasr_sr_forward_bg: same image and aggregates as the pre-fill + lasr_sr_forward_ex sequence of the reference's caller, written
+    # into an UNINITIALISED soft_colors buffer (also where no face lands: hard mode leaves the pre-filled background there)
+    from lasr_amd import _lib
+    import ctypes
+    import math
+    h = _lib.lib()
+    fv, ft, near, far = synth.raster_batch(6, 4, count=2)
+    N, F, IS, C = fv.shape[0], fv.shape[1], 80, channels
+    rng = np.random.default_rng(C + rgb)
+    attrs = rng.uniform(0, 1, (N, F, 3, C)).astype(np.float32)
+    bg = [0.3, 0.6, 0.9, 0., 0.25, 1., 0.5, 0.7, 0.1][:C]
+    m = synth.LASR_MODES
+    tail = (float(m['eps']), float(m['sigma_val']), 2, float(math.log(1. / m['dist_eps'] - 1.)), float(m['gamma_val']), rgb, alpha, 1, 1)
+    tfv = torch.from_numpy(fv).to(cuda).reshape(N, F, 9).contiguous()
+    tft = torch.from_numpy(attrs).to(cuda).contiguous()
+    ws = torch.empty(h.lasr_sr_workspace_bytes(N, F, 3, IS), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    ref_c = torch.tensor(bg + [1.0], device=cuda).view(1, C + 1, 1, 1).repeat(N, 1, IS, IS).contiguous()
+    ref_a = torch.empty(N, 2, IS, IS, device=cuda)
+    _lib.check(h.lasr_sr_forward_ex(tfv.data_ptr(), tft.data_ptr(), None, ref_a.data_ptr(), ref_c.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    N, F, 3, C, IS, float(near), float(far), None, *tail, 0, st), 'forward_ex')
+    out_c = torch.full((N, C + 1, IS, IS), float('nan'), device=cuda)
+    out_a = torch.empty(N, 2, IS, IS, device=cuda)
+    _lib.check(h.lasr_sr_forward_bg(tfv.data_ptr(), tft.data_ptr(), None, out_a.data_ptr(), out_c.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    N, F, 3, C, IS, float(near), float(far), None, *tail, (ctypes.c_float * C)(*bg), 0, st), 'forward_bg')
+    assert torch.equal(out_c, ref_c) and torch.equal(out_a, ref_a)
+    assert float((out_c[:, 0] == out_c[0, 0, 0, 0]).float().mean()) > 0.2          # a good part of the image is background
