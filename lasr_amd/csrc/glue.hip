@@ -372,10 +372,11 @@ __global__ __launch_bounds__(256) void obs_pair_kernel(const float* __restrict__
 struct PlaneValues { float v[LASR_FILL_MAX_PLANES]; };
 __global__ __launch_bounds__(256) void fill_planes_kernel(float* __restrict__ dst, PlaneValues V, int C, long long P)
 {
-    const long long plane = blockIdx.y;                      // n * C + c
+    const long long chunks = (P + 4095) / 4096;
+    const long long plane = blockIdx.x / chunks;             // n * C + c
     const float val = V.v[plane % C];
     float* __restrict__ d = dst + plane * P;
-    const long long base = (long long)blockIdx.x * 4096;     // this workgroup's 4096 floats: 4 rounds of 256 lanes x 16 B
+    const long long base = (blockIdx.x - plane * chunks) * 4096;   // this workgroup's 4096 floats: 4 rounds of 256 lanes x 16 B
     if (base + 4096 <= P && (((size_t)(d + base)) & 15) == 0) {
         const float4 q = make_float4(val, val, val, val);
         float4* o = (float4*)(d + base);
@@ -565,7 +566,8 @@ extern "C" int lasr_fill_planes(float* dst, const float* values, int n_values, i
     PlaneValues V;
     for (int k = 0; k < n_values; k++) V.v[k] = values[k];
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_FILL_PLANES, fill_planes_kernel, dim3((unsigned)((plane_elems + 4095) / 4096), (unsigned)(N * n_values)), dim3(256),
-                0, dst, V, n_values, plane_elems);
+    const long long blocks = ((plane_elems + 4095) / 4096) * (long long)N * n_values;
+    if (blocks > 0x7fffffffLL) return LASR_E_BADARG;
+    LASR_LAUNCH(K_FILL_PLANES, fill_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, dst, V, n_values, plane_elems);
     return launch_ok();
 }
