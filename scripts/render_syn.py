@@ -10,9 +10,11 @@ rendered with the hard rasteriser (lasr_sr_forward: hard distance / hard z-buffe
   .../Camera/.../%05d.txt             focal, tx, ty, quaternion (w, x, y, z), depth
   .../FlowFW|FlowBW/.../flo-%05d.pfm  flow to the next / previous frame in pixels + validity; occ-%05d.pfm = -1
   <root>/configs/<outdir>.config      the [data] section optimize.py --dataname <outdir> reads
-The reference renders spot_triangulated.obj with its surface texture (not available offline); here the default object
+The reference renders database/misc/spot/spot_triangulated.obj with its surface texture (pass it with --obj ... --surface_tex
+where a copy of that model is at hand; it is not shipped here); the default object
 is this repository's blobby geodesic sphere with per-vertex colours, or any .obj given with --obj; --surface_tex textures it
-from an atlas image through 5x5 per-face surface textures (lasr_load_textures) like the reference's textured models.
+through 5x5 per-face surface textures (lasr_load_textures) like the reference's textured models: from the .obj's own material
+atlas when it names one (the reference's spot_triangulated.obj does), else from a procedural atlas.
 """
 import argparse
 import math
@@ -82,8 +84,13 @@ def main(argv=None):
     dev = torch.device('cuda', 0)
     size, dframe, focal, depth = args.img_size, 1, 10.0, 10.0
 
+    obj_textures = None
     if args.obj:
-        v, f = sr.functional.load_obj(args.obj)
+        has_mtl = any(line.startswith('mtllib') for line in open(args.obj))
+        if args.surface_tex and has_mtl:                           # the reference's call (render_syn.py:71): the model's own atlas
+            v, f, obj_textures = sr.functional.load_obj(args.obj, load_texture=True, texture_res=5, texture_type='surface', device=dev)
+        else:
+            v, f = sr.functional.load_obj(args.obj)
         overts, faces = v[None].to(dev).float(), f[None].to(dev)
         colors = torch.ones_like(overts) * 0.7
     else:
@@ -93,7 +100,9 @@ def main(argv=None):
         colors = torch.from_numpy(tex).to(dev)[None].float()
 
     tex_type = 'vertex'
-    if args.surface_tex:
+    if obj_textures is not None:
+        colors, tex_type = obj_textures[None], 'surface'
+    elif args.surface_tex:
         # a procedural atlas (smooth colour field + checker) and spherical uv per face corner stand in for the .mtl image of
         # the reference's models; sampled into [F, 5*5, 3] surface texels by lasr_load_textures (load_textures_cuda_kernel.cu)
         yy, xx = np.mgrid[:128, :128] / 127.0

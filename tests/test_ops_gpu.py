@@ -602,3 +602,34 @@ def test_fill_planes(cuda):
         fused_ops.fill_planes(t, vals)
         want = torch.tensor(vals).view(1, -1, 1, 1).expand(shape)
         assert torch.equal(t.cpu(), want)
+
+
+def test_textured_obj_loads_surface_textures_like_the_reference(tmp_path, cuda):
+    # load_obj.py:28-101: per-face surface texels of a textured .obj = ones, then the material's Kd colour, then its atlas image
+    # (flipped vertically, /255) sampled by the load_textures kernel; rendered afterwards through the surface-texture raster mode
+    from lasr_amd.soft_renderer import functional as srf
+    from lasr_amd import soft_renderer as sr
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_path_oracle import _write_textured_quad
+    path, img = _write_textured_quad(str(tmp_path))
+    R = 5
+    v, f, tex = srf.load_obj(path, load_texture=True, texture_res=R, texture_type='surface', device=cuda)
+    assert v.shape == (5, 3) and f.shape == (4, 3) and tex.shape == (4, R * R, 3) and tex.is_cuda
+    uv, mats, colors, files = srf.obj_io.parse_obj_materials(path)
+    atlas = (img.astype(np.float32) / 255.)[::-1]
+    want = np.ones((4, R * R, 3), np.float32)
+    want[2:] = colors['flat']
+    want[:2] = po.load_textures(atlas, uv, R, np.array([1, 1, 0, 0], np.int32))[:2]
+    np.testing.assert_allclose(tex.cpu().numpy(), want, rtol=0, atol=1e-6)
+    # render the model with its texture: the image shows atlas colours on the quad, background elsewhere
+    r = sr.SoftRenderer(image_size=32, sigma_val=1e-12, camera_mode='look_at', perspective=False, aggr_func_rgb='hard',
+                        dist_func='hard', aggr_func_alpha='hard', light_intensity_ambient=1., light_intensity_directionals=0.,
+                        light_mode='surface')
+    vv = (v - v.mean(0)) * 0.6
+    out = r.render_mesh(sr.Mesh(vv[None], f[None].long(), textures=tex[None], texture_type='surface'))
+    assert out.shape == (1, 4, 32, 32) and torch.isfinite(out).all()
+    covered = out[0, 3] > 0.5
+    assert 0.05 < float(covered.float().mean()) < 0.9
+    lo, hi = float(tex.min()), float(tex.max())
+    assert float(out[0, :3][:, covered].min()) >= lo - 1e-5 and float(out[0, :3][:, covered].max()) <= hi + 1e-5

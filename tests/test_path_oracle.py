@@ -279,3 +279,46 @@ def test_glue_kernels_reject_cpu_tensors():
     for call in calls:
         with pytest.raises(TypeError):                                   # no CPU fallback behind the HIP operators
             call()
+
+
+def _write_textured_quad(d):
+    """A two-triangle quad with uv coordinates, a two-material .mtl (one atlas image, one flat colour) and a 4x4 atlas."""
+    from PIL import Image
+    img = (np.arange(4 * 4 * 3).reshape(4, 4, 3) * 5).astype(np.uint8)
+    Image.fromarray(img).save(os.path.join(d, 'atlas.png'))
+    open(os.path.join(d, 'quad.mtl'), 'w').write('newmtl skin\nKd 0.2 0.4 0.6\nmap_Kd atlas.png\n\nnewmtl flat\nKd 0.9 0.1 0.3\n')
+    open(os.path.join(d, 'quad.obj'), 'w').write(
+        'mtllib quad.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 0 0\n'
+        'vt 0.0 0.0\nvt 1.0 0.0\nvt 1.0 1.0\nvt 0.0 1.0\nvt 1.5 0.25\n'
+        'usemtl skin\nf 1/1 2/2 3/3 4/4\nusemtl flat\nf 2/2 5/5 3/3\nf 1 2 3\n')
+    return os.path.join(d, 'quad.obj'), img
+
+
+def test_obj_material_parsing(tmp_path):
+    # load_obj.py:28-71: fan triangulation of the uv indices, material per triangle, uv > 1 wraps, a corner without a texture index
+    # takes the LAST vt entry (index 0 - 1), Kd colours and atlas paths from the .mtl
+    from lasr_amd.soft_renderer.functional import obj_io
+    path, _ = _write_textured_quad(str(tmp_path))
+    uv, mats, colors, files = obj_io.parse_obj_materials(path)
+    assert uv.shape == (4, 3, 2) and mats == ['skin', 'skin', 'flat', 'flat']
+    np.testing.assert_allclose(uv[0], [[0, 0], [1, 0], [1, 1]])
+    np.testing.assert_allclose(uv[1], [[0, 0], [1, 1], [0, 1]])
+    np.testing.assert_allclose(uv[2], [[1, 0], [0.5, 0.25], [1, 1]])          # 1.5 wraps to 0.5
+    np.testing.assert_allclose(uv[3], [[0.5, 0.25]] * 3)                       # no texture index: the last vt entry (wrapped)
+    assert set(colors) == {'skin', 'flat'} and list(files) == ['skin'] and files['skin'].endswith('atlas.png')
+    np.testing.assert_allclose(colors['flat'], [0.9, 0.1, 0.3])
+    open(os.path.join(str(tmp_path), 'bare.obj'), 'w').write('v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n')
+    with pytest.raises(Exception):
+        obj_io.parse_obj_materials(os.path.join(str(tmp_path), 'bare.obj'))
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/database/misc/spot/spot_triangulated.obj'), reason='reference data not present')
+def test_obj_material_parsing_on_the_reference_model():
+    # the model scripts/render_syn.py:71 of the reference renders (read where it lies; not copied, not needed on the GPU box)
+    from lasr_amd.soft_renderer.functional import obj_io
+    path = '/root/reference/database/misc/spot/spot_triangulated.obj'
+    v, f = obj_io.load_obj(path, device='cpu')
+    uv, mats, colors, files = obj_io.parse_obj_materials(path)
+    assert v.shape == (2930, 3) and f.shape == (5856, 3) and uv.shape == (5856, 3, 2)
+    assert set(mats) == {'material_1'} and os.path.basename(files['material_1']) == 'spot_texture.png' and os.path.exists(files['material_1'])
+    assert float(uv.max()) <= 1.0 and float(uv.min()) > -0.1
