@@ -72,6 +72,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description='render data')
     ap.add_argument('--outdir', default='syn-blob3f')
     ap.add_argument('--obj', default='', help='mesh to render (default: the built-in blobby sphere)')
+    ap.add_argument('--model', default='', choices=['', 'spot'],
+                    help="per-model placement of the reference (render_syn.py:70-75): 'spot' = flip y, +0.1 in y, /1.2")
     ap.add_argument('--nframes', default=3, type=int)
     ap.add_argument('--alpha', default=1., type=float, help='0-1, fraction of a full turn')
     ap.add_argument('--img_size', default=512, type=int)
@@ -92,6 +94,10 @@ def main(argv=None):
         else:
             v, f = sr.functional.load_obj(args.obj)
         overts, faces = v[None].to(dev).float(), f[None].to(dev)
+        if args.model == 'spot':                                  # render_syn.py:72-75 of the reference
+            overts[:, :, 1] *= -1
+            overts[:, :, 1] += 0.1
+            overts /= 1.2
         colors = torch.ones_like(overts) * 0.7
     else:
         v, f, tex = synth.blobby_mesh(8)
