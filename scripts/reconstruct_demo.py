@@ -62,10 +62,15 @@ def main(argv=None):
     ap.add_argument('--n_hypo', type=int, default=8)
     ap.add_argument('--out', default='')
     ap.add_argument('--no_graph', action='store_true')
+    ap.add_argument('--obj', default='', help='render this .obj instead of the built-in blobby sphere (render_syn.py --obj)')
+    ap.add_argument('--model', default='', help="render_syn.py --model (placement preset, e.g. 'spot')")
+    ap.add_argument('--surface_tex', action='store_true', help='render_syn.py --surface_tex')
     args = ap.parse_args(argv)
     root = tempfile.mkdtemp(prefix='lasr_demo_')
     name = 'syn-blob%df' % args.nframes
-    _load('render_syn').main(['--outdir', name, '--nframes', str(args.nframes), '--root', root])
+    extra = (['--obj', args.obj] if args.obj else []) + (['--model', args.model] if args.model else []) + \
+        (['--surface_tex'] if args.surface_tex else [])
+    _load('render_syn').main(['--outdir', name, '--nframes', str(args.nframes), '--root', root] + extra)
     ev = _load('eval_mesh')
     log = os.path.join(root, 'log')
     common = ['--checkpoint_dir', log, '--dataname', name, '--data_root', root, '--sil_path', 'none', '--ngpu', '1',
@@ -92,7 +97,7 @@ def main(argv=None):
     tr1, steps1, dt1 = run_stage(['--name', 'demo-1', '--nosymmetric', '--n_bones', '26', '--n_faces', '1600', '--n_hypo', '1',
                                   '--num_epochs', str(args.epochs1), '--model_path', ckpt] + common)
     cd1 = score(tr1)
-    out = {'sequence': '%d frames, blobby sphere, full turn, 512x512 source' % args.nframes,
+    out = {'sequence': '%d frames, %s, full turn, 512x512 source' % (args.nframes, os.path.basename(args.obj) if args.obj else 'blobby sphere'),
            'chamfer_unit_sphere_template': float(np.mean(cd_sphere)),
            'stage0': {'iterations': steps0, 'seconds': dt0, 'iters_per_s': steps0 / dt0, 'chamfer': float(np.mean(cd0)), 'per_frame': cd0},
            'stage1': {'iterations': steps1, 'seconds': dt1, 'iters_per_s': steps1 / dt1, 'chamfer': float(np.mean(cd1)), 'per_frame': cd1},
