@@ -64,10 +64,9 @@ def _surface_textures(filename_obj, texture_res, device):
         textures[sel] = torch.from_numpy(color).to(device)[None, None, :]
     faces_uv = torch.from_numpy(uv).to(device)
     for name, path in files.items():
-        image = np.asarray(Image.open(path)).astype(np.float32) / 255.
-        if image.ndim == 2:                                         # grey atlas
-            image = np.stack((image,) * 3, -1)
-        image = np.ascontiguousarray(image[::-1, :, :3])            # drop alpha; v = 0 is the BOTTOM row of the picture
+        # grey, palette and RGBA atlases all become RGB (the reference stacks grey images and drops the alpha channel, :84-89)
+        image = np.asarray(Image.open(path).convert('RGB')).astype(np.float32) / 255.
+        image = np.ascontiguousarray(image[::-1])                   # v = 0 is the BOTTOM row of the picture
         upd = torch.from_numpy((mats == name).astype(np.int32)).to(device)
         sampled = load_textures(torch.from_numpy(image).to(device), faces_uv, texture_res, upd)
         sel = upd.bool()

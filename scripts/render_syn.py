@@ -88,7 +88,8 @@ def main(argv=None):
 
     obj_textures = None
     if args.obj:
-        has_mtl = any(line.startswith('mtllib') for line in open(args.obj))
+        with open(args.obj) as fh:
+            has_mtl = any(line.startswith('mtllib') for line in fh)
         if args.surface_tex and has_mtl:                           # the reference's call (render_syn.py:71): the model's own atlas
             v, f, obj_textures = sr.functional.load_obj(args.obj, load_texture=True, texture_res=5, texture_type='surface', device=dev)
         else:
