@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--img_size', type=int, default=256)
     ap.add_argument('--out', default='')
+    ap.add_argument('--bench', type=int, default=0, help='also time forward+backward of this many posed frames (soft LASR modes)')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     v, f, tex = srf.load_obj(a.obj, load_texture=True, texture_res=5, texture_type='surface', device=dev)
@@ -74,6 +75,32 @@ def main():
                            'face_index_map_equal': bool(np.array_equal(haggr[:, 1].cpu().numpy(), href['aggrs_info'][:, 1])),
                            'z_buffer_equal': bool(np.array_equal(haggr[:, 0].cpu().numpy(), href['aggrs_info'][:, 0])),
                            'distinct_faces_visible': int(len(np.unique(href['aggrs_info'][:, 1])) - 1)}
+    if a.bench:
+        import time
+        B = a.bench
+        frames = []
+        for i in range(B):                                          # 26 yaw positions, repeated (the "~26 frames" of spot3)
+            ry = 3 * 1.57 + 6.28 * (i % 26) / 26
+            R = torch.tensor([[math.cos(ry), 0, math.sin(ry)], [0, 1, 0], [-math.sin(ry), 0, math.cos(ry)]], dtype=torch.float32, device=dev)
+            p = v @ R.t()
+            frames.append(torch.stack([p[:, 0], -p[:, 1], p[:, 2] + 10.], 1)[f.long()])
+        bfv = torch.stack(frames).contiguous().requires_grad_(True)
+        bft = col[:1].repeat(B, 1, 1, 1).contiguous().requires_grad_(True)
+        bg = torch.from_numpy(synth.upstream_grad(B, IS, 1)).to(dev)
+
+        def step():
+            bfv.grad = bft.grad = None
+            srf.soft_rasterize(bfv, bft, IS, **kw).backward(bg)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        out['bench'] = {'frames_per_step': B, 'ms_per_step': dt * 1e3, 'frames_per_s': B / dt,
+                        'note': 'soft_rasterize forward + backward through the autograd operator, soft LASR modes, vertex colours'}
     print(json.dumps(out))
     if a.out:
         json.dump(out, open(a.out, 'w'), indent=1)
