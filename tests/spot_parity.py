@@ -2,12 +2,12 @@
 """HIP rasteriser vs the CPU oracle on a user-supplied mesh -- meant for the reference's textured spot model (BASELINE configs[1]:
 "spot3 256x256 ... HIP soft-rasterizer fwd/bwd vs reference tolerance check"), which is read from a reference checkout and not shipped.
 
-    python tools/spot_parity.py --obj <reference>/database/misc/spot/spot_triangulated.obj [--frames 3] [--out profiles/x.json]
+    python tests/spot_parity.py --obj <reference>/database/misc/spot/spot_triangulated.obj [--frames 3] [--out profiles/x.json]
 
 Frames are posed exactly as scripts/render_syn.py poses them (--model spot placement, yaw sweep, orthographic look_at).  Checked per frame:
   soft LASR modes (euclidean / softmax / prod, vertex colours = normalised positions): image max-abs vs oracle, gradients vs oracle;
   hard data-generation modes with the model's own 5x5 surface textures: image max-abs, face-index map and z-buffer equality.
-The oracle is test infrastructure (oracle/); this tool belongs with tests/ and profiles/, not with the product path."""
+The oracle is test infrastructure (oracle/), so this checker lives under tests/ (pytest does not collect it: it needs the model file)."""
 import argparse
 import json
 import math
