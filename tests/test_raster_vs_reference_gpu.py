@@ -1,0 +1,78 @@
+"""The HIP soft-rasteriser against the REFERENCE kernels, through the C ABI (via the autograd Function).
+
+(1) against tests/golden/sr_reference_kernels.npz -- outputs of the reference's own soft_rasterize_cuda_kernel.cu built
+    for gfx950 (oracle/build_ref.py, -ffp-contract=off) and run on an MI355X (oracle/gen_ref_vectors.py);
+(2) live against that build (oracle/_ref/sr_ref_nofma.so, when the snapshot carries it) at the sizes BASELINE names,
+    where the CPU oracle is too slow to check every frame: 64 frames of M2 at 256^2, 16 at 512^2, spot3 stage 0's M1.
+
+Bars (north_star): image max-abs <= 1e-4 (measured 2.4e-7), hard-mode face-index map and z-buffer bit-exact,
+gradients within 1e-3 of the largest entry (measured 8e-5; the reference sums with float atomics).
+"""
+import numpy as np
+import pytest
+import torch
+
+from lasr_amd import synth
+from lasr_amd.soft_renderer import functional as srf
+from oracle import sr_ref
+from tests import refvec
+
+pytestmark = pytest.mark.gpu
+
+FP32_CASES = [n for n in refvec.names() if refvec.manifest()[n]['dtype'] == 'float32']
+
+
+@pytest.mark.parametrize('name', FP32_CASES)
+def test_hip_path_reproduces_reference_kernel_outputs(cuda, name):
+    c = refvec.case(name)
+    IS, kw = c['image_size'], c['kwargs']
+    fv = torch.from_numpy(c['face_vertices']).to(cuda).requires_grad_(True)
+    ft = torch.from_numpy(c['textures']).to(cuda).requires_grad_(True)
+    img, aggr, info = srf.soft_rasterize_raw(fv, ft, IS, kw['background_color'], kw['near'], kw['far'], kw['fill_back'],
+                                             kw['eps'], kw['sigma_val'], kw['dist_func'], kw['dist_eps'], kw['gamma_val'],
+                                             kw['aggr_func_rgb'], kw['aggr_func_alpha'], kw['texture_type'],
+                                             want_faces_info=True)
+    assert np.array_equal(info.cpu().numpy().reshape(c['faces_info'].shape), c['faces_info']), 'face setup differs'
+    assert np.abs(img.cpu().numpy() - c['soft_colors']).max() <= 1e-4
+    if kw['aggr_func_rgb'] == 'hard':
+        assert np.array_equal(aggr.cpu().numpy(), c['aggrs_info']), 'hard-mode z-buffer / face-index map differs'
+    out = srf.soft_rasterize(fv, ft, IS, **kw)
+    assert np.abs(out.detach().cpu().numpy() - c['soft_colors']).max() <= 1e-4
+    out.backward(torch.from_numpy(c['grad_soft_colors']).to(cuda))
+    for mine, theirs in ((fv.grad, c['grad_faces']), (ft.grad, c['grad_textures'])):
+        scale = max(float(np.abs(theirs).max()), 1e-30)
+        assert np.abs(mine.cpu().numpy().reshape(theirs.shape) - theirs).max() <= 1e-3 * scale
+
+
+needs_ref_build = pytest.mark.skipif(not sr_ref.available('sr_ref_nofma'),
+                                     reason='oracle/_ref/sr_ref_nofma.so not in this snapshot (oracle/build_ref.py)')
+
+
+@needs_ref_build
+@pytest.mark.parametrize('nu,n_frames,count,IS,hard', [(11, 26, 64, 256, False), (11, 26, 16, 512, False),
+                                                       (8, 3, 16, 256, False), (11, 26, 26, 256, True),
+                                                       (8, 16, 16, 256, True)])
+def test_live_against_the_reference_build_at_baseline_sizes(cuda, nu, n_frames, count, IS, hard):
+    fv, ft, near, far = synth.raster_batch(nu, n_frames, count=count)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    if hard:
+        kw.update(dist_func='hard', aggr_func_rgb='hard', aggr_func_alpha='hard')
+    tfv = torch.from_numpy(fv).to(cuda)
+    tft = torch.from_numpy(ft).to(cuda)
+    g = torch.from_numpy(synth.upstream_grad(count, IS)).to(cuda)
+    s = sr_ref.forward(tfv, tft, IS, variant='sr_ref_nofma', **kw)
+    gf, gt = sr_ref.backward(s, g, IS, variant='sr_ref_nofma', **kw)
+    a, b = tfv.clone().requires_grad_(True), tft.clone().requires_grad_(True)
+    img, aggr = srf.soft_rasterize_raw(a, b, IS, kw['background_color'], kw['near'], kw['far'], kw['fill_back'],
+                                       kw['eps'], kw['sigma_val'], kw['dist_func'], kw['dist_eps'], kw['gamma_val'],
+                                       kw['aggr_func_rgb'], kw['aggr_func_alpha'], kw['texture_type'])
+    assert float((img - s['soft_colors']).abs().max()) <= 1e-4
+    if hard:
+        assert torch.equal(aggr, s['aggrs_info']), 'face-index map / z-buffer differs from the reference kernel'
+        assert int((aggr[:, 1] >= 0).sum()) > 1000 * count * (IS // 256) ** 2
+    out = srf.soft_rasterize(a, b, IS, **kw)
+    out.backward(g)
+    assert float((out.detach() - s['soft_colors']).abs().max()) <= 1e-4
+    for mine, theirs in ((a.grad, gf), (b.grad, gt)):
+        scale = max(float(theirs.abs().max()), 1e-30)
+        assert float((mine.reshape(theirs.shape) - theirs).abs().max()) <= 1e-3 * scale
