@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _MODS = {}
+_SIDE = {}
 
 DIST = {'hard': 0, 'barycentric': 1, 'euclidean': 2}
 RGB = {'hard': 0, 'softmax': 1}
@@ -45,6 +46,19 @@ def module(variant='sr_ref'):
         loader.exec_module(mod)
         _MODS[variant] = mod
     return _MODS[variant]
+
+
+def side_module(which):
+    """The reference's side kernels (rows f3 / f4): 'load_textures' (load_textures_cuda.cpp: `load_textures(image, faces,
+    textures, is_update)`) or 'chamfer_3D' (chamfer_cuda.cpp: `forward(xyz1, xyz2, dist1, dist2, idx1, idx2)`)."""
+    so, init = {'load_textures': ('load_textures_ref', 'load_textures'), 'chamfer_3D': ('chamfer_3D_ref', 'chamfer_3D_ref')}[which]
+    if so not in _SIDE:
+        import torch                                    # noqa: F401
+        loader = importlib.machinery.ExtensionFileLoader(init, path(so))
+        mod = importlib.util.module_from_spec(importlib.util.spec_from_loader(init, loader))
+        loader.exec_module(mod)
+        _SIDE[so] = mod
+    return _SIDE[so]
 
 
 def _scalars(near, far, eps, sigma_val, dist_func, dist_eps, gamma_val, aggr_func_rgb, aggr_func_alpha,
