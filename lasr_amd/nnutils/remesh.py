@@ -1,11 +1,20 @@
 """Re-meshing between optimisation stages without the external Manifold binaries.
 
 The reference (/root/reference/nnutils/train_utils.py:419-428) exports the best hypothesis, makes it watertight with
-`Manifold/build/manifold` and decimates it to `--n_faces` triangles with `Manifold/build/simplify`.  Those programs are
-not part of the repository and cannot be fetched here.  LASR's meshes are deformed spheres (the template is an
-icosphere and the regularisers keep it genus 0), so the same job -- a clean, evenly tessellated mesh of about n_faces
-triangles on the learned surface -- is done by casting the vertex directions of a geodesic sphere of the matching
-frequency from the centroid and taking the outermost intersection with the old surface."""
+`Manifold/build/manifold` (a dense, ~10^4-resolution re-sampling of the surface) and decimates that to EXACTLY `--n_faces`
+triangles with `Manifold/build/simplify -m` (manifold-preserving quadric edge collapse).  Those programs are not part of the
+repository and cannot be fetched here.  LASR's meshes are closed 2-manifolds already (the template is an icosphere and every
+hand-off starts from the previous stage's mesh), so the same job is done in place:
+
+    remesh_exact : 1 -> 4 midpoint subdivision until the mesh is at least 1.5 times as fine as requested (the dense re-sampling;
+                   every new vertex lies on the learned surface), then quadric-error edge collapses -- link condition and
+                   normal-flip tests keep the surface a manifold of the same genus, limbs included -- down to exactly
+                   n_faces triangles.  A closed manifold has an even face count and each collapse removes two faces, so every
+                   even n_faces >= 4 is reachable; scripts/template.sh's 1600 / 1920 / 2240 / 2560 / 2880 give exactly that.
+
+`remesh_star` (rounds 1-2: radial re-sampling onto a geodesic sphere, face count snapped to 20 nu^2, star-shaped surfaces
+only) is kept for callers that want a sphere-parameterised result; the trainer no longer uses it."""
+import heapq
 import math
 import warnings
 
@@ -14,6 +23,200 @@ import numpy as np
 from .. import synth
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# exact-count, topology-preserving re-mesher
+# --------------------------------------------------------------------------------------------------------------------
+def _subdivide(verts, faces):
+    """1 -> 4 midpoint subdivision; new vertices are edge midpoints (on the piecewise-linear surface)."""
+    key = {}
+    new = []
+    nv = len(verts)
+
+    def mid(a, b):
+        k = (a, b) if a < b else (b, a)
+        if k not in key:
+            key[k] = nv + len(new)
+            new.append(0.5 * (verts[a] + verts[b]))
+        return key[k]
+
+    out = []
+    for a, b, c in faces:
+        ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+        out += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+    return np.vstack([verts, np.asarray(new)]), out
+
+
+def _is_closed_manifold(faces):
+    count = {}
+    for a, b, c in faces:
+        for e in ((a, b), (b, c), (c, a)):
+            if e in count:
+                return False                      # the same directed edge twice: inconsistent orientation / non-manifold
+            count[e] = 1
+    return all((b, a) in count for (a, b) in count)
+
+
+def remesh_exact(verts, faces, n_faces, reg=1e-3, sliver=0.1):
+    """verts [V,3], faces [F,3] (numpy; a closed, consistently oriented 2-manifold) -> (new_verts [V',3] float32,
+    new_faces [n_faces,3] int64): the same surface (same genus, same orientation) with exactly n_faces triangles.
+
+    Edge collapse cost = Garland-Heckbert quadric error (area-weighted face planes of the dense mesh) at the best of
+    {optimal point, midpoint, end points} + reg * |edge|^2 * mean face area (keeps flat regions evenly tessellated, where the
+    quadric alone is zero).  A collapse is rejected when the one-rings of its end points share anything but the two
+    opposite vertices (link condition: the result would pinch), when a surviving triangle's normal would turn by more
+    than ~80 degrees, or when it would create a sliver."""
+    n_faces = int(n_faces)
+    V = np.asarray(verts, np.float64).copy()
+    F = [tuple(int(x) for x in f) for f in np.asarray(faces)]
+    if n_faces < 4 or n_faces % 2:
+        raise ValueError('remesh_exact: a closed triangle mesh has an even number of faces >= 4 (got --n_faces %d)' % n_faces)
+    if not _is_closed_manifold(F):
+        raise ValueError('remesh_exact: the input is not a closed, consistently oriented manifold')
+    while 2 * len(F) < 3 * n_faces:
+        V, F = _subdivide(V, F)
+    if len(F) == n_faces:
+        return V.astype(np.float32), np.asarray(F, np.int64)
+
+    nv = len(V)
+    faces_l = [list(f) for f in F]                       # None once removed
+    vf = [set() for _ in range(nv)]                      # vertex -> incident face ids
+    for i, f in enumerate(faces_l):
+        for v in f:
+            vf[v].add(i)
+    tri = V[np.asarray(F)]
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    area2 = np.linalg.norm(nrm, axis=1)
+    mean_area = 0.5 * float(area2.mean())
+    unit = nrm / np.maximum(area2, 1e-30)[:, None]
+    plane = np.concatenate([unit, -(unit * tri[:, 0]).sum(1, keepdims=True)], 1)            # [F,4]
+    Kf = plane[:, :, None] * plane[:, None, :] * (0.5 * area2)[:, None, None]
+    Q = np.zeros((nv, 4, 4))
+    for i, f in enumerate(F):
+        for v in f:
+            Q[v] += Kf[i]
+    stamp = [0] * nv
+    alive = [True] * nv
+    # sliver bar relative to the input's own triangles (a stretched limb is made of thin triangles to begin with)
+    emax2 = np.max([((tri[:, i] - tri[:, (i + 1) % 3]) ** 2).sum(1) for i in range(3)], axis=0)
+    sliver = min(sliver, 0.5 * float(np.percentile(area2 / np.maximum(emax2, 1e-300), 5)))
+
+    def neighbours(v):
+        out = set()
+        for fi in vf[v]:
+            out.update(faces_l[fi])
+        out.discard(v)
+        return out
+
+    def cost(a, b):
+        q = Q[a] + Q[b]
+        cands = [0.5 * (V[a] + V[b]), V[a], V[b]]
+        A3 = q[:3, :3]
+        if abs(np.linalg.det(A3)) > 1e-12 * max(np.abs(A3).max(), 1e-30) ** 3:
+            p = np.linalg.solve(A3, -q[:3, 3])
+            if np.linalg.norm(p - cands[0]) <= 2.0 * np.linalg.norm(V[a] - V[b]):            # no wild extrapolation
+                cands.insert(0, p)
+        best, bp = None, None
+        for p in cands:
+            h = np.append(p, 1.0)
+            c = float(h @ q @ h)
+            if best is None or c < best:
+                best, bp = c, p
+        return max(best, 0.0) + reg * float(((V[a] - V[b]) ** 2).sum()) * mean_area, bp
+
+    heap = []
+
+    def push(a, b):
+        if a > b:
+            a, b = b, a
+        c, p = cost(a, b)
+        heapq.heappush(heap, (c, a, b, stamp[a], stamp[b], tuple(p)))
+
+    def push_all():
+        seen = set()
+        for f in faces_l:
+            if f is None:
+                continue
+            for a, b in ((f[0], f[1]), (f[1], f[2]), (f[2], f[0])):
+                k = (a, b) if a < b else (b, a)
+                if k not in seen:
+                    seen.add(k)
+                    push(*k)
+
+    def flips(v, other, p, shared):
+        for fi in vf[v]:
+            if fi in shared:
+                continue
+            f = faces_l[fi]
+            old = [V[x] for x in f]
+            new = [p if (x == v or x == other) else V[x] for x in f]
+            n0 = np.cross(old[1] - old[0], old[2] - old[0])
+            n1 = np.cross(new[1] - new[0], new[2] - new[0])
+            l0, l1 = np.linalg.norm(n0), np.linalg.norm(n1)
+            if l1 <= 1e-14 * max(l0, 1e-30) or float(n0 @ n1) < 0.17 * l0 * l1:
+                return True
+            # no new slivers: 2 * area / longest edge^2 (0.87 for an equilateral triangle) may not fall below `sliver`
+            # unless the triangle was at least as thin before
+            q1 = l1 / max(((new[1] - new[0]) ** 2).sum(), ((new[2] - new[1]) ** 2).sum(), ((new[0] - new[2]) ** 2).sum())
+            if q1 < sliver:
+                q0 = l0 / max(((old[1] - old[0]) ** 2).sum(), ((old[2] - old[1]) ** 2).sum(), ((old[0] - old[2]) ** 2).sum())
+                if q1 < q0:
+                    return True
+        return False
+
+    push_all()
+    n_alive = len(F)
+    progress = True
+    while n_alive > n_faces:
+        if not heap:
+            # every queued edge was inadmissible when it came up; edges rejected earlier may be admissible now
+            if not progress:
+                break
+            progress = False
+            push_all()
+            continue
+        c, a, b, sa, sb, p = heapq.heappop(heap)
+        if not (alive[a] and alive[b]) or sa != stamp[a] or sb != stamp[b]:
+            continue
+        shared = vf[a] & vf[b]
+        if len(shared) != 2:
+            continue
+        opp = set()
+        for fi in shared:
+            opp.update(x for x in faces_l[fi] if x != a and x != b)
+        p = np.asarray(p)
+        if len(opp) != 2 or (neighbours(a) & neighbours(b)) != opp or any(len(vf[o]) <= 3 for o in opp) \
+                or flips(a, b, p, shared) or flips(b, a, p, shared):
+            continue
+        # collapse b into a, placed at p
+        for fi in shared:
+            for x in faces_l[fi]:
+                vf[x].discard(fi)
+            faces_l[fi] = None
+        for fi in list(vf[b]):
+            f = faces_l[fi]
+            f[f.index(b)] = a
+            vf[a].add(fi)
+        vf[b] = set()
+        alive[b] = False
+        V[a] = p
+        Q[a] = Q[a] + Q[b]
+        stamp[a] += 1                                    # queued entries of a's edges are stale (position and quadric moved)
+        n_alive -= 2
+        progress = True
+        for v in neighbours(a):
+            push(a, v)
+    if n_alive != n_faces:
+        raise RuntimeError('remesh_exact: stopped at %d faces, %d requested (no admissible collapse left)' % (n_alive, n_faces))
+    keep = [f for f in faces_l if f is not None]
+    used = sorted({v for f in keep for v in f})
+    index = {v: i for i, v in enumerate(used)}
+    out_f = np.asarray([[index[v] for v in f] for f in keep], np.int64)
+    return V[used].astype(np.float32), out_f
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# radial re-sampling (rounds 1-2); kept as a utility
+# --------------------------------------------------------------------------------------------------------------------
 def ray_mesh_outermost(origin, dirs, verts, faces, return_first=False):
     """For each unit direction the largest t > 0 with origin + t * dir on the mesh (Moeller-Trumbore against every
     triangle); NaN where the ray misses.  return_first: also the smallest such t (first crossing)."""
@@ -39,14 +242,9 @@ def ray_mesh_outermost(origin, dirs, verts, faces, return_first=False):
 
 def remesh_star(verts, faces, n_faces):
     """verts [V,3], faces [F,3] (numpy) -> (new_verts [V',3] float32, new_faces [F',3] int64) with F' = 20 nu^2 closest
-    to n_faces.
-
-    LIMITATION (warned about at run time): the result is the radial function of the surface seen from its centroid, outermost
-    crossing.  Where the learned surface is not star-shaped from there -- a ray crosses it more than once: limbs, a tail, the
-    gap between legs -- everything inside the outermost crossing is lost (webbing / collapsed concavities), and the loss
-    compounds over the five hand-offs of scripts/template.sh.  The reference's Manifold + simplify pipeline preserves such
-    geometry; a run that needs it should re-mesh externally and pass the result as the next stage's --model_path mesh.
-    Directions that miss the surface altogether take the mean radius."""
+    to n_faces: the radial function of the surface seen from its centroid (outermost crossing) sampled on a geodesic sphere.
+    Star-shaped surfaces only -- limbs, a tail, the gap between legs are webbed over (warned about at run time); the trainer
+    uses remesh_exact instead.  Directions that miss the surface altogether take the mean radius."""
     verts = np.asarray(verts, np.float64)
     faces = np.asarray(faces, np.int64)
     nu = max(1, int(round(math.sqrt(int(n_faces) / 20.0))))

@@ -443,7 +443,7 @@ class LASRTrainer:
 
     def load_network(self, network, model_path):
         """Warm start from the previous stage (train_utils.py:381-487): pick the best camera hypothesis when the new
-        stage has fewer, re-mesh to --n_faces when the symmetry constraint is dropped (own re-mesher, see remesh.py),
+        stage has fewer, re-mesh to exactly --n_faces when the symmetry constraint is dropped (own re-mesher, see remesh.py),
         keep the root bone's predictor rows and re-seed the part bones by k-means when the bone count changes, then load
         whatever still fits."""
         opts = self.opts
@@ -472,7 +472,7 @@ class LASRTrainer:
             src = states['mean_v'][0]
             if src.shape[0] < int(states['faces'].max()) + 1:
                 src = states['full_shape'][0]
-            v, f = remesh.remesh_star(src.numpy(), states['faces'].numpy(), opts.n_faces)
+            v, f = remesh.remesh_exact(src.numpy(), states['faces'].numpy(), opts.n_faces)
             mean_shape, faces = torch.from_numpy(v), torch.from_numpy(f)
             tex = torch.zeros(1, mean_shape.shape[0], 3)
         elif opts.symmetric:

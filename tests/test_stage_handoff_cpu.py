@@ -59,3 +59,133 @@ def test_checkpoint_handoff_without_a_gpu(tmp_path):
     d = (net3.rest_ts[:, None] - net3.mean_v[0][None]).norm(dim=-1).min(1)[0]
     assert float(d.max()) < 0.5                                                  # centres lie in the (unit-scale) shape
     assert torch.equal(net3.log_ctl, torch.zeros_like(net3.log_ctl))             # a fresh model's values
+
+
+# ---- exact-count, topology-preserving re-mesher (reference: Manifold + simplify, nnutils/train_utils.py:419-428) ---------------
+def _point_triangle_distance(p, tri):
+    """p [P,3], tri [F,3,3] -> [P] distance to the nearest triangle (Ericson, Real-Time Collision Detection 5.1.5)."""
+    import numpy as np
+    out = np.full(len(p), np.inf)
+    cen = tri.mean(1)
+    K = min(32, len(tri))                                 # exact test against the K triangles with the nearest centroids
+    for s in range(0, len(p), 1024):
+        q = p[s:s + 1024, None, :]
+        near = np.argpartition(((q - cen[None]) ** 2).sum(-1), K - 1, axis=1)[:, :K]
+        a, b, c = tri[near, 0], tri[near, 1], tri[near, 2]
+        ab, ac = b - a, c - a
+        ap = q - a
+        d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+        bp = q - b
+        d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+        cp = q - c
+        d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+        vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+        den = np.where(np.abs(va + vb + vc) > 1e-300, va + vb + vc, 1.0)
+        v, w = vb / den, vc / den
+        cl = a + ab * v[..., None] + ac * w[..., None]                                   # interior
+        def put(mask, pt):
+            nonlocal cl
+            cl = np.where(mask[..., None], pt, cl)
+        t = np.clip(np.where(np.abs(d4 - d3 + d5 - d6) > 1e-300, (d4 - d3) / np.where(np.abs(d4 - d3 + d5 - d6) > 1e-300, d4 - d3 + d5 - d6, 1.0), 0.0), 0, 1)
+        put((va <= 0) & (d4 - d3 >= 0) & (d5 - d6 >= 0), b + (c - b) * t[..., None])
+        t = np.clip(np.where(np.abs(d2 - d6) > 1e-300, d2 / np.where(np.abs(d2 - d6) > 1e-300, d2 - d6, 1.0), 0.0), 0, 1)
+        put((vb <= 0) & (d2 >= 0) & (d6 <= 0), a + ac * t[..., None])
+        t = np.clip(np.where(np.abs(d1 - d3) > 1e-300, d1 / np.where(np.abs(d1 - d3) > 1e-300, d1 - d3, 1.0), 0.0), 0, 1)
+        put((vc <= 0) & (d1 >= 0) & (d3 <= 0), a + ab * t[..., None])
+        put((d6 >= 0) & (d5 <= d6), np.broadcast_to(c, cl.shape))
+        put((d3 >= 0) & (d4 <= d3), np.broadcast_to(b, cl.shape))
+        put((d1 <= 0) & (d2 <= 0), np.broadcast_to(a, cl.shape))
+        out[s:s + 1024] = np.linalg.norm(q - cl, axis=-1).min(1)
+    return out
+
+
+def _surface_samples(v, f):
+    import numpy as np
+    t = v[f]
+    return np.concatenate([v, t.mean(1), (t[:, 0] + t[:, 1]) / 2, (t[:, 1] + t[:, 2]) / 2, (t[:, 2] + t[:, 0]) / 2])
+
+
+def _two_lobed_shape():
+    """A bent, waisted tube: two lobes joined by a neck, curved so that the centroid lies OUTSIDE the surface -- not star-shaped,
+    the radial re-mesher of rounds 1-2 webbed such shapes over."""
+    import numpy as np
+    from lasr_amd import synth
+    v, f = synth.geodesic_sphere(8)
+    v = v.astype(np.float64)
+    x = v[:, 0] * 1.6
+    waist = 0.35 + 0.65 * np.abs(v[:, 0]) ** 1.5                       # thin neck in the middle, fat lobes at the ends
+    y = v[:, 1] * 0.55 * waist + 1.1 * x ** 2                          # parabolic bend
+    z = v[:, 2] * 0.55 * waist
+    return np.stack([x, y, z], 1), f
+
+
+def test_remesh_exact_counts_topology_and_hausdorff():
+    import numpy as np
+    from lasr_amd.nnutils import remesh
+    v, f = _two_lobed_shape()
+    tri = v[f]
+    area = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    centroid = (tri.mean(1) * area[:, None]).sum(0) / area.sum()
+    t_last, t_first = remesh.ray_mesh_outermost(centroid, synth_dirs(), v, f, return_first=True)
+    assert (np.isfinite(t_last) & (t_last - t_first > 0.05)).any()      # genuinely not star-shaped from its centroid
+    diameter = float(np.linalg.norm(v[:, None] - v[None], axis=-1).max())
+    for n in (1600, 1920, 2240, 2560, 2880):                             # scripts/template.sh:26-31, scripts/dog15.sh
+        nv, nf = remesh.remesh_exact(v, f, n)
+        assert nf.shape == (n, 3) and nv.dtype == np.float32 and nf.dtype == np.int64
+        assert remesh._is_closed_manifold([tuple(t) for t in nf])       # closed, consistently oriented
+        edges = {tuple(sorted(e)) for t in nf for e in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0]))}
+        assert nv.shape[0] - len(edges) + n == 2                         # genus 0 kept
+        assert nv.shape[0] == n // 2 + 2
+        nt = nv[nf].astype(np.float64)
+        # orientation kept: signed volume has the sign of the input's and nearly its value
+        vol0 = (tri[:, 0] * np.cross(tri[:, 1], tri[:, 2])).sum() / 6
+        vol1 = (nt[:, 0] * np.cross(nt[:, 1], nt[:, 2])).sum() / 6
+        assert abs(vol1 - vol0) <= 0.02 * abs(vol0)
+        if n not in (1600, 2880):
+            continue
+        # two-sided Hausdorff distance between the surfaces (dense samples of each against the other's triangles)
+        d_new_to_old = _point_triangle_distance(_surface_samples(nv.astype(np.float64), nf), tri).max()
+        d_old_to_new = _point_triangle_distance(_surface_samples(v, f), nt).max()
+        assert max(d_new_to_old, d_old_to_new) < 0.02 * diameter, (n, d_new_to_old / diameter, d_old_to_new / diameter)
+        # no slivers: every triangle keeps a sane aspect (area / longest edge^2)
+        e = np.stack([np.linalg.norm(nt[:, i] - nt[:, (i + 1) % 3], axis=1) for i in range(3)], 1)
+        a2 = np.linalg.norm(np.cross(nt[:, 1] - nt[:, 0], nt[:, 2] - nt[:, 0]), axis=1)
+        assert (a2 / e.max(1) ** 2).min() > 0.02                      # the input's own thinnest triangle is at 0.034
+    # decimation below the input's own count and the identity case
+    nv, nf = remesh.remesh_exact(v, f, 500)
+    assert nf.shape == (500, 3) and remesh._is_closed_manifold([tuple(t) for t in nf])
+    nv, nf = remesh.remesh_exact(v, f, 1280)
+    assert nf.shape == (1280, 3)
+    import pytest
+    with pytest.raises(ValueError):
+        remesh.remesh_exact(v, f, 1601)                                  # odd face counts do not exist on closed meshes
+    with pytest.raises(ValueError):
+        remesh.remesh_exact(v, f[:-1], 1600)                             # an open mesh is refused, not silently patched
+
+
+def synth_dirs():
+    from lasr_amd import synth
+    import numpy as np
+    return synth.geodesic_sphere(4)[0].astype(np.float64)
+
+
+def test_template_sh_stage_counts_survive_the_checkpoint_path(tmp_path):
+    # scripts/template.sh stages 1-4 pass --n_faces 1600 / 1920 / 2240 / 2560 with --nosymmetric: each hand-off re-meshes the
+    # previous stage's shape to exactly that count (rounds 1-2 snapped them to 1620 / 2000 / 2420 / 2420)
+    o = opts_for(tmp_path, subdivide=3, n_hypo=1, n_bones=1)
+    tr = train_utils.LASRTrainer(o)
+    tr.device = torch.device('cpu')
+    torch.manual_seed(0)
+    tr.model = mesh_net.LASR((64, 64), o, nz_feat=o.nz_feat)
+    tr.epoch_nscore = torch.zeros(1)
+    tr.save('latest')
+    ckpt = os.path.join(tr.save_dir, 'pred_net_latest.pth')
+    for k, n in enumerate((1600, 1920, 2240, 2560)):
+        ok = opts_for(tmp_path, name='s%d' % k, subdivide=3, symmetric=False, n_hypo=1, n_bones=1, n_faces=str(n), model_path=ckpt)
+        net = mesh_net.LASR((64, 64), ok, nz_feat=ok.nz_feat)
+        t2 = train_utils.LASRTrainer(ok)
+        t2.load_network(net, ckpt)
+        assert net.faces.shape == (n, 3) and net.mean_v.shape == (1, n // 2 + 2, 3)
+        t2.device, t2.model, t2.epoch_nscore = torch.device('cpu'), net, torch.zeros(1)
+        t2.save('latest')
+        ckpt = os.path.join(t2.save_dir, 'pred_net_latest.pth')
