@@ -25,20 +25,46 @@ from . import path_oracle as po
 from . import sr_oracle
 
 
+RASTER = 'c_oracle'
+
+
+def set_raster(which):
+    """Which rasteriser sits behind the three render calls: 'c_oracle' = oracle/sr_oracle.c on the host cores (default);
+    'reference_build' = the reference's own kernels built for gfx950 (oracle/_ref/sr_ref_nofma.so, oracle/build_ref.py) on
+    cuda:0 -- the same arithmetic (tests/test_oracle_vs_reference_vectors.py) three orders of magnitude faster, which is what
+    makes the BASELINE-size comparisons (96 meshes per render call at dog15's stage 0) take seconds.  Returns the old value."""
+    global RASTER
+    assert which in ('c_oracle', 'reference_build')
+    old, RASTER = RASTER, which
+    return old
+
+
 class SoftRasterizeOracle(torch.autograd.Function):
-    """soft_rasterize.py:9-102 with the CUDA extension replaced by oracle/sr_oracle.c (fp32)."""
+    """soft_rasterize.py:9-102 with the CUDA extension replaced by oracle/sr_oracle.c (fp32), or by the reference
+    extension itself running on the GPU (set_raster)."""
 
     @staticmethod
     def forward(ctx, face_vertices, textures, image_size, kw):
+        ctx.kw, ctx.image_size, ctx.which = kw, image_size, RASTER
+        ctx.shapes = (face_vertices.shape, textures.shape)
+        if RASTER == 'reference_build':
+            from . import sr_ref
+            saved = sr_ref.forward(face_vertices.detach().cuda(), textures.detach().cuda(), image_size,
+                                   variant='sr_ref_nofma', **kw)
+            ctx.saved = saved
+            return saved['soft_colors'].cpu()
         fv = face_vertices.detach().numpy()
         tx = textures.detach().numpy()
         saved = sr_oracle.forward(fv, tx, image_size, **kw)
-        ctx.saved, ctx.kw, ctx.image_size = saved, kw, image_size
-        ctx.shapes = (face_vertices.shape, textures.shape)
+        ctx.saved = saved
         return torch.from_numpy(saved['soft_colors'].copy())
 
     @staticmethod
     def backward(ctx, grad):
+        if ctx.which == 'reference_build':
+            from . import sr_ref
+            gf, gt = sr_ref.backward(ctx.saved, grad.contiguous().cuda(), ctx.image_size, variant='sr_ref_nofma', **ctx.kw)
+            return gf.cpu().view(ctx.shapes[0]), gt.cpu().view(ctx.shapes[1]), None, None
         gf, gt = sr_oracle.backward(ctx.saved, grad.contiguous().numpy(), ctx.image_size, **ctx.kw)
         return (torch.from_numpy(gf).view(ctx.shapes[0]), torch.from_numpy(gt).view(ctx.shapes[1]), None, None)
 

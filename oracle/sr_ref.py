@@ -85,9 +85,13 @@ def forward(face_vertices, textures, image_size=256, background_color=(0, 0, 0),
     colors = torch.ones(N, 4, IS, IS, dtype=dt, device=fv.device)
     for k in range(3):
         colors[:, k] *= background_color[k]
+    # the reference launches on the legacy default stream (K.cu:702,717: no stream argument) whatever torch's current stream
+    # is: fence both sides so that a caller on a side stream (the trainer's graph-capture stream) sees ordered results
+    torch.cuda.synchronize()
     module(variant).forward_soft_rasterize(fv, tx, infos, aggrs, colors, IS,
                                            *_scalars(near, far, eps, sigma_val, dist_func, dist_eps, gamma_val,
                                                      aggr_func_rgb, aggr_func_alpha, texture_type, fill_back))
+    torch.cuda.synchronize()
     return dict(soft_colors=colors, aggrs_info=aggrs, faces_info=infos, face_vertices=fv, textures=tx)
 
 
@@ -100,8 +104,10 @@ def backward(saved, grad_soft_colors, image_size=256, background_color=(0, 0, 0)
     g = grad_soft_colors.detach().to(fv.dtype).contiguous()
     gf = torch.zeros_like(fv)
     gt = torch.zeros_like(tx)
+    torch.cuda.synchronize()
     module(variant).backward_soft_rasterize(fv, tx, saved['soft_colors'], saved['faces_info'], saved['aggrs_info'],
                                             gf, gt, g, int(image_size),
                                             *_scalars(near, far, eps, sigma_val, dist_func, dist_eps, gamma_val,
                                                       aggr_func_rgb, aggr_func_alpha, texture_type, fill_back))
+    torch.cuda.synchronize()
     return gf, gt

@@ -175,6 +175,8 @@ def test_graph_replay_matches_eager_forward(tmp_path, cuda):
                      only_mean_sym=False)),
 ])
 def test_other_baseline_configurations_step(tmp_path, cuda, name, over):
+    # trainer-level smoke test (train_step incl. the step tail) at these sizes; the PARITY of the forward / backward at the sizes
+    # BASELINE names is tests/test_lasr_forward_oracle_gpu.py::test_whole_forward_*_at_size
     tr = make_trainer(tmp_path, name=name, iters_per_epoch=2, **over)
     tr.model.train()
     tr.reinit_bones()

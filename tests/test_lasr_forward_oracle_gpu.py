@@ -37,8 +37,8 @@ def rel(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-20))
 
 
-def run_both(tmp_path, **over):
-    tr = make_trainer(tmp_path, **over)
+def run_both(tmp_path, independent=True, trainer=None, **over):
+    tr = trainer if trainer is not None else make_trainer(tmp_path, **over)
     tr.model.train()
     tr.reinit_bones()
     m, opts = tr.module, tr.opts
@@ -110,6 +110,9 @@ def run_both(tmp_path, **over):
     cpu_batch = {k: v.detach().cpu() for k, v in batch.items()}
     runs = []
     for inject in (None, captured):
+        if inject is None and not independent:
+            runs.append(None)
+            continue
         P = {n: getattr(m, n).detach().cpu().clone().requires_grad_(True) for n in names}
         code_cpu = [c.detach().cpu().clone().requires_grad_(True) for c in code_gpu]
         ref_loss, ref = lfo.lasr_forward(P, code_cpu, cpu_batch, dict(cfg, inject=inject))
@@ -124,8 +127,14 @@ def l2rel(a, b):
 
 
 def check(m, loss, code_gpu, captured, runs, K):
+    if runs[0] is not None:
+        check_independent(m, loss, code_gpu, captured, runs[0], K)
+    check_injected(m, loss, code_gpu, captured, runs[1], K)
+
+
+def check_independent(m, loss, code_gpu, captured, run, K):
     # ---------- independent composition
-    P, code_cpu, ref_loss, ref = runs[0]
+    P, code_cpu, ref_loss, ref = run
     for name, geo in zip(('flow_fw', 'flow_bw', 'tex'), ref['pre_raster']):
         assert rel(captured[name], geo) <= 1e-5, name                 # which frame / hypothesis / pp half feeds which render
     assert abs(captured['near_far'][0] - ref['near_far'][0]) <= 1e-5 * abs(ref['near_far'][0])
@@ -144,8 +153,13 @@ def check(m, loss, code_gpu, captured, runs, K):
     for n, a, b in zip(('scale', 'trans', 'quat', 'depth', 'ppoint'), code_gpu, code_cpu):
         assert l2rel(a.grad, b.grad) <= 0.08, (n, l2rel(a.grad, b.grad))
 
+
+
+def check_injected(m, loss, code_gpu, captured, run, K):
     # ---------- same raster geometry on both sides: tight
-    P, code_cpu, ref_loss, ref = runs[1]
+    P, code_cpu, ref_loss, ref = run
+    for name, geo in zip(('flow_fw', 'flow_bw', 'tex'), ref['pre_raster']):
+        assert rel(captured[name], geo) <= 1e-5, name                 # the oracle's own geometry, before the injection
     assert float((m.mask_pred.detach().cpu() - ref['mask_pred']).abs().max()) <= 1e-4
     assert float((m.texture_render.detach().cpu() - ref['texture_render']).abs().max()) <= 1e-4
     same_bg = (m.bgmask.cpu() == ref['bgmask'])
@@ -191,3 +205,69 @@ def test_whole_forward_ground_truth_cameras(tmp_path, cuda):
     # only enters through the camera loss (:506-514)
     out = run_both(tmp_path, n_bones=1, n_hypo=1, batch_size=1, use_gtpose=True, symmetric=False, only_mean_sym=False)
     check(*out, K=1)
+
+
+# ---- the configurations BASELINE.json names, at their real sizes ------------------------------------------
+# Value-injected comparison only (the independent one adds nothing at size and doubles the oracle's work).  The oracle's three
+# render calls run the REFERENCE's own kernels (oracle/_ref/sr_ref_nofma.so on this GPU) when the snapshot carries that build,
+# the C oracle on the host cores otherwise -- same arithmetic (tests/test_oracle_vs_reference_vectors.py), seconds instead of
+# minutes at 96 meshes per call.
+def _at_size(tmp_path, K, **over):
+    from oracle import sr_ref
+    old = lfo.set_raster('reference_build' if sr_ref.available('sr_ref_nofma') else 'c_oracle')
+    try:
+        out = run_both(tmp_path, independent=False, **over)
+        check(*out, K=K)
+        report(out, lfo.RASTER)
+    finally:
+        lfo.set_raster(old)
+    return out
+
+
+def report(out, raster):
+    """Measured deviations of an at-size comparison, appended to gpurun_out/whole_forward_parity.jsonl when that directory
+    exists (the evidence file copied to profiles/)."""
+    import inspect
+    import json
+    m, loss, code_gpu, captured, runs = out
+    P, code_cpu, ref_loss, ref = runs[1]
+    d = os.path.join(ROOT, 'gpurun_out')
+    if not os.path.isdir(d):
+        return
+    row = dict(test=inspect.stack()[2].function, raster=raster, meshes=int(m.mask_pred.shape[0]), image_size=int(m.mask_pred.shape[-1]),
+               faces=int(m.faces.shape[0]), n_hypo=int(m.opts.n_hypo) if hasattr(m, 'opts') else None,
+               mask_image_max_abs=float((m.mask_pred.detach().cpu() - ref['mask_pred']).abs().max()),
+               texture_image_max_abs=float((m.texture_render.detach().cpu() - ref['texture_render']).abs().max()),
+               total_loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
+               tables={n: rel(getattr(m, n), ref[n]) for n in ('mask_loss_sub', 'flow_rd_loss_sub', 'texture_loss_sub', 'triangle_loss_sub')},
+               param_grads={n: rel(getattr(m, n).grad, p.grad) for n, p in P.items()},
+               code_grads={n: rel(a.grad, b.grad) for n, a, b in zip(('scale', 'trans', 'quat', 'depth', 'ppoint'), code_gpu, code_cpu)})
+    with open(os.path.join(d, 'whole_forward_parity.jsonl'), 'a') as f:
+        f.write(json.dumps(row) + '\n')
+
+
+def test_whole_forward_spot3_stage0_at_size(tmp_path, cuda):
+    # scripts/spot3.sh:24 -- 256x256, 1 pair per GPU, 8 hypotheses, 21 bones, icosphere-3 (V=642, F=1280): 16 meshes per render
+    m = _at_size(tmp_path, 21, img_size=256, subdivide=3, n_bones=21, n_hypo=8, batch_size=1)[0]
+    assert m.mask_pred.shape == (16, 256, 256) and m.faces.shape[0] == 1280
+
+
+def test_whole_forward_dog15_stage0_at_size(tmp_path, cuda):
+    # scripts/dog15.sh:25 -- 256x256, 3 pairs per GPU, 16 hypotheses, 21 bones, 15 frames: 96 meshes per render call
+    m = _at_size(tmp_path, 21, img_size=256, subdivide=3, n_bones=21, n_hypo=16, batch_size=3, n_frames=15)[0]
+    assert m.mask_pred.shape == (96, 256, 256)
+
+
+def test_whole_forward_camel_stage4_at_size(tmp_path, cuda):
+    # scripts/template.sh:30 -- 512x512 (BASELINE configs[2]), 2 pairs per GPU, one hypothesis, 36 bones, --n_faces 2560,
+    # --nosymmetric: the mesh comes out of the stage hand-off (exact-count re-mesh of the previous stage's shape), the
+    # symmetry regularisers (:461-478, :500-503) are on
+    tr0 = make_trainer(tmp_path, name='stage3', subdivide=3, n_bones=1, n_hypo=1, batch_size=1)
+    tr0.epoch_nscore = torch.zeros(1, device=cuda)
+    tr0.save('latest')
+    ckpt = os.path.join(tr0.save_dir, 'pred_net_latest.pth')
+    tr = make_trainer(tmp_path, name='stage4', img_size=512, subdivide=3, n_bones=36, n_hypo=1, batch_size=2, n_frames=8,
+                      symmetric=False, only_mean_sym=False, n_faces='2560', model_path=ckpt)
+    assert tr.module.faces.shape == (2560, 3) and tr.module.mean_v.shape == (1, 1282, 3)
+    m = _at_size(tmp_path, 36, trainer=tr)[0]
+    assert m.mask_pred.shape == (4, 512, 512)
