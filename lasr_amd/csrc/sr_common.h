@@ -9,6 +9,7 @@ namespace lasr {
 struct RasterArgs {
     const float* __restrict__ recs;      // [N*F, REC]
     const short4* __restrict__ rects;    // [N*F] exact pixel rectangle (x0,x1,row0,row1) of the bbox test
+    const short4* __restrict__ grects;   // [N, ceil(F/64)] union of the pixel rects of 64 consecutive faces
     const float* __restrict__ textures;  // [N,F,T,3]
     int N, F, T, res, IS;
     float near, far, eps, sigma, gamma, thr;

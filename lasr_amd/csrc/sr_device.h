@@ -170,7 +170,7 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
     const int yi0 = first_pixel_ge(ymin, IS), yi1 = last_pixel_le(ymax, IS);    // yi counts from the bottom (K.cu:343)
     int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;                                    // rows from the top
     if (px0 > px1 || r0 > r1) { px0 = 32767; px1 = -1; r0 = 32767; r1 = -1; }    // empty
-    *rect = make_short4((short)px0, (short)px1, (short)r0, (short)r1);
+    *rect = make_short4((short)px0, (short)px1, (short)r0, (short)r1);          // caller-owned (register or global)
     rec[R_BB + 0] = __int_as_float((px0 & 0xffff) | (px1 << 16));
     rec[R_BB + 1] = __int_as_float((r0 & 0xffff) | (r1 << 16));
     {

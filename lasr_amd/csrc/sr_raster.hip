@@ -32,29 +32,56 @@
 namespace lasr {
 
 constexpr int TILE = 16;        // pixels per tile side (4 waves of 8x8)
-constexpr int LIST_CAP = 2048;  // faces scanned per round == capacity of each LDS list (u16 ids; 5 lists = 20 KB)
+#ifndef LASR_LIST_CAP
+#define LASR_LIST_CAP 2048
+#endif
+constexpr int LIST_CAP = LASR_LIST_CAP;  // capacity of each LDS face list (u16 ids relative to the round's first face; 5 lists = 20 KB)
 
 // ---------------------------------------------------------------------------
 // One thread builds one face's record -- into LDS; the block then writes its 256 records (48 KB, contiguous in the
 // workspace) with coalesced stores.  Writing the 192-B records straight from the building threads is a 192-B-strided
 // scatter: the PMC pass of round 1 showed 2x the algorithmic write traffic for it (profiles/r01i_pmc.txt).
 constexpr int SETUP_STRIDE = REC + 1;      // odd LDS stride: the building threads' stores spread over the banks
+constexpr int GROUP = 64;                  // faces per group rect (one wave of the setup kernel, one wave-load of the forward scan)
+
+__device__ __forceinline__ int groups_of(int F) { return (F + GROUP - 1) / GROUP; }
+
+// Grid: one block per (image, 256 consecutive faces of it) -- groups of 64 faces never straddle images.  Besides the records
+// and the per-face pixel rects it writes one UNION rect per group of 64 consecutive faces (grects [N, ceil(F/64)]): the forward
+// kernel tests those first and scans only the groups that can touch its tile.  Meshes number their faces patch by patch, so
+// a 16x16 tile typically meets 2-6 of the ~40 groups; an arbitrary numbering degrades to the full scan, never to a wrong list.
 __global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__ faces, float* __restrict__ recs,
-                                                       short4* __restrict__ rects, float* __restrict__ info27,
-                                                       int total, float margin, int IS)
+                                                       short4* __restrict__ rects, short4* __restrict__ grects,
+                                                       float* __restrict__ info27, int F, int blocks_per_image,
+                                                       float margin, int IS)
 {
     __shared__ float s_rec[256 * SETUP_STRIDE];
-    const int first = blockIdx.x * 256;
-    const int i = first + threadIdx.x;
-    if (i < total)
-        build_record(faces + (size_t)i * 9, s_rec + threadIdx.x * SETUP_STRIDE, rects + i, margin, IS,
-                     info27 ? info27 + (size_t)i * 27 : nullptr);
+    const int bn = blockIdx.x / blocks_per_image;
+    const int chunk = blockIdx.x - bn * blocks_per_image;
+    const int local = chunk * 256 + threadIdx.x;               // face index inside the image
+    const size_t first = (size_t)bn * F + (size_t)chunk * 256;
+    const size_t i = first + threadIdx.x;
+    short4 r = make_short4(32767, -1, 32767, -1);               // neutral element of the union (= the empty rect)
+    if (local < F) {
+        build_record(faces + i * 9, s_rec + threadIdx.x * SETUP_STRIDE, &r, margin, IS, info27 ? info27 + i * 27 : nullptr);
+        rects[i] = r;
+    }
+    // union rect of this wave's 64 faces (empty rects are neutral: x0 = 32767, x1 = -1)
+    int x0 = r.x, x1 = r.y, y0 = r.z, y1 = r.w;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, d)); x1 = max(x1, __shfl_xor(x1, d));
+        y0 = min(y0, __shfl_xor(y0, d)); y1 = max(y1, __shfl_xor(y1, d));
+    }
+    const int g = chunk * 4 + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && g < groups_of(F))
+        grects[(size_t)bn * groups_of(F) + g] = make_short4((short)x0, (short)x1, (short)y0, (short)y1);
     __syncthreads();
-    const int nflt = min(256, total - first) * REC;
-    float* __restrict__ out = recs + (size_t)first * REC;
+    const int nflt = min(256, F - chunk * 256) * REC;
+    float* __restrict__ out = recs + first * REC;
     for (int k = threadIdx.x; k < nflt; k += 256) {
-        const int r = k / REC;
-        out[k] = s_rec[r * SETUP_STRIDE + (k - r * REC)];
+        const int rr = k / REC;
+        out[k] = s_rec[rr * SETUP_STRIDE + (k - rr * REC)];
     }
 }
 
@@ -189,15 +216,52 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
     const float q_yhi = pix_center(IS - 1 - qy0, IS), q_ylo = pix_center(IS - 1 - min(qy0 + 7, IS - 1), IS);
 
-    for (int base = 0; base < A.F; base += LIST_CAP) {      // one round unless F > LIST_CAP
-        const int end = min(base + LIST_CAP, A.F);
-        if (base > 0) __syncthreads();                      // the previous round's lists are still being walked
-        // ---- level 1 (workgroup): ordered compaction of faces [base,end) whose rect touches the 16x16 tile
-        int count = 0, flip = 0;
-        for (int c = base; c < end; c += 256, flip ^= 1) {
-            const int f = c + tid;
+    // ---- level 0: which groups of 64 consecutive faces can touch this tile (union rects written by the setup kernel).  Every
+    // wave evaluates the same test on the same data, so the masks agree across the workgroup without a barrier.
+    const int G = groups_of(A.F);
+    const short4* __restrict__ grects = A.grects + (size_t)bn * G;
+    int g_next = 0;                                            // first group not yet looked at
+    unsigned long long gmask = 0;                              // touched groups among [g_mask0, g_mask0 + 64)
+    int g_mask0 = 0;
+    bool more = G > 0;
+    for (int round = 0; more; round++) {                      // one round unless a tile meets more than LIST_CAP - 256 faces
+        if (round > 0) __syncthreads();                        // the previous round's lists are still being walked
+        // ---- level 1 (workgroup): ordered compaction of the touched groups' faces whose rect touches the 16x16 tile; a
+        // round ends when the list could overflow or the u16 ids (relative to `base`) could
+        int count = 0, flip = 0, base = -1;
+        for (;;) {
+            if (gmask == 0) {
+                if (g_next >= G) { more = false; break; }
+                g_mask0 = g_next;
+                bool t = false;
+                if (g_next + lane < G) {
+                    const short4 q = grects[g_next + lane];
+                    t = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
+                }
+                gmask = __ballot(t);
+                g_next += 64;
+                continue;
+            }
+            // the next (up to) four touched groups, one per wave, in index order
+            unsigned long long mm = gmask;
+            int mine_g = -1, last_g = 0, taken = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (mm) {
+                    const int b = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    if (k == wave) mine_g = g_mask0 + b;
+                    last_g = g_mask0 + b;
+                    taken++;
+                }
+            }
+            const int first_g = g_mask0 + __builtin_ctzll(gmask);
+            if (base < 0) base = first_g * GROUP;
+            if (count + 256 > LIST_CAP || (last_g + 1) * GROUP - base > 65536) break;      // walk what we have, then continue
+            gmask = mm;
             bool hit = false;
-            if (f < end) {
+            const int f = mine_g * GROUP + lane;
+            if (mine_g >= 0 && f < A.F) {
                 const short4 q = rects[f];
                 hit = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
             }
@@ -208,7 +272,10 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
             if (hit) s_all[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
             count += c0 + c1 + c2 + c3;
+            flip ^= 1;
+            (void)taken;
         }
+        if (base < 0) base = 0;
         __syncthreads();
         // ---- level 2 (wave, no barriers from here on): 64 list entries at a time, keep those touching the quadrant
         int n_mine = 0;
@@ -243,6 +310,9 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
         }
         __builtin_amdgcn_wave_barrier();
         // ---- walk: every entry has at least one candidate pixel in this wave
+#if defined(LASR_ABL) && LASR_ABL == 2              // measurement build: binning only
+        s.a += (float)n_mine; n_mine = 0;
+#endif
         for (int i0 = 0; i0 < n_mine; i0 += 64) {
             const int chunk = (i0 + lane < n_mine) ? (int)mine[i0 + lane] : 0;
             const int n = min(64, n_mine - i0);
@@ -258,10 +328,18 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 const int lim = (A.N * A.F - (bn * A.F + fn)) * A.T;   // texels to the end of the tensor
                 const cptr_t tex = as_const(texs + (size_t)fn * texstride);
                 const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
+#if defined(LASR_ABL) && LASR_ABL == 1      // measurement build: binning + walk + reject only
+                if (cand) s.a += w0 + w1 + w2;
+                (void)lim; (void)tex; (void)mk;
+#elif defined(LASR_ABL) && LASR_ABL == 3    // measurement build: + distance and sigmoid, nothing after them
+                if (cand) { Frag fr; if (fragment_w<false, true>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, U.inv_sigma)) s.a += fr.D; }
+                (void)lim; (void)tex; (void)mk;
+#else
                 if (cand) {
                     if (mk) forward_face<LASR_FAST, true, NCH, RX>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
                     else forward_face<LASR_FAST, false, NCH>(A, m, rec, tex, fn, lim, xp, yp, w0, w1, w2, s, U);
                 }
+#endif
             }
         }
     }
@@ -339,7 +417,8 @@ extern "C" size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS)
     (void)T; (void)IS;
     if (N < 0 || F < 0) return 0;
     const size_t nf = (size_t)N * (size_t)F;
-    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) + 256;
+    const size_t ng = (size_t)N * (size_t)((F + GROUP - 1) / GROUP);
+    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) + align_up(ng * sizeof(short4), 256) + 256;
 }
 
 static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alpha, int tex)
@@ -354,14 +433,15 @@ static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alph
 
 static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T, int IS, float near, float far,
                             float eps, float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
-                            int tex, int double_side, float** recs, short4** rects)
+                            int tex, int double_side, float** recs, short4** rects, short4** grects)
 {
     const size_t nf = (size_t)N * (size_t)F;
     char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     *recs = (float*)p;
     *rects = (short4*)(p + align_up(nf * REC * sizeof(float), 256));
+    *grects = (short4*)((char*)*rects + align_up(nf * sizeof(short4), 256));
     RasterArgs A;
-    A.recs = *recs; A.rects = *rects; A.textures = textures;
+    A.recs = *recs; A.rects = *rects; A.grects = *grects; A.textures = textures;
     A.N = N; A.F = F; A.T = T; A.res = (int)sqrt((double)T); A.IS = IS;   // K.cu:696
     A.near = near; A.far = far; A.near_far_dev = nullptr; A.eps = eps; A.sigma = sigma; A.gamma = gamma;
     A.thr = dist_eps * sigma;                                              // K.cu:352 (float product)
@@ -391,9 +471,9 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     if (!aggrs_info || !soft_colors || (F > 0 && (!faces || !textures))) return LASR_E_BADARG;
     if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, IS)) return LASR_E_WORKSPACE;
     hipStream_t st = (hipStream_t)hip_stream;
-    float* recs; short4* rects;
+    float* recs; short4* rects; short4* grects;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
-                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
+                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects, &grects);
     A.near_far_dev = near_far_dev;
     if (background) {
         A.use_bg = 1;
@@ -403,8 +483,9 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     if (total > 0) {
         {
             ProfScope ps(K_SR_SETUP, st);
-            hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, rects,
-                               faces_info, total, sqrtf(A.thr), IS);
+            const int bpi = (F + 255) / 256;
+            hipLaunchKernelGGL(sr_setup_kernel, dim3((unsigned)(N * bpi)), dim3(256), 0, st, faces, recs, rects, grects,
+                               faces_info, F, bpi, sqrtf(A.thr), IS);
         }
         if ((rc = launch_ok())) return rc;
     }
@@ -440,17 +521,18 @@ static int backward_impl(const float* faces, const float* textures, const float*
         return LASR_E_BADARG;
     if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, IS)) return LASR_E_WORKSPACE;
     hipStream_t st = (hipStream_t)hip_stream;
-    float* recs; short4* rects;
+    float* recs; short4* rects; short4* grects;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,
-                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects);
+                             gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side, &recs, &rects, &grects);
     A.near_far_dev = near_far_dev;
     A.overwrite_grads = (flags & LASR_SR_GRADS_OVERWRITE) && texture_sample_type == 1;
     const int total = N * F;
     if (!(flags & LASR_SR_RECORDS_VALID)) {      // the caller vouches that the forward's records are still in the workspace
         {
             ProfScope ps(K_SR_SETUP, st);
-            hipLaunchKernelGGL(sr_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, faces, recs, rects,
-                               (float*)nullptr, total, sqrtf(A.thr), IS);
+            const int bpi = (F + 255) / 256;
+            hipLaunchKernelGGL(sr_setup_kernel, dim3((unsigned)(N * bpi)), dim3(256), 0, st, faces, recs, rects, grects,
+                               (float*)nullptr, F, bpi, sqrtf(A.thr), IS);
         }
         if ((rc = launch_ok())) return rc;
     }
