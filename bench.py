@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--rebuild-records', type=int, default=1, help='1: the backward rebuilds the per-face records (default), '
                     '0: it reuses the forward\'s (LASR_SR_RECORDS_VALID)')
     ap.add_argument('--no-lbs', action='store_true', help='skip the LBS (MFMA) micro-benchmark block')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the launch-size sweep (N = 1/4/16/64 at 256^2, 64 at 512^2)')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
     return ap.parse_args()
 
@@ -63,7 +64,10 @@ def parse():
 class RasterStep:
     """Pre-allocated buffers + one fwd/bwd pass through the C ABI."""
 
-    def __init__(self, dev, B, first_frame):
+    def __init__(self, dev, B, first_frame, image_size=None):
+        global IS
+        IS = image_size or IS
+        self.IS = IS
         self.dev, self.B = dev, B
         v, f, tex = synth.blobby_mesh(NU)
         self.V, self.F = v.shape[0], f.shape[0]
@@ -88,7 +92,7 @@ class RasterStep:
         self.white = (ctypes.c_float * 3)(1., 1., 1.)
 
     def step(self):
-        B, F, h = self.B, self.F, self.h
+        B, F, h, IS = self.B, self.F, self.h, self.IS
         # No background fill and no gradient zeroing passes: the background colour (1,1,1) is an argument of lasr_sr_forward_bg,
         # which writes every element of soft_colors (the reference pre-fills and re-reads it, soft_rasterize.py:50-53), and the
         # backward stores every gradient element (LASR_SR_GRADS_OVERWRITE).
@@ -97,7 +101,8 @@ class RasterStep:
                                   self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                                   B, F, 3, 3, IS, near, far, None, *tail, self.white, _lib.SR_DEFAULT_FLAGS, self.stream)
         _lib.check(rc, 'lasr_sr_forward_bg')
-        # the backward finds the forward's per-face records still in the workspace (what the autograd operator does)
+        # the backward rebuilds the per-face records (REBUILD_RECORDS = 1, what the autograd operator does: records written a
+        # few microseconds earlier are warmer in L2 than the forward's, profiles/r02e_records_reuse.txt)
         rc = h.lasr_sr_backward_ex(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), self.aggrs.data_ptr(),
                                    self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(), self.ws.data_ptr(),
                                    self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail,
@@ -256,39 +261,112 @@ def optimize_leg(dev, iters):
                       'multi-tensor HIP launches'}
 
 
+RASTER_SOURCES = ('sr_raster.hip', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
+VALU_PEAK_LANE_OPS = 1024 * 32 * 2.4e9      # 256 CUs x 4 SIMDs, 32 fp32 lanes per SIMD per clock (a wave64 op issues in 2), 2.4 GHz
+
+
+def raster_source_hash():
+    """sha256 over the raster kernel sources + build flags; tools/{traffic,valu}_json.py store it in the counter files they
+    write, so a committed PMC pass that predates a kernel change is recognised (and not reported) instead of going stale
+    silently.  tests/test_profiles_fresh.py fails when the newest committed files do not match."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in RASTER_SOURCES:
+        h.update(open(os.path.join(ROOT, 'lasr_amd', 'csrc', n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def _latest_profile(suffix):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)))
+    if not files:
+        return None, None, 'no profiles/*%s committed' % suffix
+    d = json.load(open(files[-1]))
+    name = os.path.basename(files[-1])
+    if d.get('source_sha') != raster_source_hash():
+        msg = ('%s was measured on other raster sources (its source_sha %s, now %s): re-run tools/prof/r03_final.sh'
+               % (name, d.get('source_sha'), raster_source_hash()))
+        print('bench.py: STALE COUNTER FILE -- ' + msg, file=sys.stderr, flush=True)
+        return None, name, msg
+    return d, name, None
+
+
 def measured_traffic(kernel, frames_per_launch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, latest round), scaled
     to this run's frames per launch.  PMC counters cannot be read from inside this process; the file records the
     exact command they came from.  None if no profile has been committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
+    d, name, stale = _latest_profile('_traffic.json')
+    if d is None:
+        return None, name, stale
     k = d.get('kernels', {}).get(kernel)
     if not k:
-        return None, None
-    return k['bytes'] * frames_per_launch / d['frames_per_launch'], os.path.basename(files[-1])
+        return None, name, 'kernel not in ' + name
+    return k['bytes'] * frames_per_launch / d['frames_per_launch'], name, None
 
 
 def valu_issue(kernel, frames_per_launch, launch_ms):
-    """What actually bounds the raster kernels: VALU issue.  Instruction mix of one launch from the committed SQ counter passes
-    (profiles/*_valu.json, built by tools/valu_json.py from rocprofv3 --pmc SQ_INSTS_VALU*), priced with the per-instruction
-    issue costs measured by tools/ubench/ and compared with this run's launch time."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_valu.json')))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
+    """What actually bounds the raster kernels: VALU issue.  Instruction counts of one launch from the committed SQ counter
+    passes (profiles/*_valu.json, built by tools/valu_json.py from rocprofv3 --pmc SQ_INSTS_VALU* / SQ_THREAD_CYCLES_VALU),
+    combined with THIS run's launch time:
+      valu_frac          = live lane-operations per second / (1024 SIMDs x 32 lanes x 2.4 GHz)   -- the tracked fraction
+      frac_of_launch_time = instruction mix priced with the issue costs measured by tools/ubench/ / launch time."""
+    d, name, stale = _latest_profile('_valu.json')
+    if d is None:
+        return {'source': name, 'stale': stale}
     k = d.get('kernels', {}).get(kernel)
     if not k:
-        return None
+        return {'source': name, 'stale': 'kernel not in ' + name}
     scale = frames_per_launch / d['frames_per_launch']
-    return {'source': os.path.basename(files[-1]), 'valu_wave_instructions_per_launch': k['valu_wave_instructions'] * scale,
-            'live_lane_fraction': k['live_lane_fraction'], 'modelled_issue_ms': k['modelled_issue_ms'] * scale,
+    lane_ops = k['valu_wave_instructions'] * scale * 64 * k['live_lane_fraction']
+    return {'source': name, 'valu_wave_instructions_per_launch': k['valu_wave_instructions'] * scale,
+            'live_lane_fraction': k['live_lane_fraction'],
+            'useful_lane_ops_per_s': lane_ops / (launch_ms * 1e-3), 'peak_lane_ops_per_s': VALU_PEAK_LANE_OPS,
+            'valu_frac': lane_ops / (launch_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+            'issue_slot_frac': k['valu_wave_instructions'] * scale * 2 / (1024 * 2.4e9 * launch_ms * 1e-3),
+            'wait_any_fraction_of_wave_cycles': k.get('wait_any_fraction_of_wave_cycles'),
+            'modelled_issue_ms': k['modelled_issue_ms'] * scale,
             'frac_of_launch_time': k['modelled_issue_ms'] * scale / launch_ms,
-            'note': 'sum over instruction kinds of count x measured issue cycles / (1024 SIMDs x 2.4 GHz); packed fp32 and '
-                    'MFMA do not apply to this arithmetic (DESIGN.md section 4)'}
+            'note': 'valu_frac counts live lanes only (an instruction with 28 of 64 lanes enabled is 28 lane-ops); '
+                    'issue_slot_frac = wave instructions x 2 cycles / SIMD cycles; modelled_issue_ms prices the mix with the '
+                    'measured per-instruction costs (SGPR-operand and transcendental ops issue slower); packed fp32 and MFMA '
+                    'do not apply to this arithmetic (DESIGN.md section 4)'}
+
+
+def sweep_leg(dev, points, steps_budget_ms=150.0):
+    """The launch sizes the reference actually uses (N = 2 / 4 / 16 / 96 meshes per render call), through the
+    same RasterStep as `value`: frames/s, us per frame and per-kernel ms (library HIP events) at each (frames, image size)."""
+    global IS
+    keep = IS
+    out = []
+    h = _lib.lib()
+    for B, size in points:
+        job = RasterStep(dev, B, 0, image_size=size)
+        for _ in range(3):
+            job.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        job.step()
+        torch.cuda.synchronize()
+        steps = int(max(5, min(200, steps_budget_ms * 1e-3 / max(time.perf_counter() - t0, 1e-5))))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        h.lasr_prof_enable(1)
+        for _ in range(min(steps, 10)):
+            job.step()
+        torch.cuda.synchronize()
+        h.lasr_prof_enable(0)
+        kt = collect_kernel_times(h)
+        out.append({'frames': B, 'image_size': size, 'frames_per_s': B / dt, 'ms_per_step': dt * 1e3,
+                    'us_per_frame': dt / B * 1e6, 'steps': steps,
+                    'kernel_ms': {k: round(v[0], 5) for k, v in kt.items()},
+                    'kernel_us_per_frame': round(sum(v[0] * (2 if k == 'sr_setup_kernel' else 1) for k, v in kt.items()) / B * 1e3, 3)})
+        del job
+    IS = keep
+    return out
 
 
 def main():
@@ -378,7 +456,8 @@ def main():
                'sr_setup_kernel': (36 + 192 + 8) * F * B}
         dom = max((k for k in ktimes if k != 'sr_setup_kernel'), key=lambda k: ktimes[k][0])
         achieved = alg[dom] / (ktimes[dom][0] * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(dom, B) if IS == 256 else (None, None)   # PMC passes were taken at 256x256
+        traffic, traffic_src, traffic_stale = measured_traffic(dom, B) if IS == 256 else (None, None, 'PMC passes are taken at 256x256')
+        vi = valu_issue(dom, B, ktimes[dom][0]) if IS == 256 else None
         frames = world * B * a.steps
         out = {
             'metric': 'rasterizer fwd+bwd frames/sec at %dx%d, 2.3k faces' % (IS, IS),
@@ -390,12 +469,24 @@ def main():
             'config': {'workload': 'soft-rasteriser fwd+bwd, mesh M2 (V=1212,F=2420), %dx%d, LASR modes '
                                    '(euclidean/softmax/prod/vertex, sigma=1e-4, gamma=1e-2)' % (IS, IS),
                        'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
-                       'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                       'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world,
+                       'step_definition': 'face setup + forward kernel (background colour passed as an argument: no pre-fill pass, '
+                                          'every element of soft_colors written) + face setup + backward kernel (stores every '
+                                          'gradient element: no zero-fill pass) + face->vertex scatter of both gradients '
+                                          '(+ RCCL all-reduce of the [2,V,3] mesh gradient for N > 1); rounds 1 and early 2 '
+                                          'also timed the two fill passes the reference caller needs (soft_rasterize.py:50-53, '
+                                          ':88-89), which these entry points make unnecessary'},
+            # achieved / peak / frac are the HBM figures SURVEY 8(d) defines (algorithmic bytes / kernel time); `bound` is what
+            # the counters say binds the kernel: VALU issue (valu_frac is the fraction to track), HBM is two orders of magnitude away
+            'roofline': {'bound': 'valu' if vi and vi.get('valu_frac') else 'hbm', 'kernel': dom, 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'traffic_stale': traffic_stale,
+                         'valu_frac': vi.get('valu_frac') if vi else None,
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ktimes[dom][0],
                          'all_kernels_avg_ms': {k: v[0] for k, v in ktimes.items()},
-                         'valu_issue': valu_issue(dom, B, ktimes[dom][0]) if IS == 256 else None},
+                         'raster_source_sha': raster_source_hash(),
+                         'valu_issue': vi},
         }
         if world == 1:
             # informational: the opt-in relaxed forward arithmetic (lasr_sr_set_forward_math(1), image within ~1e-5 of the
@@ -412,6 +503,9 @@ def main():
                                                'note': 'opt-in; distance + threshold decision bit-faithful, the rest fp32 rcp/exp'}
             finally:
                 h.lasr_sr_set_forward_math(0)
+        if world == 1 and not a.no_sweep:
+            out['sweep'] = sweep_leg(dev, [(1, 256), (4, 256), (16, 256), (64, 256), (64, 512)])
+            IS = a.image_size
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(F)
         if world == 1 and not a.no_lbs:

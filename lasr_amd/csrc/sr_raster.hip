@@ -23,6 +23,7 @@
 // Brute force in the reference is N*P*F pair tests; here a pixel only ever sees the faces binned to its quadrant.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/lasr_sr.h"
 #include "sr_device.h"
@@ -161,13 +162,26 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
 // geometry -- LASR's flow renders, nnutils/mesh_net.py:85-87, rasterise the same mesh twice with two different
 // per-vertex attributes; channels are independent, so the result equals the two separate renders) or 9 (the flow
 // attributes plus the texture colours: the texture render of a LASR step, mesh_net.py:348-363, has the same geometry).
-template <bool LASR_FAST, int NCH, bool RX = false>
+// LDSR = the small-launch variant (LASR's mode combination, vertex attributes): with few frames per launch a quadrant's
+// wave runs nearly alone on its SIMD and the walk is a serial chain of dependent scalar-cache misses (record line 0 -> test
+// -> lines 1, 2 -> attributes), ~0.5 us per list entry; here the wave copies the records + attributes of its next 16 entries
+// into LDS with wide vector loads (one round trip per 16 entries, the following 16 already in flight in registers) and reads
+// the fields back with same-address (broadcast) ds_reads.  Same arithmetic, same order: bit-identical output.  At large
+// launches the scalar-cache walk wins (7 waves per SIMD hide the misses, SGPR operands cost no LDS instruction): the host
+// picks the variant by launch size (forward_impl).
+constexpr int STAGE = 16;                  // entries staged per round: 64 lanes = 16 slots x 4 parts
+constexpr int SLOT = REC + 28;             // dwords per staged entry: record + up to 27 vertex attributes (9 channels) + 1 pad
+typedef const float __attribute__((address_space(3)))* lptr_t;
+
+template <bool LASR_FAST, int NCH, bool RX = false, bool LDSR = false>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
 {
-    __shared__ unsigned short s_all[LIST_CAP];        // faces whose pixel rect touches the 16x16 tile, index order
-    __shared__ unsigned short s_mine[4][LIST_CAP];    // per wave: the subset touching its 8x8 quadrant, index order
+    constexpr int CAP = LDSR ? 1024 : LIST_CAP;       // the staging buffers take LDS: shorter lists (more rounds when a tile is crowded)
+    __shared__ unsigned short s_all[CAP];             // faces whose pixel rect touches the 16x16 tile, index order
+    __shared__ unsigned short s_mine[4][CAP];         // per wave: the subset touching its 8x8 quadrant, index order
     __shared__ int s_wcnt[2][4];
+    __shared__ __attribute__((aligned(16))) float s_stage[LDSR ? 4 * STAGE * SLOT : 4];
 
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             }
             const int first_g = g_mask0 + __builtin_ctzll(gmask);
             if (base < 0) base = first_g * GROUP;
-            if (count + 256 > LIST_CAP || (last_g + 1) * GROUP - base > 65536) break;      // walk what we have, then continue
+            if (count + 256 > CAP || (last_g + 1) * GROUP - base > 65536) break;           // walk what we have, then continue
             gmask = mm;
             bool hit = false;
             const int f = mine_g * GROUP + lane;
@@ -313,6 +327,58 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
 #if defined(LASR_ABL) && LASR_ABL == 2              // measurement build: binning only
         s.a += (float)n_mine; n_mine = 0;
 #endif
+        if constexpr (LDSR) {
+            float* const stage = s_stage + wave * (STAGE * SLOT);
+            const int slot = lane >> 2, part = lane & 3;
+            float4 p0 = {}, p1 = {}, p2 = {}, p3 = {};
+            float pret[3 * NCH] = {};
+            // LASR_FETCH(i0): this lane's share of entries [i0, i0 + STAGE) into registers (a macro, not a lambda: captured
+            // arrays would live in scratch)
+#define LASR_FETCH(I0)                                                                                        \
+            if ((I0) + slot < n_mine) {                                                                       \
+                const int fn_ = base + (int)mine[(I0) + slot];                                                \
+                if (part < 3) {                                                                               \
+                    const float4* src = reinterpret_cast<const float4*>(recs + (size_t)fn_ * REC + part * 16); \
+                    p0 = src[0]; p1 = src[1]; p2 = src[2]; p3 = src[3];                                       \
+                } else {                                                                                      \
+                    const float* src = texs + (size_t)fn_ * texstride;                                        \
+                    _Pragma("unroll") for (int k = 0; k < 3 * NCH; k++) pret[k] = src[k];                     \
+                }                                                                                             \
+            }
+            LASR_FETCH(0)
+            for (int i0 = 0; i0 < n_mine; i0 += STAGE) {
+                const int n = min(STAGE, n_mine - i0);
+                if (slot < n) {
+                    if (part < 3) {
+                        float4* dst = reinterpret_cast<float4*>(stage + slot * SLOT + part * 16);
+                        dst[0] = p0; dst[1] = p1; dst[2] = p2; dst[3] = p3;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3 * NCH; k++) stage[slot * SLOT + REC + k] = pret[k];
+                    }
+                }
+                LASR_FETCH(i0 + STAGE)                           // in flight while this chunk is walked
+                __builtin_amdgcn_wave_barrier();
+                const int ids = (lane < n) ? (int)mine[i0 + lane] : 0;
+                for (int j = 0; j < n; j++) {
+                    const int fn = base + __builtin_amdgcn_readlane(ids, j);
+                    const lptr_t rec = (lptr_t)(stage + j * SLOT);
+                    const lptr_t tex = rec + REC;
+                    const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
+                    const bool cand = valid && px >= (int)(short)(rx & 0xffff) && px <= (rx >> 16) &&
+                                      py >= (int)(short)(ry & 0xffff) && py <= (ry >> 16);
+                    float w0, w1, w2;
+                    barycentric(rec, xp, yp, w0, w1, w2);
+                    const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);
+                    if (cand) {
+                        if (mk) forward_face<LASR_FAST, true, NCH, RX>(A, m, rec, tex, fn, 0, xp, yp, w0, w1, w2, s, U);
+                        else forward_face<LASR_FAST, false, NCH>(A, m, rec, tex, fn, 0, xp, yp, w0, w1, w2, s, U);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                 // the next round overwrites the slots
+            }
+#undef LASR_FETCH
+        } else
         for (int i0 = 0; i0 < n_mine; i0 += 64) {
             const int chunk = (i0 + lane < n_mine) ? (int)mine[i0 + lane] : 0;
             const int n = min(64, n_mine - i0);
@@ -456,6 +522,18 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
 static int g_forward_math = 0;                               // 0 = reference-faithful (default), 1 = relaxed, see forward_face
 static int default_flags() { return g_forward_math ? LASR_SR_RELAXED_MATH : 0; }
 
+// Launches of at most this many 16x16-pixel tiles (frames x tiles per frame) take the LDS-staged forward walk.  Measured on
+// an MI355X, mesh M2 at 256x256 (1024 tiles per frame), forward kernel, scalar-cache walk -> LDS walk: 1 frame 203 -> 206 us,
+// 4 frames 226 -> 219 us, 16 frames 308 -> 281 us, 64 frames 735 -> 755 us, 256 frames 2.556 -> 2.587 ms
+// (profiles/r03_lds_walk_ab.txt).  Default: up to 24 frames' worth of tiles.  Environment override
+// LASR_SR_LDS_WALK_MAX_BLOCKS (0 = never), read once; the output is bit-identical either way.
+static long long lds_walk_default()
+{
+    const char* e = getenv("LASR_SR_LDS_WALK_MAX_BLOCKS");
+    return e ? atoll(e) : 24576;
+}
+static const long long g_lds_walk_max_blocks = lds_walk_default();
+
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
 static int forward_impl(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
@@ -494,7 +572,12 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     {
         ProfScope ps(K_SR_FORWARD, st);
         const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
-        if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        // small launches: the LDS-staged walk (sr_forward_kernel<.., LDSR = true>); see g_lds_walk_max_blocks
+        const bool lds = (nch > 3 || is_lasr_fast(A.m)) && !rx && (long long)grid.x <= g_lds_walk_max_blocks;
+        if (lds && nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (lds && nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (lds) hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        else if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);

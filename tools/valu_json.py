@@ -4,8 +4,12 @@ VALU wave-instruction mix of one launch and the issue time it implies under the 
 tools/ubench/ (profiles/r02_valu_issue.txt).  bench.py attaches it to the JSON line as `valu_issue`.
 usage: valu_json.py <pmc_sq.txt> <frames_per_launch>"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import raster_source_hash          # noqa: E402  (the sources the counters were measured on)
 
 COST = {'fp32_vgpr': 2.5, 'fp32_sgpr_operand': 4.15, 'f64': 4.3, 'transcendental': 8.3, 'other': 4.1}   # cycles @ 2.4 GHz per wave64
 SGPR_SHARE = {'sr_forward_kernel': 0.28, 'sr_backward_kernel': 0.45}     # static share of fp32 mul/add/fma with an SGPR source (ISA)
@@ -18,7 +22,7 @@ for line in open(txt):
     if not m or 'ILb1ELi3ELb1' in line or 'setup' in line:
         continue
     k.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
-out = {'frames_per_launch': frames, 'cycles_per_wave_instruction': COST, 'simds': SIMDS, 'clock_ghz': GHZ, 'kernels': {}}
+out = {'frames_per_launch': frames, 'source_sha': raster_source_hash(), 'cycles_per_wave_instruction': COST, 'simds': SIMDS, 'clock_ghz': GHZ, 'kernels': {}}
 for name, c in k.items():
     fp32 = c['SQ_INSTS_VALU_MUL_F32'] + c['SQ_INSTS_VALU_FMA_F32'] + c['SQ_INSTS_VALU_ADD_F32']
     f64 = c['SQ_INSTS_VALU_MUL_F64'] + c['SQ_INSTS_VALU_FMA_F64'] + c['SQ_INSTS_VALU_ADD_F64']
