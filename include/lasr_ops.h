@@ -324,6 +324,18 @@ int lasr_mean_shape_backward(const float* tex, const float* flip, const float* m
 int lasr_obs_pair(const float* imgs, const float* masks, float* out, int n, int P, void* hip_stream);
 
 /*
+ * A training batch as one row gather: the input side of LASRTrainer.set_input, nnutils/train_utils.py:125-181, for a sequence
+ * that is resident in HBM.  table [pairs, W] holds, per distinct frame pair, the model's batch
+ * dictionary of that pair key after key (key k at columns [seg_off[k], seg_off[k] + seg_len[k]), frame t then frame t');
+ * ids [B] (int64, device) selects the pairs; out receives key k's [B, seg_len[k]] block at out_off[k] -- pair-major, the
+ * interleaved layout of train_utils.py:179-180.  One launch; n_keys <= LASR_GATHER_MAX_KEYS.  The offset arrays are HOST memory.
+ */
+#define LASR_GATHER_MAX_KEYS 24
+int lasr_gather_rows(const float* table, long long W, int pairs, const long long* ids, int B, int n_keys,
+                     const long long* seg_off, const long long* seg_len, const long long* out_off, float* out,
+                     void* hip_stream);
+
+/*
  * The optimisation-step tail, nnutils/train_utils.py:282-296: clip the mean-shape gradient to
  * norm max_norm_shape (1) and the encoder + code-predictor gradients jointly to max_norm_cam (10) with
  * torch.nn.utils.clip_grad_norm_'s coefficient min(1, max / (norm + 1e-6)); if ANY gradient element is NaN / Inf every gradient

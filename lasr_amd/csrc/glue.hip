@@ -558,6 +558,56 @@ extern "C" int lasr_obs_pair(const float* imgs, const float* masks, float* out, 
     return launch_ok();
 }
 
+// ---- a training batch as ONE row gather (SURVEY section 8 row f2 + the input side of a1) --------------------------------------
+// Every distinct frame pair of a sequence lives in HBM as one row of `table` [pairs, W]: the model's batch dictionary of the
+// pair (/root/reference/nnutils/train_utils.py:164-178), key after key, each key's segment holding frame t then frame t'.
+// A batch of B pairs is `out`, key-major: key k's segment is [B, len_k] (pair-major = the interleaved layout set_input
+// produces, train_utils.py:179-180) at out_off[k].  The reference collates B samples on the host and copies ~15 tensors per
+// iteration; the torch version of this gather was 15 index_select launches + 15 copies into the HIP graph's static inputs.
+struct GatherKeys { int n; long long seg_off[LASR_GATHER_MAX_KEYS], seg_len[LASR_GATHER_MAX_KEYS], out_off[LASR_GATHER_MAX_KEYS]; };
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, long long W, const long long* __restrict__ ids,
+                                                          GatherKeys K, float* __restrict__ out, int pairs)
+{
+    const int b = blockIdx.x;
+    long long row = ids[b];
+    row = row < 0 ? 0 : (row >= pairs ? pairs - 1 : row);          // ids are produced by the loader itself; never read out of bounds
+    const float* __restrict__ src = table + row * W;
+    for (int k = 0; k < K.n; k++) {
+        const long long len = K.seg_len[k];
+        const float* __restrict__ s = src + K.seg_off[k];
+        float* __restrict__ d = out + K.out_off[k] + (long long)b * len;
+        if (((K.seg_off[k] | len | K.out_off[k] | W) & 3) == 0) {   // 16-B aligned segment: float4 copies
+            const long long n4 = len >> 2;
+            for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < n4; i += (long long)gridDim.y * 256)
+                reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+        } else {
+            for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256) d[i] = s[i];
+        }
+    }
+}
+
+extern "C" int lasr_gather_rows(const float* table, long long W, int pairs, const long long* ids, int B, int n_keys,
+                                const long long* seg_off, const long long* seg_len, const long long* out_off, float* out,
+                                void* hip_stream)
+{
+    if (B < 0 || n_keys < 0 || n_keys > LASR_GATHER_MAX_KEYS || W < 0 || pairs < 0) return LASR_E_BADARG;
+    if (B == 0 || n_keys == 0) return LASR_OK;
+    if (!table || !ids || !seg_off || !seg_len || !out_off || !out || pairs == 0) return LASR_E_BADARG;
+    GatherKeys K;
+    K.n = n_keys;
+    long long longest = 0;
+    for (int k = 0; k < n_keys; k++) {
+        if (seg_off[k] < 0 || seg_len[k] < 0 || out_off[k] < 0 || seg_off[k] + seg_len[k] > W) return LASR_E_BADARG;
+        K.seg_off[k] = seg_off[k]; K.seg_len[k] = seg_len[k]; K.out_off[k] = out_off[k];
+        longest = seg_len[k] > longest ? seg_len[k] : longest;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const unsigned chunks = (unsigned)(longest / (4 * 256 * 8) + 1 > 64 ? 64 : longest / (4 * 256 * 8) + 1);
+    LASR_LAUNCH(K_GATHER_ROWS, gather_rows_kernel, dim3((unsigned)B, chunks), dim3(256), 0, table, W, ids, K, out, pairs);
+    return launch_ok();
+}
+
 extern "C" int lasr_fill_planes(float* dst, const float* values, int n_values, int N, long long plane_elems, void* hip_stream)
 {
     if (N < 0 || plane_elems < 0 || n_values < 1 || n_values > LASR_FILL_MAX_PLANES) return LASR_E_BADARG;

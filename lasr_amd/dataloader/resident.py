@@ -4,10 +4,12 @@ A LASR sequence is tens of frames; every distinct (frame, neighbour) pair, prepa
 (the batch dictionary of /root/reference/nnutils/train_utils.py:125-181, fp32), is ~5 MB.  Instead of decoding on
 worker processes, collating, pinning and copying a batch per iteration -- about 85 ms of host work per batch on the
 benchmark machine against a 9 ms optimisation step -- every pair is prepared ONCE, kept on the device, and a batch is a
-row gather.  The iteration order is still the sampler's (DistributedSampler over the padded pair list, vid.py:126-131).
+row gather -- ONE launch (dataloader/packed.py).  The iteration order is still the sampler's (DistributedSampler over the padded pair list, vid.py:126-131).
 """
 import torch
 from torch.utils.data.dataloader import default_collate
+
+from .packed import PackedTable
 
 
 class ResidentLoader:
@@ -24,7 +26,7 @@ class ResidentLoader:
                 key_of[k] = (len(key_of), i)
             self.pair_of_index.append(key_of[k][0])
         rows = [to_model_batch(default_collate([ds[first]])) for _, first in sorted(key_of.values())]
-        self.table = {k: torch.stack([r[k] for r in rows]).to(device) for k in rows[0]}       # [pairs, 2, ...]
+        self.table = PackedTable(rows, device)                # one [pairs, W] tensor; a batch is one gather launch (packed.py)
         self.pair_of_index = torch.tensor(self.pair_of_index, device=device)
         self.n_pairs = len(rows)
 
@@ -37,4 +39,4 @@ class ResidentLoader:
         B = self.batch_size
         for i in range(len(self)):
             ids = pairs[i * B:(i + 1) * B]
-            yield {k: t.index_select(0, ids).flatten(0, 1) for k, t in self.table.items()}    # pair-major = interleaved
+            yield self.table.gather(ids)                      # pair-major = interleaved; views into one persistent buffer

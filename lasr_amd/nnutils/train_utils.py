@@ -135,8 +135,8 @@ class LASRTrainer:
         per_epoch = opts.iters_per_epoch
         order = torch.randperm(max(npairs, per_epoch * opts.batch_size * self.world),
                                generator=torch.Generator().manual_seed(0)) % npairs
-        mine = order[self.rank::self.world]
-        self.dataloader = [mine[i * opts.batch_size:(i + 1) * opts.batch_size].tolist() for i in range(per_epoch)]
+        mine = order[self.rank::self.world].to(self.device)          # ids live on the device: a batch is a view + one gather launch
+        self.dataloader = [mine[i * opts.batch_size:(i + 1) * opts.batch_size] for i in range(per_epoch)]
 
     def set_input(self, batch):
         if not isinstance(batch, dict):
@@ -223,10 +223,12 @@ class LASRTrainer:
     def _graphed_forward_backward(self, batch, key):
         g = self._graphs.get(key) if hasattr(self, '_graphs') else None
         if g is None:
-            if not hasattr(self, '_graphs'):
-                self._graphs, self._static = {}, {k: v.clone() for k, v in batch.items()}
-            for k, v in batch.items():
-                self._static[k].copy_(v)
+            persistent = getattr(batch, 'persistent', False)     # views into a buffer that never moves (dataloader/packed.py):
+            if not hasattr(self, '_graphs'):                     # the graph reads its inputs straight from it
+                self._graphs, self._static = {}, (batch if persistent else {k: v.clone() for k, v in batch.items()})
+            if self._static is not batch:
+                for k, v in batch.items():
+                    self._static[k].copy_(v)
             # Everything (eager iterations included) runs on self._stream, a non-default stream chosen in
             # init_training: the captured backward then never has to hand gradients to an AccumulateGrad node that
             # lives on another stream (a cross-stream dependency inside a capture crashes hipStreamEndCapture here).
@@ -251,8 +253,9 @@ class LASRTrainer:
             # one live graph each replay has to point the parameters back at the gradients its graph writes
             grads = [(p, p.grad) for p in self.module.parameters() if p.grad is not None]
             g = self._graphs[key] = (graph, loss, aux, grads)
-        for k, v in batch.items():
-            self._static[k].copy_(v)
+        if self._static is not batch:
+            for k, v in batch.items():
+                self._static[k].copy_(v)
         g[0].replay()
         for p, gr in g[3]:
             p.grad = gr

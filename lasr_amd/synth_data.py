@@ -63,8 +63,25 @@ class SyntheticSequence:
     def pairs(self):
         return [(i, (i + self.dframe) % self.n_frames) for i in range(self.n_frames)]
 
+    def packed(self):
+        """The sequence as a PackedTable (dataloader/packed.py): row p = the batch dictionary of pair p, so that a batch is
+        one gather launch into a persistent buffer."""
+        from .dataloader.packed import PackedTable
+        if getattr(self, '_packed', None) is None:
+            self._packed = PackedTable([self._rows([p]) for p in range(len(self.pairs()))], self.device)
+        return self._packed
+
     def batch(self, pair_ids):
-        """pair_ids: list of B indices into pairs().  Returns the dict LASR.forward expects."""
+        """pair_ids: B indices into pairs() (list, or an int64 device tensor).  Returns the dict LASR.forward expects."""
+        if self.device.type == 'cuda' or torch.is_tensor(pair_ids):
+            n = len(self.pairs())
+            ids = pair_ids if torch.is_tensor(pair_ids) else torch.tensor([int(p) % n for p in pair_ids], dtype=torch.int64,
+                                                                          device=self.device)
+            return self.packed().gather(ids)                 # (the kernel clamps an out-of-range id to the last pair)
+        return self._rows(pair_ids)
+
+    def _rows(self, pair_ids):
+        """The batch dictionary assembled with torch ops (builds the packed table; reference layout for the tests)."""
         prs = self.pairs()
         a = [prs[p % len(prs)][0] for p in pair_ids]
         b = [prs[p % len(prs)][1] for p in pair_ids]
