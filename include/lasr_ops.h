@@ -330,6 +330,31 @@ int lasr_obs_pair(const float* imgs, const float* masks, float* out, int n, int 
  * ids [B] (int64, device) selects the pairs; out receives key k's [B, seg_len[k]] block at out_off[k] -- pair-major, the
  * interleaved layout of train_utils.py:179-180.  One launch; n_keys <= LASR_GATHER_MAX_KEYS.  The offset arrays are HOST memory.
  */
+/*
+ * Everything LASR.forward does with the render between the rasteriser and the loss sum, in one pass over the [N,10,P] output of
+ * the nine-attribute render (planes 0-2 texture colours, 3-5 own camera-space position, 6-8 the other frame's position, 9 alpha;
+ * N = I*H images, image ij = i*H + j, first half of the batch = frame t, second half = frame t') and one pass back:
+ *   flow reprojection + background mask (nnutils/mesh_net.py:87-104), silhouette table (:374-390), flow table + weighted error
+ *   map + selection mask (:393-416), texture L1 table (:419-441), and the perceptual network's input pair
+ *   rndpair [2N,3,P] = (render * alpha | render) (:436-441; pass NULL to skip it).
+ * masks / occ [I,P]; flow_obs [I,C>=2,P] with image stride flow_obs_image_stride; img_obs / img_white [I,3,P]; pp [N,2], fl [N]:
+ * image n projects its own position with (pp[n], fl[n]) (no gradient) and the other frame's with (pp[o], fl[o]), o = (n + N/2) % N.
+ * Tables [I,H] are bit-identical to lasr_mask_loss_* / lasr_flow_loss_* / lasr_tex_loss_* on contiguous copies of the planes.
+ * Backward: grad_px [N,10,P] is written whole (zeros on planes 3-5), grad_pp [N,2], grad_fl [N]; grad_rndpair may be NULL.
+ * scratch: lasr_render_tables_scratch_floats(I,H,P) floats, carried from forward to backward.
+ */
+size_t lasr_render_tables_scratch_floats(int I, int H, int P);
+int lasr_render_tables_forward(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                               long long flow_obs_image_stride, const float* img_obs, const float* img_white, const float* pp,
+                               const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab, float* tex_tab, float* flow_rd,
+                               unsigned char* bgmask, float* flow_map, unsigned char* vis_mask, float* rndpair, float* scratch,
+                               int I, int H, int P, void* hip_stream);
+int lasr_render_tables_backward(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                                long long flow_obs_image_stride, const float* img_obs, const float* img_white, const float* pp,
+                                const float* fl, float l1tex_wt, const float* grad_mask_tab, const float* grad_flow_tab,
+                                const float* grad_tex_tab, const float* grad_rndpair, const float* scratch, float* grad_px,
+                                float* grad_pp, float* grad_fl, int I, int H, int P, void* hip_stream);
+
 #define LASR_GATHER_MAX_KEYS 24
 int lasr_gather_rows(const float* table, long long W, int pairs, const long long* ids, int B, int n_keys,
                      const long long* seg_off, const long long* seg_len, const long long* out_off, float* out,

@@ -74,6 +74,9 @@ SIGNATURES = {
     'lasr_tail_chunk_elems': (_i, []),
     'lasr_tail_step': (_i, [_p, _p, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'lasr_obs_pair': (_i, [_p, _p, _p, _i, _i, _p]),
+    'lasr_render_tables_scratch_floats': (_sz, [_i, _i, _i]),
+    'lasr_render_tables_forward': (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f] + [_p] * 9 + [_i, _i, _i, _p]),
+    'lasr_render_tables_backward': (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f] + [_p] * 8 + [_i, _i, _i, _p]),
     'lasr_gather_rows': (_i, [_p, ctypes.c_longlong, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
     'lasr_mean_shape_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_mean_shape_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

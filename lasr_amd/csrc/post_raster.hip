@@ -1,0 +1,356 @@
+// post_raster.hip -- everything LASR.forward does with the render between the rasteriser and the loss sum, as ONE pass over
+// the [N,10,IS,IS] output of the nine-attribute render (planes 0-2 texture colours, 3-5 own camera-space position, 6-8 the
+// other frame's position, 9 alpha) and ONE pass back:
+//   flow reprojection + background mask            nnutils/mesh_net.py:87-104 (render_flow_soft_2's tail)
+//   silhouette loss table                          :374-390
+//   flow loss table (+ weighted error map, vis)    :393-416
+//   texture L1 loss table                          :419-441
+//   the perceptual network's input pair            :436-441 (render * alpha | render), written here instead of mul + cat
+// The separate operators (ops.hip / fused.hip: lasr_mask_loss_*, lasr_flow_loss_*, lasr_tex_loss_*, lasr_flow_reproject_*)
+// stay for callers that render the pieces separately; this file reads the planes IN PLACE (no contiguous copies of channel
+// slices) and its backward writes every plane of grad_px itself (no split / cat / accumulate kernels of autograd).
+// Arithmetic, chunking and fold order are those of the separate kernels, so the tables are bit-identical to theirs.
+//
+// Scratch (floats): part[N][nch][8] | tot[N][8] | img[I][4] | part2[N][nch][4] | part3[N][nch][4]
+#include <hip/hip_runtime.h>
+
+#include "../../include/lasr_ops.h"
+#include "ops_common.h"
+
+namespace lasr {
+
+constexpr int PR_PX_PER_BLOCK = 2048;
+__host__ __device__ inline int pr_nch(int P) { int n = (P + PR_PX_PER_BLOCK - 1) / PR_PX_PER_BLOCK; return n < 1 ? 1 : (n > 64 ? 64 : n); }
+
+struct PrScratch { float *part, *tot, *img, *part2, *part3; };
+__host__ __device__ inline PrScratch pr_scratch(float* base, int I, int H, int P)
+{
+    const size_t N = (size_t)I * H, nch = (size_t)pr_nch(P);
+    PrScratch s;
+    s.part = base;
+    s.tot = s.part + N * nch * 8;
+    s.img = s.tot + N * 8;
+    s.part2 = s.img + (size_t)I * 4;
+    s.part3 = s.part2 + N * nch * 4;
+    return s;
+}
+
+__device__ __forceinline__ float pr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float pr_sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ void pr_range(int P, int nch, int ch, int& p0, int& p1)
+{
+    const int per = (P + nch - 1) / nch;
+    p0 = ch * per;
+    p1 = min(P, p0 + per);
+}
+
+struct PrArgs {
+    const float* px;        // [N,10,P]
+    const float* masks;     // [I,P]
+    const float* occ;       // [I,P]
+    const float* obs;       // [I,C>=2,P] observed flow, image stride obs_stride
+    const float* img_obs;   // [I,3,P]
+    const float* img_white; // [I,3,P]
+    const float* pp;        // [N,2] principal points; image n reprojects the other frame's position with pp[(n + half) % N]
+    const float* fl;        // [N]   focal lengths, same indexing
+    int I, H, P, nch, half;
+    long long obs_stride;
+};
+
+// ---- forward pass 1: everything that needs one look at the render ------------------------------------------------------------
+__global__ __launch_bounds__(256) void render_tables_forward_kernel(PrArgs A, float2* __restrict__ flow, unsigned char* __restrict__ bg,
+                                                                    float* __restrict__ rndpair, float* __restrict__ part)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, N = A.I * A.H;
+    const float* q = A.px + (size_t)ij * 10 * P;
+    const float* m = A.masks + (size_t)i * P;
+    const float* oc = A.occ + (size_t)i * P;
+    const float* io = A.img_obs + (size_t)i * 3 * P;
+    const float* iw = A.img_white + (size_t)i * 3 * P;
+    const int other = (ij + A.half) % N;
+    const float c0x = A.pp[2 * ij], c0y = A.pp[2 * ij + 1], c1x = A.pp[2 * other], c1y = A.pp[2 * other + 1];
+    const float f0 = A.fl[ij], f1 = A.fl[other];
+    int p0, p1;
+    pr_range(P, A.nch, ch, p0, p1);
+    float s_mask = 0.f, c_occ = 0.f, s1 = 0.f, s2 = 0.f, s_sig = 0.f, c_sel = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float a = q[9 * (size_t)P + p];
+        const float r0 = q[p], r1 = q[P + p], r2 = q[2 * (size_t)P + p];
+        float x0 = q[3 * (size_t)P + p], y0 = q[4 * (size_t)P + p], z0 = q[5 * (size_t)P + p];
+        float x1 = q[6 * (size_t)P + p], y1 = q[7 * (size_t)P + p], z1 = q[8 * (size_t)P + p];
+        // reprojection (mesh_net.py:93-104 == flow_reproject_forward_kernel)
+        const bool b = (z0 < 1e-9f) | (z1 < 1e-9f);
+        if (b) x0 = y0 = z0 = x1 = y1 = z1 = 10.f;
+        const float u0 = c0x + (x0 * f0) / z0, v0 = c0y + (y0 * f0) / z0;
+        const float u1 = c1x + (x1 * f1) / z1, v1 = c1y + (y1 * f1) / z1;
+        flow[(size_t)ij * P + p] = make_float2(u1 - u0, v1 - v0);
+        bg[(size_t)ij * P + p] = b ? 1 : 0;
+        const float o = oc[p];
+        if (o != 0.f) {
+            const float d = a - m[p];                                   // silhouette (== mask_loss_forward_kernel)
+            s_mask += d * d; c_occ += 1.f;
+            const float e1 = fabsf(io[p] - r0 * a) + fabsf(io[P + p] - r1 * a) + fabsf(io[2 * (size_t)P + p] - r2 * a);
+            const float e2 = fabsf(iw[p] - r0) + fabsf(iw[P + p] - r1) + fabsf(iw[2 * (size_t)P + p] - r2);
+            s1 += e1 / 3.f; s2 += e2 / 3.f;                             // texture L1 (== tex_loss_forward_kernel)
+            if (!b && m[p] > 0.f) { s_sig += pr_sigmoid(-o); c_sel += 1.f; }   // (== flow_loss_stats_kernel)
+        }
+        if (rndpair) {
+            float* o1 = rndpair + (size_t)ij * 3 * P + p;
+            float* o2 = rndpair + ((size_t)N + ij) * 3 * P + p;
+            o1[0] = r0 * a; o1[P] = r1 * a; o1[2 * (size_t)P] = r2 * a;
+            o2[0] = r0; o2[P] = r1; o2[2 * (size_t)P] = r2;
+        }
+    }
+    s_mask = block_sum(s_mask, red); c_occ = block_sum(c_occ, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+    s_sig = block_sum(s_sig, red); c_sel = block_sum(c_sel, red);
+    if (threadIdx.x == 0) {
+        float* o = part + ((size_t)ij * A.nch + ch) * 8;
+        o[0] = s_mask; o[1] = c_occ; o[2] = s1; o[3] = s2; o[4] = s_sig; o[5] = c_sel; o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+// one block per image i, thread j = hypothesis: fold the chunk partials in chunk order, form the silhouette / texture tables, and
+// the image's flow weight statistics over (j, chunk) in that order (== flow_loss_stats_fold_kernel)
+__global__ __launch_bounds__(64) void render_tables_fold_kernel(const float* __restrict__ part, float* __restrict__ tot, float* __restrict__ img,
+                                                                float* __restrict__ mask_tab, float* __restrict__ tex_tab, int H, int nch,
+                                                                float tex_scale)
+{
+    const int i = blockIdx.x;
+    for (int j = threadIdx.x; j < H; j += 64) {
+        const int ij = i * H + j;
+        float a = 0.f, c = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < nch; k++) {
+            const float* o = part + ((size_t)ij * nch + k) * 8;
+            a += o[0]; c += o[1]; s1 += o[2]; s2 += o[3];
+        }
+        float* t = tot + (size_t)ij * 8;
+        t[0] = a; t[1] = c; t[2] = s1; t[3] = s2;
+        mask_tab[ij] = 0.5f * (a / c);                      // NaN when empty, like torch (mesh_net.py:388)
+        tex_tab[ij] = (s1 / c + s2 / c) * tex_scale;        // 2 * wt * (mean1 + mean2)
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f, c = 0.f;
+        for (int j = 0; j < H; j++)
+            for (int k = 0; k < nch; k++) {
+                const float* o = part + (((size_t)i * H + j) * nch + k) * 8;
+                s += o[4]; c += o[5];
+            }
+        img[4 * i] = s; img[4 * i + 1] = c;
+    }
+}
+
+// ---- forward pass 2: the flow loss needs the image's mean weight first (== flow_loss_forward_kernel) ----------------------------
+__global__ __launch_bounds__(256) void render_tables_flow_kernel(PrArgs A, const float2* __restrict__ flow, const unsigned char* __restrict__ bg,
+                                                                 const float* __restrict__ img, float* __restrict__ part2,
+                                                                 float* __restrict__ fmap, unsigned char* __restrict__ vis)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P;
+    const float* oc = A.occ + (size_t)i * P;
+    const float* m = A.masks + (size_t)i * P;
+    const float* ox = A.obs + (size_t)i * A.obs_stride;
+    const float* oy = ox + P;
+    const float wmean = img[4 * i] / img[4 * i + 1];
+    int p0, p1;
+    pr_range(P, A.nch, ch, p0, p1);
+    float s = 0.f, c = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float2 f = flow[(size_t)ij * P + p];
+        const float dx = f.x - ox[p], dy = f.y - oy[p];
+        const float e = sqrtf(dx * dx + dy * dy) * (pr_sigmoid(-oc[p]) / wmean);
+        fmap[(size_t)ij * P + p] = e;
+        const bool sel = !bg[(size_t)ij * P + p] && oc[p] != 0.f && m[p] > 0.f;
+        vis[(size_t)ij * P + p] = sel ? 1 : 0;
+        if (sel) { s += e; c += 1.f; }
+    }
+    s = block_sum(s, red); c = block_sum(c, red);
+    if (threadIdx.x == 0) { float* o = part2 + ((size_t)ij * A.nch + ch) * 4; o[0] = s; o[1] = c; o[2] = 0.f; o[3] = 0.f; }
+}
+
+__global__ __launch_bounds__(256) void render_tables_flow_fold_kernel(const float* __restrict__ part2, float* __restrict__ tot,
+                                                                      float* __restrict__ flow_tab, int N, int nch)
+{
+    const int ij = blockIdx.x * 256 + threadIdx.x;
+    if (ij >= N) return;
+    float s = 0.f, c = 0.f;
+    for (int k = 0; k < nch; k++) { s += part2[((size_t)ij * nch + k) * 4]; c += part2[((size_t)ij * nch + k) * 4 + 1]; }
+    tot[(size_t)ij * 8 + 4] = s; tot[(size_t)ij * 8 + 5] = c;
+    flow_tab[ij] = c > 0.f ? 0.5f * (s / c) : 0.f;          // 0 when nothing is selected (mesh_net.py:412)
+}
+
+// ---- backward: every plane of grad_px in one pass --------------------------------------------------------------------------------
+// g_rndpair may be null (perceptual term off).  Planes 3-5 (the rendering frame's own position) get zeros: its projection is
+// detached (mesh_net.py:101-102).  part3[n][chunk] = (d pp.x, d pp.y, d fl, -) of the OTHER frame's intrinsics.
+__global__ __launch_bounds__(256) void render_tables_backward_kernel(PrArgs A, const float* __restrict__ tot, const float* __restrict__ img,
+                                                                     const float* __restrict__ g_mask, const float* __restrict__ g_flow,
+                                                                     const float* __restrict__ g_tex, const float* __restrict__ g_rndpair,
+                                                                     float wt, float* __restrict__ gpx, float* __restrict__ part3)
+{
+    __shared__ float red[4];
+    const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, N = A.I * A.H;
+    const float* q = A.px + (size_t)ij * 10 * P;
+    float* g = gpx + (size_t)ij * 10 * P;
+    const float* m = A.masks + (size_t)i * P;
+    const float* oc = A.occ + (size_t)i * P;
+    const float* io = A.img_obs + (size_t)i * 3 * P;
+    const float* iw = A.img_white + (size_t)i * 3 * P;
+    const float* ox = A.obs + (size_t)i * A.obs_stride;
+    const float* oy = ox + P;
+    const int other = (ij + A.half) % N;
+    const float c0x = A.pp[2 * ij], c0y = A.pp[2 * ij + 1], c1x = A.pp[2 * other], c1y = A.pp[2 * other + 1];
+    const float f0 = A.fl[ij], f1 = A.fl[other];
+    const float* t = tot + (size_t)ij * 8;
+    const float k_mask = g_mask[ij] / t[1];                               // 0.5 * 2 * g / count (== mask_loss_backward_kernel)
+    const float k_tex = g_tex[ij] * (2.f * wt) / (3.f * t[1]);            // (== tex_loss_backward_kernel)
+    const float k_flow = t[5] > 0.f ? 0.5f * g_flow[ij] / t[5] : 0.f;     // (== flow_loss_backward_kernel)
+    const float wmean = img[4 * i] / img[4 * i + 1];
+    int p0, p1;
+    pr_range(P, A.nch, ch, p0, p1);
+    float sx = 0.f, sy = 0.f, sf = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float a = q[9 * (size_t)P + p];
+        const float r[3] = {q[p], q[P + p], q[2 * (size_t)P + p]};
+        const float o = oc[p];
+        const bool on = o != 0.f;
+        float ga = on ? k_mask * (a - m[p]) : 0.f;
+        float gr[3] = {0.f, 0.f, 0.f};
+        if (on) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float s1 = pr_sgn(io[(size_t)c * P + p] - r[c] * a);
+                const float s2 = pr_sgn(iw[(size_t)c * P + p] - r[c]);
+                gr[c] = -k_tex * (s1 * a + s2);
+                ga += -k_tex * s1 * r[c];
+            }
+        }
+        if (g_rndpair) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float g1 = g_rndpair[((size_t)ij * 3 + c) * P + p], g2 = g_rndpair[(((size_t)N + ij) * 3 + c) * P + p];
+                gr[c] += g1 * a + g2;
+                ga += g1 * r[c];
+            }
+        }
+        // flow: loss -> rendered flow -> the other frame's position (planes 6-8) and intrinsics
+        float x0 = q[3 * (size_t)P + p], y0 = q[4 * (size_t)P + p], z0 = q[5 * (size_t)P + p];
+        float x1 = q[6 * (size_t)P + p], y1 = q[7 * (size_t)P + p], z1 = q[8 * (size_t)P + p];
+        const bool b = (z0 < 1e-9f) | (z1 < 1e-9f);
+        float gx1 = 0.f, gy1 = 0.f, gz1 = 0.f;
+        {
+            if (b) x0 = y0 = z0 = x1 = y1 = z1 = 10.f;
+            const float u0 = c0x + (x0 * f0) / z0, v0 = c0y + (y0 * f0) / z0;
+            const float u1 = c1x + (x1 * f1) / z1, v1 = c1y + (y1 * f1) / z1;
+            const float dx = (u1 - u0) - ox[p], dy = (v1 - v0) - oy[p];
+            const bool sel = !b && on && m[p] > 0.f;
+            // when image i has no selected pixel at all wmean is NaN and 0 * NaN = NaN reaches every pixel, exactly what
+            // autograd does with the reference code (flow_loss_backward_kernel keeps the same behaviour)
+            const float gn = (sel ? k_flow : 0.f) * (pr_sigmoid(-o) / wmean);
+            const float nrm = sqrtf(dx * dx + dy * dy);
+            float2 gf = make_float2(0.f, 0.f);
+            if (nrm > 0.f) gf = make_float2(gn / nrm * dx, gn / nrm * dy);
+            if (!b) {
+                const float ax = gf.x / z1, ay = gf.y / z1;
+                gx1 = ax * f1; gy1 = ay * f1;
+                gz1 = -(ax * ((x1 * f1) / z1) + ay * ((y1 * f1) / z1));
+                sx += gf.x; sy += gf.y; sf += ax * x1 + ay * y1;
+            }
+        }
+        g[p] = gr[0]; g[P + p] = gr[1]; g[2 * (size_t)P + p] = gr[2];
+        g[3 * (size_t)P + p] = 0.f; g[4 * (size_t)P + p] = 0.f; g[5 * (size_t)P + p] = 0.f;
+        g[6 * (size_t)P + p] = gx1; g[7 * (size_t)P + p] = gy1; g[8 * (size_t)P + p] = gz1;
+        g[9 * (size_t)P + p] = ga;
+    }
+    sx = block_sum(sx, red); sy = block_sum(sy, red); sf = block_sum(sf, red);
+    if (threadIdx.x == 0) {
+        float* o = part3 + ((size_t)ij * A.nch + ch) * 4;
+        o[0] = sx; o[1] = sy; o[2] = sf; o[3] = 0.f;
+    }
+}
+
+// image n's sums belong to the intrinsics of image (n + half) % N
+__global__ __launch_bounds__(256) void render_tables_intrinsics_fold_kernel(const float* __restrict__ part3, float* __restrict__ gpp,
+                                                                            float* __restrict__ gfl, int N, int nch, int half)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int k = 0; k < nch; k++) {
+        const float* o = part3 + ((size_t)n * nch + k) * 4;
+        a += o[0]; b += o[1]; c += o[2];
+    }
+    const int other = (n + half) % N;
+    gpp[2 * other] = a; gpp[2 * other + 1] = b; gfl[other] = c;
+}
+
+}  // namespace lasr
+
+using namespace lasr;
+
+extern "C" size_t lasr_render_tables_scratch_floats(int I, int H, int P)
+{
+    if (I < 0 || H < 0 || P < 0) return 0;
+    const size_t N = (size_t)I * H, nch = (size_t)pr_nch(P);
+    return N * nch * 8 + N * 8 + (size_t)I * 4 + N * nch * 4 + N * nch * 4 + 16;
+}
+
+static int pr_args(PrArgs& A, const float* px, const float* masks, const float* occ, const float* flow_obs, long long obs_stride,
+                   const float* img_obs, const float* img_white, const float* pp, const float* fl, int I, int H, int P)
+{
+    if (I < 0 || H < 0 || P < 0) return LASR_E_BADARG;
+    if (I == 0 || H == 0 || P == 0) return LASR_OK;
+    if (!px || !masks || !occ || !flow_obs || !img_obs || !img_white || !pp || !fl || obs_stride < 2LL * P) return LASR_E_BADARG;
+    if (((long long)I * H) % 2) return LASR_E_BADARG;                 // [frame t block ; frame t' block]
+    A.px = px; A.masks = masks; A.occ = occ; A.obs = flow_obs; A.img_obs = img_obs; A.img_white = img_white; A.pp = pp; A.fl = fl;
+    A.I = I; A.H = H; A.P = P; A.nch = pr_nch(P); A.half = I * H / 2; A.obs_stride = obs_stride;
+    return LASR_OK;
+}
+
+extern "C" int lasr_render_tables_forward(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                                          long long flow_obs_image_stride, const float* img_obs, const float* img_white,
+                                          const float* pp, const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab,
+                                          float* tex_tab, float* flow_rd, unsigned char* bgmask, float* flow_map, unsigned char* vis_mask,
+                                          float* rndpair, float* scratch, int I, int H, int P, void* hip_stream)
+{
+    PrArgs A;
+    int rc = pr_args(A, px, masks, occ, flow_obs, flow_obs_image_stride, img_obs, img_white, pp, fl, I, H, P);
+    if (rc || I == 0 || H == 0 || P == 0) return rc;
+    if (!mask_tab || !flow_tab || !tex_tab || !flow_rd || !bgmask || !flow_map || !vis_mask || !scratch) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const PrScratch S = pr_scratch(scratch, I, H, P);
+    const int N = I * H;
+    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_forward_kernel, dim3(N, A.nch), dim3(256), 0, A, (float2*)flow_rd, bgmask,
+                rndpair, S.part);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_fold_kernel, dim3(I), dim3(64), 0, S.part, S.tot, S.img, mask_tab, tex_tab, H,
+                A.nch, 2.f * l1tex_wt);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_flow_kernel, dim3(N, A.nch), dim3(256), 0, A, (const float2*)flow_rd, bgmask,
+                S.img, S.part2, flow_map, vis_mask);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_flow_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part2, S.tot, flow_tab,
+                N, A.nch);
+    return launch_ok();
+}
+
+extern "C" int lasr_render_tables_backward(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                                           long long flow_obs_image_stride, const float* img_obs, const float* img_white,
+                                           const float* pp, const float* fl, float l1tex_wt, const float* grad_mask_tab,
+                                           const float* grad_flow_tab, const float* grad_tex_tab, const float* grad_rndpair,
+                                           const float* scratch, float* grad_px, float* grad_pp, float* grad_fl, int I, int H, int P,
+                                           void* hip_stream)
+{
+    PrArgs A;
+    int rc = pr_args(A, px, masks, occ, flow_obs, flow_obs_image_stride, img_obs, img_white, pp, fl, I, H, P);
+    if (rc || I == 0 || H == 0 || P == 0) return rc;
+    if (!grad_mask_tab || !grad_flow_tab || !grad_tex_tab || !scratch || !grad_px || !grad_pp || !grad_fl) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const PrScratch S = pr_scratch(const_cast<float*>(scratch), I, H, P);
+    const int N = I * H;
+    LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_backward_kernel, dim3(N, A.nch), dim3(256), 0, A, S.tot, S.img, grad_mask_tab,
+                grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_intrinsics_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part3, grad_pp,
+                grad_fl, N, A.nch, A.half);
+    return launch_ok();
+}

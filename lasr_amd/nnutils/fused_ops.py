@@ -96,6 +96,86 @@ class _FlowReprojectPlanes(Function):
         return gpos, None, gpp1, None, gfl1
 
 
+class _RenderTables(Function):
+    """lasr_render_tables_*: see render_tables()."""
+
+    @staticmethod
+    def forward(ctx, px, masks, occ, flow_obs, obspair, pp, fl, wt, want_pair):
+        _lib.need_cuda(px, masks, occ, flow_obs, obspair, pp, fl)
+        N, I = px.shape[0], masks.shape[0]
+        H, P = N // max(I, 1), masks[0].numel()
+        if px.dtype != torch.float32 or px.shape[1] != 10 or N != I * H or obspair.shape[0] != 2 * I:
+            raise ValueError('px must be float32 [I*H,10,IS,IS], obspair [2I,3,IS,IS]')
+        px = px.contiguous()
+        masks, occ, flow_obs = masks.contiguous().float(), occ.contiguous().float(), flow_obs.contiguous().float()
+        obspair, pp, fl = obspair.contiguous().float(), pp.contiguous().float(), fl.contiguous().float()
+        dev, hw = px.device, px.shape[2:]
+        h = _lib.lib()
+        tabs = torch.empty(3, I, H, dtype=torch.float32, device=dev)
+        flow = torch.empty(N, *hw, 2, dtype=torch.float32, device=dev)
+        bg = torch.empty(N, *hw, dtype=torch.uint8, device=dev)
+        fmap = torch.empty(N, *hw, dtype=torch.float32, device=dev)
+        vis = torch.empty(N, *hw, dtype=torch.uint8, device=dev)
+        pair = torch.empty(2 * N, 3, *hw, dtype=torch.float32, device=dev) if want_pair else None
+        scratch = torch.empty(h.lasr_render_tables_scratch_floats(I, H, P), dtype=torch.float32, device=dev)
+        guard, st = _lib.stream_of(px)
+        with guard:
+            rc = h.lasr_render_tables_forward(px.data_ptr(), masks.data_ptr(), occ.data_ptr(), flow_obs.data_ptr(), flow_obs[0].numel(),
+                                              obspair.data_ptr(), obspair[I:].data_ptr(), pp.data_ptr(), fl.data_ptr(), float(wt),
+                                              tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), flow.data_ptr(),
+                                              bg.data_ptr(), fmap.data_ptr(), vis.data_ptr(),
+                                              pair.data_ptr() if want_pair else None, scratch.data_ptr(), I, H, P, st)
+        _lib.check(rc, 'lasr_render_tables_forward')
+        ctx.save_for_backward(px, masks, occ, flow_obs, obspair, pp, fl, scratch)
+        ctx.wt, ctx.geom = float(wt), (I, H, P)
+        bg, vis = bg.view(torch.bool), vis.view(torch.bool)
+        ctx.mark_non_differentiable(flow, bg, fmap, vis)
+        ctx.set_materialize_grads(False)
+        if want_pair:
+            return tabs[0], tabs[1], tabs[2], flow, bg, fmap, vis, pair
+        return tabs[0], tabs[1], tabs[2], flow, bg, fmap, vis
+
+    @staticmethod
+    def backward(ctx, g_mask, g_flow, g_tex, _gf=None, _gb=None, _gm=None, _gv=None, g_pair=None):
+        px, masks, occ, flow_obs, obspair, pp, fl, scratch = ctx.saved_tensors
+        I, H, P = ctx.geom
+        dev = px.device
+        zero = None
+
+        def tab(g):
+            nonlocal zero
+            if g is None:
+                if zero is None:
+                    zero = torch.zeros(I, H, dtype=torch.float32, device=dev)
+                return zero
+            return g.contiguous().float()
+        g_mask, g_flow, g_tex = tab(g_mask), tab(g_flow), tab(g_tex)
+        g_pair = g_pair.contiguous().float() if g_pair is not None else None
+        gpx = torch.empty_like(px)
+        gpp = torch.empty_like(pp)
+        gfl = torch.empty_like(fl)
+        guard, st = _lib.stream_of(px)
+        with guard:
+            rc = _lib.lib().lasr_render_tables_backward(
+                px.data_ptr(), masks.data_ptr(), occ.data_ptr(), flow_obs.data_ptr(), flow_obs[0].numel(), obspair.data_ptr(),
+                obspair[I:].data_ptr(), pp.data_ptr(), fl.data_ptr(), ctx.wt, g_mask.data_ptr(), g_flow.data_ptr(), g_tex.data_ptr(),
+                g_pair.data_ptr() if g_pair is not None else None, scratch.data_ptr(), gpx.data_ptr(), gpp.data_ptr(),
+                gfl.data_ptr(), I, H, P, st)
+        _lib.check(rc, 'lasr_render_tables_backward')
+        return gpx, None, None, None, None, gpp, gfl, None, None
+
+
+def render_tables(px, masks, occ, flow_obs, obspair, pp, fl, l1tex_wt=1.0, want_pair=False):
+    """Everything between the nine-attribute render and the loss sum (/root/reference/nnutils/mesh_net.py:87-104, :374-441) in one
+    pass over px [N,10,IS,IS] (texture colours | own position | other frame's position | alpha; N = I*H, first half of the batch
+    frame t, second half frame t') and one pass back -- no contiguous copies of channel slices, no split / cat / accumulate
+    kernels in the backward.  masks / occ [I,IS,IS], flow_obs [I,>=2,IS,IS], obspair [2I,3,IS,IS] (fused_ops.obs_pair),
+    pp [N,2], fl [N] (image n reprojects the other frame's position with the intrinsics of image (n + N/2) % N).
+    -> mask table [I,H], flow table [I,H], texture L1 table [I,H] (= 2 wt (mean1 + mean2)), flow_rd [N,IS,IS,2], bgmask,
+       weighted flow error map, vis_mask [N,IS,IS] (+ rndpair [2N,3,IS,IS] = (render * alpha | render) when want_pair)."""
+    return _RenderTables.apply(px, masks, occ, flow_obs, obspair, pp, fl, l1tex_wt, want_pair)
+
+
 def flow_reproject_planes(pos6, pp0, pp1, fl0, fl1):
     """flow_reproject on the six position planes [N,6,IS,IS] of a wider render (a channel slice of the [N,10,IS,IS] output of the
     9-attribute pass: consecutive images further apart than 6 planes) -> flow [N,IS,IS,2], bgmask [N,IS,IS] bool."""

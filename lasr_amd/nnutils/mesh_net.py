@@ -630,16 +630,20 @@ class LASR(MeshNet):
         attrs = torch.cat([tex, verts_cam, other_frame(verts_cam)], -1)          # [N,V,9]
         self.renderer_softtex.rasterizer.background_color = [1, 1, 1, 0, 0, 0, 0, 0, 0]
         px = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=attrs, texture_type='vertex'))
-        self.texture_render, pos6, alpha = px.split([3, 6, 1], 1)
-        self.mask_pred = alpha.squeeze(1)
+        self.texture_render, alpha = px[:, :3], px[:, 9]                         # views of the wide render
+        self.mask_pred = alpha
         pp_all = ppoint[:, None].repeat(1, H, 1).view(N, 2)
-        sc_all = scale.reshape(N, 1)
-        self.flow_rd, self.bgmask = fused_ops.flow_reproject_planes(pos6, pp_all, other_frame(pp_all), sc_all, other_frame(sc_all))
+        sc_all = scale.reshape(N)
+        obspair = fused_ops.obs_pair(self.imgs, self.masks)                     # observed object on black | on white (:364-366)
+        # ---- reprojection + the three image-loss tables (+ the perceptual net's input pair) in one pass over the render and
+        # one pass back (fused_ops.render_tables; mesh_net.py:87-104, :374-441)
+        want_pair = self.ptex_loss is not None
+        rt = fused_ops.render_tables(px, self.masks, self.occ, self.flow, obspair, pp_all, sc_all, opts.l1tex_wt, want_pair)
+        self.mask_loss_sub, self.flow_rd_loss_sub, tex_l1, self.flow_rd, self.bgmask, flow_map, vis = rt[:7]
+        self.flow_rd_map, self.vis_mask = flow_map.view(n2, H, IS, IS), vis.view(n2, H, IS, IS)
         self.flow_fw, self.flow_bw = self.flow_rd[:BH], self.flow_rd[BH:]         # the reference's per-direction attributes (views)
         self.bgmask_fw, self.bgmask_bw = self.bgmask[:BH], self.bgmask[BH:]
         self.fgmask_flowf, self.fgmask_flowb = self.mask_pred[:BH], self.mask_pred[BH:]
-        obspair = fused_ops.obs_pair(self.imgs, self.masks)                     # observed object on black | on white (:364-366)
-        img_obs, img_white = obspair[:n2], obspair[n2:]
         if K > 1 and self.iters == 0:                                            # part rendering, logging only (:368-370)
             with torch.no_grad():
                 cmap = torch.tensor(synth.label_palette(K - 1), dtype=torch.float32, device=tex.device)
@@ -653,23 +657,15 @@ class LASR(MeshNet):
         # totals) and the total in the same order (fused_ops.weighted_mean_sum).
         G_MASK, G_FLOW, G_TEX, G_TRI, G_SYM, G_LMOTION, G_ARAP, G_BONESYM, G_CAM, G_AUX = range(10)
         terms = []
-        # 1) silhouette (:374-390)
-        self.mask_loss_sub = image_losses.mask_loss_table(self.mask_pred.view(n2, H, IS, IS), self.masks, self.occ)
+        # 1) silhouette (:374-390), 2) flow (:393-416), 3) texture L1 (:419-441): tables of render_tables above
         terms.append((self.mask_loss_sub, 1., G_MASK))
-        # 2) flow (:393-416)
-        self.flow_rd_loss_sub, self.flow_rd_map, self.vis_mask = image_losses.flow_loss_table(
-            self.flow_rd.view(n2, H, IS, IS, 2), self.flow, self.bgmask.view(n2, H, IS, IS), self.occ, self.masks, with_vis=True)
         terms.append((self.flow_rd_loss_sub, 1., G_FLOW))
-        # 3) texture (:419-447)
-        tr = self.texture_render.view(n2, H, 3, IS, IS)
-        tmp = image_losses.tex_loss_table(img_obs, img_white, tr, self.mask_pred.view(n2, H, IS, IS), self.occ,
-                                          opts.l1tex_wt)
+        tmp = tex_l1
         if self.ptex_loss is not None:
-            img_rnd = self.texture_render * self.mask_pred[:, None]
-            # the observed side is the same image for all H hypotheses: its features are computed once per image
-            rndpair = torch.cat([img_rnd, self.texture_render], 0)
+            # rndpair = (render * alpha | render) comes out of render_tables; the observed side is the same image for all H
+            # hypotheses: its features are computed once per image
             # (the [0,1] -> [-1,1] map of :436-441 is folded into the network's input normalisation: unit_range)
-            percept = self.ptex_loss.forward_pair(obspair, rndpair, repeat=H, unit_range=True)
+            percept = self.ptex_loss.forward_pair(obspair, rt[7], repeat=H, unit_range=True)
             tmp = torch.add(tmp, percept.view(2, -1).sum(0).view(n2, H), alpha=0.005)
         self.texture_loss_sub = 0.25 * tmp
         terms.append((self.texture_loss_sub, 1., G_TEX))
