@@ -27,10 +27,17 @@ extern "C" {
  */
 int lasr_lbs_forward(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out,
                      int N, int V, int K, int tocam, void* hip_stream);
+/* Both results of one blend: out_cam (tocam = 1) and out_blend (the vertices before the body transform, tocam = 0) -- what
+ * LASR.forward needs as verts_cam and deform_v (nnutils/mesh_net.py:291,298; two obj_to_cam calls in the reference). */
+int lasr_lbs_forward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out_cam,
+                          float* out_blend, int N, int V, int K, void* hip_stream);
 size_t lasr_lbs_backward_scratch_floats(int N, int V, int K);     /* chunk partials of the transform gradients */
 int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                       const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
                       float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream);
+int lasr_lbs_backward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
+                           const float* grad_out_cam, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
+                           float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, void* hip_stream);
 
 /*
  * Pinhole projection, nnutils/geom_utils.py:27-34 (pinhole_cam), with pp / fl already expanded per mesh:
@@ -354,6 +361,19 @@ int lasr_render_tables_backward(const float* px, const float* masks, const float
                                 const float* fl, float l1tex_wt, const float* grad_mask_tab, const float* grad_flow_tab,
                                 const float* grad_tex_tab, const float* grad_rndpair, const float* scratch, float* grad_px,
                                 float* grad_pp, float* grad_fl, int I, int H, int P, void* hip_stream);
+
+/*
+ * What LASR.forward builds from the camera-space vertices before it calls the rasteriser (nnutils/mesh_net.py:298-311, :350-356;
+ * geom_utils.py:27-34), in one launch + a one-block finish: verts_pre [N,V,3] = (pinhole(verts_cam; pp, fl) + eye) * (1,-1,1),
+ * attrs [N,V,9] = (tex | verts_cam | verts_cam of image (n + N/2) % N), near_far [2] = (zmin - r/2, zmax + r/2), r = zmax - zmin
+ * over all N meshes.  verts_cam / tex [N,V,3], pp [N,2], fl [N], eye: 3 HOST floats; scratch: 2 N floats.  N even.
+ * Backward: grad_verts_cam (projection + both attribute uses), grad_tex, grad_pp [N,2], grad_fl [N], all overwritten.
+ */
+int lasr_raster_inputs_forward(const float* verts_cam, const float* tex, const float* pp, const float* fl, const float* eye,
+                               float* verts_pre, float* attrs, float* near_far, float* scratch, int N, int V, void* hip_stream);
+int lasr_raster_inputs_backward(const float* verts_cam, const float* fl, const float* grad_verts_pre, const float* grad_attrs,
+                                float* grad_verts_cam, float* grad_tex, float* grad_pp, float* grad_fl, int N, int V,
+                                void* hip_stream);
 
 #define LASR_GATHER_MAX_KEYS 24
 int lasr_gather_rows(const float* table, long long W, int pairs, const long long* ids, int B, int n_keys,

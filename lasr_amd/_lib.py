@@ -23,6 +23,8 @@ SIGNATURES = {
     'lasr_sr_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz] + _RASTER_SCALARS),
     # include/lasr_ops.h
     'lasr_lbs_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_lbs_forward_both': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_lbs_backward_both': (_i, [_p] * 11 + [_i, _i, _i, _p]),
     'lasr_lbs_backward_scratch_floats': (_sz, [_i, _i, _i]),
     'lasr_lbs_backward': (_i, [_p] * 10 + [_i, _i, _i, _i, _p]),
     'lasr_pinhole_forward': (_i, [_p, _p, _p, _p, _i, _i, _p]),
@@ -77,6 +79,8 @@ SIGNATURES = {
     'lasr_render_tables_scratch_floats': (_sz, [_i, _i, _i]),
     'lasr_render_tables_forward': (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f] + [_p] * 9 + [_i, _i, _i, _p]),
     'lasr_render_tables_backward': (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f] + [_p] * 8 + [_i, _i, _i, _p]),
+    'lasr_raster_inputs_forward': (_i, [_p] * 9 + [_i, _i, _p]),
+    'lasr_raster_inputs_backward': (_i, [_p] * 8 + [_i, _i, _p]),
     'lasr_gather_rows': (_i, [_p, ctypes.c_longlong, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
     'lasr_mean_shape_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_mean_shape_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

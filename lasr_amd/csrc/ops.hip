@@ -41,8 +41,11 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl)
 // C[row = (lane >> 4) * 4 + r][col = lane & 15].
 __global__ __launch_bounds__(256) void lbs_forward_kernel(const float* __restrict__ verts, const float* __restrict__ Rmat,
                                                           const float* __restrict__ Tmat, const float* __restrict__ skin,
-                                                          float* __restrict__ out, int N, int V, int K, int tocam)
+                                                          float* __restrict__ out, int N, int V, int K, int tocam,
+                                                          float* __restrict__ out_blend)
 {
+    // out_blend (optional, with tocam): the blended vertices BEFORE the body transform as a second output -- LASR.forward needs
+    // both (deform_v, nnutils/mesh_net.py:291, and the camera-space vertices, :298) and the reference calls obj_to_cam twice
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v0 = (blockIdx.x * 4 + wave) * 16;
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(const float* __restric
         } else {
             x = (col >= 9 && col < 12) ? p[col - 9] : 0.f;
         }
+        if (out_blend && live && col >= 9 && col < 12) out_blend[((size_t)n * V + vert) * 3 + (col - 9)] = x;
         if (tocam) {
             // lanes 8..11 form a quad: broadcast vs_0..2 from its lanes 1..3
             const float s0 = dpp_f(x, 0x55), s1 = dpp_f(x, 0xAA), s2 = dpp_f(x, 0xFF);
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(const float* __restri
                                                            const float* __restrict__ Tmat, const float* __restrict__ skin,
                                                            const float* __restrict__ gout, float* __restrict__ gverts,
                                                            float* __restrict__ gskin, float* __restrict__ partial,
-                                                           int N, int V, int K, int tocam)
+                                                           int N, int V, int K, int tocam, const float* __restrict__ gout_blend)
 {
     extern __shared__ float lds[];          // RT[K*12] | G[256*13] | red[4]
     const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, tid = threadIdx.x, nb = K - 1;
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(256) void lbs_backward_kernel(const float* __restri
             h1 = g0 * RT[3] + g1 * RT[4] + g2 * RT[5];
             h2 = g0 * RT[6] + g1 * RT[7] + g2 * RT[8];
         }
+        if (gout_blend) { h0 += gout_blend[o]; h1 += gout_blend[o + 1]; h2 += gout_blend[o + 2]; }   // second output's gradient
         float M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
         if (nb > 0) {
 #pragma unroll
@@ -574,7 +579,19 @@ extern "C" int lasr_lbs_forward(const float* verts, const float* Rmat, const flo
     if (!verts || !Rmat || !Tmat || !out || (K > 1 && !skin)) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
     LASR_LAUNCH(K_LBS_FORWARD, lbs_forward_kernel, dim3((V + 63) / 64, N), dim3(256), 0, verts, Rmat, Tmat, skin, out,
-                N, V, K, tocam);
+                N, V, K, tocam, (float*)nullptr);
+    return launch_ok();
+}
+
+extern "C" int lasr_lbs_forward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out_cam,
+                                     float* out_blend, int N, int V, int K, void* hip_stream)
+{
+    if (N < 0 || V < 0 || K < 1) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!verts || !Rmat || !Tmat || !out_cam || !out_blend || (K > 1 && !skin)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_LBS_FORWARD, lbs_forward_kernel, dim3((V + 63) / 64, N), dim3(256), 0, verts, Rmat, Tmat, skin, out_cam,
+                N, V, K, 1, out_blend);
     return launch_ok();
 }
 
@@ -584,9 +601,31 @@ extern "C" size_t lasr_lbs_backward_scratch_floats(int N, int V, int K)
     return (size_t)N * ((V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1) * K * 12;
 }
 
+static int lbs_backward_impl(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
+                             const float* grad_out, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
+                             float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream);
+
 extern "C" int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                                  const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
                                  float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream)
+{
+    return lbs_backward_impl(verts, Rmat, Tmat, skin, grad_out, nullptr, grad_verts, grad_Rmat, grad_Tmat, grad_skin, scratch,
+                             N, V, K, tocam, hip_stream);
+}
+
+extern "C" int lasr_lbs_backward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
+                                      const float* grad_out_cam, const float* grad_out_blend, float* grad_verts,
+                                      float* grad_Rmat, float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K,
+                                      void* hip_stream)
+{
+    if (!grad_out_blend) return LASR_E_BADARG;
+    return lbs_backward_impl(verts, Rmat, Tmat, skin, grad_out_cam, grad_out_blend, grad_verts, grad_Rmat, grad_Tmat, grad_skin,
+                             scratch, N, V, K, 1, hip_stream);
+}
+
+static int lbs_backward_impl(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
+                             const float* grad_out, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
+                             float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream)
 {
     if (N < 0 || V < 0 || K < 1 || K > 1024) return LASR_E_BADARG;
     if (N == 0) return LASR_OK;
@@ -595,7 +634,7 @@ extern "C" int lasr_lbs_backward(const float* verts, const float* Rmat, const fl
     const int nchunks = (V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1;
     const size_t lds = (size_t)(K * 12 + LBS_CHUNK * 13 + 4) * sizeof(float);
     LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_kernel, dim3(nchunks, N), dim3(256), lds, verts, Rmat, Tmat, skin, grad_out,
-                grad_verts, grad_skin, scratch, N, V, K, tocam);
+                grad_verts, grad_skin, scratch, N, V, K, tocam, grad_out_blend);
     int rc = launch_ok();
     if (rc) return rc;
     LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_fold_kernel, dim3(N), dim3(256), 0, scratch, grad_Rmat, grad_Tmat, K, nchunks);

@@ -283,9 +283,121 @@ __global__ __launch_bounds__(256) void render_tables_intrinsics_fold_kernel(cons
     gpp[2 * other] = a; gpp[2 * other + 1] = b; gfl[other] = c;
 }
 
+// =====================================================================================================================
+// The other side of the render: what LASR.forward builds from the camera-space vertices before it calls the rasteriser
+// (nnutils/mesh_net.py:298-311, :350-356; geom_utils.py:27-34), in one launch:
+//   pinhole projection of [x y z 1] with the frame's principal point and the hypothesis' focal length,
+//   raster-space vertices verts_pre = (proj + eye) * (1,-1,1)   (the renderer's look_at subtracts eye again, :81-82, :354-355),
+//   the nine vertex attributes (colour | own camera-space position | the other frame's position),
+//   and the min / max of the projected depth for the near / far planes (:304-311), finished by a one-block second kernel.
+// verts_cam [N,V,3], tex [N,V,3], pp [N/H... expanded by the caller to N,2], fl [N]; image n's "other frame" is (n + N/2) % N.
+struct RiArgs { const float* verts_cam; const float* tex; const float* pp; const float* fl; int N, V, half; float ex, ey, ez; };
+
+__global__ __launch_bounds__(256) void raster_inputs_forward_kernel(RiArgs A, float* __restrict__ verts_pre, float* __restrict__ attrs,
+                                                                    float* __restrict__ zpart)
+{
+    __shared__ float red[8];
+    const int n = blockIdx.x, tid = threadIdx.x, V = A.V;
+    const int other = (n + A.half) % A.N;
+    const float f = A.fl[n], cx = A.pp[2 * n], cy = A.pp[2 * n + 1];
+    float zmin = 3.4e38f, zmax = -3.4e38f;
+    for (int v = tid; v < V; v += 256) {
+        const size_t i = (size_t)n * V + v, o = (size_t)other * V + v;
+        const float x = A.verts_cam[3 * i], y = A.verts_cam[3 * i + 1], z = A.verts_cam[3 * i + 2];
+        // geom_utils.py:32-33: pp + (x * fl) / z; then (+ eye) * (1, -1, 1)
+        const float px = cx + x * f / z, py = cy + y * f / z;
+        verts_pre[3 * i] = (px + A.ex) * 1.f;
+        verts_pre[3 * i + 1] = (py + A.ey) * -1.f;
+        verts_pre[3 * i + 2] = (z + A.ez) * 1.f;
+        float* a = attrs + 9 * i;
+        a[0] = A.tex[3 * i]; a[1] = A.tex[3 * i + 1]; a[2] = A.tex[3 * i + 2];
+        a[3] = x; a[4] = y; a[5] = z;
+        a[6] = A.verts_cam[3 * o]; a[7] = A.verts_cam[3 * o + 1]; a[8] = A.verts_cam[3 * o + 2];
+        zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+    }
+    // block min / max (NaN depth: fminf / fmaxf drop it, like torch.aminmax does not -- a NaN vertex already poisons the step)
+    for (int d = 32; d >= 1; d >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, d)); zmax = fmaxf(zmax, __shfl_xor(zmax, d)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = zmin; red[4 + (tid >> 6)] = zmax; }
+    __syncthreads();
+    if (tid == 0) {
+        zpart[2 * n] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        zpart[2 * n + 1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    }
+}
+
+__global__ __launch_bounds__(64) void raster_inputs_nearfar_kernel(const float* __restrict__ zpart, float* __restrict__ near_far, int N)
+{
+    float zmin = 3.4e38f, zmax = -3.4e38f;
+    for (int n = threadIdx.x; n < N; n += 64) { zmin = fminf(zmin, zpart[2 * n]); zmax = fmaxf(zmax, zpart[2 * n + 1]); }
+    for (int d = 32; d >= 1; d >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, d)); zmax = fmaxf(zmax, __shfl_xor(zmax, d)); }
+    if (threadIdx.x == 0) {
+        const float half_range = (zmax - zmin) / 2.f;              // mesh_net.py:306-311
+        near_far[0] = zmin - half_range;
+        near_far[1] = zmax + half_range;
+    }
+}
+
+// one block per image: d verts_cam (own projection + own position attribute + the position attribute it lends to the other
+// frame), d tex, d pp, d fl
+__global__ __launch_bounds__(256) void raster_inputs_backward_kernel(RiArgs A, const float* __restrict__ g_pre, const float* __restrict__ g_attrs,
+                                                                     float* __restrict__ g_cam, float* __restrict__ g_tex,
+                                                                     float* __restrict__ g_pp, float* __restrict__ g_fl)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x, V = A.V;
+    const int other = (n + A.half) % A.N;              // the image whose attributes 6..8 are THIS image's positions
+    const float f = A.fl[n];
+    float sx = 0.f, sy = 0.f, sf = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        const size_t i = (size_t)n * V + v, o = (size_t)other * V + v;
+        const float x = A.verts_cam[3 * i], y = A.verts_cam[3 * i + 1], z = A.verts_cam[3 * i + 2];
+        const float gx = g_pre[3 * i], gy = -g_pre[3 * i + 1], gz = g_pre[3 * i + 2];
+        const float iz = 1.f / z, xz = x * iz, yz = y * iz;                   // == pinhole_backward_kernel
+        const float* ga = g_attrs + 9 * i;
+        const float* go = g_attrs + 9 * o;
+        g_cam[3 * i] = gx * f * iz + ga[3] + go[6];
+        g_cam[3 * i + 1] = gy * f * iz + ga[4] + go[7];
+        g_cam[3 * i + 2] = gz - (gx * xz + gy * yz) * f * iz + ga[5] + go[8];
+        g_tex[3 * i] = ga[0]; g_tex[3 * i + 1] = ga[1]; g_tex[3 * i + 2] = ga[2];
+        sx += gx; sy += gy; sf += gx * xz + gy * yz;
+    }
+    sx = block_sum(sx, red); sy = block_sum(sy, red); sf = block_sum(sf, red);
+    if (tid == 0) { g_pp[2 * n] = sx; g_pp[2 * n + 1] = sy; g_fl[n] = sf; }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
+
+extern "C" int lasr_raster_inputs_forward(const float* verts_cam, const float* tex, const float* pp, const float* fl, const float* eye,
+                                          float* verts_pre, float* attrs, float* near_far, float* scratch, int N, int V,
+                                          void* hip_stream)
+{
+    if (N < 0 || V < 0 || (N % 2)) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!verts_cam || !tex || !pp || !fl || !eye || !verts_pre || !attrs || !near_far || !scratch) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    RiArgs A{verts_cam, tex, pp, fl, N, V, N / 2, eye[0], eye[1], eye[2]};
+    LASR_LAUNCH(K_RASTER_INPUTS, raster_inputs_forward_kernel, dim3(N), dim3(256), 0, A, verts_pre, attrs, scratch);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_RASTER_INPUTS, raster_inputs_nearfar_kernel, dim3(1), dim3(64), 0, scratch, near_far, N);
+    return launch_ok();
+}
+
+extern "C" int lasr_raster_inputs_backward(const float* verts_cam, const float* fl, const float* grad_verts_pre,
+                                           const float* grad_attrs, float* grad_verts_cam, float* grad_tex, float* grad_pp,
+                                           float* grad_fl, int N, int V, void* hip_stream)
+{
+    if (N < 0 || V < 0 || (N % 2)) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!verts_cam || !fl || !grad_verts_pre || !grad_attrs || !grad_verts_cam || !grad_tex || !grad_pp || !grad_fl) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    RiArgs A{verts_cam, nullptr, nullptr, fl, N, V, N / 2, 0.f, 0.f, 0.f};
+    LASR_LAUNCH(K_RASTER_INPUTS, raster_inputs_backward_kernel, dim3(N), dim3(256), 0, A, grad_verts_pre, grad_attrs, grad_verts_cam,
+                grad_tex, grad_pp, grad_fl);
+    return launch_ok();
+}
 
 extern "C" size_t lasr_render_tables_scratch_floats(int I, int H, int P)
 {

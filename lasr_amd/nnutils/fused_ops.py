@@ -176,6 +176,54 @@ def render_tables(px, masks, occ, flow_obs, obspair, pp, fl, l1tex_wt=1.0, want_
     return _RenderTables.apply(px, masks, occ, flow_obs, obspair, pp, fl, l1tex_wt, want_pair)
 
 
+class _RasterInputs(Function):
+    @staticmethod
+    def forward(ctx, verts_cam, tex, pp, fl, eye):
+        _lib.need_cuda(verts_cam, tex, pp, fl)
+        import ctypes
+        N, V = verts_cam.shape[:2]
+        verts_cam, tex = verts_cam.contiguous().float(), tex.contiguous().float()
+        pp, fl = pp.contiguous().float(), fl.contiguous().float()
+        dev = verts_cam.device
+        pre = torch.empty(N, V, 3, dtype=torch.float32, device=dev)
+        attrs = torch.empty(N, V, 9, dtype=torch.float32, device=dev)
+        nf = torch.empty(2, dtype=torch.float32, device=dev)
+        scratch = torch.empty(2 * N, dtype=torch.float32, device=dev)
+        guard, st = _lib.stream_of(verts_cam)
+        with guard:
+            rc = _lib.lib().lasr_raster_inputs_forward(verts_cam.data_ptr(), tex.data_ptr(), pp.data_ptr(), fl.data_ptr(),
+                                                       (ctypes.c_float * 3)(*[float(e) for e in eye]), pre.data_ptr(),
+                                                       attrs.data_ptr(), nf.data_ptr(), scratch.data_ptr(), N, V, st)
+        _lib.check(rc, 'lasr_raster_inputs_forward')
+        ctx.save_for_backward(verts_cam, fl)
+        ctx.mark_non_differentiable(nf)
+        return pre, attrs, nf
+
+    @staticmethod
+    def backward(ctx, g_pre, g_attrs, _g_nf=None):
+        verts_cam, fl = ctx.saved_tensors
+        N, V = verts_cam.shape[:2]
+        dev = verts_cam.device
+        g_pre = g_pre.contiguous().float() if g_pre is not None else torch.zeros(N, V, 3, device=dev)
+        g_attrs = g_attrs.contiguous().float() if g_attrs is not None else torch.zeros(N, V, 9, device=dev)
+        g_cam, g_tex = torch.empty_like(verts_cam), torch.empty_like(verts_cam)
+        g_pp, g_fl = torch.empty(N, 2, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)
+        guard, st = _lib.stream_of(verts_cam)
+        with guard:
+            rc = _lib.lib().lasr_raster_inputs_backward(verts_cam.data_ptr(), fl.data_ptr(), g_pre.data_ptr(), g_attrs.data_ptr(),
+                                                        g_cam.data_ptr(), g_tex.data_ptr(), g_pp.data_ptr(), g_fl.data_ptr(), N, V, st)
+        _lib.check(rc, 'lasr_raster_inputs_backward')
+        return g_cam, g_tex, g_pp, g_fl, None
+
+
+def raster_inputs(verts_cam, tex, pp, fl, eye):
+    """What LASR.forward builds from the camera-space vertices before the render (/root/reference/nnutils/mesh_net.py:298-311,
+    :350-356; geom_utils.py:27-34) in one launch: verts_cam / tex [N,V,3], pp [N,2], fl [N], eye (3 Python floats) ->
+    verts_pre [N,V,3] = (pinhole(verts_cam) + eye) * (1,-1,1), attrs [N,V,9] = (tex | verts_cam | the other frame's verts_cam;
+    other = (n + N/2) % N), near_far [2] device floats (zmin - r/2, zmax + r/2 over all meshes; no gradient)."""
+    return _RasterInputs.apply(verts_cam, tex, pp, fl, eye)
+
+
 def flow_reproject_planes(pos6, pp0, pp1, fl0, fl1):
     """flow_reproject on the six position planes [N,6,IS,IS] of a wider render (a channel slice of the [N,10,IS,IS] output of the
     9-attribute pass: consecutive images further apart than 6 planes) -> flow [N,IS,IS,2], bgmask [N,IS,IS] bool."""

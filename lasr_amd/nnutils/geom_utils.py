@@ -47,6 +47,71 @@ class _LBS(Function):
         return gv, gR, gT, gs, None, None
 
 
+class _LBSBoth(Function):
+    """One blend, two results: (camera-space vertices, blended vertices before the body transform)."""
+
+    @staticmethod
+    def forward(ctx, verts, Rmat, Tmat, skin, K):
+        _lib.need_cuda(verts, Rmat, Tmat, skin)
+        N, V = verts.shape[:2]
+        verts, Rmat, Tmat = verts.contiguous().float(), Rmat.contiguous().float(), Tmat.contiguous().float()
+        if K > 1:
+            skin = skin.contiguous().float()
+        out = torch.empty(2, N, V, 3, dtype=torch.float32, device=verts.device)
+        guard, st = _lib.stream_of(verts)
+        with guard:
+            rc = _lib.lib().lasr_lbs_forward_both(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(),
+                                                  skin.data_ptr() if K > 1 else None, out[0].data_ptr(), out[1].data_ptr(),
+                                                  N, V, K, st)
+        _lib.check(rc, 'lasr_lbs_forward_both')
+        ctx.save_for_backward(verts, Rmat, Tmat, skin if K > 1 else verts.new_empty(0))
+        ctx.meta = (N, V, K)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, gcam, gblend):
+        verts, Rmat, Tmat, skin = ctx.saved_tensors
+        N, V, K = ctx.meta
+        gcam, gblend = gcam.contiguous().float(), gblend.contiguous().float()
+        gv, gR, gT = torch.empty_like(verts), torch.empty_like(Rmat), torch.empty_like(Tmat)
+        gs = torch.empty(N, K - 1, V, dtype=torch.float32, device=verts.device) if K > 1 else None
+        h = _lib.lib()
+        scratch = torch.empty(h.lasr_lbs_backward_scratch_floats(N, V, K), dtype=torch.float32, device=verts.device)
+        guard, st = _lib.stream_of(verts)
+        with guard:
+            rc = h.lasr_lbs_backward_both(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(), skin.data_ptr() if K > 1 else None,
+                                          gcam.data_ptr(), gblend.data_ptr(), gv.data_ptr(), gR.data_ptr(), gT.data_ptr(),
+                                          gs.data_ptr() if K > 1 else None, scratch.data_ptr(), N, V, K, st)
+        _lib.check(rc, 'lasr_lbs_backward_both')
+        return gv, gR, gT, gs, None
+
+
+def _lbs_args(verts, Rmat, Tmat, nmesh, skin):
+    verts = verts.view(-1, verts.shape[1], 3)
+    N = verts.shape[0]
+    V, K = verts.shape[1], int(nmesh)
+    Rm = Rmat.reshape(-1, 9)
+    Tm = Tmat.reshape(-1, 3)
+    if Rm.shape[0] != N * K or Tm.shape[0] != N * K:
+        raise ValueError('Rmat/Tmat hold %d/%d transforms, expected %d meshes x %d bones'
+                         % (Rm.shape[0], Tm.shape[0], N, K))
+    sk = None
+    if K > 1:
+        sk = skin.reshape(skin.shape[0], K - 1, V)
+        if sk.shape[0] != N:                             # e.g. the identity skin of the joints (mesh_net.py:285)
+            sk = sk.expand(N, K - 1, V)
+    return verts, Rm, Tm, sk, K
+
+
+def obj_to_cam_both(verts, Rmat, Tmat, nmesh, n_hypo, skin):
+    """(obj_to_cam(..., tocam=True), obj_to_cam(..., tocam=False)) from ONE blend launch and one backward launch: the two calls
+    LASR.forward makes back to back on the same arguments (/root/reference/nnutils/mesh_net.py:291 and :298)."""
+    if verts.device.type != 'cuda':
+        return (obj_to_cam(verts, Rmat, Tmat, nmesh, n_hypo, skin), obj_to_cam(verts, Rmat, Tmat, nmesh, n_hypo, skin, tocam=False))
+    verts, Rm, Tm, sk, K = _lbs_args(verts, Rmat, Tmat, nmesh, skin)
+    return _LBSBoth.apply(verts, Rm, Tm, sk, K)
+
+
 def obj_to_cam(verts, Rmat, Tmat, nmesh, n_hypo, skin, tocam=True):
     """Canonical object coordinates -> camera coordinates with linear-blend skinning (geom_utils.py:45-71).
 

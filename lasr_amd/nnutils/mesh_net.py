@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from .. import soft_renderer as sr
 from .. import synth
 from . import fused_ops, image_losses
-from .geom_utils import obj_to_cam, pinhole_cam
+from .geom_utils import obj_to_cam, obj_to_cam_both, pinhole_cam
 
 
 # ----------------------------------------------------------------------------------------------
@@ -593,18 +593,19 @@ class LASR(MeshNet):
             jc = obj_to_cam(pts, Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
             proj = pinhole_cam(torch.cat([jc, torch.ones_like(jc[:, :, :1])], -1), ppoint.detach(), scale.detach())
             self.joints_proj, self.ctl_proj = proj.split([K - 1, K - 1], 1)
-        self.deform_v = obj_to_cam(pred_v, Rmat.reshape(-1, 3, 3), Tmat[:, None, :], K, H, skin, tocam=False)
-
-        # ---- 1) flow rendering (:298-335)
-        verts_cam = obj_to_cam(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
+        # ---- 1) flow rendering (:298-335); deform_v (:291) is the same blend before the body transform: one launch for both
+        verts_cam, self.deform_v = obj_to_cam_both(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
         self.verts_cam = verts_cam.detach()                                      # per-frame shape in camera space (export)
         # what cam_export needs (views, no kernels: the export arithmetic runs only when extract.py asks for it)
         self._cam_src = (Rmat.detach(), Tmat.detach(), scale.detach(), ppoint.detach(), self.cams, self.pp, n2, H, K, IS)
-        verts_fl = pinhole_cam(torch.cat([verts_cam, torch.ones_like(verts_cam[:, :, :1])], -1), ppoint, scale)
-        with torch.no_grad():                                                    # near/far stay on the device (:304-311)
-            dmin, dmax = torch.aminmax(verts_fl[:, :, 2])                        # one reduction for both
-            half_range = (dmax - dmin) / 2
-            near, far = dmin - half_range, dmax + half_range
+        # pinhole projection (:302), near / far from the projected depth range (:304-311, kept on the device), the raster-space
+        # vertices (:81-82, :354-355) and the nine vertex attributes of the merged render: one launch (fused_ops.raster_inputs)
+        N, BH = n2 * H, B * H
+        pp_all = ppoint[:, None].repeat(1, H, 1).view(N, 2)
+        sc_all = scale.reshape(N)
+        verts_pre, attrs, near_far = fused_ops.raster_inputs(verts_cam, tex, pp_all, sc_all,
+                                                             self.renderer_softtex.transform.transformer._eye)
+        near, far = near_far[0], near_far[1]                                     # views of one 2-float device tensor
         for r in (self.renderer_softflf, self.renderer_softflb, self.renderer_softtex):
             r.rasterizer.near, r.rasterizer.far = near, far
             if opts.sigval != 1e-4:
@@ -618,22 +619,13 @@ class LASR(MeshNet):
         # All three rasterise the same 2B*H meshes with the same settings, so one 9-attribute pass (colour, own position, the
         # other frame's position; background white / black / black) yields the same images -- channels are blended
         # independently -- for one distance / sigmoid / depth evaluation per fragment instead of two.
-        N, BH = n2 * H, B * H
-        eye3 = sr.functional.const_tensor(self.renderer_softtex.transform.transformer._eye, verts_fl.device)[None, None]
-        verts_pre = (verts_fl[:, :, :3] + eye3) * sr.functional.const_tensor([1, -1, 1], verts_fl.device)
         faces_rep = self._faces_rep                                             # reset by get_mean_shape when the key changes
         if faces_rep is None:
             faces_rep = self._faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
-
-        def other_frame(t):                                                      # [t; t'] -> [t'; t] along the batch
-            return t.reshape(2, BH, *t.shape[1:]).flip(0).reshape(t.shape)
-        attrs = torch.cat([tex, verts_cam, other_frame(verts_cam)], -1)          # [N,V,9]
         self.renderer_softtex.rasterizer.background_color = [1, 1, 1, 0, 0, 0, 0, 0, 0]
         px = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=attrs, texture_type='vertex'))
         self.texture_render, alpha = px[:, :3], px[:, 9]                         # views of the wide render
         self.mask_pred = alpha
-        pp_all = ppoint[:, None].repeat(1, H, 1).view(N, 2)
-        sc_all = scale.reshape(N)
         obspair = fused_ops.obs_pair(self.imgs, self.masks)                     # observed object on black | on white (:364-366)
         # ---- reprojection + the three image-loss tables (+ the perceptual net's input pair) in one pass over the render and
         # one pass back (fused_ops.render_tables; mesh_net.py:87-104, :374-441)

@@ -61,6 +61,10 @@ def _as_float(v):
 def _near_far_dev(near, far, dev):
     """LASR stores 0-dim DEVICE tensors in rasterizer.near/far (mesh_net.py:306-311).  Returns a 2-float device tensor
     for the *_dev entry points (no host sync), or None when both are plain numbers."""
+    if (torch.is_tensor(near) and torch.is_tensor(far) and near.device.type == 'cuda' and near._base is not None
+            and near._base is far._base and near._base.shape == (2,) and near._base.dtype == torch.float32
+            and near.data_ptr() == near._base.data_ptr() and far.data_ptr() == near.data_ptr() + 4):
+        return near._base.detach()                       # already {near, far} side by side (fused_ops.raster_inputs): no launch
     if torch.is_tensor(near) and near.device.type == 'cuda' or torch.is_tensor(far) and far.device.type == 'cuda':
         return torch.stack([torch.as_tensor(near, dtype=torch.float32, device=dev).reshape(()),
                             torch.as_tensor(far, dtype=torch.float32, device=dev).reshape(())]).detach()

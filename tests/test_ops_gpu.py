@@ -69,6 +69,31 @@ def test_obj_to_cam_vs_oracle_at_lasr_sizes(cuda, N, V, K):
             close(a.grad, b.grad, 2e-5, 'grad %s tocam=%s' % (name, tocam))
 
 
+@pytest.mark.parametrize('N,V,K', [(16, 642, 21), (4, 1282, 36), (3, 17, 2), (2, 70, 1)])
+def test_obj_to_cam_both_equals_the_two_calls(cuda, N, V, K):
+    # nnutils/mesh_net.py:291,298: deform_v = obj_to_cam(..., tocam=False), verts = obj_to_cam(...) on the same arguments; one
+    # blend launch yields both (values bit-identical to the separate calls, gradients equal to the sum of their gradients)
+    rng = np.random.default_rng(N + V + K)
+    v = rng.standard_normal((N, V, 3)).astype(np.float32)
+    R = rng.standard_normal((N * K, 3, 3)).astype(np.float32)
+    T = rng.standard_normal((N * K, 1, 3)).astype(np.float32)
+    s = torch.softmax(torch.from_numpy(rng.standard_normal((N, max(K - 1, 1), V, 1)).astype(np.float32)), 1).numpy()
+    up1, up2 = rng.standard_normal((2, N, V, 3)).astype(np.float32)
+    a_in = [dev_t(a, cuda, True) for a in (v, R, T, s)]
+    cam, blend = geom_utils.obj_to_cam_both(a_in[0], a_in[1], a_in[2], K, 1, a_in[3] if K > 1 else None)
+    b_in = [dev_t(a, cuda, True) for a in (v, R, T, s)]
+    cam2 = geom_utils.obj_to_cam(b_in[0], b_in[1], b_in[2], K, 1, b_in[3] if K > 1 else None)
+    blend2 = geom_utils.obj_to_cam(b_in[0], b_in[1], b_in[2], K, 1, b_in[3] if K > 1 else None, tocam=False)
+    assert torch.equal(cam, cam2) and torch.equal(blend, blend2)
+    ((cam * dev_t(up1, cuda)).sum() + (blend * dev_t(up2, cuda)).sum()).backward()
+    ((cam2 * dev_t(up1, cuda)).sum() + (blend2 * dev_t(up2, cuda)).sum()).backward()
+    for name, a, b in zip(('verts', 'Rmat', 'Tmat', 'skin'), a_in, b_in):
+        if b.grad is None:
+            assert a.grad is None or float(a.grad.abs().max()) == 0.0
+            continue
+        close(a.grad, b.grad, 2e-5, 'grad ' + name)
+
+
 def test_joint_projection_call_pattern_with_broadcast_identity_skin(cuda):
     # mesh_net.py:285: obj_to_cam(rest_ts[:,:,:,0], Rmat, Tmat[:,None], n_bones, n_hypo, eye(K-1)[None,:,:,None])
     rng = np.random.default_rng(5)

@@ -123,3 +123,43 @@ def test_cpu_tensors_are_rejected(cuda):
     px, masks, occ, flow_obs, imgs, pp, fl = make_case(2, 1, 8)
     with pytest.raises(TypeError):
         fused_ops.render_tables(px, masks, occ, flow_obs, torch.cat([imgs, imgs]), pp, fl)
+
+
+# ---- the pre-raster side: fused_ops.raster_inputs ---------------------------------------------------------------------------
+@pytest.mark.parametrize('n2,H,V', [(2, 8, 642), (4, 1, 1282), (6, 16, 37)])
+def test_raster_inputs_against_the_reference_lines(cuda, n2, H, V):
+    # nnutils/mesh_net.py:298-311 (pinhole of [x y z 1], near/far from the depth range), :81-82 / :354-355 (+ eye, y flip) and the
+    # attribute triples of the three render calls (:85-87, :357): restated with torch ops + oracle/path_oracle.pinhole_cam
+    g = torch.Generator().manual_seed(n2 + H + V)
+    N = n2 * H
+    cam = torch.randn(N, V, 3, generator=g)
+    cam[:, :, 2] = cam[:, :, 2].abs() + 5
+    tex = torch.rand(N, V, 3, generator=g)
+    ppoint = torch.randn(n2, 2, generator=g) * 0.1
+    scale = torch.rand(n2, H, generator=g) + 8
+    eye = [0.0, 0.0, -2.732]
+    up_pre, up_attr = torch.randn(N, V, 3, generator=g), torch.randn(N, V, 9, generator=g)
+
+    leaves = [t.clone().double().requires_grad_(True) for t in (cam, tex, ppoint, scale)]
+    c, t, pp, sc = leaves
+    fl = po.pinhole_cam(torch.cat([c, torch.ones_like(c[:, :, :1])], -1), pp, sc)
+    dmin, dmax = fl[:, :, 2].min(), fl[:, :, 2].max()
+    near, far = dmin - (dmax - dmin) / 2, dmax + (dmax - dmin) / 2
+    pre = (fl[:, :, :3] + torch.tensor(eye).double()[None, None]) * torch.tensor([1., -1., 1.]).double()
+    other = c.reshape(2, N // 2, V, 3).flip(0).reshape(N, V, 3)
+    attrs = torch.cat([t, c, other], -1)
+    ((pre * up_pre.double()).sum() + (attrs * up_attr.double()).sum()).backward()
+
+    d = [x.to(cuda).requires_grad_(True) for x in (cam, tex, ppoint, scale)]
+    pp_all = d[2][:, None].repeat(1, H, 1).view(N, 2)
+    got_pre, got_attrs, nf = fused_ops.raster_inputs(d[0], d[1], pp_all, d[3].reshape(N), eye)
+    np.testing.assert_allclose(got_pre.detach().cpu().numpy(), pre.detach().numpy(), rtol=2e-6, atol=2e-6)
+    assert torch.equal(got_attrs.detach().cpu(), attrs.detach().float())                       # copies: exact
+    np.testing.assert_allclose(nf.cpu().numpy(), [float(near), float(far)], rtol=1e-6)
+    ((got_pre * up_pre.to(cuda)).sum() + (got_attrs * up_attr.to(cuda)).sum()).backward()
+    for mine, theirs, name in zip(d, leaves, ('verts_cam', 'tex', 'ppoint', 'scale')):
+        scl = float(theirs.grad.abs().max())
+        assert float((mine.grad.cpu().double() - theirs.grad).abs().max()) <= 2e-5 * scl, name
+    # the pair of views the trainer stores in rasterizer.near / .far goes to the kernels without a launch
+    from lasr_amd.soft_renderer.functional.soft_rasterize import _near_far_dev
+    assert _near_far_dev(nf[0], nf[1], cuda).data_ptr() == nf.data_ptr()

@@ -35,7 +35,7 @@ def mark(obj, name, label=None):
 m = tr.module
 for name in ('mask_loss_table', 'flow_loss_table', 'tex_loss_table'):
     mark(image_losses, name)
-mark(mesh_net, 'render_flow_soft_2'); mark(mesh_net, 'obj_to_cam'); mark(mesh_net, 'pinhole_cam')
+mark(mesh_net, 'render_flow_soft_2'); mark(mesh_net, 'obj_to_cam'); mark(mesh_net, 'obj_to_cam_both', 'obj_to_cam'); mark(mesh_net, 'pinhole_cam')
 mark(mesh_net, 'geodesic_distance'); mark(mesh_net, 'chamfer_distance'); mark(mesh_net, 'point_mesh_face_distance')
 mark(m, '_skinning'); mark(m, 'get_mean_shape'); mark(m.encoder, 'forward', 'encoder'); mark(m.code_predictor, 'forward', 'code_predictor')
 if m.ptex_loss is not None:
