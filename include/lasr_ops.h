@@ -390,14 +390,15 @@ int lasr_gather_rows(const float* table, long long W, int pairs, const long long
  *   table   device array, one row of 8 x 64 bit per tensor: {param, grad, exp_avg, exp_avg_sq, step (float*, may be 0), numel,
  *           group index, clip class (0 none, 1 mean shape, 2 camera networks)}
  *   chunks  device int32 [n_chunks, 2] = (table row, element offset), one per lasr_tail_chunk_elems() elements of a tensor
- *   partials device float [n_chunks] scratch; ctl device float [8]: out {clip coefficient shape, cam, all-finite flag,
+ *   partials device DOUBLE [n_chunks] scratch (sums of squares cannot overflow into a false NaN verdict); ctl device float [8]:
+ *   ctl[6] counts the steps whose gradients were zeroed (the caller zeroes it once); out {clip coefficient shape, cam, all-finite flag,
  *           shape gradient norm after clipping, camera-network gradient norm before clipping, norm of all gradients}
  *   lr .. weight_decay: HOST arrays per parameter group (n_groups <= LASR_TAIL_MAX_GROUPS); bias_correction1/2 = 1 - beta^t of
  *           the step being taken, evaluated by the caller in double.
  */
 #define LASR_TAIL_MAX_GROUPS 16
 int lasr_tail_chunk_elems(void);
-int lasr_tail_step(const void* table, const int* chunks, int n_chunks, float* partials, float* ctl, float max_norm_shape,
+int lasr_tail_step(const void* table, const int* chunks, int n_chunks, double* partials, float* ctl, float max_norm_shape,
                    float max_norm_cam, const float* lr, const float* beta1, const float* beta2, const float* eps,
                    const float* weight_decay, const double* bias_correction1, const double* bias_correction2, int n_groups,
                    void* hip_stream);

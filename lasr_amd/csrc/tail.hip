@@ -21,29 +21,33 @@ struct TailRow {                            // one parameter tensor: 8 x 64 bit,
 };
 
 __global__ __launch_bounds__(256) void tail_sumsq_kernel(const TailRow* __restrict__ table, const int2* __restrict__ chunks,
-                                                         float* __restrict__ partials)
+                                                         double* __restrict__ partials)
 {
-    __shared__ float red[4];
+    // squares and sums in double: a large but finite gradient (|g| > 1.8e19 squares to +Inf in fp32) must not look like the
+    // NaN the guard is there for (nnutils/train_utils.py:289 tests isnan); the kernel streams its input once, fp64 adds are free
+    __shared__ double red[4];
     const int2 ck = chunks[blockIdx.x];
     const TailRow row = table[ck.x];
     const float* __restrict__ g = row.g + ck.y;
     const int n = (int)min((long long)TAIL_CHUNK, row.numel - ck.y);
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) { const float x = g[i]; s += x * x; }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    double s = 0.;
+    for (int i = threadIdx.x; i < n; i += 256) { const double x = (double)g[i]; s += x * x; }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ctl[0] = clip coefficient of the mean shape, ctl[1] = of the camera networks, ctl[2] = 1 if every gradient is finite,
 // ctl[3] = mean-shape gradient norm AFTER clipping (what the reference logs), ctl[4] = camera-network norm before clipping
 __global__ __launch_bounds__(256) void tail_finalize_kernel(const TailRow* __restrict__ table, const int2* __restrict__ chunks,
-                                                            int n_chunks, const float* __restrict__ partials, float max_norm_shape,
+                                                            int n_chunks, const double* __restrict__ partials, float max_norm_shape,
                                                             float max_norm_cam, float* __restrict__ ctl)
 {
     __shared__ double acc[3][256];
     double all = 0., shape = 0., cam = 0.;
     for (int c = threadIdx.x; c < n_chunks; c += 256) {
-        const double s = (double)partials[c];
+        const double s = partials[c];
         const long long cls = table[chunks[c].x].clip;
         all += s;
         if (cls == 1) shape += s; else if (cls == 2) cam += s;
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void tail_finalize_kernel(const TailRow* __res
         const float c_cam = fminf(max_norm_cam / (n_cam + 1e-6f), 1.f);
         const bool finite = isfinite(acc[0][0]);                                // NaN or Inf anywhere poisons the sum
         ctl[0] = c_shape; ctl[1] = c_cam; ctl[2] = finite ? 1.f : 0.f; ctl[3] = n_shape * c_shape; ctl[4] = n_cam;
-        ctl[5] = (float)sqrt(acc[0][0]); ctl[6] = 0.f; ctl[7] = 0.f;
+        ctl[5] = (float)sqrt(acc[0][0]); ctl[6] += finite ? 0.f : 1.f; ctl[7] = 0.f;     // ctl[6]: steps skipped so far (caller zeroes it)
     }
 }
 
@@ -110,7 +114,7 @@ using namespace lasr;
 
 extern "C" int lasr_tail_chunk_elems(void) { return TAIL_CHUNK; }
 
-extern "C" int lasr_tail_step(const void* table, const int* chunks, int n_chunks, float* partials, float* ctl, float max_norm_shape,
+extern "C" int lasr_tail_step(const void* table, const int* chunks, int n_chunks, double* partials, float* ctl, float max_norm_shape,
                               float max_norm_cam, const float* lr, const float* beta1, const float* beta2, const float* eps,
                               const float* weight_decay, const double* bias_correction1, const double* bias_correction2,
                               int n_groups, void* hip_stream)

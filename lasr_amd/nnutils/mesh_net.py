@@ -152,6 +152,23 @@ class ResNetConv(nn.Module):
         return x
 
 
+def reference_resnet_key(own_key):
+    """Inverse of map_resnet_key for a key of THIS model's state_dict: 'encoder.resnet_conv.layers.1.0.conv1.weight' ->
+    'encoder.resnet_conv.resnet.layer2.0.conv1.weight' (the name /root/reference/third_party/ext_nnutils/net_blocks.py:291-313
+    gives it), or None when the key is not a trunk tensor."""
+    pre = 'encoder.resnet_conv.'
+    if not own_key.startswith(pre):
+        return None
+    k = own_key[len(pre):]
+    head = k.split('.')[0]
+    if head in ('conv1', 'bn1'):
+        return pre + 'resnet.' + k
+    if head == 'layers':
+        _, idx, rest = k.split('.', 2)
+        return pre + 'resnet.layer%d.%s' % (int(idx) + 1, rest)
+    return None
+
+
 def map_resnet_key(key):
     """torchvision / reference names of the ResNet-18 trunk -> this module's names, or None if the key is not a trunk
     tensor.  torchvision: 'layer2.0.downsample.1.weight'; reference checkpoints: 'encoder.resnet_conv.resnet.layer2...'
@@ -438,7 +455,7 @@ class MeshNet(nn.Module):
     def get_mean_shape(self, local_batch_size):
         """-> mean_v [2B*H,V,3], tex [2B*H,V,3] (sigmoid), faces [2B,F,3] (ext_nnutils/mesh_net.py:171-185)."""
         n2 = 2 * local_batch_size
-        key = (n2, self.faces.data_ptr(), tuple(self.faces.shape))
+        key = (n2, self.faces.data_ptr(), tuple(self.faces.shape), self.faces._version)       # _version: in-place edits count too
         if getattr(self, '_faces_key', None) != key:                         # connectivity is fixed: repeat it once, not per step
             self._faces_key, self._faces_n2, self._faces_rep = key, self.faces[None].repeat(n2, 1, 1), None
         faces = self._faces_n2
@@ -504,6 +521,14 @@ class LASR(MeshNet):
         self.optim_idx = 0
         # criteria attached by the trainer in the reference (train_utils.py:113-123); None until then
         self.triangle_loss_fn_sr = self.arap_loss_fn = self.flatten_loss = self.ptex_loss = None
+
+    def __setattr__(self, name, value):
+        # a new connectivity (load_network, re-meshing) may land on the old tensor's address with the old shape: drop the
+        # repeated copies forward() caches, whatever the key says
+        if name == 'faces':
+            self.__dict__.pop('_faces_key', None)
+            self.__dict__['_faces_n2'] = self.__dict__['_faces_rep'] = None
+        super().__setattr__(name, value)
 
     def schedule_scalars(self):
         """Refresh the schedule-dependent scalars of forward() from (epoch, iters): the regulariser decay (:106-113, :449)

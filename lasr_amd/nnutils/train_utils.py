@@ -40,6 +40,16 @@ def kmeans(x, k, iters=20):
     return a, c
 
 
+def set_deterministic():
+    """--deterministic: the same run twice gives the same numbers.  Every lasr_amd kernel is deterministic by construction
+    (ordered reductions, no float atomics on the training path); what varies between runs is outside them: MIOpen's timing-based
+    algorithm search (benchmark mode) and non-deterministic library kernels.  Pins: immediate-mode algorithm choice,
+    deterministic convolution kernels, torch's deterministic algorithms (warn where none exists)."""
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
+    torch.use_deterministic_algorithms(True, warn_only=True)
+
+
 class LASRTrainer:
     def __init__(self, opts):
         self.opts = opts
@@ -182,6 +192,8 @@ class LASRTrainer:
     # ---- optimisation -----------------------------------------------------------------------
     def init_training(self):
         opts = self.opts
+        if getattr(opts, 'deterministic', False):
+            set_deterministic()
         if getattr(opts, 'use_graph', False) and self.device.type == 'cuda':
             self._stream = torch.cuda.Stream(self.device)     # see _graphed_forward_backward
             torch.cuda.set_stream(self._stream)
@@ -269,7 +281,10 @@ class LASRTrainer:
         if key is not None:
             total_loss, aux = self._graphed_forward_backward(batch, key)
         else:
-            self.optimizer.zero_grad(set_to_none=not hasattr(self, '_graphs'))
+            # eager step: keep the gradient tensors (zero them in place) once the fused tail has a table of their addresses --
+            # set_to_none would reallocate them every step and force a table rebuild with a host sync each time
+            keep = hasattr(self, '_graphs') or bool(getattr(self, '_tail_caches', None))
+            self.optimizer.zero_grad(set_to_none=not keep)
             total_loss, aux = self.model(batch)
             total_loss.mean().backward()
         if getattr(self, 'manual_dp', False):              # mean of the ranks' gradients, one flat message over RCCL
@@ -303,6 +318,7 @@ class LASRTrainer:
         self.skipped_nan = bool(grads) and not bool(torch.isfinite(torch.stack(torch._foreach_norm(grads)).sum()))
         if self.skipped_nan:
             torch._foreach_zero_(grads)
+            self._skipped_eager = getattr(self, '_skipped_eager', 0) + 1
         self.optimizer.step()
         self.scheduler.step()
 
@@ -317,6 +333,12 @@ class LASRTrainer:
     @skipped_nan.setter
     def skipped_nan(self, v):
         self._skipped_nan = v
+
+    def skipped_steps(self):
+        """How many steps of this run found a NaN / Inf gradient (every gradient zeroed, AdamW still stepped).  One host read."""
+        ctl = getattr(self, '_tail_ctl', None)
+        n = int(ctl[6]) if ctl is not None else 0
+        return n + getattr(self, '_skipped_eager', 0)
 
     def _tail_table(self):
         """Device table of (param, grad, exp_avg, exp_avg_sq, step, numel, group, clip class) rows, rebuilt when an address
@@ -345,21 +367,31 @@ class LASRTrainer:
                 key.append(st['step'])
         if not rows or len(opt.param_groups) > _lib.TAIL_MAX_GROUPS:
             return None
-        cached = getattr(self, '_tail_cache', None)
-        if cached is not None and cached['rows'] == rows:
+        # one table per set of addresses: with --use_graph the gradients alternate between the graphs' memory pools (plain /
+        # pose-noise iterations, hypothesis switches), and each set is built -- one host sync -- only once
+        caches = self.__dict__.setdefault('_tail_caches', {})
+        rkey = tuple(rows)
+        cached = caches.get(rkey)
+        if cached is not None:
+            self._tail_cache = cached
             return cached if cached.get('table') is not None else None
-        steps = torch.stack([t.reshape(()) for t in key]).cpu()                 # one sync per (re)build
+        steps = torch.stack([t.reshape(()) for t in key]).cpu()                 # one sync per NEW address set
         if float(steps.min()) != float(steps.max()):                             # tensors at different step counts (a parameter
-            self._tail_cache = dict(rows=rows, table=None)                       # joined later): torch path, decided once
+            self._tail_cache = caches[rkey] = dict(rows=rows, table=None)        # joined later): torch path, decided once
             return None
+        self._tail_t = int(steps[0])                                             # shared by all tables: the optimizer's step count
         h = _lib.lib()
         ch = h.lasr_tail_chunk_elems()
         chunks = [(i, off) for i, r in enumerate(rows) for off in range(0, r[5], ch)]
         dev = self.device
-        self._tail_cache = cached = dict(
-            rows=rows, t=int(steps[0]), n_chunks=len(chunks),
+        if getattr(self, '_tail_ctl', None) is None:
+            self._tail_ctl = torch.zeros(8, dtype=torch.float32, device=dev)     # ctl[6] counts the skipped (NaN) steps of the run
+        if len(caches) > 8:
+            caches.clear()                                                       # addresses keep changing (eager + set_to_none): bounded
+        self._tail_cache = cached = caches[rkey] = dict(
+            rows=rows, n_chunks=len(chunks),
             table=torch.tensor(rows, dtype=torch.int64).to(dev), chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
-            partials=torch.empty(len(chunks), dtype=torch.float32, device=dev), ctl=torch.zeros(8, dtype=torch.float32, device=dev))
+            partials=torch.empty(len(chunks), dtype=torch.float64, device=dev), ctl=self._tail_ctl)
         return cached
 
     def _step_tail_hip(self):
@@ -367,7 +399,7 @@ class LASRTrainer:
         c = self._tail_cache
         groups = self.optimizer.param_groups
         n = len(groups)
-        t = c['t'] + 1
+        t = self._tail_t + 1
 
         def arr(kind, vals):
             return (kind * n)(*vals)
@@ -380,7 +412,7 @@ class LASRTrainer:
                 arr(ctypes.c_float, [g['eps'] for g in groups]), arr(ctypes.c_float, [g['weight_decay'] for g in groups]),
                 arr(ctypes.c_double, [1. - b ** t for b in b1]), arr(ctypes.c_double, [1. - b ** t for b in b2]), n, st)
         _lib.check(rc, 'lasr_tail_step')
-        c['t'] = t
+        self._tail_t = t
         ctl = c['ctl']
         self.grad_meanv_norm, self.grad_cam_norm = ctl[3], ctl[4]                # device scalars, read when logged
         self._skipped_nan = lambda: float(ctl[2]) == 0.                          # host sync only if somebody asks
@@ -428,6 +460,10 @@ class LASRTrainer:
                 total_steps += 1
             if self.distributed:                              # keep hypothesis selection identical on all ranks
                 dist.all_reduce(self.epoch_nscore)
+            skipped = self.skipped_steps()                    # steps whose gradients held a NaN and were zeroed (:289-290)
+            if skipped and self.rank == 0:
+                print('[lasr_amd] epoch %d: %d step(s) so far had a non-finite gradient and were taken with zeroed gradients'
+                      % (epoch, skipped), file=sys.stderr)
             if self.rank == 0 and opts.checkpoint_dir:
                 self.save('latest')
                 if (epoch + 1) % max(1, opts.save_epoch_freq) == 0:
@@ -438,6 +474,12 @@ class LASRTrainer:
     def save(self, label):
         m = self.module
         states = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        # the ResNet-18 trunk also under the reference's key names (encoder.resnet_conv.resnet.layerN.*), so that the reference's
+        # predictor / extract tools find the encoder weights in these checkpoints; aliases share storage (no extra bytes on disk)
+        for k in list(states):
+            ref = mesh_net.reference_resnet_key(k)
+            if ref is not None:
+                states[ref] = states[k]
         states['faces'] = m.faces.cpu()
         states['full_shape'] = [m.symmetrize(v).detach().cpu() for v in m.mean_v]
         states['full_tex'] = [m.symmetrize_color(t).detach().cpu() for t in m.tex]

@@ -35,7 +35,10 @@ DEFAULTS = dict(
     # reference LASR checkpoint) for the two networks the reference takes ImageNet-pretrained; '' = random init (no network here)
     # fused_tail: clipping + NaN guard + AdamW as three multi-tensor HIP launches (--nofused_tail = torch.optim.AdamW every step)
     n_frames=3, iters_per_epoch=200, perceptual=True, use_graph=True, data_root='.', encoder_weights='', alexnet_weights='',
-    fused_tail=True)
+    fused_tail=True,
+    # deterministic: run-to-run reproducible optimisation (MIOpen immediate mode with deterministic kernels, torch's
+    # deterministic algorithms; every kernel of lasr_amd is deterministic by construction).  Slower convolutions.
+    deterministic=False)
 
 
 def parse_flags(argv, defaults=DEFAULTS):
@@ -80,7 +83,7 @@ def main(argv):
     import torch.distributed as dist
     if torch.cuda.is_available():
         torch.cuda.set_device(opts.local_rank)
-        torch.backends.cudnn.benchmark = True               # optimize.py:30-31 (on ROCm: MIOpen's find mode; 122.6 -> 124.3 it/s)
+        torch.backends.cudnn.benchmark = not getattr(opts, 'deterministic', False)   # optimize.py:30-31 (on ROCm: MIOpen's find mode)
     world = int(os.environ.get('WORLD_SIZE', opts.ngpu))
     if world > 1 or 'RANK' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -62,6 +62,8 @@ def main(argv=None):
     ap.add_argument('--n_hypo', type=int, default=8)
     ap.add_argument('--out', default='')
     ap.add_argument('--no_graph', action='store_true')
+    ap.add_argument('--deterministic', action='store_true', help='optimize.py --deterministic: the same command twice gives the same numbers')
+    ap.add_argument('--img_size', type=int, default=256)
     ap.add_argument('--obj', default='', help='render this .obj instead of the built-in blobby sphere (render_syn.py --obj)')
     ap.add_argument('--model', default='', help="render_syn.py --model (placement preset, e.g. 'spot')")
     ap.add_argument('--surface_tex', action='store_true', help='render_syn.py --surface_tex')
@@ -74,7 +76,8 @@ def main(argv=None):
     ev = _load('eval_mesh')
     log = os.path.join(root, 'log')
     common = ['--checkpoint_dir', log, '--dataname', name, '--data_root', root, '--sil_path', 'none', '--ngpu', '1',
-              '--batch_size', '1', '--opt_tex', 'yes', '--nouse_gtpose', '--subdivide', '3'] + (['--nouse_graph'] if args.no_graph else ['--use_graph'])
+              '--batch_size', '1', '--opt_tex', 'yes', '--nouse_gtpose', '--subdivide', '3', '--img_size', str(args.img_size)] + \
+        (['--nouse_graph'] if args.no_graph else ['--use_graph']) + (['--deterministic'] if args.deterministic else [])
     # scripts/spot3.sh:24-25
     tr0, steps0, dt0 = run_stage(['--name', 'demo-0', '--only_mean_sym', '--n_bones', '21', '--n_hypo', str(args.n_hypo),
                                   '--num_epochs', str(args.epochs0)] + common)

@@ -189,3 +189,41 @@ def test_template_sh_stage_counts_survive_the_checkpoint_path(tmp_path):
         t2.device, t2.model, t2.epoch_nscore = torch.device('cpu'), net, torch.zeros(1)
         t2.save('latest')
         ckpt = os.path.join(t2.save_dir, 'pred_net_latest.pth')
+
+
+def test_checkpoints_carry_the_reference_key_names_of_the_trunk(tmp_path):
+    # the reference's predictor / extract tools look for encoder.resnet_conv.resnet.layerN.* (net_blocks.py:291-313)
+    o = opts_for(tmp_path, name='k')
+    tr = train_utils.LASRTrainer(o)
+    tr.device = torch.device('cpu')
+    torch.manual_seed(0)
+    tr.model = mesh_net.LASR((64, 64), o, nz_feat=o.nz_feat)
+    tr.save('latest')
+    st = torch.load(os.path.join(tr.save_dir, 'pred_net_latest.pth'), map_location='cpu')
+    own = tr.model.state_dict()
+    trunk = [k for k in own if k.startswith('encoder.resnet_conv.')]
+    assert trunk
+    for k in trunk:
+        ref = mesh_net.reference_resnet_key(k)
+        assert ref is not None and ref.startswith('encoder.resnet_conv.resnet.') and torch.equal(st[ref], own[k]), k
+        assert 'encoder.resnet_conv.' + mesh_net.map_resnet_key(ref) == k          # the two maps are inverse
+    assert 'encoder.resnet_conv.resnet.layer1.0.conv1.weight' in st and 'encoder.resnet_conv.resnet.conv1.weight' in st
+    net = mesh_net.LASR((64, 64), o, nz_feat=o.nz_feat)                            # and the file still loads here
+    train_utils.LASRTrainer(o).load_network(net, os.path.join(tr.save_dir, 'pred_net_latest.pth'))
+    assert torch.equal(net.encoder.resnet_conv.layers[1][0].conv1.weight, tr.model.encoder.resnet_conv.layers[1][0].conv1.weight)
+
+
+def test_assigning_faces_drops_the_repeated_connectivity_caches(tmp_path):
+    o = opts_for(tmp_path, name='f')
+    net = mesh_net.LASR((64, 64), o, nz_feat=o.nz_feat)
+    _, _, f1 = net.get_mean_shape(1)
+    assert net._faces_n2 is not None
+    new = net.faces.clone()
+    new[0] = new[0].flip(0)
+    net.faces = new                                                                # e.g. load_network / re-meshing
+    assert net._faces_n2 is None and net._faces_rep is None
+    _, _, f2 = net.get_mean_shape(1)
+    assert torch.equal(f2[0], new) and not torch.equal(f1[0], f2[0])
+    net.faces[1] = net.faces[1].flip(0)                                            # an in-place edit moves the version counter
+    _, _, f3 = net.get_mean_shape(1)
+    assert torch.equal(f3[0], net.faces)

@@ -52,7 +52,7 @@ def test_fused_tail_equals_the_torch_tail_step_by_step(tmp_path, cuda):
             set_grads(tr, seed, scale, nan_in)
             tr.step_tail()
         if i >= 1:                                                   # first step: torch creates the optimizer state; then the
-            assert a._tail_table() is not None and a._tail_cache['t'] == i + 1        # kernels count the steps themselves
+            assert a._tail_table() is not None and a._tail_t == i + 1                  # kernels count the steps themselves
         assert getattr(b, '_tail_cache', None) is None
         assert a.skipped_nan == b.skipped_nan == (nan_in is not None)
         if nan_in is None:
@@ -118,9 +118,51 @@ def test_fused_tail_steps_aside_when_step_counts_differ(tmp_path, cuda):
     assert tr._tail_table() is not None
     tr.optimizer.state[tr.module.mean_v]['step'] += 3
     tr._tail_cache = None
+    tr._tail_caches.clear()                                          # force a rebuild of the table (new step counts)
     set_grads(tr, 2, 1.0)
     before = tr.module.tex.detach().clone()
     tr.step_tail()
     assert tr._tail_table() is None and tr._tail_cache['table'] is None
     assert float((tr.module.tex - before).abs().max()) > 0           # the torch path stepped
     assert float(tr.optimizer.state[tr.module.tex]['step']) == 2 and float(tr.optimizer.state[tr.module.mean_v]['step']) == 5
+
+
+def test_huge_finite_gradient_is_not_mistaken_for_nan_and_skips_are_counted(tmp_path, cuda):
+    # nnutils/train_utils.py:289 tests isnan: a finite gradient of 1e20 (its square overflows fp32) must be clipped, not zeroed;
+    # the sums of squares run in double.  Skipped steps are counted on the device (ctl[6]) and reported by skipped_steps().
+    a = make(tmp_path / 'a', cuda, fused=True)
+    set_grads(a, 1, 1.0)
+    a.step_tail()                                                     # torch path creates the optimizer state
+    set_grads(a, 2, 1.0)
+    with torch.no_grad():
+        a.module.mean_v.grad.view(-1)[0] = 1e20
+    before = a.module.mean_v.detach().clone()
+    a.step_tail()
+    assert a._tail_table() is not None
+    assert a.skipped_nan is False
+    assert abs(float(a.grad_meanv_norm) - 1.0) <= 1e-4                 # clipped to norm 1 (clip_grad_norm_ semantics)
+    assert torch.isfinite(a.module.mean_v).all() and not torch.equal(a.module.mean_v, before)
+    assert a.skipped_steps() == 0
+    set_grads(a, 3, 1.0, nan_in='ctl_ts')
+    a.step_tail()
+    set_grads(a, 4, 1.0, nan_in='tex')
+    a.step_tail()
+    assert a.skipped_nan is True and a.skipped_steps() == 2
+
+
+def test_eager_steps_keep_their_gradient_buffers_and_the_tail_table(tmp_path, cuda):
+    # --nouse_graph: once the fused tail has a table of the gradients' addresses, zero_grad keeps the tensors (zeroed in
+    # place) -- set_to_none would reallocate them every step and force a rebuild + host sync per step
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_lasr_forward_gpu import make_trainer
+    a = make_trainer(tmp_path, iters_per_epoch=4)                    # eager (use_graph=False), fused tail on by default
+    a.model.train()
+    a.reinit_bones()
+    for i in range(4):
+        a.module.iters = i + 1
+        a.train_step(a.set_input(a.dataloader[i]))
+        if i == 1:
+            table = a._tail_cache['table']
+            ptrs = sorted(p.grad.data_ptr() for p in a.module.parameters() if p.grad is not None)
+    assert a._tail_cache['table'] is table and len(a._tail_caches) == 1
+    assert ptrs == sorted(p.grad.data_ptr() for p in a.module.parameters() if p.grad is not None)
