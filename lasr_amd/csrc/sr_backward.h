@@ -37,7 +37,18 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     unsigned int* ring = s_ring[threadIdx.x >> 6];
     // blocks of one image stay on one XCD (block b runs on XCD b % 8): its 10 pixel planes (2.6 MB at 256x256) then
     // live in a single 4 MB L2 instead of being fetched by all eight
+#if defined(LASR_BWD_ORDER) && LASR_BWD_ORDER == 1      // measurement build: the XCD's images interleaved face by face
+    int blk = xcd_remap(blockIdx.x, gridDim.x);
+    {
+        const int total = gridDim.x, per = total >> 3;
+        if ((total & 7) == 0 && per % A.F == 0) {
+            const int m = per / A.F, i = blockIdx.x >> 3, rank = i / m;
+            blk = ((blockIdx.x & 7) * m + (i - rank * m)) * A.F + rank;
+        }
+    }
+#else
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
+#endif
     const int gw = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
     if (gw >= A.N * A.F) return;
     const int bn = gw / A.F, fn = gw - bn * A.F;
