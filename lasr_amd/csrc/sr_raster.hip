@@ -224,27 +224,31 @@ constexpr int STAGE = 16;                  // entries staged per round: 64 lanes
 constexpr int SLOT = REC + 28;             // dwords per staged entry: record + up to 27 vertex attributes (9 channels) + 1 pad
 typedef const float __attribute__((address_space(3)))* lptr_t;
 
-template <bool LASR_FAST, int NCH, bool RX = false, bool LDSR = false>
+// W1 = one wave per workgroup, the workgroup's tile IS the wave's 8x8 quadrant: no workgroup barrier anywhere and nothing held
+// until the slowest of four waves is done.  Affordable since the group rects (level 0) made the face scan cheap: a lone wave
+// tests the ~40 group rects, then scans only the groups that can touch its 64 pixels, compacting straight into its own list.
+template <bool LASR_FAST, int NCH, bool RX = false, bool LDSR = false, bool W1 = false>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
 {
     constexpr int CAP = LDSR ? 1024 : LIST_CAP;       // the staging buffers take LDS: shorter lists (more rounds when a tile is crowded)
-    __shared__ unsigned short s_all[CAP];             // faces whose pixel rect touches the 16x16 tile, index order
-    __shared__ unsigned short s_mine[4][CAP];         // per wave: the subset touching its 8x8 quadrant, index order
+    constexpr int NW = W1 ? 1 : 4, TW = W1 ? 8 : TILE;
+    __shared__ unsigned short s_all[W1 ? 1 : CAP];    // faces whose pixel rect touches the 16x16 tile, index order
+    __shared__ unsigned short s_mine[NW][CAP];        // per wave: the subset touching its 8x8 quadrant, index order
     __shared__ int s_wcnt[2][4];
-    __shared__ __attribute__((aligned(16))) float s_stage[LDSR ? 4 * STAGE * SLOT : 4];
+    __shared__ __attribute__((aligned(16))) float s_stage[LDSR ? NW * STAGE * SLOT : 4];
 
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
 
     const int IS = A.IS, P = IS * IS;
-    const int tiles_x = (IS + TILE - 1) / TILE;
+    const int tiles_x = (IS + TW - 1) / TW;
     int bn, tx, ty;
     tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = W1 ? 0 : tid >> 6, lane = tid & 63;
 
-    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;   // this wave's quadrant
+    const int qx0 = tx * TW + (wave & 1) * 8, qy0 = ty * TW + (wave >> 1) * 8;       // this wave's quadrant
     const int px = qx0 + (lane & 7);
     const int py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
@@ -272,11 +276,34 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     UniRecip U;
     U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
     U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
-    const int tX0 = tx * TILE, tX1 = tX0 + TILE - 1, tY0 = ty * TILE, tY1 = tY0 + TILE - 1;
+    const int tX0 = tx * TW, tX1 = tX0 + TW - 1, tY0 = ty * TW, tY1 = tY0 + TW - 1;
     unsigned short* mine = s_mine[wave];
     const float thr_pad2 = A.thr * 1.10f;
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
     const float q_yhi = pix_center(IS - 1 - qy0, IS), q_ylo = pix_center(IS - 1 - min(qy0 + 7, IS - 1), IS);
+
+    // does face f (index inside the image) reach this wave's 8x8 quadrant?  Pixel-rect overlap, then a tighter cull (lanes =
+    // faces): the barycentric w_k is linear in the pixel position, so if all four corners of the quadrant lie beyond edge k's
+    // line by more than sqrt(1.10 thr), every pixel of the quadrant does too, i.e. the reference's `dis >= threshold` test
+    // (K.cu:402) drops every one of them.  Same faces contribute, ~20 % fewer entries to walk.  Well-conditioned faces only.
+    auto touches_quadrant = [&](int f) -> bool {
+        const short4 q = rects[f];
+        bool hit = !(q.x > qx0 + 7 || q.y < qx0 || q.z > qy0 + 7 || q.w < qy0);
+        if (hit && m.dist == 2) {
+            const float* R = recs + (size_t)f * REC;
+            if (__float_as_int(R[R_FLAGS]) & 16) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float a = R[R_INV + 3 * k], b = R[R_INV + 3 * k + 1], c = R[R_INV + 3 * k + 2];
+                    const float w00 = a * q_xlo + b * q_ylo + c, w01 = a * q_xhi + b * q_ylo + c;
+                    const float w10 = a * q_xlo + b * q_yhi + c, w11 = a * q_xhi + b * q_yhi + c;
+                    const float wmax = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));   // least negative corner
+                    if (wmax < 0.f && wmax * wmax * R[R_HK2 + k] > thr_pad2) hit = false;
+                }
+            }
+        }
+        return hit;
+    };
 
     // ---- level 0: which groups of 64 consecutive faces can touch this tile (union rects written by the setup kernel).  Every
     // wave evaluates the same test on the same data, so the masks agree across the workgroup without a barrier.
@@ -287,7 +314,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     int g_mask0 = 0;
     bool more = G > 0;
     for (int round = 0; more; round++) {                      // one round unless a tile meets more than LIST_CAP - 256 faces
-        if (round > 0) __syncthreads();                        // the previous round's lists are still being walked
+        if (round > 0 && !W1) __syncthreads();                 // the previous round's lists are still being walked
         // ---- level 1 (workgroup): ordered compaction of the touched groups' faces whose rect touches the 16x16 tile; a
         // round ends when the list could overflow or the u16 ids (relative to `base`) could
         int count = 0, flip = 0, base = -1;
@@ -302,6 +329,19 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 }
                 gmask = __ballot(t);
                 g_next += 64;
+                continue;
+            }
+            if constexpr (W1) {
+                // one touched group per step: its 64 faces against the quadrant, survivors straight into the wave's list
+                const int g = g_mask0 + __builtin_ctzll(gmask);
+                if (base < 0) base = g * GROUP;
+                if (count + 64 > CAP || (g + 1) * GROUP - base > 65536) break;             // walk what we have, then continue
+                gmask &= gmask - 1;
+                const int f = g * GROUP + lane;
+                const bool hit = f < A.F && touches_quadrant(f);
+                const unsigned long long mask = __ballot(hit);
+                if (hit) mine[count + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+                count += __popcll(mask);
                 continue;
             }
             // the next (up to) four touched groups, one per wave, in index order
@@ -338,38 +378,22 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             (void)taken;
         }
         if (base < 0) base = 0;
+        int n_mine = 0;
+        if constexpr (!W1) {
         __syncthreads();
         // ---- level 2 (wave, no barriers from here on): 64 list entries at a time, keep those touching the quadrant
-        int n_mine = 0;
         for (int i0 = 0; i0 < count; i0 += 64) {
             bool hit = false;
             int e = 0;
             if (i0 + lane < count) {
                 e = s_all[i0 + lane];
-                const short4 q = rects[base + e];
-                hit = !(q.x > qx0 + 7 || q.y < qx0 || q.z > qy0 + 7 || q.w < qy0);
-                if (hit && m.dist == 2) {
-                    // Tighter cull, lanes = list entries: the barycentric w_k is linear in the pixel position, so if
-                    // all four corners of the quadrant lie beyond edge k's line by more than sqrt(1.10 thr), every
-                    // pixel of the quadrant does too, i.e. the reference's `dis >= threshold` test (K.cu:402) drops
-                    // every one of them.  Same faces contribute, ~20 % fewer entries to walk.  Well-conditioned faces only.
-                    const float* R = recs + (size_t)(base + e) * REC;
-                    if (__float_as_int(R[R_FLAGS]) & 16) {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            const float a = R[R_INV + 3 * k], b = R[R_INV + 3 * k + 1], c = R[R_INV + 3 * k + 2];
-                            const float w00 = a * q_xlo + b * q_ylo + c, w01 = a * q_xhi + b * q_ylo + c;
-                            const float w10 = a * q_xlo + b * q_yhi + c, w11 = a * q_xhi + b * q_yhi + c;
-                            const float wmax = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));   // least negative corner
-                            if (wmax < 0.f && wmax * wmax * R[R_HK2 + k] > thr_pad2) hit = false;
-                        }
-                    }
-                }
+                hit = touches_quadrant(base + e);
             }
             const unsigned long long mask = __ballot(hit);
             if (hit) mine[n_mine + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)e;
             n_mine += __popcll(mask);
         }
+        } else n_mine = count;
         __builtin_amdgcn_wave_barrier();
         // ---- walk: every entry has at least one candidate pixel in this wave
 #if defined(LASR_ABL) && LASR_ABL == 2              // measurement build: binning only
@@ -578,9 +602,19 @@ static int default_flags() { return g_forward_math ? LASR_SR_RELAXED_MATH : 0; }
 static long long lds_walk_default()
 {
     const char* e = getenv("LASR_SR_LDS_WALK_MAX_BLOCKS");
-    return e ? atoll(e) : 24576;
+    return e ? atoll(e) : 24576;           // (launches above LASR_SR_W1_MIN_BLOCKS tiles take the W1 kernel before this is asked)
 }
 static const long long g_lds_walk_max_blocks = lds_walk_default();
+// Launches of more than this many 16x16 tiles take the one-wave-per-8x8-tile kernel (W1).  Measured (MI355X, mesh M2, forward
+// kernel, four-wave 16x16 tiles -> W1): 256 frames at 256x256 2.370 -> 2.163 ms, 64 frames 0.696 -> 0.649 ms, 64 frames at 512x512
+// 1.574 -> 1.474 ms, 16 frames 0.284 -> 0.280 ms, 4 frames 0.210 -> 0.221 ms, 1 frame 0.206 -> 0.221 ms (profiles/r03_w1_ab.txt).
+// Environment override LASR_SR_W1_MIN_BLOCKS (a huge value = never), read once; bit-identical output either way.
+static long long w1_default()
+{
+    const char* e = getenv("LASR_SR_W1_MIN_BLOCKS");
+    return e ? atoll(e) : 8192;
+}
+static const long long g_w1_min_blocks = w1_default();
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -622,6 +656,14 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
         const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
         // small launches: the LDS-staged walk (sr_forward_kernel<.., LDSR = true>); see g_lds_walk_max_blocks
         const bool lds = (nch > 3 || is_lasr_fast(A.m)) && !rx && (long long)grid.x <= g_lds_walk_max_blocks;
+        if ((long long)grid.x > g_w1_min_blocks && (nch > 3 || is_lasr_fast(A.m)) && !rx) {
+            // one wave per 8x8 tile (sr_forward_kernel<.., W1 = true>)
+            const int t8 = (IS + 7) / 8;
+            const dim3 grid8((unsigned)(N * t8 * t8));
+            if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+        } else
         if (lds && nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (lds && nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (lds) hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
