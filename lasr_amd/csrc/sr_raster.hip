@@ -253,8 +253,6 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const int py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
     const int pn = py * IS + px;
-    const float xp = pix_center(px, IS);
-    const float yp = pix_center(IS - 1 - py, IS);
 
     PixState<NCH> s;
     s.a = (m.alpha == 2) ? 1.f : 0.f;
@@ -269,6 +267,25 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
         s.c[k] = m.rgb == 0 ? bg : bg * s.ssum;
     }
 
+    // ---- level 0 first: which groups of 64 consecutive faces can touch this tile (union rects written by the setup kernel).
+    // Three quarters of the tiles of a LASR frame meet none: they leave here with the background, before any per-pixel set-up
+    // (pixel centres, reciprocals, quadrant corners are divisions).  In a four-wave workgroup every wave evaluates the same
+    // test on the same data, so the masks agree without a barrier.
+    const int G = groups_of(A.F);
+    const short4* __restrict__ grects = A.grects + (size_t)bn * G;
+    const int tX0 = tx * TW, tX1 = tX0 + TW - 1, tY0 = ty * TW, tY1 = tY0 + TW - 1;
+    unsigned long long gmask = 0;                              // touched groups among [g_mask0, g_mask0 + 64)
+    {
+        bool t = false;
+        if (lane < G) {
+            const short4 q = grects[lane];
+            t = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
+        }
+        gmask = __ballot(t);
+    }
+    if (gmask != 0 || G > 64) {
+    const float xp = pix_center(px, IS);
+    const float yp = pix_center(IS - 1 - py, IS);
     const short4* __restrict__ rects = A.rects + (size_t)bn * A.F;
     const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
@@ -276,7 +293,6 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     UniRecip U;
     U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
     U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
-    const int tX0 = tx * TW, tX1 = tX0 + TW - 1, tY0 = ty * TW, tY1 = tY0 + TW - 1;
     unsigned short* mine = s_mine[wave];
     const float thr_pad2 = A.thr * 1.10f;
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
@@ -305,14 +321,9 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
         return hit;
     };
 
-    // ---- level 0: which groups of 64 consecutive faces can touch this tile (union rects written by the setup kernel).  Every
-    // wave evaluates the same test on the same data, so the masks agree across the workgroup without a barrier.
-    const int G = groups_of(A.F);
-    const short4* __restrict__ grects = A.grects + (size_t)bn * G;
-    int g_next = 0;                                            // first group not yet looked at
-    unsigned long long gmask = 0;                              // touched groups among [g_mask0, g_mask0 + 64)
+    int g_next = 64;                                           // first group not yet looked at (the first 64 were tested above)
     int g_mask0 = 0;
-    bool more = G > 0;
+    bool more = true;
     for (int round = 0; more; round++) {                      // one round unless a tile meets more than LIST_CAP - 256 faces
         if (round > 0 && !W1) __syncthreads();                 // the previous round's lists are still being walked
         // ---- level 1 (workgroup): ordered compaction of the touched groups' faces whose rect touches the 16x16 tile; a
@@ -481,6 +492,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             }
         }
     }
+
+    }   // tile meets at least one group
 
     if (!valid) return;
     // ---- finalise (K.cu:458-482)
