@@ -163,7 +163,7 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
 // per-vertex attributes; channels are independent, so the result equals the two separate renders) or 9 (the flow
 // attributes plus the texture colours: the texture render of a LASR step, mesh_net.py:348-363, has the same geometry).
 // Block -> (image, tile).  An image's tiles stay on one XCD (xcd_remap: its records are fetched into a single L2).  Inside an
-// XCD the blocks are issued rank-major over the XCD's images and CENTRE-OUT inside an image (square spiral from the middle):
+// XCD the blocks are issued rank-major over groups of four images and CENTRE-OUT inside an image (square spiral from the middle):
 // the crowded tiles -- LASR crops every frame around the object, dataloader/vidbase.py:105-135 -- start first and the empty
 // border tiles fill the tail of the launch.  With few frames per launch the crowded tiles' serial walks are the critical
 // path (0.2 ms for ONE frame); starting them last cost up to 40 % of a 16-frame launch.  Any order is correct; odd tile
@@ -180,8 +180,14 @@ __device__ __forceinline__ void tile_of_block(int b, int total, int tiles_x, int
         if ((total & 7) == 0 && per % tiles == 0) {
             const int m = per / tiles;              // images per XCD
             const int i = b >> 3;                   // position in this XCD's issue order
-            rank = i / m;
-            bn = (b & 7) * m + (i - rank * m);
+#ifndef LASR_ILV
+#define LASR_ILV 4      // images interleaved at a time: the records of 4 images (1.9 MB at 2420 faces) stay in the XCD's 4 MB L2.
+#endif                  // All 32 of the XCD: forward 2.16 ms but 700 MB fetched per 256 frames; 4: 2.18 ms, 170 MB (profiles/r03_tile_order_ab.txt)
+            const int g = m < LASR_ILV ? m : LASR_ILV;
+            const int grp = i / (tiles * g), j = i - grp * tiles * g;
+            rank = j / g;
+            bn = (b & 7) * m + grp * g + (j - rank * g);
+            if (m % g) { rank = i / m; bn = (b & 7) * m + (i - rank * m); }
             if (LASR_ORDER == 3) { bn = (b & 7) * m + i / tiles; rank = i % tiles; }      // measurement: spiral, image-major
         } else {                                    // fewer images than XCDs (or a ragged count): rank-major over all images
             const int n_img = total / tiles;

@@ -9,7 +9,8 @@ B="python $R/bench.py --no-cpu-baseline --no-lbs --no-sweep --lasr-iters 0"
 rocprofv3 --kernel-trace -d $O/prof_k -o k -- $B --steps 30 --warmup 3 > /dev/null 2>&1
 python $R/tools/rocpd_stats.py $(find $O/prof_k -name "*.db" | head -1) > $O/${T}_kernel_stats.txt; rm -rf $O/prof_k
 rocprofv3 --kernel-trace -d $O/prof_o -o o -- python $R/bench.py --no-cpu-baseline --no-lbs --no-sweep --steps 1 --warmup 1 --frames 16 --lasr-iters 30 > /dev/null 2>&1
-python $R/tools/rocpd_stats.py $(find $O/prof_o -name "*.db" | head -1) 90 > $O/${T}_optimize_step_kernel_stats.txt; rm -rf $O/prof_o
+python $R/tools/rocpd_stats.py $(find $O/prof_o -name "*.db" | head -1) 90 > $O/${T}_optimize_step_kernel_stats.txt
+python $R/tools/step_sequence.py $(find $O/prof_o -name "*.db" | head -1) > $O/${T}_step_sequence.txt; rm -rf $O/prof_o
 pmc() {  # $1 = output file, $2 = extra bench args, rest = counters
   out=$1; extra=$2; shift; shift
   rocprofv3 --pmc "$@" -d $O/pmc_x -o p -- $B $extra --steps 3 --warmup 1 > /dev/null 2>&1
