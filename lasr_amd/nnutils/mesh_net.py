@@ -147,9 +147,21 @@ class ResNetConv(nn.Module):
 
     def forward(self, x):
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
-        for layer in self.layers[:self.n_blocks]:
+        for i, layer in enumerate(self.layers[:self.n_blocks]):
             x = layer(x)
+            if i == self.boundary_after:
+                self.boundary = x          # the trainer cuts the captured backward here (graph-replay data parallelism)
         return x
+
+    boundary_after = -1                     # index of the layer whose output is kept in .boundary (-1: none)
+    boundary = None
+
+    def early_parameters(self):
+        """Parameters whose gradients only exist after the backward pass has gone below the boundary."""
+        early = list(self.conv1.parameters()) + list(self.bn1.parameters())
+        for layer in self.layers[:self.boundary_after + 1]:
+            early += list(layer.parameters())
+        return early
 
 
 def reference_resnet_key(own_key):

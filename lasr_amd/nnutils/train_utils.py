@@ -258,20 +258,58 @@ class LASRTrainer:
             self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=self._stream):
-                loss, aux = self.model(self._static)
-                loss.mean().backward()
-            # the backward pass of the capture created the .grad tensors inside THIS graph's memory pool; with more than
-            # one live graph each replay has to point the parameters back at the gradients its graph writes
-            grads = [(p, p.grad) for p in self.module.parameters() if p.grad is not None]
-            g = self._graphs[key] = (graph, loss, aux, grads)
+            if getattr(self, 'manual_dp', False) and getattr(self.opts, 'overlap_allreduce', True):
+                g = self._graphs[key] = self._capture_split(graph)
+            else:
+                with torch.cuda.graph(graph, stream=self._stream):
+                    loss, aux = self.model(self._static)
+                    loss.mean().backward()
+                # the backward pass of the capture created the .grad tensors inside THIS graph's memory pool; with more than
+                # one live graph each replay has to point the parameters back at the gradients its graph writes
+                grads = [(p, p.grad) for p in self.module.parameters() if p.grad is not None]
+                g = self._graphs[key] = (graph, loss, aux, grads)
         if self._static is not batch:
             for k, v in batch.items():
                 self._static[k].copy_(v)
         g[0].replay()
+        if len(g) > 4:
+            # graph-replay data parallelism with overlap: the first graph ends when the backward pass reaches the encoder's
+            # layer-3 output; the gradients that exist by then (mesh, bones, heads, layer 4: ~80 % of the bytes) are all-reduced
+            # on the communication stream WHILE the second graph runs the rest of the encoder's backward -- what DDP's bucket
+            # hooks do in the reference (nnutils/train_utils.py:104-109, :277), which cannot live inside a capture
+            from .. import parallel
+            late, early, graph_b = g[4], g[5], g[6]
+            work = parallel.allreduce_grads_async([gr for _, gr in late], average=True)
+            graph_b.replay()
+            parallel.allreduce_grads_([gr for _, gr in early], average=True)
+            work()
+            self._dp_reduced = True
         for p, gr in g[3]:
             p.grad = gr
         return g[1], g[2]
+
+    def _capture_split(self, graph_a):
+        """Capture forward + backward as TWO graphs that share a memory pool, cut where the backward pass crosses the output of
+        the encoder's third residual layer: graph A = forward + backward down to that tensor (autograd.grad with the boundary
+        tensor and every parameter above it as inputs), graph B = the backward of the layers below it, seeded with the
+        boundary's gradient.  Same kernels, same order, same numbers as the single graph."""
+        trunk = self.module.encoder.resnet_conv
+        trunk.boundary_after = min(2, trunk.n_blocks - 2)
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        early_ids = {id(p) for p in trunk.early_parameters()}
+        late = [p for p in params if id(p) not in early_ids]
+        early = [p for p in params if id(p) in early_ids]
+        with torch.cuda.graph(graph_a, stream=self._stream):
+            loss, aux = self.model(self._static)
+            xb = trunk.boundary
+            ga = torch.autograd.grad(loss.mean(), [xb] + late, retain_graph=True, allow_unused=True)
+        graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_b, stream=self._stream, pool=graph_a.pool()):
+            gb = torch.autograd.grad(xb, early, grad_outputs=ga[0], allow_unused=True)
+        late_g = [(p, gr) for p, gr in zip(late, ga[1:]) if gr is not None]
+        early_g = [(p, gr) for p, gr in zip(early, gb) if gr is not None]
+        self._split_keepalive = (loss, xb)               # the autograd graph of the capture must outlive it (graph B replays it)
+        return (graph_a, loss, aux, late_g + early_g, late_g, early_g, graph_b)
 
     def train_step(self, batch):
         """forward, backward (DDP all-reduces the gradients), clipping + NaN guard, AdamW, OneCycleLR (:274-296)."""
@@ -287,8 +325,8 @@ class LASRTrainer:
             self.optimizer.zero_grad(set_to_none=not keep)
             total_loss, aux = self.model(batch)
             total_loss.mean().backward()
-        if getattr(self, 'manual_dp', False):              # mean of the ranks' gradients, one flat message over RCCL
-            from .. import parallel
+        if getattr(self, 'manual_dp', False) and not self.__dict__.pop('_dp_reduced', False):
+            from .. import parallel                        # mean of the ranks' gradients, one flat message over RCCL
             parallel.allreduce_grads_([p.grad for p in m.parameters() if p.grad is not None], average=True)
         self.step_tail()
         return total_loss.detach(), aux

@@ -44,3 +44,27 @@ def allreduce_grads_(tensors, average=True, group=None):
         t.copy_(flat[o:o + n].view_as(t))
         o += n
     return tensors
+
+
+def allreduce_grads_async(tensors, average=True, group=None):
+    """allreduce_grads_ started on the process group's communication stream; returns a function that waits for it and
+    scatters the reduced values back into the tensors.  The caller runs other kernels in between (the rest of the backward
+    pass): with RCCL the collective's kernels then overlap them, as DDP's bucket hooks do in the reference."""
+    tensors = [t for t in tensors if t is not None]
+    if not tensors or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return lambda: tensors
+    world = dist.get_world_size(group)
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    work = dist.all_reduce(flat, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        if average:
+            flat.div_(world)
+        o = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[o:o + n].view_as(t))
+            o += n
+        return tensors
+    return finish

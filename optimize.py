@@ -38,7 +38,11 @@ DEFAULTS = dict(
     fused_tail=True,
     # deterministic: run-to-run reproducible optimisation (MIOpen immediate mode with deterministic kernels, torch's
     # deterministic algorithms; every kernel of lasr_amd is deterministic by construction).  Slower convolutions.
-    deterministic=False)
+    deterministic=False,
+    # overlap_allreduce: under torch.distributed with --use_graph, cut the captured backward at the encoder's layer-3 output and
+    # all-reduce the gradients that exist by then while the rest of the backward replays (--nooverlap_allreduce: one message
+    # after the whole replay)
+    overlap_allreduce=True)
 
 
 def parse_flags(argv, defaults=DEFAULTS):

@@ -16,13 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def make_opts(tmp, use_graph=True):
+def make_opts(tmp, use_graph=True, overlap=True, deterministic=False):
     sys.path.insert(0, ROOT)
     import optimize
     return optimize.parse_flags(['--name', 'dp', '--checkpoint_dir', tmp, '--img_size', '64', '--subdivide', '2', '--n_bones', '5',
                                  '--n_hypo', '2', '--batch_size', '1', '--num_epochs', '1', '--opt_tex', 'yes', '--nouse_gtpose',
                                  '--only_mean_sym', '--n_frames', '4', '--iters_per_epoch', '5', '--noperceptual']
-                                + (['--use_graph'] if use_graph else ['--nouse_graph']))
+                                + (['--use_graph'] if use_graph else ['--nouse_graph'])
+                                + ([] if overlap else ['--nooverlap_allreduce']) + (['--deterministic'] if deterministic else []))
 
 
 def run_steps(tr, n=4):
@@ -35,29 +36,30 @@ def run_steps(tr, n=4):
     return float(loss), torch.cat([p.detach().reshape(-1) for p in tr.module.parameters()]).double().cpu()
 
 
-def worker(rank, world, port, tmp, q, use_graph=True):
+def worker(rank, world, port, tmp, q, use_graph=True, overlap=True, deterministic=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from lasr_amd.nnutils import train_utils
     torch.manual_seed(rank)                                   # different initial weights: the broadcast must fix that
-    tr = train_utils.LASRTrainer(make_opts(tmp, use_graph)).init_training()
+    tr = train_utils.LASRTrainer(make_opts(tmp, use_graph, overlap, deterministic)).init_training()
     assert tr.manual_dp == use_graph and hasattr(tr.model, 'module') != use_graph      # DDP wrapper only without graphs
     loss, flat = run_steps(tr)
+    if use_graph:                                             # the capture was cut in two exactly when the overlap is on
+        assert all((len(g) > 4) == overlap for g in tr._graphs.values()) and len(tr._graphs) >= 1
     q.put((rank, loss, flat.numpy(), [int(x) for b in tr.dataloader[:4] for x in b]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('use_graph', [True, False])
-def test_two_ranks_stay_in_lockstep(tmp_path, cuda, use_graph):
+def spawn_two(tmp_path, use_graph, overlap=True, deterministic=False):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path), q, use_graph)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, str(tmp_path), q, use_graph, overlap, deterministic)) for r in range(2)]
     for p in procs:
         p.start()
     import queue
@@ -76,6 +78,28 @@ def test_two_ranks_stay_in_lockstep(tmp_path, cuda, use_graph):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    return out
+
+
+def test_overlapped_allreduce_equals_the_single_message(tmp_path, cuda):
+    # graph-replay DP: backward captured as two graphs cut at the encoder's layer-3 output, the gradients above the cut
+    # all-reduced while the second graph replays (what DDP's bucket hooks do, nnutils/train_utils.py:104-109,277) -- against the
+    # one-graph + one-message arrangement: same kernels, same sums, bit-identical parameters after four steps
+    # (--deterministic on both sides: without it MIOpen may pick different convolution algorithms for the two capture shapes,
+    # and Adam turns that rounding noise into steps of a few lr on near-zero gradient entries)
+    # The first run on a fresh machine fills MIOpen's kernel / find caches and can pick other algorithms than every later run:
+    # it is run once and discarded.
+    spawn_two(tmp_path / 'warm', True, overlap=False, deterministic=True)
+    a = spawn_two(tmp_path / 'a', True, overlap=True, deterministic=True)
+    b = spawn_two(tmp_path / 'b', True, overlap=False, deterministic=True)
+    assert (a[0][2] == a[1][2]).all() and (b[0][2] == b[1][2]).all()
+    d = abs(a[0][2] - b[0][2])
+    assert (a[0][2] == b[0][2]).all(), (d.max(), abs(b[0][2]).max(), int((d > 0).sum()), d.size)
+
+
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_two_ranks_stay_in_lockstep(tmp_path, cuda, use_graph):
+    out = spawn_two(tmp_path, use_graph)
     (_, l0, f0, ids0), (_, l1, f1, ids1) = out
     assert all(map(lambda v: v == v, (l0, l1)))               # finite
     assert ids0 != ids1                                        # the ranks saw different pairs
