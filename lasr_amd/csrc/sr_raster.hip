@@ -675,12 +675,15 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
         const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
         // small launches: the LDS-staged walk (sr_forward_kernel<.., LDSR = true>); see g_lds_walk_max_blocks
         const bool lds = (nch > 3 || is_lasr_fast(A.m)) && !rx && (long long)grid.x <= g_lds_walk_max_blocks;
-        if ((long long)grid.x > g_w1_min_blocks && (nch > 3 || is_lasr_fast(A.m)) && !rx) {
+        if ((long long)grid.x > g_w1_min_blocks && (nch > 3 || is_lasr_fast(A.m))) {
             // one wave per 8x8 tile (sr_forward_kernel<.., W1 = true>)
             const int t8 = (IS + 7) / 8;
             const dim3 grid8((unsigned)(N * t8 * t8));
-            if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
             else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
             else hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
         } else
         if (lds && nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);

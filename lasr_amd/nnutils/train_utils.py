@@ -319,10 +319,10 @@ class LASRTrainer:
         if key is not None:
             total_loss, aux = self._graphed_forward_backward(batch, key)
         else:
-            # eager step: keep the gradient tensors (zero them in place) once the fused tail has a table of their addresses --
-            # set_to_none would reallocate them every step and force a table rebuild with a host sync each time
-            keep = hasattr(self, '_graphs') or bool(getattr(self, '_tail_caches', None))
-            self.optimizer.zero_grad(set_to_none=not keep)
+            # eager step: gradients are dropped, not zeroed (zeroing would turn every parameter's gradient write into a
+            # read-add-write launch of autograd's accumulation).  The caching allocator hands the same blocks back in steady
+            # state, and the fused tail keeps one table per address set (_tail_table), so no rebuild / host sync follows.
+            self.optimizer.zero_grad(set_to_none=not hasattr(self, '_graphs'))
             total_loss, aux = self.model(batch)
             total_loss.mean().backward()
         if getattr(self, 'manual_dp', False) and not self.__dict__.pop('_dp_reduced', False):

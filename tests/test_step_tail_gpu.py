@@ -150,19 +150,19 @@ def test_huge_finite_gradient_is_not_mistaken_for_nan_and_skips_are_counted(tmp_
     assert a.skipped_nan is True and a.skipped_steps() == 2
 
 
-def test_eager_steps_keep_their_gradient_buffers_and_the_tail_table(tmp_path, cuda):
-    # --nouse_graph: once the fused tail has a table of the gradients' addresses, zero_grad keeps the tensors (zeroed in
-    # place) -- set_to_none would reallocate them every step and force a rebuild + host sync per step
+def test_eager_steps_do_not_rebuild_the_tail_table(tmp_path, cuda):
+    # --nouse_graph: zero_grad(set_to_none=True) reallocates the gradients every step; the caching allocator returns the same
+    # blocks in steady state and the trainer keeps one table per address set, so the table (one host sync to build) is built
+    # once or twice, not once per step
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_lasr_forward_gpu import make_trainer
-    a = make_trainer(tmp_path, iters_per_epoch=4)                    # eager (use_graph=False), fused tail on by default
+    a = make_trainer(tmp_path, iters_per_epoch=8)                    # eager (use_graph=False), fused tail on by default
     a.model.train()
     a.reinit_bones()
-    for i in range(4):
+    seen = []
+    for i in range(8):
         a.module.iters = i + 1
         a.train_step(a.set_input(a.dataloader[i]))
-        if i == 1:
-            table = a._tail_cache['table']
-            ptrs = sorted(p.grad.data_ptr() for p in a.module.parameters() if p.grad is not None)
-    assert a._tail_cache['table'] is table and len(a._tail_caches) == 1
-    assert ptrs == sorted(p.grad.data_ptr() for p in a.module.parameters() if p.grad is not None)
+        seen.append(len(getattr(a, '_tail_caches', {})))
+    assert a._tail_cache.get('table') is not None
+    assert seen[-1] <= 3 and seen[-1] == seen[3], seen               # no new address set after the first few steps
