@@ -614,9 +614,10 @@ static int g_forward_math = 0;                               // 0 = reference-fa
 static int default_flags() { return g_forward_math ? LASR_SR_RELAXED_MATH : 0; }
 
 // Launches of at most this many 16x16-pixel tiles (frames x tiles per frame) take the LDS-staged forward walk.  Measured on
-// an MI355X, mesh M2 at 256x256 (1024 tiles per frame), forward kernel, scalar-cache walk -> LDS walk: 1 frame 203 -> 206 us,
+// an MI355X, mesh M2 at 256x256 (256 tiles per frame), forward kernel, scalar-cache walk -> LDS walk: 1 frame 203 -> 206 us,
 // 4 frames 226 -> 219 us, 16 frames 308 -> 281 us, 64 frames 735 -> 755 us, 256 frames 2.556 -> 2.587 ms
-// (profiles/r03_lds_walk_ab.txt).  Default: up to 24 frames' worth of tiles.  Environment override
+// (profiles/r03_lds_walk_ab.txt).  Default: up to 24576 tiles (launches above LASR_SR_W1_MIN_BLOCKS = 8192 tiles, 32 frames at
+// 256x256, take the one-wave-per-8x8-tile kernel first, so this variant serves 1..32 frames).  Environment override
 // LASR_SR_LDS_WALK_MAX_BLOCKS (0 = never), read once; the output is bit-identical either way.
 static long long lds_walk_default()
 {
