@@ -14,7 +14,7 @@ What can be pinned this way is the Python part of the hot path (SURVEY.md sectio
 The compiled CUDA extension modules (soft_renderer.cuda.*) and skimage are absent here; they
 are replaced by empty placeholder modules so that `import soft_renderer` succeeds -- none of the
 functions captured below call into them (the rasterise call itself is intercepted to record its
-inputs; the CUDA kernel cannot be run, see oracle/sr_oracle.c header).
+inputs; the CUDA kernels themselves are pinned separately: oracle/build_ref.py + oracle/gen_ref_vectors.py).
 """
 import os
 import sys

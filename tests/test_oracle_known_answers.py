@@ -1,6 +1,6 @@
 """Pins for the CPU oracle (oracle/sr_oracle.c).
 
-The reference kernel cannot be built here (CUDA-only, no tests upstream), so the oracle is pinned by
+Besides the outputs of the reference kernels themselves (tests/test_oracle_vs_reference_vectors.py, round 3) the oracle is pinned by
   (1) the known answers SURVEY.md App. A/B recorded from a run of the reference kernel,
   (2) hand-computable analytic cases,
   (3) finite differences of its own fp64 forward for the parts of the reference backward that are exact
