@@ -53,3 +53,32 @@ for name, args in (('8x8 quadrant per wave (now)', (8, 8, 1, 1)), ('two 4x8 halv
                    ('four 4x4 blocks per wave', (4, 4, 2, 2)), ('16x4 strip per wave', (4, 16, 1, 1)), ('eight 2x4 blocks', (2, 4, 4, 2))):
     it, lanes, entries = count(*args)
     print('%-32s wave-iterations %6d  live lanes %.3f  block entries %d' % (name, it, lanes, entries))
+
+
+def chunked(chunk):
+    """Four 4x4 blocks per wave walking a SHARED staged window: the tile's entry list (index order) is cut into chunks of `chunk`
+    entries, the wave iterates max over its four blocks of the block's entries inside the chunk (the measured variant,
+    profiles/experiments/README.md round 3)."""
+    nb = IS // 4
+    per_block = [[] for _ in range(nb * nb)]                  # face ids per 4x4 block, index order
+    for fi, (rr, cc) in enumerate(surv):
+        if len(rr) == 0: continue
+        for b in np.unique((rr // 4) * nb + (cc // 4)):
+            per_block[b].append(fi)
+    total = 0
+    for ty in range(IS // 8):
+        for tx in range(IS // 8):
+            blocks = [per_block[(2 * ty + dy) * nb + 2 * tx + dx] for dy in (0, 1) for dx in (0, 1)]
+            tile = sorted(set().union(*blocks))
+            if not tile: continue
+            pos = {fid: i for i, fid in enumerate(tile)}
+            n_chunks = (len(tile) + chunk - 1) // chunk
+            cnt = np.zeros((4, n_chunks), int)
+            for b, lst in enumerate(blocks):
+                for fid in lst: cnt[b, pos[fid] // chunk] += 1
+            total += int(cnt.max(axis=0).sum())
+    return total
+
+
+for c in (16, 32, 64, 1 << 20):
+    print('four 4x4 blocks, shared window of %7d entries: wave-iterations %d' % (c, chunked(c)))
