@@ -82,3 +82,16 @@ def chunked(chunk):
 
 for c in (16, 32, 64, 1 << 20):
     print('four 4x4 blocks, shared window of %7d entries: wave-iterations %d' % (c, chunked(c)))
+
+
+def longest(bh, bw):
+    nby, nbx = IS // bh, IS // bw
+    L = np.zeros(nby * nbx, int)
+    for rr, cc in surv:
+        if len(rr): L[np.unique((rr // bh) * nbx + (cc // bw))] += 1
+    return int(L.max()), float(L[L > 0].mean())
+
+
+# the serial walk of the busiest block sets the floor of a small launch (one frame: 0.21 ms)
+for bh, bw in ((8, 8), (4, 8), (4, 4), (2, 4), (2, 2)):
+    print('longest list of a %dx%d block: %d entries (mean over non-empty blocks %.1f)' % ((bh, bw) + longest(bh, bw)))

@@ -1,9 +1,6 @@
 # the measurement set of the round: bash tools/prof/r03_final.sh <tag>   (one MI355X)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; T=${1:-r03}
 cd $R
-python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
-python bench.py --image-size 512 --frames 64 --no-lbs --no-sweep --lasr-iters 0 > $O/${T}_bench_512.json 2>/dev/null
-python tools/cosdist_bench.py > $O/${T}_cosdist.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-lbs --no-sweep --lasr-iters 0"
 rocprofv3 --kernel-trace -d $O/prof_k -o k -- $B --steps 30 --warmup 3 > /dev/null 2>&1
@@ -36,6 +33,12 @@ for n in 16 4; do
 done
 cd $R; python tools/op_census.py 2>&1 | grep -v -i warn > $O/${T}_op_census.txt
 python tools/traffic_json.py $O/${T}_pmc.txt 256 "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py --no-cpu-baseline --no-lbs --lasr-iters 0 --steps 3 --warmup 1 (256 frames per launch, mesh M2, 256x256); KiB per dispatch summed over all TCC instances; bytes = (FETCH_SIZE + WRITE_SIZE) * 1024 raw (the gfx950 x2 read correction of MI355X_MICROARCH.md is calibrated for 16 B/lane coalesced streams only; these kernels gather 4 B/lane and read records through the scalar cache)" > $O/${T}_traffic.json
+# the bench line quotes traffic / valu_frac from the counter files of THIS build: put them where bench.py looks, then run it
+cp $O/${T}_traffic.json $O/${T}_valu.json $R/profiles/
+cd $R
+python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
+python bench.py --image-size 512 --frames 64 --no-lbs --no-sweep --lasr-iters 0 > $O/${T}_bench_512.json 2>/dev/null
+python tools/cosdist_bench.py > $O/${T}_cosdist.json 2>/dev/null
 python -c "
 import json;d=json.load(open('$O/${T}_bench.json'))
 print(d['value'], d['ms_per_step'], d['roofline']['all_kernels_avg_ms'], d['roofline']['frac'], d['roofline']['traffic']); print(d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline']['one_thread_frames_per_s']); print(d.get('optimize_py',{}).get('iters_per_s'))
