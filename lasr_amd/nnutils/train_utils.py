@@ -406,31 +406,48 @@ class LASRTrainer:
         if not rows or len(opt.param_groups) > _lib.TAIL_MAX_GROUPS:
             return None
         # one table per set of addresses: with --use_graph the gradients alternate between the graphs' memory pools (plain /
-        # pose-noise iterations, hypothesis switches), and each set is built -- one host sync -- only once
+        # pose-noise iterations, hypothesis switches).  What needs a host sync -- reading the optimizer's step counts -- depends on
+        # the parameters and their state only and is done once per such set (`_tail_shared`); a set that differs in the GRADIENT
+        # addresses alone (eager steps with zero_grad(set_to_none=True): the allocator hands out other blocks) costs one
+        # asynchronous upload of the row table from pinned memory, no sync
         caches = self.__dict__.setdefault('_tail_caches', {})
         rkey = tuple(rows)
         cached = caches.get(rkey)
         if cached is not None:
             self._tail_cache = cached
             return cached if cached.get('table') is not None else None
-        steps = torch.stack([t.reshape(()) for t in key]).cpu()                 # one sync per NEW address set
-        if float(steps.min()) != float(steps.max()):                             # tensors at different step counts (a parameter
-            self._tail_cache = caches[rkey] = dict(rows=rows, table=None)        # joined later): torch path, decided once
-            return None
-        self._tail_t = int(steps[0])                                             # shared by all tables: the optimizer's step count
-        h = _lib.lib()
-        ch = h.lasr_tail_chunk_elems()
-        chunks = [(i, off) for i, r in enumerate(rows) for off in range(0, r[5], ch)]
+        shared = self.__dict__.setdefault('_tail_shared', {})
+        skey = tuple(r[:1] + r[2:] for r in rows)                                # everything but the gradient address
+        sh = shared.get(skey)
         dev = self.device
-        if getattr(self, '_tail_ctl', None) is None:
-            self._tail_ctl = torch.zeros(8, dtype=torch.float32, device=dev)     # ctl[6] counts the skipped (NaN) steps of the run
+        if sh is None:
+            steps = torch.stack([t.reshape(()) for t in key]).cpu()             # the one sync per parameter / state set
+            self._tail_syncs = getattr(self, '_tail_syncs', 0) + 1
+            if float(steps.min()) != float(steps.max()):                         # tensors at different step counts (a parameter
+                sh = shared[skey] = dict(valid=False)                            # joined later): torch path, decided once
+            else:
+                self._tail_t = int(steps[0])                                     # shared by all tables: the optimizer's step count
+                ch = _lib.lib().lasr_tail_chunk_elems()
+                chunks = [(i, off) for i, r in enumerate(rows) for off in range(0, r[5], ch)]
+                if getattr(self, '_tail_ctl', None) is None:
+                    self._tail_ctl = torch.zeros(8, dtype=torch.float32, device=dev)   # ctl[6] counts the skipped (NaN) steps of the run
+                sh = shared[skey] = dict(valid=True, n_chunks=len(chunks), chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
+                                         partials=torch.empty(len(chunks), dtype=torch.float64, device=dev))
         if len(caches) > 8:
-            caches.clear()                                                       # addresses keep changing (eager + set_to_none): bounded
-        self._tail_cache = cached = caches[rkey] = dict(
-            rows=rows, n_chunks=len(chunks),
-            table=torch.tensor(rows, dtype=torch.int64).to(dev), chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
-            partials=torch.empty(len(chunks), dtype=torch.float64, device=dev), ctl=self._tail_ctl)
+            caches.clear()                                                       # addresses keep changing (eager steps): bounded
+        if not sh['valid']:
+            self._tail_cache = caches[rkey] = dict(rows=rows, table=None)
+            return None
+        table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        self._tail_cache = cached = caches[rkey] = dict(rows=rows, n_chunks=sh['n_chunks'], table=table, chunks=sh['chunks'],
+                                                        partials=sh['partials'], ctl=self._tail_ctl)
         return cached
+
+    def _tail_reset(self):
+        """Forget the cached tables (after the optimizer state was edited by hand)."""
+        self._tail_cache = None
+        self.__dict__.pop('_tail_caches', None)
+        self.__dict__.pop('_tail_shared', None)
 
     def _step_tail_hip(self):
         import ctypes

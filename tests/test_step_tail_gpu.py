@@ -117,8 +117,7 @@ def test_fused_tail_steps_aside_when_step_counts_differ(tmp_path, cuda):
     tr.step_tail()
     assert tr._tail_table() is not None
     tr.optimizer.state[tr.module.mean_v]['step'] += 3
-    tr._tail_cache = None
-    tr._tail_caches.clear()                                          # force a rebuild of the table (new step counts)
+    tr._tail_reset()                                                 # force a rebuild of the table (new step counts)
     set_grads(tr, 2, 1.0)
     before = tr.module.tex.detach().clone()
     tr.step_tail()
@@ -150,19 +149,26 @@ def test_huge_finite_gradient_is_not_mistaken_for_nan_and_skips_are_counted(tmp_
     assert a.skipped_nan is True and a.skipped_steps() == 2
 
 
-def test_eager_steps_do_not_rebuild_the_tail_table(tmp_path, cuda):
-    # --nouse_graph: zero_grad(set_to_none=True) reallocates the gradients every step; the caching allocator returns the same
-    # blocks in steady state and the trainer keeps one table per address set, so the table (one host sync to build) is built
-    # once or twice, not once per step
+def test_eager_steps_do_not_sync_for_the_tail_table(tmp_path, cuda):
+    # --nouse_graph: zero_grad(set_to_none=True) reallocates the gradients every step and the allocator may hand out other
+    # blocks each time.  The host sync of the table (reading the optimizer's step counts) belongs to the parameter / state set
+    # and happens once; new gradient addresses cost an asynchronous upload only, and the table cache stays bounded
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_lasr_forward_gpu import make_trainer
-    a = make_trainer(tmp_path, iters_per_epoch=8)                    # eager (use_graph=False), fused tail on by default
+    a = make_trainer(tmp_path, iters_per_epoch=12)                   # eager (use_graph=False), fused tail on by default
     a.model.train()
     a.reinit_bones()
-    seen = []
-    for i in range(8):
+    before = [p.detach().clone() for p in a.module.parameters()]
+    for i in range(12):
         a.module.iters = i + 1
         a.train_step(a.set_input(a.dataloader[i]))
-        seen.append(len(getattr(a, '_tail_caches', {})))
-    assert a._tail_cache.get('table') is not None
-    assert seen[-1] <= 3 and seen[-1] == seen[3], seen               # no new address set after the first few steps
+        c = getattr(a, '_tail_cache', None)
+        if i >= 1:                                                   # (the first step is torch's: it creates the optimizer state)
+            assert c.get('table') is not None and a._tail_t == i + 1
+            assert torch.equal(c['table'].cpu(), torch.tensor(c['rows'], dtype=torch.int64))
+    assert a._tail_syncs == 1 and len(a._tail_shared) == 1 and len(a._tail_caches) <= 9
+    assert a.skipped_steps() == 0
+    moved = [float((p - q).abs().max()) for p, q in zip(a.module.parameters(), before) if p.requires_grad]
+    assert all(np.isfinite(moved)) and max(moved) > 0
+    st = a.optimizer.state[a.module.mean_v]
+    assert float(st['step']) == 12
