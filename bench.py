@@ -261,7 +261,7 @@ def optimize_leg(dev, iters):
                       'multi-tensor HIP launches'}
 
 
-RASTER_SOURCES = ('sr_raster.hip', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
+RASTER_SOURCES = ('sr_raster.hip', 'sr_forward_coop.h', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
 VALU_PEAK_LANE_OPS = 1024 * 32 * 2.4e9      # 256 CUs x 4 SIMDs, 32 fp32 lanes per SIMD per clock (a wave64 op issues in 2), 2.4 GHz
 
 

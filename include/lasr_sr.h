@@ -182,6 +182,16 @@ int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launch
 int lasr_sr_set_forward_math(int mode);
 
 /*
+ * Which forward kernel a launch of LASR's mode combination takes, by its size in 16x16-pixel tiles (frames x tiles per frame);
+ * process-wide, no reference counterpart, the output is bit-identical whichever kernel runs (tests/test_raster_parity_gpu.py runs
+ * every one on the same inputs).  Up to coop8_max_blocks: eight waves share an 8x8 tile; up to coop_max_blocks: four waves
+ * (sr_forward_coop.h: latency designs for launches that cannot fill the chip); above w1_min_blocks: one wave per 8x8 tile; in
+ * between: four waves per 16x16 tile.  Defaults 1536 / 8192 / 8192 (measured on an MI355X, csrc/sr_raster.hip), also settable
+ * through LASR_SR_COOP8_MAX_BLOCKS / LASR_SR_COOP_MAX_BLOCKS / LASR_SR_W1_MIN_BLOCKS.  A negative argument keeps the current value.
+ */
+int lasr_sr_set_launch_thresholds(long long coop8_max_blocks, long long coop_max_blocks, long long w1_min_blocks);
+
+/*
  * Test hook (no reference counterpart): adds to *mismatches the number of pairs for which the library's
  * exact division-by-reciprocal (sr_device.h) differs bitwise from the IEEE quotient a[i] / b[i].
  */

@@ -1,0 +1,248 @@
+// sr_forward_coop.h -- the forward raster kernel for SMALL launches: four or eight waves share one 8x8-pixel tile.
+//
+// With few frames per launch the forward pass is a latency problem, not a throughput problem: a wave that is alone on its SIMD
+// issues one instruction every ~5 cycles whatever the instruction is, a list entry costs ~380 VALU + SALU instructions, and the
+// busiest 8x8 quadrant of a LASR frame walks ~140 entries one after the other -- 0.2 ms for ONE frame while most of the chip
+// idles (profiles/r03_pmc_sq_n4.txt: 13 cycles per VALU instruction per wave, 40 % of the wave time in s_waitcnt).  The pixels'
+// face lists cannot be split between waves (the alpha product and the online depth-softmax see the faces in index order, and
+// neither is associative in floating point), but most of an entry's work does not touch that state:
+//
+//   part I  (producers, ~250 instructions per entry): rect test, barycentrics, distance, sigmoid, clip / normalise, depth,
+//           normalised depth, the interpolated attributes -- functions of (pixel, face) only;
+//   part S  (consumer, ~40 instructions per entry):   alpha product, running maximum, the one exponential, the rescaled sums.
+//
+// Per step of seven list entries waves 1..3 evaluate part I of two entries each and wave 0 of one (eight-wave form: waves 1..7
+// one entry each, wave 0 none), into an LDS buffer [entry][field][pixel]; wave 0 then applies part S to the previous step's
+// seven entries IN LIST ORDER while the others are already on the next step (two buffers, one workgroup barrier per step).  Every (pixel, face) pair goes through exactly the
+// arithmetic of sr_forward_kernel's forward_face, in the same order per pixel: the output is bit-identical.  The host picks
+// this kernel by launch size (forward_impl); large launches keep the one-wave-per-tile kernel, which spends fewer instructions
+// per entry in total.
+#pragma once
+
+namespace lasr {
+
+constexpr int COOP_CAP = 1024;        // list entries per round (u16 ids relative to the round's first face)
+
+// NW waves per tile; per step waves 1..NW-1 evaluate part I of EPW entries each (slots (w-1)*EPW ..) and wave 0 of E0 (the last slots)
+template <int NCH, int NW = 4, int EPW = 2, int E0 = 1>
+__global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, float* __restrict__ aggrs,
+                                                                  float* __restrict__ colors)
+{
+    constexpr int COOP_STEP = (NW - 1) * EPW + E0;
+    constexpr int FIELDS = 3 + NCH;                     // flags, D, zn, NCH interpolated attributes
+    __shared__ unsigned short s_list[COOP_CAP];
+    __shared__ int s_wcnt[2][NW];
+    __shared__ float s_buf[2][COOP_STEP][FIELDS][64];
+
+    const Modes m = Modes{2, 1, 2, 1, 1};               // LASR's configuration: euclidean, softmax, prod, vertex, double-sided
+    if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
+    const int IS = A.IS, P = IS * IS;
+    const int tiles_x = (IS + 7) / 8;
+    int bn, tx, ty;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int qx0 = tx * 8, qy0 = ty * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool valid = px < IS && py < IS;
+    const int pn = py * IS + px;
+
+    PixState<NCH> s;                                    // lives in wave 0 only
+    s.a = 1.f;
+    s.fbest = -1;
+    s.ssum = expf(A.eps / A.gamma); s.smax = A.eps;
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        const float bg = A.use_bg ? A.bg[k] : (valid ? colors[((size_t)bn * (NCH + 1) + k) * P + pn] : 1.f);
+        s.c[k] = bg * s.ssum;
+    }
+
+    // level 0: the groups of 64 consecutive faces whose union rect meets the tile (every wave evaluates the same test)
+    const int G = groups_of(A.F);
+    const short4* __restrict__ grects = A.grects + (size_t)bn * G;
+    const int tX1 = qx0 + 7, tY1 = qy0 + 7;
+    unsigned long long gmask;
+    {
+        bool t = false;
+        if (lane < G) {
+            const short4 q = grects[lane];
+            t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
+        }
+        gmask = __ballot(t);
+    }
+    if (gmask != 0 || G > 64) {
+    const float xp = pix_center(px, IS);
+    const float yp = pix_center(IS - 1 - py, IS);
+    const short4* __restrict__ rects = A.rects + (size_t)bn * A.F;
+    const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
+    const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
+    const int texstride = A.T * NCH;
+    UniRecip U;
+    U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
+    U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
+    const float fmn = A.far - A.near;
+    const float thr_pad2 = A.thr * 1.10f;
+    const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
+    const float q_yhi = pix_center(IS - 1 - qy0, IS), q_ylo = pix_center(IS - 1 - min(qy0 + 7, IS - 1), IS);
+
+    // rect overlap + the conservative corner cull of sr_forward_kernel (same faces contribute, fewer entries to walk)
+    auto touches_tile = [&](int f) -> bool {
+        const short4 q = rects[f];
+        bool hit = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
+        if (hit) {
+            const float* R = recs + (size_t)f * REC;
+            if (__float_as_int(R[R_FLAGS]) & 16) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float a = R[R_INV + 3 * k], b = R[R_INV + 3 * k + 1], c = R[R_INV + 3 * k + 2];
+                    const float w00 = a * q_xlo + b * q_ylo + c, w01 = a * q_xhi + b * q_ylo + c;
+                    const float w10 = a * q_xlo + b * q_yhi + c, w11 = a * q_xhi + b * q_yhi + c;
+                    const float wmax = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
+                    if (wmax < 0.f && wmax * wmax * R[R_HK2 + k] > thr_pad2) hit = false;
+                }
+            }
+        }
+        return hit;
+    };
+
+    // part I of list entry e into slot `slot` of buffer `b` (the calling wave's 64 pixels)
+    auto produce = [&](int b, int slot, int e, int base) {
+        const int fn = __builtin_amdgcn_readfirstlane(base + (int)s_list[e]);
+        const cptr_t rec = as_const(recs + (size_t)fn * REC);
+        const cptr_t tex = as_const(texs + (size_t)fn * texstride);
+        const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
+        const bool cand = valid && px >= (int)(short)(rx & 0xffff) && px <= (rx >> 16) &&
+                          py >= (int)(short)(ry & 0xffff) && py <= (ry >> 16);
+        float w0, w1, w2;
+        barycentric(rec, xp, yp, w0, w1, w2);
+        const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
+        int fl = 0;
+        if (cand) {
+            Frag fr;
+            const bool ok = mk ? fragment_w<false, true>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, U.inv_sigma)
+                               : fragment_w<false, false>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, U.inv_sigma);
+            if (ok) {
+                fl = mk ? 5 : 1;
+                s_buf[b][slot][1][lane] = fr.D;
+                float c0 = w0, c1 = w1, c2 = w2;
+                clip_normalise<false>(c0, c1, c2);
+                const float zp = mk ? depth_at<false, true>(rec, c0, c1, c2) : depth_at<false, false>(rec, c0, c1, c2);
+                if (!(zp < A.near || zp > A.far)) {
+                    fl |= 2;
+                    s_buf[b][slot][2][lane] = mk ? div_by_recip(A.far - zp, fmn, U.inv_fmn) : (A.far - zp) / fmn;
+#pragma unroll
+                    for (int k = 0; k < NCH; k++)
+                        s_buf[b][slot][3 + k][lane] = sample_colour(tex, c0, c1, c2, A.res, k, m.tex, 0, NCH);
+                }
+            }
+        }
+        s_buf[b][slot][0][lane] = __int_as_float(fl);
+    };
+
+    // part S of slot `slot` of buffer `b`: forward_face's state update, K.cu:409-446 (wave 0)
+    auto consume = [&](int b, int slot) {
+        const int fl = __float_as_int(s_buf[b][slot][0][lane]);
+        if (fl & 1) {
+            const float D = s_buf[b][slot][1][lane];
+            s.a = (float)((double)s.a * (1. - (double)D));
+            if (fl & 2) {
+                const float zn = s_buf[b][slot][2][lane];
+                const bool up = zn > s.smax;
+                const float d = up ? s.smax - zn : zn - s.smax;
+                const float E = exp_1ulp((fl & 4) ? div_by_recip(d, A.gamma, U.inv_gamma) : d / A.gamma);
+                const float hist = up ? E : 1.f, wgt = up ? D : E * D;
+                s.smax = up ? zn : s.smax;
+                s.ssum = hist * s.ssum + wgt;
+#pragma unroll
+                for (int k = 0; k < NCH; k++) s.c[k] = hist * s.c[k] + wgt * s_buf[b][slot][3 + k][lane];
+            }
+        }
+    };
+
+    int g_next = 64, g_mask0 = 0;
+    bool more = true;
+    while (more) {                                    // one round unless the tile meets more than COOP_CAP - 64 NW faces
+        // ---- ordered list of the faces that reach the tile: four touched groups per step, one per wave
+        int count = 0, flip = 0, base = -1;
+        for (;;) {
+            if (gmask == 0) {
+                if (g_next >= G) { more = false; break; }
+                g_mask0 = g_next;
+                bool t = false;
+                if (g_next + lane < G) {
+                    const short4 q = grects[g_next + lane];
+                    t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
+                }
+                gmask = __ballot(t);
+                g_next += 64;
+                continue;
+            }
+            unsigned long long mm = gmask;
+            int mine_g = -1, last_g = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                if (mm) {
+                    const int bit = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    if (k == wave) mine_g = g_mask0 + bit;
+                    last_g = g_mask0 + bit;
+                }
+            }
+            const int first_g = g_mask0 + __builtin_ctzll(gmask);
+            if (base < 0) base = first_g * GROUP;
+            if (count + NW * 64 > COOP_CAP || (last_g + 1) * GROUP - base > 65536) break;  // walk what we have, then continue
+            gmask = mm;
+            const int f = mine_g * GROUP + lane;
+            const bool hit = mine_g >= 0 && f < A.F && touches_tile(f);
+            const unsigned long long mask = __ballot(hit);
+            if (lane == 0) s_wcnt[flip][wave] = __popcll(mask);
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int c = s_wcnt[flip][k];
+                if (k < wave) before += c;
+                all += c;
+            }
+            if (hit) s_list[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+            count += all;
+            flip ^= 1;
+        }
+        if (base < 0) base = 0;
+        __syncthreads();
+        // ---- the walk, software-pipelined over steps of COOP_STEP entries: step k is produced while step k - 1 is consumed
+        const int steps = (count + COOP_STEP - 1) / COOP_STEP;
+        for (int k = 0; k <= steps; k++) {
+            if (k < steps) {
+                const int e0 = k * COOP_STEP, b = k & 1;
+                if (wave == 0) {
+#pragma unroll
+                    for (int j = (NW - 1) * EPW; j < COOP_STEP; j++)
+                        if (e0 + j < count) produce(b, j, e0 + j, base);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < EPW; i++) {
+                        const int j = (wave - 1) * EPW + i;
+                        if (e0 + j < count) produce(b, j, e0 + j, base);
+                    }
+                }
+            }
+            if (k > 0 && wave == 0) {
+                const int e0 = (k - 1) * COOP_STEP, b = (k - 1) & 1;
+                const int n = min(COOP_STEP, count - e0);
+                for (int j = 0; j < n; j++) consume(b, j);
+            }
+            __syncthreads();
+        }
+    }
+    }   // tile meets at least one group
+
+    if (!valid || wave != 0) return;
+    // ---- finalise (K.cu:458-482)
+    colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = (float)(1. - (double)s.a);
+#pragma unroll
+    for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k] / s.ssum;
+    aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
+    aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
+}
+
+}  // namespace lasr

@@ -219,30 +219,18 @@ __device__ __forceinline__ void tile_of_block(int b, int total, int tiles_x, int
     tx = tl - ty * tiles_x;
 }
 
-// LDSR = the small-launch variant (LASR's mode combination, vertex attributes): with few frames per launch a quadrant's
-// wave runs nearly alone on its SIMD and the walk is a serial chain of dependent scalar-cache misses (record line 0 -> test
-// -> lines 1, 2 -> attributes), ~0.5 us per list entry; here the wave copies the records + attributes of its next 16 entries
-// into LDS with wide vector loads (one round trip per 16 entries, the following 16 already in flight in registers) and reads
-// the fields back with same-address (broadcast) ds_reads.  Same arithmetic, same order: bit-identical output.  At large
-// launches the scalar-cache walk wins (7 waves per SIMD hide the misses, SGPR operands cost no LDS instruction): the host
-// picks the variant by launch size (forward_impl).
-constexpr int STAGE = 16;                  // entries staged per round: 64 lanes = 16 slots x 4 parts
-constexpr int SLOT = REC + 28;             // dwords per staged entry: record + up to 27 vertex attributes (9 channels) + 1 pad
-typedef const float __attribute__((address_space(3)))* lptr_t;
-
 // W1 = one wave per workgroup, the workgroup's tile IS the wave's 8x8 quadrant: no workgroup barrier anywhere and nothing held
 // until the slowest of four waves is done.  Affordable since the group rects (level 0) made the face scan cheap: a lone wave
 // tests the ~40 group rects, then scans only the groups that can touch its 64 pixels, compacting straight into its own list.
-template <bool LASR_FAST, int NCH, bool RX = false, bool LDSR = false, bool W1 = false>
+template <bool LASR_FAST, int NCH, bool RX = false, bool W1 = false>
 __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                          float* __restrict__ colors)
 {
-    constexpr int CAP = LDSR ? 1024 : LIST_CAP;       // the staging buffers take LDS: shorter lists (more rounds when a tile is crowded)
+    constexpr int CAP = LIST_CAP;
     constexpr int NW = W1 ? 1 : 4, TW = W1 ? 8 : TILE;
     __shared__ unsigned short s_all[W1 ? 1 : CAP];    // faces whose pixel rect touches the 16x16 tile, index order
     __shared__ unsigned short s_mine[NW][CAP];        // per wave: the subset touching its 8x8 quadrant, index order
     __shared__ int s_wcnt[2][4];
-    __shared__ __attribute__((aligned(16))) float s_stage[LDSR ? NW * STAGE * SLOT : 4];
 
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
@@ -416,58 +404,6 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
 #if defined(LASR_ABL) && LASR_ABL == 2              // measurement build: binning only
         s.a += (float)n_mine; n_mine = 0;
 #endif
-        if constexpr (LDSR) {
-            float* const stage = s_stage + wave * (STAGE * SLOT);
-            const int slot = lane >> 2, part = lane & 3;
-            float4 p0 = {}, p1 = {}, p2 = {}, p3 = {};
-            float pret[3 * NCH] = {};
-            // LASR_FETCH(i0): this lane's share of entries [i0, i0 + STAGE) into registers (a macro, not a lambda: captured
-            // arrays would live in scratch)
-#define LASR_FETCH(I0)                                                                                        \
-            if ((I0) + slot < n_mine) {                                                                       \
-                const int fn_ = base + (int)mine[(I0) + slot];                                                \
-                if (part < 3) {                                                                               \
-                    const float4* src = reinterpret_cast<const float4*>(recs + (size_t)fn_ * REC + part * 16); \
-                    p0 = src[0]; p1 = src[1]; p2 = src[2]; p3 = src[3];                                       \
-                } else {                                                                                      \
-                    const float* src = texs + (size_t)fn_ * texstride;                                        \
-                    _Pragma("unroll") for (int k = 0; k < 3 * NCH; k++) pret[k] = src[k];                     \
-                }                                                                                             \
-            }
-            LASR_FETCH(0)
-            for (int i0 = 0; i0 < n_mine; i0 += STAGE) {
-                const int n = min(STAGE, n_mine - i0);
-                if (slot < n) {
-                    if (part < 3) {
-                        float4* dst = reinterpret_cast<float4*>(stage + slot * SLOT + part * 16);
-                        dst[0] = p0; dst[1] = p1; dst[2] = p2; dst[3] = p3;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 3 * NCH; k++) stage[slot * SLOT + REC + k] = pret[k];
-                    }
-                }
-                LASR_FETCH(i0 + STAGE)                           // in flight while this chunk is walked
-                __builtin_amdgcn_wave_barrier();
-                const int ids = (lane < n) ? (int)mine[i0 + lane] : 0;
-                for (int j = 0; j < n; j++) {
-                    const int fn = base + __builtin_amdgcn_readlane(ids, j);
-                    const lptr_t rec = (lptr_t)(stage + j * SLOT);
-                    const lptr_t tex = rec + REC;
-                    const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
-                    const bool cand = valid && px >= (int)(short)(rx & 0xffff) && px <= (rx >> 16) &&
-                                      py >= (int)(short)(ry & 0xffff) && py <= (ry >> 16);
-                    float w0, w1, w2;
-                    barycentric(rec, xp, yp, w0, w1, w2);
-                    const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);
-                    if (cand) {
-                        if (mk) forward_face<LASR_FAST, true, NCH, RX>(A, m, rec, tex, fn, 0, xp, yp, w0, w1, w2, s, U);
-                        else forward_face<LASR_FAST, false, NCH>(A, m, rec, tex, fn, 0, xp, yp, w0, w1, w2, s, U);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();                 // the next round overwrites the slots
-            }
-#undef LASR_FETCH
-        } else
         for (int i0 = 0; i0 < n_mine; i0 += 64) {
             const int chunk = (i0 + lane < n_mine) ? (int)mine[i0 + lane] : 0;
             const int n = min(64, n_mine - i0);
@@ -525,6 +461,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
 
 
 }  // namespace lasr
+#include "sr_forward_coop.h"
 #include "sr_backward.h"
 namespace lasr {
 
@@ -613,28 +550,29 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
 static int g_forward_math = 0;                               // 0 = reference-faithful (default), 1 = relaxed, see forward_face
 static int default_flags() { return g_forward_math ? LASR_SR_RELAXED_MATH : 0; }
 
-// Launches of at most this many 16x16-pixel tiles (frames x tiles per frame) take the LDS-staged forward walk.  Measured on
-// an MI355X, mesh M2 at 256x256 (256 tiles per frame), forward kernel, scalar-cache walk -> LDS walk: 1 frame 203 -> 206 us,
-// 4 frames 226 -> 219 us, 16 frames 308 -> 281 us, 64 frames 735 -> 755 us, 256 frames 2.556 -> 2.587 ms
-// (profiles/r03_lds_walk_ab.txt).  Default: up to 24576 tiles (launches above LASR_SR_W1_MIN_BLOCKS = 8192 tiles, 32 frames at
-// 256x256, take the one-wave-per-8x8-tile kernel first, so this variant serves 1..32 frames).  Environment override
-// LASR_SR_LDS_WALK_MAX_BLOCKS (0 = never), read once; the output is bit-identical either way.
-static long long lds_walk_default()
+static long long env_blocks(const char* name, long long dflt)
 {
-    const char* e = getenv("LASR_SR_LDS_WALK_MAX_BLOCKS");
-    return e ? atoll(e) : 24576;           // (launches above LASR_SR_W1_MIN_BLOCKS tiles take the W1 kernel before this is asked)
+    const char* e = getenv(name);
+    return e ? atoll(e) : dflt;
 }
-static const long long g_lds_walk_max_blocks = lds_walk_default();
 // Launches of more than this many 16x16 tiles take the one-wave-per-8x8-tile kernel (W1).  Measured (MI355X, mesh M2, forward
 // kernel, four-wave 16x16 tiles -> W1): 256 frames at 256x256 2.370 -> 2.163 ms, 64 frames 0.696 -> 0.649 ms, 64 frames at 512x512
 // 1.574 -> 1.474 ms, 16 frames 0.284 -> 0.280 ms, 4 frames 0.210 -> 0.221 ms, 1 frame 0.206 -> 0.221 ms (profiles/r03_w1_ab.txt).
-// Environment override LASR_SR_W1_MIN_BLOCKS (a huge value = never), read once; bit-identical output either way.
-static long long w1_default()
-{
-    const char* e = getenv("LASR_SR_W1_MIN_BLOCKS");
-    return e ? atoll(e) : 8192;
-}
-static const long long g_w1_min_blocks = w1_default();
+// Environment override LASR_SR_W1_MIN_BLOCKS (a huge value = never), read once, or lasr_sr_set_launch_thresholds; bit-identical
+// output either way.
+static long long g_w1_min_blocks = env_blocks("LASR_SR_W1_MIN_BLOCKS", 8192);
+
+// Launches of at most g_coop_max_blocks 16x16-pixel tiles (frames x tiles per frame) take the cooperative kernel of
+// sr_forward_coop.h (several waves share one 8x8 tile: a latency design for launches that cannot fill the chip), with eight
+// waves per tile up to g_coop8_max_blocks and four above.  Measured on an MI355X, mesh M2 at 256x256 (256 tiles per frame),
+// three channels, forward kernel ms, [previous choice] -> four waves / eight waves (profiles/r03_coop_ab.txt):
+//   1 frame 0.209 -> 0.084 / 0.052     2 frames 0.205 -> 0.084 / 0.057     4 frames 0.211 -> 0.094 / 0.087
+//   8 frames 0.223 -> 0.140 / 0.140    16 frames 0.285 -> 0.219 / 0.256    24 frames 0.355 -> 0.298 / 0.381
+//   32 frames 0.424 -> 0.397 / 0.528   48 frames 0.529 -> 0.564 / 0.762    (64 frames 0.648 -> 0.78; 256 frames 2.18 -> 3.13)
+// Environment overrides LASR_SR_COOP_MAX_BLOCKS / LASR_SR_COOP8_MAX_BLOCKS (0 = never), read once, or
+// lasr_sr_set_launch_thresholds; bit-identical output.
+static long long g_coop_max_blocks = env_blocks("LASR_SR_COOP_MAX_BLOCKS", 8192);
+static long long g_coop8_max_blocks = env_blocks("LASR_SR_COOP8_MAX_BLOCKS", 1536);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -674,23 +612,30 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     {
         ProfScope ps(K_SR_FORWARD, st);
         const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
-        // small launches: the LDS-staged walk (sr_forward_kernel<.., LDSR = true>); see g_lds_walk_max_blocks
-        const bool lds = (nch > 3 || is_lasr_fast(A.m)) && !rx && (long long)grid.x <= g_lds_walk_max_blocks;
+        if ((long long)grid.x <= g_coop_max_blocks && is_lasr_fast(A.m) && !rx) {
+            // small launches: several waves per 8x8 tile (sr_forward_coop_kernel); see g_coop_max_blocks
+            const int t8 = (IS + 7) / 8;
+            const dim3 grid8((unsigned)(N * t8 * t8));
+            const bool w8 = (long long)grid.x <= g_coop8_max_blocks;
+            if (nch == 9 && w8) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 9) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 6 && w8) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            else if (w8) hipLaunchKernelGGL((sr_forward_coop_kernel<3, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+            else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        } else
         if ((long long)grid.x > g_w1_min_blocks && (nch > 3 || is_lasr_fast(A.m))) {
             // one wave per 8x8 tile (sr_forward_kernel<.., W1 = true>)
             const int t8 = (IS + 7) / 8;
             const dim3 grid8((unsigned)(N * t8 * t8));
-            if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            else hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
         } else
-        if (lds && nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (lds && nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (lds) hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+        if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
         else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
@@ -904,6 +849,14 @@ extern "C" int lasr_selftest_div3(const float* a, const float* b, int* mismatche
     if (n == 0) return LASR_OK;
     hipLaunchKernelGGL(selftest_div3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, a, b, mismatches, n);
     return launch_ok();
+}
+
+extern "C" int lasr_sr_set_launch_thresholds(long long coop8_max_blocks, long long coop_max_blocks, long long w1_min_blocks)
+{
+    if (coop8_max_blocks >= 0) g_coop8_max_blocks = coop8_max_blocks;
+    if (coop_max_blocks >= 0) g_coop_max_blocks = coop_max_blocks;
+    if (w1_min_blocks >= 0) g_w1_min_blocks = w1_min_blocks;
+    return LASR_OK;
 }
 
 extern "C" int lasr_sr_set_forward_math(int mode)

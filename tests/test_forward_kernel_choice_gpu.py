@@ -1,0 +1,118 @@
+"""The forward pass picks one of four kernels by launch size (lasr_amd/csrc/sr_raster.hip forward_impl: eight or four waves
+sharing an 8x8 tile for launches that cannot fill the chip -- sr_forward_coop.h --, four waves per 16x16 tile, one wave per 8x8
+tile for large launches).  They evaluate every (pixel, face) pair with the same instruction sequence and visit the faces of a
+pixel in index order, so their outputs must be IDENTICAL bit for bit: this file forces each one in turn
+(lasr_sr_set_launch_thresholds, include/lasr_sr.h) on the same inputs -- ragged image sizes, 3 / 6 / 9 channels, a tile whose
+list needs more than one round, device-resident near/far, the background as an argument, an empty mesh -- and compares the
+raw bits; one of them is also held against the oracle, which pins all four."""
+import numpy as np
+import pytest
+import torch
+
+from lasr_amd import _lib, synth
+from lasr_amd.soft_renderer import functional as srf
+
+pytestmark = pytest.mark.gpu
+
+BIG = 10 ** 12
+#            coop8_max  coop_max  w1_min
+VARIANTS = {'eight waves per 8x8 tile': (BIG, BIG, BIG),
+            'four waves per 8x8 tile': (0, BIG, BIG),
+            'four waves per 16x16 tile': (0, 0, BIG),
+            'one wave per 8x8 tile': (0, 0, 0)}
+DEFAULTS = (1536, 8192, 8192)
+
+
+@pytest.fixture
+def thresholds():
+    h = _lib.lib()
+    yield lambda name: _lib.check(h.lasr_sr_set_launch_thresholds(*VARIANTS[name]), 'lasr_sr_set_launch_thresholds')
+    h.lasr_sr_set_launch_thresholds(*DEFAULTS)
+
+
+def render(dev, fv, ft, IS, kw):
+    tfv, tft = torch.from_numpy(fv).to(dev), torch.from_numpy(ft).to(dev)
+    img = srf.soft_rasterize(tfv, tft, IS, **kw)
+    torch.cuda.synchronize()
+    return img.cpu().numpy()
+
+
+def all_variants(thresholds, dev, fv, ft, IS, kw):
+    out = {}
+    for name in VARIANTS:
+        thresholds(name)
+        out[name] = render(dev, fv, ft, IS, kw)
+    first = next(iter(out))
+    for name, img in out.items():
+        assert img.shape == out[first].shape
+        assert np.array_equal(img.view(np.uint32), out[first].view(np.uint32)), \
+            '%s differs from %s: max %.3e' % (name, first, np.abs(img - out[first]).max())
+    return out[first]
+
+
+@pytest.mark.parametrize('IS', [1, 7, 8, 20, 33, 64, 100])
+def test_every_kernel_gives_the_same_bits_on_ragged_image_sizes(thresholds, oracle, cuda, IS):
+    fv, ft, near, far = synth.raster_batch(4, 3, count=3)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    img = all_variants(thresholds, cuda, fv, ft, IS, kw)
+    ref = oracle.forward(fv, ft, IS, **kw)
+    assert np.abs(img - ref['soft_colors']).max() <= 1e-6
+
+
+@pytest.mark.parametrize('channels', [6, 9])
+def test_every_kernel_gives_the_same_bits_with_six_and_nine_channels(thresholds, cuda, channels):
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    rng = np.random.default_rng(channels)
+    tex = np.concatenate([ft] + [rng.uniform(-2, 2, ft.shape).astype(np.float32) for _ in range(channels // 3 - 1)], -1)
+    kw = dict(synth.LASR_MODES, near=near, far=far, background_color=[0.25 * k for k in range(channels)])
+    img = all_variants(thresholds, cuda, fv, tex, 72, kw)
+    assert img.shape == (2, channels + 1, 72, 72) and np.isfinite(img).all()
+    # the first triple is the three-channel render of the same geometry
+    thresholds('four waves per 8x8 tile')
+    img3 = render(cuda, fv, ft, 72, dict(kw, background_color=[0., 0.25, 0.5]))
+    assert np.array_equal(img[:, :3], img3[:, :3]) and np.array_equal(img[:, channels], img3[:, 3])
+
+
+def test_every_kernel_gives_the_same_bits_when_a_tile_needs_more_than_one_list_round(thresholds, oracle, cuda):
+    # 2500 faces in the centre of the image: the tiles there meet more faces than one LDS list holds (1024 / 2048 entries)
+    rng = np.random.default_rng(7)
+    F = 2500
+    c = rng.uniform(-0.15, 0.15, (2, F, 1, 2))
+    tri = c + rng.uniform(-0.08, 0.08, (2, F, 3, 2))
+    z = rng.uniform(2, 4, (2, F, 3, 1))
+    fv = np.concatenate([tri, z], -1).astype(np.float32)
+    fv[0, 0] = [[-1.5, -1.2, 3], [1.4, -1.1, 3.5], [0.1, 1.6, 2.5]]
+    ft = rng.uniform(0, 1, fv.shape).astype(np.float32)
+    kw = dict(synth.LASR_MODES, near=1.0, far=5.0)
+    img = all_variants(thresholds, cuda, fv, ft, 64, kw)
+    ref = oracle.forward(fv, ft, 64, **kw)
+    assert np.abs(img - ref['soft_colors']).max() <= 1e-5
+
+
+def test_every_kernel_takes_device_resident_near_far_and_an_empty_mesh(thresholds, cuda):
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    nf = torch.tensor([near, far], dtype=torch.float32, device=cuda)
+    kw = dict(synth.LASR_MODES, near=nf[0], far=nf[1])
+    a = all_variants(thresholds, cuda, fv, ft, 48, kw)
+    b = all_variants(thresholds, cuda, fv, ft, 48, dict(kw, near=near, far=far))
+    assert np.array_equal(a, b)
+    empty = np.zeros((2, 0, 3, 3), np.float32)
+    img = all_variants(thresholds, cuda, empty, empty.copy(), 24, dict(synth.LASR_MODES, near=1.0, far=5.0))
+    assert np.array_equal(img[:, :3], np.ones_like(img[:, :3])) and not img[:, 3].any()
+
+
+def test_every_kernel_at_the_launch_sizes_lasr_uses(thresholds, cuda):
+    # 16 meshes of 1280 faces at 256x256 (spot3 stage 0: 2 images x 8 hypotheses) and 4 of 2420 faces
+    for nu, count in ((8, 16), (11, 4)):
+        fv, ft, near, far = synth.raster_batch(nu, 3, count=count)
+        all_variants(thresholds, cuda, fv, ft, 256, dict(synth.LASR_MODES, near=near, far=far))
+
+
+def test_default_thresholds_pick_by_launch_size(cuda):
+    # the defaults are in force outside this file's fixture: a 1-frame and a 16-frame launch go through without error and agree
+    # with each other frame by frame (a frame rendered alone or in a batch gives the same bits)
+    fv, ft, near, far = synth.raster_batch(8, 3, count=16)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    batch = render(cuda, fv, ft, 256, kw)
+    one = render(cuda, fv[5:6], ft[5:6], 256, kw)
+    assert np.array_equal(batch[5:6], one)
