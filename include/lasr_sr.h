@@ -182,14 +182,20 @@ int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launch
 int lasr_sr_set_forward_math(int mode);
 
 /*
- * Which forward kernel a launch of LASR's mode combination takes, by its size in 16x16-pixel tiles (frames x tiles per frame);
- * process-wide, no reference counterpart, the output is bit-identical whichever kernel runs (tests/test_raster_parity_gpu.py runs
- * every one on the same inputs).  Up to coop8_max_blocks: eight waves share an 8x8 tile; up to coop_max_blocks: four waves
- * (sr_forward_coop.h: latency designs for launches that cannot fill the chip); above w1_min_blocks: one wave per 8x8 tile; in
- * between: four waves per 16x16 tile.  Defaults 1536 / 8192 / 8192 (measured on an MI355X, csrc/sr_raster.hip), also settable
- * through LASR_SR_COOP8_MAX_BLOCKS / LASR_SR_COOP_MAX_BLOCKS / LASR_SR_W1_MIN_BLOCKS.  A negative argument keeps the current value.
+ * Which forward kernel a launch of LASR's mode combination takes, by its size in 8x8-pixel tiles (frames x tiles per frame);
+ * process-wide, no reference counterpart, the output is bit-identical whichever kernel runs (tests/test_forward_kernel_choice_gpu.py
+ * runs every one on the same inputs).  Up to coop8_max_tiles: eight waves share a tile; up to coop_max_tiles: four waves
+ * (csrc/sr_forward_coop.h: latency designs for launches that cannot fill the chip); up to choose_max_tiles: a one-wave kernel
+ * estimates the BUSY tiles from the meshes' pixel bounding boxes on the device and picks four waves per tile (estimate at most
+ * coop_max_tiles) or one wave per tile -- both are launched, the one not chosen returns at once; above: one wave per tile.
+ * Defaults 2200 / 14336 / 49152 (5/8 of that for six and nine channels; measured on an MI355X, csrc/sr_raster.hip), also settable
+ * through LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES / LASR_SR_CHOOSE_MAX_TILES.  A negative argument keeps the current value.
+ * lasr_sr_peek_choice (test hook, synchronises the stream): what the device-side choice of the LAST forward call on `workspace`
+ * was -- 0 one wave per tile, 1 four waves per tile; meaningful only if that call's size was in the device-decided range.
  */
-int lasr_sr_set_launch_thresholds(long long coop8_max_blocks, long long coop_max_blocks, long long w1_min_blocks);
+int lasr_sr_set_launch_thresholds(long long coop8_max_tiles, long long coop_max_tiles, long long choose_max_tiles);
+int lasr_sr_peek_choice(const void* workspace, int N, int F, int* choice, void* hip_stream);
+
 
 /*
  * Test hook (no reference counterpart): adds to *mismatches the number of pairs for which the library's

@@ -93,6 +93,7 @@ SIGNATURES = {
     'lasr_sr_backward_ex': (_i, [_p] * 8 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
     'lasr_sr_set_forward_math': (_i, [_i]),
     'lasr_sr_set_launch_thresholds': (_i, [ctypes.c_longlong] * 3),
+    'lasr_sr_peek_choice': (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _p]),
     'lasr_selftest_div': (_i, [_p, _p, _p, _i, _p]),
     'lasr_selftest_div3': (_i, [_p, _p, _p, _i, _p]),
     'lasr_prof_enable': (_i, [_i]),

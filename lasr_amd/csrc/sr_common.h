@@ -17,8 +17,12 @@ struct RasterArgs {
     Modes m;
     int overwrite_grads;                      // backward, vertex attributes: store the face's gradients instead of adding to them
     int use_bg;                               // forward: the background colour comes from bg[] instead of the pre-filled soft_colors
+    const int* __restrict__ choice;           // forward, optional: device word written by sr_choose_kernel; a forward kernel whose
+                                              // id (CHOICE_*) differs returns at once (both candidates are launched)
     float bg[9];
 };
+
+constexpr int CHOICE_ONE_WAVE = 0, CHOICE_COOP = 1;
 
 // Block -> (image, tile) with all tiles of an image kept on one XCD (block b runs
 // on XCD b % 8; an image's records are then fetched into a single L2).

@@ -12,7 +12,7 @@
 //   part S  (consumer, ~40 instructions per entry):   alpha product, running maximum, the one exponential, the rescaled sums.
 //
 // Per step of seven list entries waves 1..3 evaluate part I of two entries each and wave 0 of one (eight-wave form: waves 1..7
-// one entry each, wave 0 none), into an LDS buffer [entry][field][pixel]; wave 0 then applies part S to the previous step's
+// one entry each, wave 0 none; nine channels: waves 1..3 one entry each -- forward_impl has the measurements), into an LDS buffer [entry][field][pixel]; wave 0 then applies part S to the previous step's
 // seven entries IN LIST ORDER while the others are already on the next step (two buffers, one workgroup barrier per step).  Every (pixel, face) pair goes through exactly the
 // arithmetic of sr_forward_kernel's forward_face, in the same order per pixel: the output is bit-identical.  The host picks
 // this kernel by launch size (forward_impl); large launches keep the one-wave-per-tile kernel, which spends fewer instructions
@@ -24,6 +24,32 @@ namespace lasr {
 constexpr int COOP_CAP = 1024;        // list entries per round (u16 ids relative to the round's first face)
 
 // NW waves per tile; per step waves 1..NW-1 evaluate part I of EPW entries each (slots (w-1)*EPW ..) and wave 0 of E0 (the last slots)
+// Latency or throughput?  What decides is how many 8x8 tiles have work: below ~8 busy tiles per SIMD the chip is not full and
+// the serial walks set the time (cooperative kernel), above it the total instruction count does (one wave per tile).  The
+// host only knows frames x tiles; LASR frames are cropped around the object (dataloader/vidbase.py:105-135), so most tiles are
+// busy there, while a small object leaves three quarters of them empty.  For launches in the range where that matters one
+// wave estimates the busy tiles from the group rects the setup kernel has just written (lane = image: the union of its group
+// rects is the mesh's pixel bounding box) and leaves its choice in the workspace; both candidates are launched and the one
+// not chosen returns at its first instruction.
+__global__ __launch_bounds__(64) void sr_choose_kernel(const short4* __restrict__ grects, int N, int G, int IS,
+                                                       long long coop_max_tiles, int* __restrict__ choice)
+{
+    long long tiles = 0;
+    for (int i = threadIdx.x; i < N; i += 64) {
+        int x0 = 32767, x1 = -1, y0 = 32767, y1 = -1;
+#pragma unroll 8
+        for (int g = 0; g < G; g++) {                 // (an empty group rect is (32767, -1, 32767, -1): it changes nothing)
+            const short4 q = grects[(size_t)i * G + g];
+            x0 = min(x0, (int)q.x); x1 = max(x1, (int)q.y); y0 = min(y0, (int)q.z); y1 = max(y1, (int)q.w);
+        }
+        x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, IS - 1); y1 = min(y1, IS - 1);
+        if (x0 <= x1 && y0 <= y1) tiles += (long long)((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tiles += __shfl_xor(tiles, o);
+    if (threadIdx.x == 0) *choice = tiles <= coop_max_tiles ? CHOICE_COOP : CHOICE_ONE_WAVE;
+}
+
 template <int NCH, int NW = 4, int EPW = 2, int E0 = 1>
 __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, float* __restrict__ aggrs,
                                                                   float* __restrict__ colors)
@@ -34,6 +60,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
     __shared__ int s_wcnt[2][NW];
     __shared__ float s_buf[2][COOP_STEP][FIELDS][64];
 
+    if (A.choice && *A.choice != CHOICE_COOP) return;   // the launch was left to sr_choose_kernel, which took the other kernel
     const Modes m = Modes{2, 1, 2, 1, 1};               // LASR's configuration: euclidean, softmax, prod, vertex, double-sided
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
     const int IS = A.IS, P = IS * IS;

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     __shared__ unsigned short s_mine[NW][CAP];        // per wave: the subset touching its 8x8 quadrant, index order
     __shared__ int s_wcnt[2][4];
 
+    if (W1 && A.choice && *A.choice != CHOICE_ONE_WAVE) return;      // sr_choose_kernel took the cooperative kernel for this launch
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
@@ -504,6 +505,7 @@ using namespace lasr;
 
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int groups_of_host(int F) { return (F + GROUP - 1) / GROUP; }
 
 
 extern "C" size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS)
@@ -512,7 +514,7 @@ extern "C" size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS)
     if (N < 0 || F < 0) return 0;
     const size_t nf = (size_t)N * (size_t)F;
     const size_t ng = (size_t)N * (size_t)((F + GROUP - 1) / GROUP);
-    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) + align_up(ng * sizeof(short4), 256) + 256;
+    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) + align_up(ng * sizeof(short4), 256) + 256 /* sr_choose_kernel's word */ + 256;
 }
 
 static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alpha, int tex)
@@ -542,6 +544,7 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     A.m = Modes{dist, rgb, alpha, tex, double_side ? 1 : 0};
     A.overwrite_grads = 0;
     A.use_bg = 0;
+    A.choice = nullptr;
     return A;
 }
 
@@ -555,24 +558,30 @@ static long long env_blocks(const char* name, long long dflt)
     const char* e = getenv(name);
     return e ? atoll(e) : dflt;
 }
-// Launches of more than this many 16x16 tiles take the one-wave-per-8x8-tile kernel (W1).  Measured (MI355X, mesh M2, forward
-// kernel, four-wave 16x16 tiles -> W1): 256 frames at 256x256 2.370 -> 2.163 ms, 64 frames 0.696 -> 0.649 ms, 64 frames at 512x512
-// 1.574 -> 1.474 ms, 16 frames 0.284 -> 0.280 ms, 4 frames 0.210 -> 0.221 ms, 1 frame 0.206 -> 0.221 ms (profiles/r03_w1_ab.txt).
-// Environment override LASR_SR_W1_MIN_BLOCKS (a huge value = never), read once, or lasr_sr_set_launch_thresholds; bit-identical
-// output either way.
-static long long g_w1_min_blocks = env_blocks("LASR_SR_W1_MIN_BLOCKS", 8192);
-
-// Launches of at most g_coop_max_blocks 16x16-pixel tiles (frames x tiles per frame) take the cooperative kernel of
-// sr_forward_coop.h (several waves share one 8x8 tile: a latency design for launches that cannot fill the chip), with eight
-// waves per tile up to g_coop8_max_blocks and four above.  Measured on an MI355X, mesh M2 at 256x256 (256 tiles per frame),
-// three channels, forward kernel ms, [previous choice] -> four waves / eight waves (profiles/r03_coop_ab.txt):
+// Which forward kernel a launch of LASR's mode combination takes.  All sizes are 8x8-pixel tiles (frames x tiles per frame):
+//   up to g_coop8_max_tiles              eight waves share a tile        (sr_forward_coop.h: latency designs for launches that
+//   up to g_coop_max_tiles               four waves share a tile          cannot fill the chip)
+//   up to g_choose_max_tiles             decided on the device: sr_choose_kernel estimates the BUSY tiles from the meshes' pixel
+//                                        bounding boxes -- at most g_coop_max_tiles: four waves per tile, else one wave per tile
+//   above                                one wave per tile (W1)
+// Six and nine channels hand more through LDS per entry (fewer tiles in flight per CU): their bounds are 5/8 of the numbers.
+// Measured on an MI355X, forward kernel ms (profiles/r03_coop_ab.txt).  Mesh M2 (2420 faces, the object covers a third of the
+// tiles) at 256x256 (1024 tiles per frame), three channels, [four waves per 16x16 tile, the choice until then] -> four / eight waves:
 //   1 frame 0.209 -> 0.084 / 0.052     2 frames 0.205 -> 0.084 / 0.057     4 frames 0.211 -> 0.094 / 0.087
 //   8 frames 0.223 -> 0.140 / 0.140    16 frames 0.285 -> 0.219 / 0.256    24 frames 0.355 -> 0.298 / 0.381
 //   32 frames 0.424 -> 0.397 / 0.528   48 frames 0.529 -> 0.564 / 0.762    (64 frames 0.648 -> 0.78; 256 frames 2.18 -> 3.13)
-// Environment overrides LASR_SR_COOP_MAX_BLOCKS / LASR_SR_COOP8_MAX_BLOCKS (0 = never), read once, or
-// lasr_sr_set_launch_thresholds; bit-identical output.
-static long long g_coop_max_blocks = env_blocks("LASR_SR_COOP_MAX_BLOCKS", 8192);
-static long long g_coop8_max_blocks = env_blocks("LASR_SR_COOP8_MAX_BLOCKS", 1536);
+// Nine channels (the render of a LASR step), 1280 faces: 2 meshes 0.136 -> 0.065 / 0.044, 4 meshes 0.135 -> 0.071 / 0.064,
+// 16 meshes 0.203 -> 0.166, 32 meshes 0.287 -> 0.309; 16 meshes of 2420 faces 0.336 -> 0.284.  The SAME 16 x 1280 faces filling
+// the frame (937 of 1024 tiles busy, lists of at most 39 entries: the first iterations of optimize.py): one wave per tile
+// 0.149, four waves per 16x16 tile 0.151, cooperative 0.187 -- the launch is throughput bound and the chooser must say so.
+// W1 against four waves per 16x16 tile: 256 frames 2.370 -> 2.163 ms, 64 frames 0.696 -> 0.649, 16 frames 0.284 -> 0.280,
+// 4 frames 0.210 -> 0.221 (profiles/r03_w1_ab.txt): launches that small now take the cooperative kernel, and the four-wave
+// 16x16 kernel is left to the other mode combinations.
+// Environment overrides LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES / LASR_SR_CHOOSE_MAX_TILES, read once, or
+// lasr_sr_set_launch_thresholds; the output is bit-identical whichever kernel runs.
+static long long g_coop8_max_tiles = env_blocks("LASR_SR_COOP8_MAX_TILES", 2200);
+static long long g_coop_max_tiles = env_blocks("LASR_SR_COOP_MAX_TILES", 14336);
+static long long g_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES", 49152);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -612,36 +621,39 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     {
         ProfScope ps(K_SR_FORWARD, st);
         const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
-        if ((long long)grid.x <= g_coop_max_blocks && is_lasr_fast(A.m) && !rx) {
-            // small launches: several waves per 8x8 tile (sr_forward_coop_kernel); see g_coop_max_blocks
+        if (nch > 3 || is_lasr_fast(A.m)) {
             const int t8 = (IS + 7) / 8;
-            const dim3 grid8((unsigned)(N * t8 * t8));
-            const bool w8 = (long long)grid.x <= g_coop8_max_blocks;
-            if (nch == 9 && w8) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 9) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 6 && w8) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
-            else if (w8) hipLaunchKernelGGL((sr_forward_coop_kernel<3, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
-            else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        } else
-        if ((long long)grid.x > g_w1_min_blocks && (nch > 3 || is_lasr_fast(A.m))) {
-            // one wave per 8x8 tile (sr_forward_kernel<.., W1 = true>)
-            const int t8 = (IS + 7) / 8;
-            const dim3 grid8((unsigned)(N * t8 * t8));
-            if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-            else hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
-        } else
-        if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else if (is_lasr_fast(A.m)) hipLaunchKernelGGL((sr_forward_kernel<true, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
-        else hipLaunchKernelGGL((sr_forward_kernel<false, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            const long long tiles8 = (long long)N * t8 * t8;
+            const dim3 grid8((unsigned)tiles8);
+            const long long coop8_max = nch > 3 ? g_coop8_max_tiles / 8 * 5 : g_coop8_max_tiles;
+            const long long coop_max = nch > 3 ? g_coop_max_tiles / 8 * 5 : g_coop_max_tiles;
+            const long long choose_max = nch > 3 ? g_choose_max_tiles / 8 * 5 : g_choose_max_tiles;
+            // 0: one wave per tile, 1: four waves, 2: eight waves, 3: four waves AND one wave, the device chooses
+            const int plan = rx ? 0 : tiles8 <= coop8_max ? 2 : tiles8 <= coop_max ? 1 : (tiles8 <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;
+            if (plan == 3) {
+                int* choice = (int*)((char*)grects + align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256));
+                hipLaunchKernelGGL(sr_choose_kernel, dim3(1), dim3(64), 0, st, grects, N, groups_of_host(F), IS, coop_max, choice);
+                A.choice = choice;
+            }
+            if (plan == 2) {
+                if (nch == 9) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+            }
+            if (plan == 1 || plan == 3) {
+                if (nch == 9) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 4, 1, 0>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 4, 1, 0>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            }
+            if (plan == 0 || plan == 3) {
+                if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 9) hipLaunchKernelGGL((sr_forward_kernel<true, 9, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 6, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6) hipLaunchKernelGGL((sr_forward_kernel<true, 6, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+                else if (rx) hipLaunchKernelGGL((sr_forward_kernel<true, 3, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_kernel<true, 3, false, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);
+            }
+        } else hipLaunchKernelGGL((sr_forward_kernel<false, 3>), grid, dim3(256), 0, st, A, aggrs_info, soft_colors);
     }
     return launch_ok();
 }
@@ -851,12 +863,23 @@ extern "C" int lasr_selftest_div3(const float* a, const float* b, int* mismatche
     return launch_ok();
 }
 
-extern "C" int lasr_sr_set_launch_thresholds(long long coop8_max_blocks, long long coop_max_blocks, long long w1_min_blocks)
+extern "C" int lasr_sr_set_launch_thresholds(long long coop8_max_tiles, long long coop_max_tiles, long long choose_max_tiles)
 {
-    if (coop8_max_blocks >= 0) g_coop8_max_blocks = coop8_max_blocks;
-    if (coop_max_blocks >= 0) g_coop_max_blocks = coop_max_blocks;
-    if (w1_min_blocks >= 0) g_w1_min_blocks = w1_min_blocks;
+    if (coop8_max_tiles >= 0) g_coop8_max_tiles = coop8_max_tiles;
+    if (coop_max_tiles >= 0) g_coop_max_tiles = coop_max_tiles;
+    if (choose_max_tiles >= 0) g_choose_max_tiles = choose_max_tiles;
     return LASR_OK;
+}
+
+extern "C" int lasr_sr_peek_choice(const void* workspace, int N, int F, int* choice, void* hip_stream)
+{
+    if (!workspace || !choice || N < 0 || F < 0) return LASR_E_BADARG;
+    const size_t nf = (size_t)N * (size_t)F;
+    const char* p = (const char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    p += align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) +
+         align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256);
+    if (hipMemcpyAsync(choice, p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)hip_stream) != hipSuccess) return LASR_E_LAUNCH;
+    return hipStreamSynchronize((hipStream_t)hip_stream) == hipSuccess ? LASR_OK : LASR_E_LAUNCH;
 }
 
 extern "C" int lasr_sr_set_forward_math(int mode)

@@ -1,10 +1,11 @@
-"""The forward pass picks one of four kernels by launch size (lasr_amd/csrc/sr_raster.hip forward_impl: eight or four waves
-sharing an 8x8 tile for launches that cannot fill the chip -- sr_forward_coop.h --, four waves per 16x16 tile, one wave per 8x8
-tile for large launches).  They evaluate every (pixel, face) pair with the same instruction sequence and visit the faces of a
-pixel in index order, so their outputs must be IDENTICAL bit for bit: this file forces each one in turn
-(lasr_sr_set_launch_thresholds, include/lasr_sr.h) on the same inputs -- ragged image sizes, 3 / 6 / 9 channels, a tile whose
-list needs more than one round, device-resident near/far, the background as an argument, an empty mesh -- and compares the
-raw bits; one of them is also held against the oracle, which pins all four."""
+"""The forward pass of LASR's mode combination picks one of three kernels by launch size (lasr_amd/csrc/sr_raster.hip
+forward_impl): eight or four waves sharing an 8x8 tile for launches that cannot fill the chip (sr_forward_coop.h), one wave per
+8x8 tile for the rest; in between a one-wave kernel estimates the busy tiles ON THE DEVICE and both candidates are launched.
+The kernels evaluate every (pixel, face) pair with the same instruction sequence and visit the faces of a pixel in index
+order, so their outputs must be IDENTICAL bit for bit: this file forces each one in turn (lasr_sr_set_launch_thresholds,
+include/lasr_sr.h) on the same inputs -- ragged image sizes, 3 / 6 / 9 channels, a tile whose list needs more than one round,
+device-resident near/far, an empty mesh -- and compares the raw bits; one of them is also held against the oracle, which pins
+all of them.  The device-side choice is checked against both of its outcomes."""
 import numpy as np
 import pytest
 import torch
@@ -15,12 +16,11 @@ from lasr_amd.soft_renderer import functional as srf
 pytestmark = pytest.mark.gpu
 
 BIG = 10 ** 12
-#            coop8_max  coop_max  w1_min
+#            coop8_max  coop_max  choose_max   (8x8-pixel tiles)
 VARIANTS = {'eight waves per 8x8 tile': (BIG, BIG, BIG),
             'four waves per 8x8 tile': (0, BIG, BIG),
-            'four waves per 16x16 tile': (0, 0, BIG),
             'one wave per 8x8 tile': (0, 0, 0)}
-DEFAULTS = (1536, 8192, 8192)
+DEFAULTS = (2200, 14336, 49152)
 
 
 @pytest.fixture
@@ -106,6 +106,29 @@ def test_every_kernel_at_the_launch_sizes_lasr_uses(thresholds, cuda):
     for nu, count in ((8, 16), (11, 4)):
         fv, ft, near, far = synth.raster_batch(nu, 3, count=count)
         all_variants(thresholds, cuda, fv, ft, 256, dict(synth.LASR_MODES, near=near, far=far))
+
+
+def test_the_device_side_choice_takes_either_kernel_and_the_bits_do_not_change(thresholds, cuda):
+    # 6 frames of 64x64 = 384 tiles; the object's bounding boxes cover about half of them.  coop_max between the estimate and
+    # the launch size: the device picks four waves per tile; below the estimate: one wave per tile.
+    import importlib
+    sr_mod = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
+    fv, ft, near, far = synth.raster_batch(4, 3, count=6)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    h = _lib.lib()
+    thresholds('one wave per 8x8 tile')
+    want = render(cuda, fv, ft, 64, kw)
+    import ctypes
+    seen = {}
+    for coop_max in (300, 40):
+        _lib.check(h.lasr_sr_set_launch_thresholds(0, coop_max, BIG), 'thresholds')
+        got = render(cuda, fv, ft, 64, kw)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
+        c = ctypes.c_int(-1)
+        _lib.check(h.lasr_sr_peek_choice(ws.data_ptr(), fv.shape[0], fv.shape[1], ctypes.byref(c), None), 'peek')
+        seen[coop_max] = c.value
+    assert seen == {300: 1, 40: 0}, seen
 
 
 def test_default_thresholds_pick_by_launch_size(cuda):
