@@ -188,7 +188,8 @@ int lasr_sr_set_forward_math(int mode);
  * (csrc/sr_forward_coop.h: latency designs for launches that cannot fill the chip); up to choose_max_tiles: a one-wave kernel
  * estimates the BUSY tiles from the meshes' pixel bounding boxes on the device and picks four waves per tile (estimate at most
  * coop_max_tiles) or one wave per tile -- both are launched, the one not chosen returns at once; above: one wave per tile.
- * Defaults 2200 / 14336 / 49152 (5/8 of that for six and nine channels; measured on an MI355X, csrc/sr_raster.hip), also settable
+ * Defaults 2200 / 14336 / 49152 (six and nine channels: 5/8 of the first two and no device-decided range; measured on an MI355X,
+ * csrc/sr_raster.hip), also settable
  * through LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES / LASR_SR_CHOOSE_MAX_TILES.  A negative argument keeps the current value.
  * lasr_sr_peek_choice (test hook, synchronises the stream): what the device-side choice of the LAST forward call on `workspace`
  * was -- 0 one wave per tile, 1 four waves per tile; meaningful only if that call's size was in the device-decided range.

@@ -564,7 +564,9 @@ static long long env_blocks(const char* name, long long dflt)
 //   up to g_choose_max_tiles             decided on the device: sr_choose_kernel estimates the BUSY tiles from the meshes' pixel
 //                                        bounding boxes -- at most g_coop_max_tiles: four waves per tile, else one wave per tile
 //   above                                one wave per tile (W1)
-// Six and nine channels hand more through LDS per entry (fewer tiles in flight per CU): their bounds are 5/8 of the numbers.
+// Six and nine channels hand more through LDS per entry (fewer tiles in flight per CU): their bounds are 5/8 of the numbers,
+// and they skip the device-side range (see forward_impl).  The device-side choice costs two launches of ~5 us (the chooser and
+// the kernel that returns at once).
 // Measured on an MI355X, forward kernel ms (profiles/r03_coop_ab.txt).  Mesh M2 (2420 faces, the object covers a third of the
 // tiles) at 256x256 (1024 tiles per frame), three channels, [four waves per 16x16 tile, the choice until then] -> four / eight waves:
 //   1 frame 0.209 -> 0.084 / 0.052     2 frames 0.205 -> 0.084 / 0.057     4 frames 0.211 -> 0.094 / 0.087
@@ -627,7 +629,9 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
             const dim3 grid8((unsigned)tiles8);
             const long long coop8_max = nch > 3 ? g_coop8_max_tiles / 8 * 5 : g_coop8_max_tiles;
             const long long coop_max = nch > 3 ? g_coop_max_tiles / 8 * 5 : g_coop_max_tiles;
-            const long long choose_max = nch > 3 ? g_choose_max_tiles / 8 * 5 : g_choose_max_tiles;
+            // (six / nine channels are LASR.forward's render: its frames are cropped around the object and nearly every tile is
+            // busy, so the launch size itself is the estimate and the two extra launches of the device-side choice are saved)
+            const long long choose_max = nch > 3 ? coop_max : g_choose_max_tiles;
             // 0: one wave per tile, 1: four waves, 2: eight waves, 3: four waves AND one wave, the device chooses
             const int plan = rx ? 0 : tiles8 <= coop8_max ? 2 : tiles8 <= coop_max ? 1 : (tiles8 <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;
             if (plan == 3) {
