@@ -292,8 +292,8 @@ def _latest_profile(suffix):
 
 
 def measured_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, latest round), scaled
-    to this run's frames per launch.  PMC counters cannot be read from inside this process; the file records the
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, latest round), quoted when
+    this run launches the same number of frames.  PMC counters cannot be read from inside this process; the file records the
     exact command they came from.  None if no profile has been committed."""
     d, name, stale = _latest_profile('_traffic.json')
     if d is None:
@@ -301,7 +301,9 @@ def measured_traffic(kernel, frames_per_launch):
     k = d.get('kernels', {}).get(kernel)
     if not k:
         return None, name, 'kernel not in ' + name
-    return k['bytes'] * frames_per_launch / d['frames_per_launch'], name, None
+    if frames_per_launch != d['frames_per_launch']:      # another launch size may run another forward kernel (forward_impl)
+        return None, name, 'counters were taken at %d frames per launch' % d['frames_per_launch']
+    return k['bytes'], name, None
 
 
 def valu_issue(kernel, frames_per_launch, launch_ms):
@@ -316,7 +318,9 @@ def valu_issue(kernel, frames_per_launch, launch_ms):
     k = d.get('kernels', {}).get(kernel)
     if not k:
         return {'source': name, 'stale': 'kernel not in ' + name}
-    scale = frames_per_launch / d['frames_per_launch']
+    if frames_per_launch != d['frames_per_launch']:      # another launch size may run another forward kernel (forward_impl)
+        return {'source': name, 'stale': 'counters were taken at %d frames per launch' % d['frames_per_launch']}
+    scale = 1.0
     lane_ops = k['valu_wave_instructions'] * scale * 64 * k['live_lane_fraction']
     return {'source': name, 'valu_wave_instructions_per_launch': k['valu_wave_instructions'] * scale,
             'live_lane_fraction': k['live_lane_fraction'],

@@ -40,7 +40,9 @@ def test_bench_single_gpu_line_has_every_block(cuda):
     out = run_bench(['--steps', '3', '--warmup', '1', '--frames', '32', '--lasr-iters', '0'])
     assert out['n_gpus'] == 1 and out['dtype'] == 'f32' and out['vs_baseline'] is None
     r, c, l = out['roofline'], out['cpu_baseline'], out['lbs']
-    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    # (32 frames per launch: the committed counter files are for 256, so no VALU fraction / traffic is quoted from them)
+    assert r['bound'] == 'hbm' and r['valu_frac'] is None and r['traffic'] is None and 'frames per launch' in r['traffic_stale']
+    assert r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['one_thread_frames_per_s'] > 0
     assert l['mfma_instruction'] == 'v_mfma_f32_16x16x4_f32' and set(l['sizes']) == {'S0', 'dog15', 'batch256'}
     assert all(v['us_per_call'] > 0 and v['mfma_instructions'] > 0 for v in l['sizes'].values())
