@@ -42,7 +42,7 @@ MFMA_F32_PEAK_TF = 157.3       # dense fp32-input MFMA peak (same guide)
 IS = 256
 NU = 11                        # mesh M2
 N_FRAMES_CYCLE = 26            # yaw positions ("~26 frames" of BASELINE configs)
-REBUILD_RECORDS = 1
+REBUILD_RECORDS = -1            # -1: what the autograd operator does (reuse the forward's records up to 200k faces per launch)
 
 
 def parse():
@@ -53,8 +53,8 @@ def parse():
     ap.add_argument('--frames', type=int, default=256, help='frames per GPU per step (SURVEY 8d batches: 1/16/64/256)')
     ap.add_argument('--image-size', type=int, default=256, help='256 = the headline metric; 512 = BASELINE configs[2] (camel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--rebuild-records', type=int, default=1, help='1: the backward rebuilds the per-face records (default), '
-                    '0: it reuses the forward\'s (LASR_SR_RECORDS_VALID)')
+    ap.add_argument('--rebuild-records', type=int, default=-1, help='1: the backward rebuilds the per-face records, 0: it reuses the '
+                    'forward\'s (LASR_SR_RECORDS_VALID), -1 (default): as the autograd operator does -- reuse up to 200k faces per launch')
     ap.add_argument('--no-lbs', action='store_true', help='skip the LBS (MFMA) micro-benchmark block')
     ap.add_argument('--no-sweep', action='store_true', help='skip the launch-size sweep (N = 1/4/16/64 at 256^2, 64 at 512^2)')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
@@ -101,12 +101,14 @@ class RasterStep:
                                   self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                                   B, F, 3, 3, IS, near, far, None, *tail, self.white, _lib.SR_DEFAULT_FLAGS, self.stream)
         _lib.check(rc, 'lasr_sr_forward_bg')
-        # the backward rebuilds the per-face records (REBUILD_RECORDS = 1, what the autograd operator does: records written a
-        # few microseconds earlier are warmer in L2 than the forward's, profiles/r02e_records_reuse.txt)
+        # the per-face records in the backward, as the autograd operator handles them (soft_rasterize.py: _records_of): launches
+        # up to 200k faces reuse the forward's (one launch less on a latency-bound step), larger ones rebuild them (records written
+        # a few microseconds earlier are warmer in L2 than the forward's, profiles/r02e_records_reuse.txt)
+        rebuild = REBUILD_RECORDS if REBUILD_RECORDS >= 0 else (B * F > 200000)
         rc = h.lasr_sr_backward_ex(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), self.aggrs.data_ptr(),
                                    self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(), self.ws.data_ptr(),
                                    self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail,
-                                   _lib.SR_GRADS_OVERWRITE | (0 if REBUILD_RECORDS else _lib.SR_RECORDS_VALID), self.stream)
+                                   _lib.SR_GRADS_OVERWRITE | (0 if rebuild else _lib.SR_RECORDS_VALID), self.stream)
         _lib.check(rc, 'lasr_sr_backward_ex')
         # face -> vertex gradient scatter (autograd of face_vertices.py:4-22), summed over the rank's frames
         self.mesh_grad.zero_()
@@ -475,7 +477,8 @@ def main():
                        'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
                        'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world,
                        'step_definition': 'face setup + forward kernel (background colour passed as an argument: no pre-fill pass, '
-                                          'every element of soft_colors written) + face setup + backward kernel (stores every '
+                                          'every element of soft_colors written) + face setup (launches above 200k faces; smaller ones '
+                                          'reuse the forward\'s records, as the autograd operator does) + backward kernel (stores every '
                                           'gradient element: no zero-fill pass) + face->vertex scatter of both gradients '
                                           '(+ RCCL all-reduce of the [2,V,3] mesh gradient for N > 1); rounds 1 and early 2 '
                                           'also timed the two fill passes the reference caller needs (soft_rasterize.py:50-53, '

@@ -45,13 +45,30 @@ def _texels(textures):
     return max(n // 3, 1)
 
 
+# Whose per-face records does a workspace hold?  Every call that writes records into it (a forward, or a backward that rebuilds
+# them) takes the next number; a backward may skip its setup launch (LASR_SR_RECORDS_VALID) exactly when the number its forward
+# took is still the current one.  Worth it for launches that are latency bound -- measured on an MI355X, mesh M2 at 256x256,
+# fwd+bwd frames/s with rebuilt -> reused records: 1 frame 9.6 k -> 10.2 k, 4 frames 24.7 k -> 25.7 k, 16 frames 42.3 k -> 43.4 k,
+# 64 frames 58.6 k -> 59.3 k -- and not for large ones, where freshly written records are warmer in L2 / Infinity Cache when the
+# face-major backward reads them than the forward's (256 frames: 1.88 ms with reuse vs 1.83 ms, profiles/r02e_records_reuse.txt).
+REUSE_RECORDS_MAX_FACES = 200000
+_records_of = {}
+
+
 def _workspace(device, stream, nbytes):
     key = (device.index, stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+        _records_of[key] = _records_of.get(key, 0) + 1           # whatever records the old buffer held are gone
     return ws
+
+
+def _new_records(device, stream):
+    key = (device.index, stream)
+    _records_of[key] = _records_of.get(key, 0) + 1
+    return key, _records_of[key]
 
 
 def _as_float(v):
@@ -116,10 +133,8 @@ class SoftRasterizeFunction(Function):
         soft_colors = torch.empty(N, C + 1, IS, IS, dtype=torch.float32, device=dev)
 
         h = _lib.lib()
-        # One scratch buffer per (device, stream) serves every call: the backward rebuilds the per-face records (29 us for
-        # 620k faces) instead of keeping them alive per call (LASR_SR_RECORDS_VALID) -- measured: the freshly written records
-        # are still in L2 / Infinity Cache when the face-major backward reads them, which saves more (0.06 ms per 256 frames)
-        # than the setup launch costs (0.03 ms); profiles/r02e_records_reuse.txt.
+        # One scratch buffer per (device, stream) serves every call; large launches rebuild the per-face records in the backward
+        # (29 us for 620k faces), small ones reuse the forward's when nothing else has written into the buffer since (_records_of).
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
@@ -128,6 +143,7 @@ class SoftRasterizeFunction(Function):
                                       nf.data_ptr() if nf is not None else None, *tail, (ctypes.c_float * C)(*bg[:C]),
                                       forward_flags(), stream)
         _lib.check(rc, 'lasr_sr_forward')
+        ctx.records = _new_records(dev, stream)
         ctx.save_for_backward(fv, tx, soft_colors, aggrs_info)
         ctx.mark_non_differentiable(aggrs_info)
         return soft_colors
@@ -150,11 +166,15 @@ class SoftRasterizeFunction(Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
+            key = (dev.index, stream)
+            reuse = N * F <= REUSE_RECORDS_MAX_FACES and ctx.records == (key, _records_of.get(key))
+            if not reuse:
+                _new_records(dev, stream)                                   # this call's setup launch overwrites the workspace
             rc = h.lasr_sr_backward_ex(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), aggrs_info.data_ptr(),
                                        grad_faces.data_ptr(), grad_textures.data_ptr(), g.data_ptr(), ws.data_ptr(),
                                        ws.numel(), N, F, T, C, IS, *ctx.near_far,
                                        nf.data_ptr() if nf is not None else None, *tail,
-                                       _lib.SR_GRADS_OVERWRITE if vertex else 0, stream)
+                                       (_lib.SR_GRADS_OVERWRITE if vertex else 0) | (_lib.SR_RECORDS_VALID if reuse else 0), stream)
         _lib.check(rc, 'lasr_sr_backward')
         fshape, tshape = ctx.in_shapes
         return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),
@@ -203,4 +223,5 @@ def soft_rasterize_raw(face_vertices, textures, image_size, background_color, ne
                                aggrs_info.data_ptr(), soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
                                N, F, T, IS, *scalars, stream)
     _lib.check(rc, 'lasr_sr_forward')
+    _new_records(dev, stream)
     return (soft_colors, aggrs_info, faces_info) if want_faces_info else (soft_colors, aggrs_info)

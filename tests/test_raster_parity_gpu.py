@@ -507,3 +507,47 @@ def test_forward_with_the_background_as_an_argument(cuda, rgb, alpha, channels):
                                     N, F, 3, C, IS, float(near), float(far), None, *tail, (ctypes.c_float * C)(*bg), 0, st), 'forward_bg')
     assert torch.equal(out_c, ref_c) and torch.equal(out_a, ref_a)
     assert float((out_c[:, 0] == out_c[0, 0, 0, 0]).float().mean()) > 0.2          # a good part of the image is background
+
+
+def test_autograd_backward_reuses_the_forwards_records_only_while_they_are_there(cuda):
+    # small launches skip the backward's setup launch when the workspace still holds the records their own forward wrote
+    # (soft_rasterize.py: _records_of); a second render in between, or a backward that rebuilt its records, takes that away
+    import importlib
+    sr = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
+    fa, ta, near, far = synth.raster_batch(4, 3, count=2)
+    fb = fa[::-1].copy() * np.float32(0.9)
+    fb[..., 2] = fa[::-1][..., 2]
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    g = torch.from_numpy(synth.upstream_grad(2, 64, 2)).to(cuda)
+    key = (cuda.index, torch.cuda.current_stream(cuda).cuda_stream)
+
+    def leaf(x):
+        return torch.from_numpy(x).to(cuda).requires_grad_(True)
+
+    def alone(fv):
+        v, t = leaf(fv), leaf(ta)
+        img = srf.soft_rasterize(v, t, 64, **kw)
+        before = sr._records_of[key]
+        img.backward(g)
+        assert sr._records_of[key] == before                  # reused: the backward wrote no records
+        return v.grad.clone(), t.grad.clone()
+    want_a, want_b = alone(fa), alone(fb)
+    va, tta, vb, ttb = leaf(fa), leaf(ta), leaf(fb), leaf(ta)
+    ia = srf.soft_rasterize(va, tta, 64, **kw)
+    ib = srf.soft_rasterize(vb, ttb, 64, **kw)               # the workspace now holds B's records
+    before = sr._records_of[key]
+    ia.backward(g)                                            # must rebuild A's
+    assert sr._records_of[key] == before + 1
+    ib.backward(g)                                            # ... which took B's away: rebuild again
+    assert sr._records_of[key] == before + 2
+    for got, want in ((va.grad, want_a[0]), (tta.grad, want_a[1]), (vb.grad, want_b[0]), (ttb.grad, want_b[1])):
+        assert torch.equal(got, want)
+    old, sr.REUSE_RECORDS_MAX_FACES = sr.REUSE_RECORDS_MAX_FACES, 0     # large launches always rebuild
+    try:
+        v, t = leaf(fa), leaf(ta)
+        img = srf.soft_rasterize(v, t, 64, **kw)
+        before = sr._records_of[key]
+        img.backward(g)
+        assert sr._records_of[key] == before + 1 and torch.equal(v.grad, want_a[0])
+    finally:
+        sr.REUSE_RECORDS_MAX_FACES = old
