@@ -8,6 +8,7 @@ instead of the `soft_renderer.cuda.soft_rasterize` pybind module.
 """
 import ctypes
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -51,7 +52,7 @@ def _texels(textures):
 # fwd+bwd frames/s with rebuilt -> reused records: 1 frame 9.6 k -> 10.2 k, 4 frames 24.7 k -> 25.7 k, 16 frames 42.3 k -> 43.4 k,
 # 64 frames 58.6 k -> 59.3 k -- and not for large ones, where freshly written records are warmer in L2 / Infinity Cache when the
 # face-major backward reads them than the forward's (256 frames: 1.88 ms with reuse vs 1.83 ms, profiles/r02e_records_reuse.txt).
-REUSE_RECORDS_MAX_FACES = 200000
+REUSE_RECORDS_MAX_FACES = int(os.environ.get('LASR_SR_REUSE_RECORDS_MAX_FACES', 200000))     # 0 = the backward always rebuilds
 _records_of = {}
 
 
