@@ -56,6 +56,45 @@ def _is_closed_manifold(faces):
     return all((b, a) in count for (a, b) in count)
 
 
+# The collapse order decides the result, and it hangs on comparisons of double-precision costs: the few small dense operations
+# are written out in plain arithmetic so that no BLAS / LAPACK build (which pick kernels -- FMA or not, blocking -- by CPU) has
+# a say, and the same input gives the same mesh on every machine.
+def _dot3(a, b):
+    return float(a[0]) * float(b[0]) + float(a[1]) * float(b[1]) + float(a[2]) * float(b[2])
+
+
+def _norm3(a):
+    return math.sqrt(_dot3(a, a))
+
+
+def _det3(m):
+    a, b, c, d, e, f, g, h, i = (float(x) for x in (m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]))
+    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+
+
+def _solve3(m, r, det):
+    """Cramer's rule for the symmetric 3x3 system of the optimal collapse point (det = _det3(m), already known non-zero)."""
+    cols = [[float(m[k][j]) for k in range(3)] for j in range(3)]
+    rhs = [float(x) for x in r]
+    out = []
+    for j in range(3):
+        mj = [[rhs[k] if jj == j else cols[jj][k] for jj in range(3)] for k in range(3)]
+        out.append(_det3(mj) / det)
+    return np.asarray(out)
+
+
+def _quadric(q, p):
+    """[p, 1] q [p, 1]^T summed in a fixed order."""
+    h = (float(p[0]), float(p[1]), float(p[2]), 1.0)
+    total = 0.0
+    for i in range(4):
+        row = 0.0
+        for j in range(4):
+            row += float(q[i][j]) * h[j]
+        total += h[i] * row
+    return total
+
+
 def remesh_exact(verts, faces, n_faces, reg=1e-3, sliver=0.1):
     """verts [V,3], faces [F,3] (numpy; a closed, consistently oriented 2-manifold) -> (new_verts [V',3] float32,
     new_faces [n_faces,3] int64): the same surface (same genus, same orientation) with exactly n_faces triangles.
@@ -111,14 +150,14 @@ def remesh_exact(verts, faces, n_faces, reg=1e-3, sliver=0.1):
         q = Q[a] + Q[b]
         cands = [0.5 * (V[a] + V[b]), V[a], V[b]]
         A3 = q[:3, :3]
-        if abs(np.linalg.det(A3)) > 1e-12 * max(np.abs(A3).max(), 1e-30) ** 3:
-            p = np.linalg.solve(A3, -q[:3, 3])
-            if np.linalg.norm(p - cands[0]) <= 2.0 * np.linalg.norm(V[a] - V[b]):            # no wild extrapolation
+        det = _det3(A3)
+        if abs(det) > 1e-12 * max(np.abs(A3).max(), 1e-30) ** 3:
+            p = _solve3(A3, -q[:3, 3], det)
+            if _norm3(p - cands[0]) <= 2.0 * _norm3(V[a] - V[b]):                             # no wild extrapolation
                 cands.insert(0, p)
         best, bp = None, None
         for p in cands:
-            h = np.append(p, 1.0)
-            c = float(h @ q @ h)
+            c = _quadric(q, p)
             if best is None or c < best:
                 best, bp = c, p
         return max(best, 0.0) + reg * float(((V[a] - V[b]) ** 2).sum()) * mean_area, bp
@@ -151,8 +190,8 @@ def remesh_exact(verts, faces, n_faces, reg=1e-3, sliver=0.1):
             new = [p if (x == v or x == other) else V[x] for x in f]
             n0 = np.cross(old[1] - old[0], old[2] - old[0])
             n1 = np.cross(new[1] - new[0], new[2] - new[0])
-            l0, l1 = np.linalg.norm(n0), np.linalg.norm(n1)
-            if l1 <= 1e-14 * max(l0, 1e-30) or float(n0 @ n1) < 0.17 * l0 * l1:
+            l0, l1 = _norm3(n0), _norm3(n1)
+            if l1 <= 1e-14 * max(l0, 1e-30) or _dot3(n0, n1) < 0.17 * l0 * l1:
                 return True
             # no new slivers: 2 * area / longest edge^2 (0.87 for an equilateral triangle) may not fall below `sliver`
             # unless the triangle was at least as thin before
