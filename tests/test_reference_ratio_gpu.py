@@ -1,0 +1,66 @@
+"""north_star's target is a RATIO: ">= N x reference single-GPU soft-rasterizer forward+backward throughput".  This test puts
+that ratio into the driver's own record: the reference's kernels built with the compiler's default flags (oracle/_ref/sr_ref.so --
+the reference as it would ship on this GPU; soft_rasterize_cuda_kernel.cu:308-668 behind soft_rasterize_cuda.cpp:59-138, zero
+fills and clones of soft_rasterize.py:41-53,88-89 included, as the reference's own Function does them) and the HIP operator
+(lasr_amd.soft_renderer.functional.soft_rasterize, forward + backward through autograd) are timed on the same GPU, same inputs:
+mesh M2 (2420 faces), LASR modes.  Floors asserted (measured in round 3: 35x / 50x / 56x / 65x); the numbers are printed and
+appended to gpurun_out/reference_ratio.jsonl.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from lasr_amd import synth
+from lasr_amd.soft_renderer import functional as srf
+from oracle import sr_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not sr_ref.available('sr_ref'), reason='oracle/_ref/sr_ref.so not in this snapshot (oracle/build_ref.py)')
+@pytest.mark.parametrize('count,IS,floor', [(16, 256, 20.), (64, 256, 30.), (256, 256, 40.), (16, 512, 30.)])
+def test_speedup_over_the_reference_build_on_the_same_gpu(cuda, tmp_path, count, IS, floor):
+    fv, ft, near, far = synth.raster_batch(11, 26, count=count)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    g = synth.upstream_grad(count, IS)
+    src, dst = str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')
+    kwj = np.frombuffer(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}).encode(), np.uint8)
+    np.savez(src, face_vertices=fv, textures=ft, image_size=IS, kwargs=kwj, grad_soft_colors=g, reps=3)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tests', 'ref_build_worker.py'), 'sr_ref', src, dst], cwd=ROOT)
+    with np.load(dst) as z:
+        ref_ms = float(z['ms_per_step'])
+
+    a = torch.from_numpy(fv).to(cuda).requires_grad_(True)
+    b = torch.from_numpy(ft).to(cuda).requires_grad_(True)
+    tg = torch.from_numpy(g).to(cuda)
+
+    def step():
+        a.grad = b.grad = None
+        srf.soft_rasterize(a, b, IS, **kw).backward(tg)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    hip_ms = (time.perf_counter() - t0) / reps * 1e3
+    entry = dict(frames=count, image_size=IS, faces=int(fv.shape[1]), reference_build='sr_ref (compiler defaults)',
+                 reference_ms=ref_ms, reference_frames_per_s=count / ref_ms * 1e3, hip_ms=hip_ms,
+                 hip_frames_per_s=count / hip_ms * 1e3, speedup=ref_ms / hip_ms, device=torch.cuda.get_device_name(0))
+    print(json.dumps(entry))
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'reference_ratio.jsonl'), 'a') as f:
+            f.write(json.dumps(entry) + '\n')
+    except OSError:
+        pass
+    assert entry['speedup'] >= floor, entry
