@@ -59,10 +59,10 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
 
     // exact pixel rectangle of the bbox test (columns x0..x1, rows r0..r1 from the top); empty when x0 > x1.  Read from the
     // record's first cache line (the flags sit there too) rather than from the separate rect array the forward's binning scans
-    const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
-    const int x0 = (int)(short)(rx & 0xffff), x1 = rx >> 16, r0 = (int)(short)(ry & 0xffff), r1 = ry >> 16;
-    const int bw = x1 - x0 + 1, bh = r1 - r0 + 1;
-    const bool empty = !(bw > 0 && bh > 0);
+    const unsigned rlo = (unsigned)__float_as_int(rec[R_BB + 0]), rext = (unsigned)__float_as_int(rec[R_BB + 1]);
+    const int x0 = (int)(rlo & 0xffff), r0 = (int)(rlo >> 16);
+    const int bw = (int)(rext & 0xffff) + 1, bh = (int)(rext >> 16) + 1;
+    const bool empty = rlo == 0xffffffffu;
     const int npx = empty ? 0 : bw * bh;
 
     float gv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2)
@@ -79,6 +79,45 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     const float thr_pad = A.thr * 1.05f;
     const float inv_is = 1.f / (float)IS;
     const bool pow2 = (IS & (IS - 1)) == 0;      // then n * (1/IS) == n / IS exactly: skip the division per pixel
+    // pixel centres as ONE fma of the converted index: (2 i + 1 - IS) / IS = i * (2 / IS) + (1 - IS) / IS (K.cu:343-346; rows count
+    // from the top: yi = IS - 1 - row).  For a power-of-two image every term and the result are exact in fp32; other sizes keep
+    // the division in stage 2 (the distance code is ill-conditioned in the pixel position on edge-on faces, and the surface
+    // texel choice must see the forward's barycentrics) and use the fma -- within an ulp -- for stage 1's conservative reject only
+    const float cx_a = 2.f * inv_is, cx_b = (float)(1 - IS) * inv_is, cy_b = (float)(IS - 1) * inv_is;
+    auto centre_x = [&](int xi) { return OPT_BWD_S1 && pow2 ? __builtin_fmaf((float)xi, cx_a, cx_b) : pix_center_p2(xi, IS, inv_is, pow2); };
+    auto centre_y = [&](int row) { return OPT_BWD_S1 && pow2 ? __builtin_fmaf((float)row, -cx_a, cy_b) : pix_center_p2(IS - 1 - row, IS, inv_is, pow2); };
+    // stage 1's reject as signed line distances: d_k = w_k * h_k (h_k = height of vertex k over its opposite edge) is linear in
+    // the pixel, so the coefficients are scaled once per face and a pixel costs six fmas, one v_min3 and one compare:
+    // "some d_k < -sqrt(thr_pad)" == certainly_far (conservative either way: 5 % slack on thr, fused vs unfused ~1e-7)
+    float ld[9];
+    const float far_t = -sqrtf(thr_pad);
+    if (OPT_BWD_S1 && use_far) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float h = sqrtf(rec[R_HK2 + k]);
+            ld[3 * k] = rec[R_INV + 3 * k] * h; ld[3 * k + 1] = rec[R_INV + 3 * k + 1] * h; ld[3 * k + 2] = rec[R_INV + 3 * k + 2] * h;
+        }
+    }
+    // K.cu:599: a fragment the forward pass depth-culled gets no gradient.  A well-conditioned face whose vertex depths lie
+    // strictly inside (near, far) cannot be culled anywhere (its clipped barycentrics are >= 0 and sum to 1 within 1e-4, so the
+    // interpolated depth stays within the vertex range up to rounding): one test per face instead of one per fragment
+    bool depth_safe = false;
+    if (OPT_BWD_MATH && (flags & 16)) {
+        const float z0 = rec[R_FACE + 2], z1 = rec[R_FACE + 5], z2 = rec[R_FACE + 8];
+        const float zlo = fminf(fminf(z0, z1), z2), zhi = fmaxf(fmaxf(z0, z1), z2);
+        depth_safe = zlo > 0.f && zlo * (1.f - 1e-4f) > A.near && zhi * (1.f + 1e-4f) < A.far;
+    }
+    // the ten pixel planes this face reads, through buffer descriptors: one 32-bit byte offset per pixel (voffset) and the
+    // plane's offset as a scalar (soffset) instead of a 64-bit address computation per load
+    const unsigned P4 = (unsigned)P * 4u;
+    const __amdgpu_buffer_rsrc_t rs_col = __builtin_amdgcn_make_buffer_rsrc((void*)(colors + (size_t)bn * (NCH + 1) * P), 0, (int)(P4 * (NCH + 1)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gcol = __builtin_amdgcn_make_buffer_rsrc((void*)(gcolors + (size_t)bn * (NCH + 1) * P), 0, (int)(P4 * (NCH + 1)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_aggr = __builtin_amdgcn_make_buffer_rsrc((void*)(aggrs + (size_t)bn * 2 * P), 0, (int)(P4 * 2), 0x00020000);
+    auto ld_plane = [&](const __amdgpu_buffer_rsrc_t& rs, const float* base, int nplanes, int plane, int pn_) -> float {
+        if (OPT_BWD_MEM && LASR_FAST)
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, pn_ * 4, (int)(P4 * (unsigned)plane), 0));
+        return base[((size_t)bn * nplanes + plane) * P + pn_];
+    };
 
     // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
     int r = 0, c = 0;
@@ -95,7 +134,15 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
             if (c >= bw) { c -= bw; r += 1; }
             base += 64;
             bool keep = in_range;                              // every pixel of the rect passes the bbox test
-            if (in_range && use_far) {
+            if (OPT_BWD_S1) {
+                if (use_far) {
+                    const float xp = __builtin_fmaf((float)xi, cx_a, cx_b), yp = __builtin_fmaf((float)row, -cx_a, cy_b);
+                    const float d0 = __builtin_fmaf(ld[0], xp, __builtin_fmaf(ld[1], yp, ld[2]));
+                    const float d1 = __builtin_fmaf(ld[3], xp, __builtin_fmaf(ld[4], yp, ld[5]));
+                    const float d2 = __builtin_fmaf(ld[6], xp, __builtin_fmaf(ld[7], yp, ld[8]));
+                    keep = in_range && !(fminf(fminf(d0, d1), d2) < far_t);
+                }
+            } else if (in_range && use_far) {
                 float w0, w1, w2;
                 barycentric(rec, pix_center_p2(xi, IS, inv_is, pow2), pix_center_p2(IS - 1 - row, IS, inv_is, pow2), w0, w1, w2);
                 keep = !certainly_far(rec, w0, w1, w2, thr_pad);
@@ -117,27 +164,30 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
         if (!active) continue;
         const int xi = packed & 0xffff, row = packed >> 16;
         const int pn = row * IS + xi;
-        const float xp = pix_center_p2(xi, IS, inv_is, pow2), yp = pix_center_p2(IS - 1 - row, IS, inv_is, pow2);
+        const float xp = centre_x(xi), yp = centre_y(row);
 
         float w0, w1, w2;
         Frag fr;
-        if (!fragment<FM>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+        if (!fragment<FM, cptr_t, (OPT_BWD_MATH && LASR_FAST)>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
         const float D = fr.D;
 
         // alpha path (K.cu:583-593); hard alpha: the reference still adds g_alpha into C
-        float Ca = gcolors[((size_t)bn * (NCH + 1) + NCH) * P + pn];
+        float Ca = ld_plane(rs_gcol, gcolors, NCH + 1, NCH, pn);
         if (m.alpha == 1) Ca = div_<FM>(Ca, (float)A.F);
         else if (m.alpha == 2) {
-            const float a_out = colors[((size_t)bn * (NCH + 1) + NCH) * P + pn];
+            const float a_out = ld_plane(rs_col, colors, NCH + 1, NCH, pn);
             Ca *= div_<FM>(1 - a_out, fmaxf(1 - D, 1e-6f));
         }
         float C = Ca;
 
         const float u0 = w0, u1 = w1, u2 = w2;       // unclipped barycentrics (w0 of K.cu:596)
         // surface sampling picks a texel from (int)(w * res): keep the exact division there
-        if (vertex_tex) clip_normalise<FM>(w0, w1, w2); else clip_normalise<false>(w0, w1, w2);
-        const float zp = depth_at<FM>(rec, w0, w1, w2);
-        {   // K.cu:599: no gradient at all for a fragment the forward pass depth-culled.  The fast-math depth decides unless it
+        if (vertex_tex) clip_normalise<FM, (OPT_BWD_MATH && LASR_FAST)>(w0, w1, w2); else clip_normalise<false>(w0, w1, w2);
+        // (the record holds the correctly rounded 1 / z_k: no v_rcp per fragment)
+        const float q0 = w0 * rec[R_IZ + 0], q1 = w1 * rec[R_IZ + 1], q2 = w2 * rec[R_IZ + 2];
+        const float zp = OPT_BWD_MATH && LASR_FAST ? __builtin_amdgcn_rcpf(q0 + q1 + q2) : depth_at<FM>(rec, w0, w1, w2);
+        if (!depth_safe) {
+            // K.cu:599: no gradient at all for a fragment the forward pass depth-culled.  The fast-math depth decides unless it
             // lies within 1e-4 relative of a plane; then the forward's own arithmetic is re-run so both passes agree.
             float zc = zp;
             const float tol = 1e-4f * fabsf(zp);
@@ -147,10 +197,10 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
 
         float gz0 = 0, gz1 = 0, gz2 = 0;
         if (m.rgb == 0) {
-            if ((float)fn == aggrs[((size_t)bn * 2 + 1) * P + pn]) {       // K.cu:603
+            if ((float)fn == ld_plane(rs_aggr, aggrs, 2, 1, pn)) {       // K.cu:603
                 float g[NCH];
 #pragma unroll
-                for (int k = 0; k < NCH; k++) g[k] = gcolors[((size_t)bn * (NCH + 1) + k) * P + pn];
+                for (int k = 0; k < NCH; k++) g[k] = ld_plane(rs_gcol, gcolors, NCH + 1, k, pn);
                 if (vertex_tex) {
 #pragma unroll
                     for (int k = 0; k < NCH; k++) {
@@ -165,13 +215,13 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
                 }
             }
         } else if (front || m.double_side) {                                 // K.cu:611-640
-            const float ssum = aggrs[((size_t)bn * 2 + 0) * P + pn];
-            const float smax = aggrs[((size_t)bn * 2 + 1) * P + pn];
+            const float ssum = ld_plane(rs_aggr, aggrs, 2, 0, pn);
+            const float smax = ld_plane(rs_aggr, aggrs, 2, 1, pn);
             const float zn = div_<FM>(A.far - zp, A.far - A.near);
             const float sm = div_<FM>(D * exp_<FM>(div_<FM>(zn - smax, A.gamma)), ssum);
             float g[NCH];
 #pragma unroll
-            for (int k = 0; k < NCH; k++) g[k] = gcolors[((size_t)bn * (NCH + 1) + k) * P + pn];
+            for (int k = 0; k < NCH; k++) g[k] = ld_plane(rs_gcol, gcolors, NCH + 1, k, pn);
             if (vertex_tex) {
 #pragma unroll
                 for (int k = 0; k < NCH; k++) {
@@ -187,15 +237,18 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
             float Crgb = 0.f;
 #pragma unroll
             for (int k = 0; k < NCH; k++)
-                Crgb += g[k] * (sample_colour(tex, w0, w1, w2, A.res, k, m.tex, lim, NCH) -
-                                colors[((size_t)bn * (NCH + 1) + k) * P + pn]);
+                Crgb += g[k] * (sample_colour(tex, w0, w1, w2, A.res, k, m.tex, lim, NCH) - ld_plane(rs_col, colors, NCH + 1, k, pn));
             Crgb *= sm;
             C += div_<FM>(Crgb, D);
             const float Cz = div_<FM>(div_<FM>(Crgb, A.gamma), A.near - A.far) * zp * zp;
-            const float iz0 = __builtin_amdgcn_rcpf(rec[R_FACE + 2]), iz1 = __builtin_amdgcn_rcpf(rec[R_FACE + 5]), iz2 = __builtin_amdgcn_rcpf(rec[R_FACE + 8]);
-            gz0 = Cz * w0 * iz0 * iz0;
-            gz1 = Cz * w1 * iz1 * iz1;
-            gz2 = Cz * w2 * iz2 * iz2;
+            if (OPT_BWD_MATH && LASR_FAST) {
+                gz0 = Cz * q0 * rec[R_IZ + 0]; gz1 = Cz * q1 * rec[R_IZ + 1]; gz2 = Cz * q2 * rec[R_IZ + 2];       // q_k = w_k / z_k
+            } else {
+                const float iz0 = __builtin_amdgcn_rcpf(rec[R_FACE + 2]), iz1 = __builtin_amdgcn_rcpf(rec[R_FACE + 5]), iz2 = __builtin_amdgcn_rcpf(rec[R_FACE + 8]);
+                gz0 = Cz * w0 * iz0 * iz0;
+                gz1 = Cz * w1 * iz1 * iz1;
+                gz2 = Cz * w2 * iz2 * iz2;
+            }
         }
 
         C *= div_<FM>(D * (1 - D), A.sigma);                                  // K.cu:644

@@ -21,9 +21,14 @@ namespace lasr {
 // fetched through the scalar cache with dependent loads: three aligned lines instead of the 3-4 a packed 176-B record
 // straddles; measured -1.8 % on the backward kernel, which starts every wave with this fetch).
 // line 0  [0..1]   rect : the pixels that pass the bbox test of K.cu:33-38, as EXACT integer bounds (own addition):
-//                         [0] = x0 | x1 << 16 (columns), [1] = r0 | r1 << 16 (rows from the top); empty = x0 > x1
+//                         [0] = x0 | r0 << 16 (first column, first row from the top), [1] = (x1 - x0) | (r1 - r0) << 16
+//                         (extents), so that "pixel in rect" is one packed u16 subtract + min + compare;
+//                         empty = [0] all ones, [1] zero
 //         [2]      flags: bit0..2 first obtuse corner (K.cu:296-304), bit3 front-facing (K.cu:41-44),
-//                         bit4 well-conditioned (the cheap line-distance reject below may be used), bit5 reciprocals usable
+//                         bit4 well-conditioned (the cheap line-distance reject below may be used), bit5 TAME record:
+//                         reciprocals usable, every inv entry finite and below 1e30 (so the barycentrics of a pixel are
+//                         finite: min3 / max3 / med3 then equal the reference's compare chains), vertex depths positive
+//                         and within [1e-6, 1e6] (so 1 / sum(c_k / z_k) needs no scaling)
 //         [3..11]  inv  : rows of adj([x y 1])/det                         (K.cu:274-286)
 //         [12..14] hk2  : squared height of vertex k over its opposite edge (own addition: w_k * h_k is the
 //                         signed distance of a pixel to that edge's line, a lower bound of the true distance)
@@ -34,6 +39,21 @@ namespace lasr {
 //         [41..43] iz   : RN(1/z_k)      } flags bit5 says they are usable (finite, denominators in a safe range)
 //         [15], [31], [44..47] padding
 constexpr int REC = 48;
+
+// Round-4 instruction-mix options (profiles/r04_opt_ab.txt has the A/B of each bit; every one leaves the forward's output
+// bit-identical -- the kernel-choice, reference-vector and oracle suites run with all of them on).  Measurement builds switch
+// bits off: make variant NAME=x DEFS=-DLASR_OPT=<mask>.
+#ifndef LASR_OPT
+#define LASR_OPT 0xffff
+#endif
+constexpr bool OPT_PKRECT = (LASR_OPT & 1) != 0;      // rect test as one packed u16 compare
+constexpr bool OPT_MED3 = (LASR_OPT & 2) != 0;        // clamps / inside test as v_med3 / v_min3 / v_max3 on tame records
+constexpr bool OPT_NOSCALE = (LASR_OPT & 4) != 0;     // 1/x and the f64 sigmoid division without v_div_scale / v_div_fixup
+constexpr bool OPT_SIGNFOLD = (LASR_OPT & 8) != 0;    // threshold cut inside the outside branch, no float sign
+constexpr bool OPT_SOFTMAX = (LASR_OPT & 16) != 0;    // depth-softmax update with -|zn - smax| and v_max
+constexpr bool OPT_BWD_MEM = (LASR_OPT & 32) != 0;    // backward: pixel planes through buffer descriptors (32-bit offsets)
+constexpr bool OPT_BWD_S1 = (LASR_OPT & 64) != 0;     // backward stage 1: branch-free conservative reject, fused centres
+constexpr bool OPT_BWD_MATH = (LASR_OPT & 128) != 0;  // backward stage 2: record reciprocals, med3, per-face depth-range test
 constexpr int R_BB = 0, R_FLAGS = 2, R_INV = 3, R_HK2 = 12, R_FACE = 16, R_DEN = 25, R_IDEN = 28, R_E = 32, R_IZ = 41;
 
 // Read-only buffers written by an EARLIER kernel are viewed through the constant address
@@ -72,6 +92,45 @@ __device__ __forceinline__ float div_by_recip(float a, float b, float y)
     q = __builtin_fmaf(e, y, q);
     e = __builtin_fmaf(-b, q, a);
     return __builtin_fmaf(e, y, q);
+}
+
+// 1 / x bit-identical to the IEEE division `1.f / x` for 2^-60 < |x| < 2^60: the instruction sequence the compiler emits for
+// that division (v_rcp_f32, one Newton step, quotient, two residual corrections) minus v_div_scale x 2 / v_div_fixup, which
+// are identities in that range, and with v_div_fmas as a plain fma (7 instead of 11 VALU ops; lasr_selftest_recip).
+__device__ __forceinline__ float recip_noscale(float x)
+{
+    float y = __builtin_amdgcn_rcpf(x);
+    y = __builtin_fmaf(__builtin_fmaf(-x, y, 1.f), y, y);
+    float q = y;                                             // 1 * y
+    q = __builtin_fmaf(__builtin_fmaf(-x, q, 1.f), y, q);
+    return __builtin_fmaf(__builtin_fmaf(-x, q, 1.f), y, q);
+}
+// (float)(1. / x) for a double 1 <= x < 2^128: the compiler's f64 division expansion (v_rcp_f64, two Newton steps, quotient,
+// one residual correction) without v_div_scale_f64 x 2 / v_div_fixup_f64 (identities here); same bits (lasr_selftest_recip).
+__device__ __forceinline__ double recip64_noscale(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.), y, y);
+    const double q = y;                                      // 1 * y
+    return __builtin_fma(__builtin_fma(-x, q, 1.), y, q);
+}
+
+// max(a, b) of two finite floats as one v_med3_f32 (fmaxf makes the compiler quiet a possible signalling NaN first: two ops)
+__device__ __forceinline__ float max_finite(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+
+// "pixel (px | py << 16) lies in the record's rect" (record fields R_BB, R_BB + 1): per 16-bit half d = p - first must not
+// exceed the extent; a pixel left of / above the rect wraps to d >= 32769 > any extent, the empty rect (first = 0xffff) holds none.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool rect_has(int lo, int ext, int pxy)
+{
+    if (OPT_PKRECT) {
+        const u16x2_t d = __builtin_bit_cast(u16x2_t, pxy) - __builtin_bit_cast(u16x2_t, lo);
+        const u16x2_t m = __builtin_elementwise_min(d, __builtin_bit_cast(u16x2_t, ext));
+        return __builtin_bit_cast(int, m) == __builtin_bit_cast(int, d);
+    }
+    const int px = pxy & 0xffff, py = (unsigned)pxy >> 16, x0 = lo & 0xffff, r0 = (unsigned)lo >> 16;
+    return px >= x0 && px <= x0 + (ext & 0xffff) && py >= r0 && py <= r0 + (int)((unsigned)ext >> 16);
 }
 
 // Pixel-index bounds equivalent to the float test `lo <= pix_center(i) <= hi` (pix_center is monotone in i):
@@ -171,8 +230,11 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
     int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;                                    // rows from the top
     if (px0 > px1 || r0 > r1) { px0 = 32767; px1 = -1; r0 = 32767; r1 = -1; }    // empty
     *rect = make_short4((short)px0, (short)px1, (short)r0, (short)r1);          // caller-owned (register or global)
-    rec[R_BB + 0] = __int_as_float((px0 & 0xffff) | (px1 << 16));
-    rec[R_BB + 1] = __int_as_float((r0 & 0xffff) | (r1 << 16));
+    if (px0 > px1) { rec[R_BB + 0] = __int_as_float(-1); rec[R_BB + 1] = __int_as_float(0); }
+    else {
+        rec[R_BB + 0] = __int_as_float((px0 & 0xffff) | (r0 << 16));
+        rec[R_BB + 1] = __int_as_float(((px1 - px0) & 0xffff) | ((r1 - r0) << 16));
+    }
     {
         bool ok = true;
 #pragma unroll
@@ -180,8 +242,10 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
             const float d = rec[R_DEN + k], z = f[3 * k + 2];
             rec[R_IDEN + k] = 1.f / d;
             rec[R_IZ + k] = 1.f / z;
-            ok = ok && recip_safe(d) && recip_safe(z);
+            ok = ok && recip_safe(d) && z >= 1e-6f && z <= 1e6f;
         }
+#pragma unroll
+        for (int k = 0; k < 9; k++) ok = ok && fabsf(inv[k]) < 1e30f;          // false for NaN / inf as well
         if (ok) rec[R_FLAGS] = __int_as_float(__float_as_int(rec[R_FLAGS]) | 32);
         rec[15] = 0.f; rec[31] = 0.f;                               // padding: defined bytes in the workspace
 #pragma unroll
@@ -222,12 +286,20 @@ __device__ __forceinline__ void div3_shared(float& a0, float& a1, float& a2, flo
 }
 
 // K.cu:53-58
-template <bool FM = false>
+// TAME: the barycentrics are known finite (record flag bit5, or the backward pass where NaN propagation is not pinned): the clamp
+// is one v_med3_f32 (for finite w, med3(w, 0, 1) == max(min(w, 1), 0) up to the sign of a zero, which no later result depends on)
+template <bool FM = false, bool TAME = false>
 __device__ __forceinline__ void clip_normalise(float& w0, float& w1, float& w2)
 {
-    w0 = fmaxf(fminf(w0, 1.f), 0.f);     // == the reference's double-literal clamp (the bounds are exact)
-    w1 = fmaxf(fminf(w1, 1.f), 0.f);
-    w2 = fmaxf(fminf(w2, 1.f), 0.f);
+    if (TAME) {
+        w0 = __builtin_amdgcn_fmed3f(w0, 0.f, 1.f);
+        w1 = __builtin_amdgcn_fmed3f(w1, 0.f, 1.f);
+        w2 = __builtin_amdgcn_fmed3f(w2, 0.f, 1.f);
+    } else {
+        w0 = fmaxf(fminf(w0, 1.f), 0.f);     // == the reference's double-literal clamp (the bounds are exact)
+        w1 = fmaxf(fminf(w1, 1.f), 0.f);
+        w2 = fmaxf(fminf(w2, 1.f), 0.f);
+    }
     const float s = fmaxf(w0 + w1 + w2, 1e-5f);   // (float)max((double)s, 1e-5) == fmaxf(s, 1e-5f) for every float s
     if (FM) { const float r = __builtin_amdgcn_rcpf(s); w0 *= r; w1 *= r; w2 *= r; }
     else div3_shared(w0, w1, w2, s);
@@ -253,9 +325,11 @@ __device__ __forceinline__ float exp_1ulp(float x)
     return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 template <bool FM> __device__ __forceinline__ float exp_(float x) { return FM ? __expf(x) : exp_1ulp(x); }
-template <bool FM> __device__ __forceinline__ float sigmoid_neg_(float neg_arg)
+// NOSCALE: the caller guarantees neg_arg < 80, so 1 + e is a double in [1, 2^116]
+template <bool FM, bool NOSCALE = false> __device__ __forceinline__ float sigmoid_neg_(float neg_arg)
 {
     if (FM) return __builtin_amdgcn_rcpf(1.f + __expf(neg_arg));
+    if (NOSCALE) return (float)recip64_noscale(1. + (double)exp_1ulp(neg_arg));
     return (float)(1. / (1. + (double)exp_1ulp(neg_arg)));   // K.cu:397,403 promote this to double
 }
 
@@ -271,7 +345,7 @@ __device__ __forceinline__ bool certainly_far(RP rec, float w0, float w1, float 
 
 // One edge projection with compile-time edge K (a=K, b=K+1, c=K+2 mod 3): K.cu:85-95 / 136-148.
 // Returns u (already minus w) in (u0,u1,u2).  CLAMP selects the outside-branch variant.
-template <int K, bool CLAMP, bool FM = false, bool MK = false, typename RP = cptr_t>
+template <int K, bool CLAMP, bool FM = false, bool MK = false, typename RP = cptr_t, bool IDEN = false>
 __device__ __forceinline__ void edge_project(RP rec, float w0, float w1, float w2,
                                              float& u0, float& u1, float& u2)
 {
@@ -284,7 +358,8 @@ __device__ __forceinline__ void edge_project(RP rec, float w0, float w1, float w
     const float e0 = rec[R_E + 3 * K + 0], e1 = rec[R_E + 3 * K + 1], e2 = rec[R_E + 3 * K + 2];
     const float eb = rec[R_E + 3 * K + B];
     const float num = w0 * e0 + w1 * e1 + w2 * e2 - eb;
-    float ta = MK ? div_by_recip(num, rec[R_DEN + K], rec[R_IDEN + K]) : div_<FM>(num, rec[R_DEN + K]);
+    float ta = MK ? div_by_recip(num, rec[R_DEN + K], rec[R_IDEN + K])
+                  : (FM && IDEN) ? num * rec[R_IDEN + K] : div_<FM>(num, rec[R_DEN + K]);     // IDEN: the record's RN(1 / den)
     float tb = 1 - ta;
     float tc = 0;
     if (CLAMP) {
@@ -301,20 +376,27 @@ struct Frag {
     float sign, dx, dy; // euclidean: signed displacement
     float t0, t1, t2;   // euclidean/barycentric: saved for backward
     float dis;
+    float narg;         // euclidean, forward-only form (euclid<.., FWD = true>): -sign * dis, the numerator of the sigmoid's exponent
 };
 
 // Euclidean point-to-face distance: K.cu:61-151
-template <bool FM = false, bool MK = false, typename RP = cptr_t>
-__device__ __forceinline__ void euclid(RP rec, float xp, float yp,
-                                       float w0, float w1, float w2, Frag& fr)
+// FWD (forward pass, tame records): the caller only needs D, so the two branches leave -sign * dis in fr.narg themselves (the
+// negation folds into the last subtraction: -(a + b) == (-a) - b bit for bit) and the `sign < 0 && dis >= thr` cut of
+// K.cu:402 is taken inside the outside branch -- no float sign, one compare less.  Returns false when the face is cut.
+// TAME: w0..w2 are finite, so the strict-inside test is min3 > 0 && max3 < 1.
+template <bool FM = false, bool MK = false, typename RP = cptr_t, bool FWD = false, bool TAME = false, bool IDEN = false>
+__device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
+                                       float w0, float w1, float w2, Frag& fr, float thr = 0.f)
 {
 #pragma clang fp contract(off)   // see edge_project
     const float x0 = rec[R_FACE + 0], y0 = rec[R_FACE + 1], x1 = rec[R_FACE + 3], y1 = rec[R_FACE + 4], x2 = rec[R_FACE + 6], y2 = rec[R_FACE + 7];
-    if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
+    const bool inside = TAME ? ((fminf(fminf(w0, w1), w2) > 0) & (fmaxf(fmaxf(w0, w1), w2) < 1))     // (no short-circuit branch)
+                             : (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1);
+    if (inside) {
         float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
         float u0, u1, u2;
 #define LASR_TRY_EDGE(K)                                                          \
-        edge_project<K, false, FM, MK>(rec, w0, w1, w2, u0, u1, u2);                      \
+        edge_project<K, false, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);            \
         {                                                                         \
             const float px = u0 * x0 + u1 * x1 + u2 * x2;                         \
             const float py = u0 * y0 + u1 * y1 + u2 * y2;                         \
@@ -323,6 +405,7 @@ __device__ __forceinline__ void euclid(RP rec, float xp, float yp,
         }
         LASR_TRY_EDGE(0) LASR_TRY_EDGE(1) LASR_TRY_EDGE(2)
 #undef LASR_TRY_EDGE
+        if (FWD) { fr.narg = (-bx) * bx - by * by; return true; }
         fr.dx = bx; fr.dy = by; fr.t0 = b0; fr.t1 = b1; fr.t2 = b2; fr.sign = 1.f;
     } else {
         const int flags = __float_as_int(rec[R_FLAGS]);
@@ -341,13 +424,15 @@ __device__ __forceinline__ void euclid(RP rec, float xp, float yp,
         else if (w2 <= 0) a = 0;
         if (a < 0) a = 0;   // reference indexes [-1] here (UB); pinned to edge 0 like the oracle
         float u0, u1, u2;
-        if (a == 0) edge_project<0, true, FM, MK>(rec, w0, w1, w2, u0, u1, u2);
-        else if (a == 1) edge_project<1, true, FM, MK>(rec, w0, w1, w2, u0, u1, u2);
-        else edge_project<2, true, FM, MK>(rec, w0, w1, w2, u0, u1, u2);
+        if (a == 0) edge_project<0, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
+        else if (a == 1) edge_project<1, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
+        else edge_project<2, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
         fr.dx = u0 * x0 + u1 * x1 + u2 * x2;
         fr.dy = u0 * y0 + u1 * y1 + u2 * y2;
+        if (FWD) { fr.narg = fr.dx * fr.dx + fr.dy * fr.dy; return !(fr.narg >= thr); }
         fr.t0 = u0; fr.t1 = u1; fr.t2 = u2; fr.sign = -1.f;
     }
+    return true;
 }
 
 // Fragment probability of the face in `rec` at (xp,yp): K.cu:387-404.  false = face skipped.
@@ -360,20 +445,22 @@ __device__ __forceinline__ void barycentric(RP rec, float xp, float yp, float& w
     w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
 }
 
-template <bool FM = false, bool MK = false, typename RP = cptr_t>
+template <bool FM = false, bool MK = false, typename RP = cptr_t, bool BT = false>
 __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float sigma,
                                            float xp, float yp, float w0, float w1, float w2, Frag& fr,
                                            float inv_sigma = 0.f);
 
-template <bool FM = false, typename RP = cptr_t>
+// BT (backward pass, LASR's modes): NaN propagation is not pinned there (gradient bar 1e-3 relative), so the inside test runs
+// as min3 / max3 and the edge projection multiplies by the record's 1 / den instead of a v_rcp per fragment
+template <bool FM = false, typename RP = cptr_t, bool BT = false>
 __device__ __forceinline__ bool fragment(RP rec, int dist, float thr, float sigma,
                                          float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
 {
     barycentric(rec, xp, yp, w0, w1, w2);
-    return fragment_w<FM>(rec, dist, thr, sigma, xp, yp, w0, w1, w2, fr);
+    return fragment_w<FM, false, RP, BT>(rec, dist, thr, sigma, xp, yp, w0, w1, w2, fr);
 }
 
-template <bool FM, bool MK, typename RP>
+template <bool FM, bool MK, typename RP, bool BT>
 __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float sigma,
                                            float xp, float yp, float w0, float w1, float w2, Frag& fr, float inv_sigma)
 {
@@ -387,11 +474,14 @@ __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float si
         fr.dis = d; fr.t0 = w0; fr.t1 = w1; fr.t2 = w2;
         if (-d >= thr) return false;
         fr.D = sigmoid_neg_<FM>(MK ? div_by_recip(-d, sigma, inv_sigma) : div_<FM>(-d, sigma));
+    } else if (!FM && MK && OPT_SIGNFOLD) {
+        if (!euclid<FM, MK, RP, true, OPT_MED3>(rec, xp, yp, w0, w1, w2, fr, thr)) return false;
+        fr.D = sigmoid_neg_<FM, OPT_NOSCALE>(div_by_recip(fr.narg, sigma, inv_sigma));
     } else {
-        euclid<FM, MK>(rec, xp, yp, w0, w1, w2, fr);
+        euclid<FM, MK, RP, false, (!FM && MK && OPT_MED3) || BT, BT>(rec, xp, yp, w0, w1, w2, fr);
         fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
         if (fr.sign < 0 && fr.dis >= thr) return false;
-        fr.D = sigmoid_neg_<FM>(MK ? div_by_recip(-fr.sign * fr.dis, sigma, inv_sigma) : div_<FM>(-fr.sign * fr.dis, sigma));
+        fr.D = sigmoid_neg_<FM, (!FM && MK && OPT_NOSCALE)>(MK ? div_by_recip(-fr.sign * fr.dis, sigma, inv_sigma) : div_<FM>(-fr.sign * fr.dis, sigma));
     }
     return true;
 }
@@ -401,9 +491,12 @@ __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float si
 template <bool FM = false, bool MK = false, typename RP = cptr_t>
 __device__ __forceinline__ float depth_at(RP rec, float c0, float c1, float c2)
 {
-    if (MK)
-        return 1.f / (div_by_recip(c0, rec[R_FACE + 2], rec[R_IZ + 0]) + div_by_recip(c1, rec[R_FACE + 5], rec[R_IZ + 1]) +
-                      div_by_recip(c2, rec[R_FACE + 8], rec[R_IZ + 2]));
+    if (MK) {
+        // tame record: 0 <= c_k <= 1 with sum >= 1e-5-ish and 1e-6 <= z_k <= 1e6, so the sum lies in [1e-11, 3e6]: no scaling
+        const float s = div_by_recip(c0, rec[R_FACE + 2], rec[R_IZ + 0]) + div_by_recip(c1, rec[R_FACE + 5], rec[R_IZ + 1]) +
+                        div_by_recip(c2, rec[R_FACE + 8], rec[R_IZ + 2]);
+        return OPT_NOSCALE ? recip_noscale(s) : 1.f / s;
+    }
     return div_<FM>(1.f, div_<FM>(c0, rec[R_FACE + 2]) + div_<FM>(c1, rec[R_FACE + 5]) + div_<FM>(c2, rec[R_FACE + 8]));
 }
 

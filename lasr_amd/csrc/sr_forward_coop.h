@@ -72,6 +72,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
     const int pn = py * IS + px;
+    const int pxy = valid ? px | (py << 16) : -1;                  // (-1 lies in no rect: rect_has)
 
     PixState<NCH> s;                                    // lives in wave 0 only
     s.a = 1.f;
@@ -103,9 +104,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
     const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
     const int texstride = A.T * NCH;
-    UniRecip U;
-    U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
-    U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
+    const UniRecip U = uni_recip(A);
     const float fmn = A.far - A.near;
     const float thr_pad2 = A.thr * 1.10f;
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
@@ -136,9 +135,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
         const int fn = __builtin_amdgcn_readfirstlane(base + (int)s_list[e]);
         const cptr_t rec = as_const(recs + (size_t)fn * REC);
         const cptr_t tex = as_const(texs + (size_t)fn * texstride);
-        const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
-        const bool cand = valid && px >= (int)(short)(rx & 0xffff) && px <= (rx >> 16) &&
-                          py >= (int)(short)(ry & 0xffff) && py <= (ry >> 16);
+        const bool cand = rect_has(__float_as_int(rec[R_BB + 0]), __float_as_int(rec[R_BB + 1]), pxy);
         float w0, w1, w2;
         barycentric(rec, xp, yp, w0, w1, w2);
         const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
@@ -151,9 +148,11 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
                 fl = mk ? 5 : 1;
                 s_buf[b][slot][1][lane] = fr.D;
                 float c0 = w0, c1 = w1, c2 = w2;
-                clip_normalise<false>(c0, c1, c2);
-                const float zp = mk ? depth_at<false, true>(rec, c0, c1, c2) : depth_at<false, false>(rec, c0, c1, c2);
-                if (!(zp < A.near || zp > A.far)) {
+                float zp;
+                if (mk) { clip_normalise<false, OPT_MED3>(c0, c1, c2); zp = depth_at<false, true>(rec, c0, c1, c2); }
+                else { clip_normalise<false>(c0, c1, c2); zp = depth_at<false, false>(rec, c0, c1, c2); }
+                // (a tame record's NaN depth stands for the reference's 1 / 0 = inf: cut, see forward_face)
+                if (mk && OPT_NOSCALE ? (zp >= A.near && zp <= A.far) : !(zp < A.near || zp > A.far)) {
                     fl |= 2;
                     s_buf[b][slot][2][lane] = mk ? div_by_recip(A.far - zp, fmn, U.inv_fmn) : (A.far - zp) / fmn;
 #pragma unroll
@@ -174,10 +173,10 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
             if (fl & 2) {
                 const float zn = s_buf[b][slot][2][lane];
                 const bool up = zn > s.smax;
-                const float d = up ? s.smax - zn : zn - s.smax;
+                const float d = OPT_SOFTMAX ? -fabsf(zn - s.smax) : (up ? s.smax - zn : zn - s.smax);      // see forward_face
                 const float E = exp_1ulp((fl & 4) ? div_by_recip(d, A.gamma, U.inv_gamma) : d / A.gamma);
                 const float hist = up ? E : 1.f, wgt = up ? D : E * D;
-                s.smax = up ? zn : s.smax;
+                s.smax = OPT_SOFTMAX && (fl & 4) ? max_finite(zn, s.smax) : (up ? zn : s.smax);
                 s.ssum = hist * s.ssum + wgt;
 #pragma unroll
                 for (int k = 0; k < NCH; k++) s.c[k] = hist * s.c[k] + wgt * s_buf[b][slot][3 + k][lane];

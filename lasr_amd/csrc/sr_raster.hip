@@ -98,6 +98,15 @@ struct PixState {
 
 // uniform reciprocals for the exact division-by-reciprocal (sr_device.h); ok = all three divisors are in the safe range
 struct UniRecip { float inv_sigma, inv_gamma, inv_fmn; bool ok; };
+// ok also vouches for what the tame-record arithmetic of sr_device.h assumes about the launch: the sigmoid's exponent stays
+// below 80 (recip64_noscale) and a depth beyond 1e15 is beyond the far plane (recip_noscale is only exact up to 2^60)
+__device__ __forceinline__ UniRecip uni_recip(const RasterArgs& A)
+{
+    UniRecip U;
+    U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
+    U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near) && A.thr * U.inv_sigma < 80.f && A.far < 1e15f;
+    return U;
+}
 
 // RX = relaxed arithmetic (opt-in, lasr_sr_set_forward_math(1); LASR's mode combination only): the distance and the
 // `dis >= threshold` decision stay bit-faithful -- that is where the reference is ill-conditioned -- but everything after
@@ -123,10 +132,11 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
     else s.a = (float)((double)s.a * (1. - (double)D));
 
     float c0 = w0, c1 = w1, c2 = w2;
-    clip_normalise<RX>(c0, c1, c2);
+    clip_normalise<RX, (MK && OPT_MED3)>(c0, c1, c2);
     const float zp = RX ? __builtin_amdgcn_rcpf(c0 * rec[R_IZ + 0] + c1 * rec[R_IZ + 1] + c2 * rec[R_IZ + 2])
                         : depth_at<false, MK>(rec, c0, c1, c2);
-    if (zp < A.near || zp > A.far) return;
+    // tame records: the only NaN depth is recip_noscale(0) where the reference has 1 / 0 = inf, beyond any far plane
+    if (MK && OPT_NOSCALE ? !(zp >= A.near && zp <= A.far) : (zp < A.near || zp > A.far)) return;
 
     const bool front = (__float_as_int(rec[R_FLAGS]) & 8) != 0;
     if (m.rgb == 0) {
@@ -145,11 +155,12 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
             // and the fragment gets exp((zn - smax)/gamma).  One exponential of -|zn - smax|/gamma serves both cases with
             // identical bits (exp_1ulp(0) == 1, x * 1 == x).
             const bool up = zn > s.smax;
-            const float d = up ? s.smax - zn : zn - s.smax;
+            // -|zn - smax| is (up ? smax - zn : zn - smax) bit for bit (a - b == -(b - a)); the new maximum is a v_max
+            const float d = OPT_SOFTMAX ? -fabsf(zn - s.smax) : (up ? s.smax - zn : zn - s.smax);
             const float E = RX ? __expf(d * U.inv_gamma)
                                : exp_1ulp(MK ? div_by_recip(d, A.gamma, U.inv_gamma) : d / A.gamma);
             const float hist = up ? E : 1.f, wgt = up ? D : E * D;     // (rescale, ez * D) of the reference, branch-free
-            s.smax = up ? zn : s.smax;
+            s.smax = OPT_SOFTMAX && MK ? max_finite(zn, s.smax) : (up ? zn : s.smax);
             s.ssum = hist * s.ssum + wgt;
 #pragma unroll
             for (int k = 0; k < NCH; k++)
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const int py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
     const int pn = py * IS + px;
+    const int pxy = valid ? px | (py << 16) : -1;                  // (-1 lies in no rect: rect_has)
 
     PixState<NCH> s;
     s.a = (m.alpha == 2) ? 1.f : 0.f;
@@ -285,9 +297,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
     const int texstride = A.T * NCH;
-    UniRecip U;
-    U.inv_sigma = 1.f / A.sigma; U.inv_gamma = 1.f / A.gamma; U.inv_fmn = 1.f / (A.far - A.near);
-    U.ok = recip_safe(A.sigma) && recip_safe(A.gamma) && recip_safe(A.far - A.near);
+    const UniRecip U = uni_recip(A);
     unsigned short* mine = s_mine[wave];
     const float thr_pad2 = A.thr * 1.10f;
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
@@ -411,10 +421,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             for (int j = 0; j < n; j++) {
                 const int fn = base + __builtin_amdgcn_readlane(chunk, j);     // wave-uniform -> scalar loads
                 const cptr_t rec = as_const(recs + (size_t)fn * REC);
-                const int rx = __float_as_int(rec[R_BB + 0]), ry = __float_as_int(rec[R_BB + 1]);
                 // exact integer form of the bbox test K.cu:375 (see first_pixel_ge / last_pixel_le)
-                bool cand = valid && px >= (int)(short)(rx & 0xffff) && px <= (rx >> 16) &&
-                            py >= (int)(short)(ry & 0xffff) && py <= (ry >> 16);
+                const bool cand = rect_has(__float_as_int(rec[R_BB + 0]), __float_as_int(rec[R_BB + 1]), pxy);
                 float w0, w1, w2;
                 barycentric(rec, xp, yp, w0, w1, w2);
                 const int lim = (A.N * A.F - (bn * A.F + fn)) * A.T;   // texels to the end of the tensor

@@ -39,6 +39,30 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
     if (MODE == 26) BODY("v_sub_f32 %0, %3, %0")
     if (MODE == 27) BODY("s_mov_b32 s22, s23")
     if (MODE == 28) BODY("s_and_b64 s[20:21], s[20:21], exec")
+    if (MODE == 29) BODY("v_med3_f32 %0, %0, %1, %2")
+    if (MODE == 30) BODY("v_min3_f32 %0, %0, %1, %2")
+    if (MODE == 31) BODY("v_max3_f32 %0, %0, %1, %2")
+    if (MODE == 32) BODY("v_pk_sub_u16 %0, %0, %1")
+    if (MODE == 33) BODY("v_pk_min_u16 %0, %0, %1")
+    if (MODE == 34) BODY("v_cmp_eq_u32 vcc, %0, %1")
+    if (MODE == 35) BODY("v_lshl_add_u32 %0, %0, 1, %1")
+    if (MODE == 36) BODY("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
+    if (MODE == 37) BODY("v_cmp_lt_f32 s[20:21], %0, %1\n v_cndmask_b32 %0, %0, %1, s[20:21]")
+    if (MODE == 38) BODY("v_sub_u32 %0, %0, %1")
+    if (MODE == 39) BODY("v_min_u32 %0, %0, %1")
+    if (MODE == 40) BODY("v_mad_i32_i24 %0, %0, %1, %2")
+    if (MODE == 41) BODY("v_add_f64 v[200:201], v[200:201], v[202:203]")
+    if (MODE == 42) BODY("v_cvt_f32_i32 %0, %0")
+    if (MODE == 43) BODY("v_add_f32 %0, |%0|, -%1")
+    if (MODE == 44) BODY("v_mul_f32 %0, %0, %1 clamp")
+    if (MODE == 45) BODY("v_bfe_u32 %0, %0, 3, 5")
+    if (MODE == 46) BODY("v_cmp_class_f32 vcc, %0, %1")
+    if (MODE == 47) BODY("v_div_scale_f64 v[200:201], vcc, v[200:201], v[202:203], v[200:201]")
+    if (MODE == 48) BODY("v_div_fixup_f64 v[200:201], v[200:201], v[202:203], v[204:205]")
+    if (MODE == 49) BODY("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
+    if (MODE == 50) BODY("v_fma_f32 %0, %0, %1, %2\n s_nop 0")
+    if (MODE == 51) BODY("v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[20:21], exec")
+    if (MODE == 52) BODY("v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[20:21], exec\n s_or_b64 s[22:23], s[22:23], exec")
     float s = 0;
     for (int i = 0; i < 8; i++) s += x[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -74,5 +98,11 @@ int main()
     run<12>("v_div_scale_f32", d, b); run<13>("v_div_fmas_f32", d, b); run<14>("v_div_fixup_f32", d, b);
     run<5>("v_cvt_f64_f32", d, b); run<17>("v_cvt_f32_f64", d, b); run<16>("v_mul_f64", d, b); run<15>("v_rcp_f64", d, b);
     run<18>("v_readlane_b32", d, b); run<19>("v_mbcnt_lo", d, b); run<27>("s_mov_b32", d, b); run<28>("s_and_b64", d, b);
+    run<29>("v_med3_f32", d, b); run<30>("v_min3_f32", d, b); run<31>("v_max3_f32", d, b); run<32>("v_pk_sub_u16", d, b); run<33>("v_pk_min_u16", d, b);
+    run<34>("v_cmp_eq_u32 vcc", d, b); run<35>("v_lshl_add_u32", d, b); run<36>("v_cmp+v_cndmask via vcc (pair)", d, b); run<37>("v_cmp+v_cndmask via sgpr pair (pair)", d, b);
+    run<38>("v_sub_u32", d, b); run<39>("v_min_u32", d, b); run<40>("v_mad_i32_i24", d, b); run<41>("v_add_f64", d, b); run<42>("v_cvt_f32_i32", d, b);
+    run<43>("v_add_f32 with abs/neg modifiers", d, b); run<44>("v_mul_f32 clamp", d, b); run<45>("v_bfe_u32", d, b); run<46>("v_cmp_class_f32", d, b);
+    run<47>("v_div_scale_f64", d, b); run<48>("v_div_fixup_f64", d, b); run<49>("v_mov_b32_dpp", d, b);
+    run<50>("v_fma + s_nop (pair)", d, b); run<51>("v_fma + s_and_b64 (pair)", d, b); run<52>("v_fma + 2 salu (triple)", d, b);
     return 0;
 }
