@@ -53,7 +53,8 @@ constexpr bool OPT_SIGNFOLD = (LASR_OPT & 8) != 0;    // threshold cut inside th
 constexpr bool OPT_SOFTMAX = (LASR_OPT & 16) != 0;    // depth-softmax update with -|zn - smax| and v_max
 constexpr bool OPT_BWD_MEM = (LASR_OPT & 32) != 0;    // backward: pixel planes through buffer descriptors (32-bit offsets)
 constexpr bool OPT_BWD_S1 = (LASR_OPT & 64) != 0;     // backward stage 1: branch-free conservative reject, fused centres
-constexpr bool OPT_BWD_MATH = (LASR_OPT & 128) != 0;  // backward stage 2: record reciprocals, med3, per-face depth-range test
+constexpr bool OPT_BWD_MATH = (LASR_OPT & 128) != 0;
+constexpr bool OPT_EDGESEL = (LASR_OPT & 256) != 0;   // which edge an outside pixel projects to: lane-mask algebra, not a nested if chain  // backward stage 2: record reciprocals, med3, per-face depth-range test
 constexpr int R_BB = 0, R_FLAGS = 2, R_INV = 3, R_HK2 = 12, R_FACE = 16, R_DEN = 25, R_IDEN = 28, R_E = 32, R_IZ = 41;
 
 // Read-only buffers written by an EARLIER kernel are viewed through the constant address
@@ -116,8 +117,13 @@ __device__ __forceinline__ double recip64_noscale(double x)
     return __builtin_fma(__builtin_fma(-x, q, 1.), y, q);
 }
 
-// max(a, b) of two finite floats as one v_med3_f32 (fmaxf makes the compiler quiet a possible signalling NaN first: two ops)
-__device__ __forceinline__ float max_finite(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+// max(a, b) of two finite floats as ONE v_max_f32 (fmaxf makes the compiler quiet a possible signalling NaN first: two ops)
+__device__ __forceinline__ float max_finite(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // "pixel (px | py << 16) lies in the record's rect" (record fields R_BB, R_BB + 1): per 16-bit half d = p - first must not
 // exceed the extent; a pixel left of / above the rect wraps to d >= 32769 > any extent, the empty rect (first = 0xffff) holds none.
@@ -409,6 +415,26 @@ __device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
         fr.dx = bx; fr.dy = by; fr.t0 = b0; fr.t1 = b1; fr.t2 = b2; fr.sign = 1.f;
     } else {
         const int flags = __float_as_int(rec[R_FLAGS]);
+        float u0, u1, u2;
+        if (OPT_EDGESEL) {
+            // K.cu:113-125 as lane-mask algebra instead of a nested if chain (which the compiler turns into a dozen exec-mask
+            // regions per entry): which edge a pixel outside the face projects to follows from the sign pattern of its
+            // barycentrics, with the obtuse-corner override; every lane takes exactly one of the three projections
+            const bool n0 = w0 <= 0, n1 = w1 <= 0, n2 = w2 <= 0;
+            bool o0 = false, o1 = false, o2 = false;                 // at most one corner of a face is obtuse (wave-uniform flags)
+            if (flags & 7) {
+                if (flags & 1) o0 = (xp - x0) * (x2 - x0) + (yp - y0) * (y2 - y0) > 0;
+                if (flags & 2) o1 = (xp - x1) * (x0 - x1) + (yp - y1) * (y0 - y1) > 0;
+                if (flags & 4) o2 = (xp - x2) * (x1 - x2) + (yp - y2) * (y1 - y2) > 0;
+            }
+            const bool c12 = n1 & n2, c20 = n2 & n0 & !n1, c01 = n0 & n1 & !n2;        // two (or three) non-positive: a corner region
+            const bool e1 = (c20 & !o1) | (c01 & o2) | (n0 & !n1 & !n2);
+            const bool e2 = (c01 & !o2) | (c12 & o0) | (n1 & !n0 & !n2);
+            const bool e0 = !(e1 | e2);             // incl. "none <= 0" (the reference indexes [-1] there: UB; pinned to edge 0 like the oracle)
+            if (e0) edge_project<0, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
+            if (e1) edge_project<1, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
+            if (e2) edge_project<2, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
+        } else {
         int a = -1;
         if (w1 <= 0 && w2 <= 0) {
             a = 0;
@@ -423,10 +449,10 @@ __device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
         else if (w1 <= 0) a = 2;
         else if (w2 <= 0) a = 0;
         if (a < 0) a = 0;   // reference indexes [-1] here (UB); pinned to edge 0 like the oracle
-        float u0, u1, u2;
         if (a == 0) edge_project<0, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
         else if (a == 1) edge_project<1, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
         else edge_project<2, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
+        }
         fr.dx = u0 * x0 + u1 * x1 + u2 * x2;
         fr.dy = u0 * y0 + u1 * y1 + u2 * y2;
         if (FWD) { fr.narg = fr.dx * fr.dx + fr.dy * fr.dy; return !(fr.narg >= thr); }

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
     const int texstride = A.T * NCH;
     const UniRecip U = uni_recip(A);
+    const int ok_bit = U.ok ? 32 : 0;
     const float fmn = A.far - A.near;
     const float thr_pad2 = A.thr * 1.10f;
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
         const bool cand = rect_has(__float_as_int(rec[R_BB + 0]), __float_as_int(rec[R_BB + 1]), pxy);
         float w0, w1, w2;
         barycentric(rec, xp, yp, w0, w1, w2);
-        const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
+        const bool mk = (__float_as_int(rec[R_FLAGS]) & ok_bit) != 0;     // wave-uniform; ok_bit = U.ok ? 32 : 0 (no branch on U.ok per entry)
         int fl = 0;
         if (cand) {
             Frag fr;

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
     const int texstride = A.T * NCH;
     const UniRecip U = uni_recip(A);
+    const int ok_bit = U.ok ? 32 : 0;
     unsigned short* mine = s_mine[wave];
     const float thr_pad2 = A.thr * 1.10f;
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 barycentric(rec, xp, yp, w0, w1, w2);
                 const int lim = (A.N * A.F - (bn * A.F + fn)) * A.T;   // texels to the end of the tensor
                 const cptr_t tex = as_const(texs + (size_t)fn * texstride);
-                const bool mk = U.ok && (__float_as_int(rec[R_FLAGS]) & 32);     // wave-uniform
+                const bool mk = (__float_as_int(rec[R_FLAGS]) & ok_bit) != 0;     // wave-uniform; ok_bit = U.ok ? 32 : 0 (no branch on U.ok per entry)
 #if defined(LASR_ABL) && LASR_ABL == 1      // measurement build: binning + walk + reject only
                 if (cand) s.a += w0 + w1 + w2;
                 (void)lim; (void)tex; (void)mk;
