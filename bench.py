@@ -13,7 +13,8 @@ step, upstream gradient N(0,1)/P.  Inputs are resident in HBM before the timed r
 
 One step = for the rank's B frames: forward (face setup + raster kernel; the background colour is an argument, every element of
 soft_colors is written), backward (face setup + raster kernel; it stores every gradient element) through the C ABI,
-scatter-add the face gradients to per-vertex mesh gradients; for N > 1 the [2,V,3] mesh
+reduce the face gradients to per-vertex gradients (the product's deterministic lasr_face_gather_backward) and sum them over the
+frames; for N > 1 the [2,V,3] mesh
 gradient is then all-reduced over RCCL (frames are sharded data-parallel, weak scaling).
 Nothing inside the timed region touches the CPU oracle.
 
@@ -90,6 +91,10 @@ class RasterStep:
                         float(math.log(1. / m['dist_eps'] - 1.)), float(m['gamma_val']), 1, 2, 1, 1)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
         self.white = (ctypes.c_float * 3)(1., 1., 1.)
+        self.forward_flags = 0                                    # per-call flag of the forward pass (_lib.SR_RELAXED_MATH: opt-in)
+        # face -> vertex reduction of the product (lasr_face_gather_backward, fused_ops.py): per-frame vertex gradients
+        self.faces_n = self.faces_idx[None].expand(B, self.F, 3).contiguous()
+        self.gv = torch.empty(2, B, self.V, 3, device=dev)
 
     def step(self):
         B, F, h, IS = self.B, self.F, self.h, self.IS
@@ -99,7 +104,7 @@ class RasterStep:
         near, far, tail = self.scalars[0], self.scalars[1], self.scalars[2:]
         rc = h.lasr_sr_forward_bg(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
                                   self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                                  B, F, 3, 3, IS, near, far, None, *tail, self.white, _lib.SR_DEFAULT_FLAGS, self.stream)
+                                  B, F, 3, 3, IS, near, far, None, *tail, self.white, self.forward_flags, self.stream)
         _lib.check(rc, 'lasr_sr_forward_bg')
         # the per-face records in the backward, as the autograd operator handles them (soft_rasterize.py: _records_of): launches
         # up to 200k faces reuse the forward's (one launch less on a latency-bound step), larger ones rebuild them (records written
@@ -110,18 +115,21 @@ class RasterStep:
                                    self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail,
                                    _lib.SR_GRADS_OVERWRITE | (0 if rebuild else _lib.SR_RECORDS_VALID), self.stream)
         _lib.check(rc, 'lasr_sr_backward_ex')
-        # face -> vertex gradient scatter (autograd of face_vertices.py:4-22), summed over the rank's frames
-        self.mesh_grad.zero_()
-        self.mesh_grad[0].index_add_(0, self.scatter_idx, self.gf.sum(0).reshape(F * 3, 3))
-        self.mesh_grad[1].index_add_(0, self.scatter_idx, self.gt.sum(0).reshape(F * 3, 3))
+        # face -> vertex gradient reduction (autograd of face_vertices.py:4-22) with the product's own kernel -- deterministic:
+        # a vertex sums its incident corners in ascending order, no atomics (the reference's autograd uses atomic index_add_) --
+        # then the sum over the rank's frames (the mesh is shared by the frames: nnutils/mesh_net.py:255-283)
+        for k, gsrc in enumerate((self.gf, self.gt)):
+            _lib.check(h.lasr_face_gather_backward(gsrc.data_ptr(), self.faces_n.data_ptr(), self.gv[k].data_ptr(), B, self.V, F, 3,
+                                                   self.stream), 'lasr_face_gather_backward')
+        torch.sum(self.gv, dim=1, out=self.mesh_grad)
         return self.mesh_grad
 
 
-def collect_kernel_times(h):
+def collect_kernel_times(h, stream):
     out = {}
     for k in range(h.lasr_prof_kernel_count()):
         ms, n = ctypes.c_double(0), ctypes.c_longlong(0)
-        h.lasr_prof_collect(k, ctypes.byref(ms), ctypes.byref(n))
+        h.lasr_prof_collect(stream, k, ctypes.byref(ms), ctypes.byref(n))
         if n.value:
             out[h.lasr_prof_kernel_name(k).decode()] = (ms.value / n.value, n.value)
     return out
@@ -263,6 +271,57 @@ def optimize_leg(dev, iters):
                       'multi-tensor HIP launches'}
 
 
+def optimize_dp_leg(dev, iters, rank, world, dist):
+    """north_star's ">= 0.9 scaling of the gradient all-reduce" is about THIS message: the ~57 MB of DDP gradients of the
+    optimisation step (nnutils/train_utils.py:104-109, :277 of the reference), not the 29 KB mesh gradient of the raster
+    micro-benchmark.  Every rank runs optimize.py's step on its own frame pairs (the trainer shards them like
+    DistributedSampler: weak scaling), forward + backward replayed as HIP graphs, gradients averaged over the ranks -- once
+    with the all-reduce of the late gradients overlapped with the rest of the backward replay (the default), once as one flat
+    message after it (--nooverlap_allreduce).  Per variant: step ms (barrier on both sides, max over ranks), the collective's
+    span and its exposed part from HIP events on the trainer's stream (max over ranks of the per-rank means), iterations/s."""
+    import optimize
+    from lasr_amd.nnutils import train_utils
+    out = {'world_size': world, 'iters': iters,
+           'config': 'spot3 stage 0 per rank (batch 1 pair, n_hypo 8, n_bones 21, V=642/F=1280, 256x256), --use_graph; weak scaling: '
+                     'global batch = world_size pairs; random-init encoder / perceptual net, synthetic 3-frame sequence'}
+    for name, extra in (('overlap', []), ('no_overlap', ['--nooverlap_allreduce'])):
+        opts = optimize.parse_flags(['--name', 'bench', '--checkpoint_dir', '', '--only_mean_sym', '--nouse_gtpose',
+                                     '--subdivide', '3', '--n_bones', '21', '--n_hypo', '8', '--num_epochs', '5',
+                                     '--batch_size', '1', '--opt_tex', 'yes', '--iters_per_epoch', str(iters + 6), '--use_graph'] + extra)
+        opts.local_rank = dev.index
+        torch.manual_seed(0)
+        tr = train_utils.LASRTrainer(opts).init_training()
+        tr.model.train()
+        tr.reinit_bones()
+        for i in range(6):
+            tr.module.iters = i
+            tr.train_step(tr.set_input(tr.dataloader[i]))
+        nbytes = sum(p.grad.numel() * 4 for p in tr.module.parameters() if p.grad is not None)
+        tr.time_comm = True
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            tr.module.iters = 6 + i
+            loss, _ = tr.train_step(tr.set_input(tr.dataloader[6 + i]))
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ct = tr.comm_times_ms()
+        span = sum(c[0] for c in ct) / max(len(ct), 1)
+        exposed = sum(c[1] for c in ct) / max(len(ct), 1)
+        t = torch.tensor([dt, span, exposed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, span, exposed = (float(x) for x in t.tolist())
+        out[name] = {'ms_per_iter': dt / iters * 1e3, 'iters_per_s': iters / dt, 'pairs_per_s': world * iters / dt,
+                     'allreduce_span_ms': span, 'allreduce_exposed_ms': exposed, 'grad_message_bytes': nbytes,
+                     'allreduce_busbw_GBs': (2.0 * (world - 1) / world * nbytes / (span * 1e-3) / 1e9) if span > 0 else None,
+                     'final_loss': float(loss)}
+        del tr
+        torch.cuda.synchronize()
+    return out
+
+
 RASTER_SOURCES = ('sr_raster.hip', 'sr_forward_coop.h', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
 VALU_PEAK_LANE_OPS = 1024 * 32 * 2.4e9      # 256 CUs x 4 SIMDs, 32 fp32 lanes per SIMD per clock (a wave64 op issues in 2), 2.4 GHz
 
@@ -360,16 +419,16 @@ def sweep_leg(dev, points, steps_budget_ms=150.0):
             job.step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        h.lasr_prof_enable(1)
+        h.lasr_prof_enable(job.stream, 1)
         for _ in range(min(steps, 10)):
             job.step()
         torch.cuda.synchronize()
-        h.lasr_prof_enable(0)
-        kt = collect_kernel_times(h)
+        h.lasr_prof_enable(job.stream, 0)
+        kt = collect_kernel_times(h, job.stream)
         out.append({'frames': B, 'image_size': size, 'frames_per_s': B / dt, 'ms_per_step': dt * 1e3,
                     'us_per_frame': dt / B * 1e6, 'steps': steps,
                     'kernel_ms': {k: round(v[0], 5) for k, v in kt.items()},
-                    'kernel_us_per_frame': round(sum(v[0] * (2 if k == 'sr_setup_kernel' else 1) for k, v in kt.items()) / B * 1e3, 3)})
+                    'kernel_us_per_frame': round(sum(v[0] * v[1] for k, v in kt.items()) / min(steps, 10) / B * 1e3, 3)})
         del job
     IS = keep
     return out
@@ -449,18 +508,18 @@ def main():
 
     # ---- roofline leg: per-kernel HIP-event timing inside the library (separate pass) ----
     h = job.h
-    h.lasr_prof_enable(1)
+    h.lasr_prof_enable(job.stream, 1)
     for _ in range(min(a.steps, 10)):
         job.step()
     torch.cuda.synchronize()
-    h.lasr_prof_enable(0)
-    ktimes = collect_kernel_times(h)
+    h.lasr_prof_enable(job.stream, 0)
+    ktimes = collect_kernel_times(h, job.stream)
 
     if rank == 0:
         F, P = job.F, IS * IS
         alg = {'sr_forward_kernel': (72 * F + 24 * P) * B, 'sr_backward_kernel': (144 * F + 40 * P) * B,
                'sr_setup_kernel': (36 + 192 + 8) * F * B}
-        dom = max((k for k in ktimes if k != 'sr_setup_kernel'), key=lambda k: ktimes[k][0])
+        dom = max((k for k in ktimes if k in ('sr_forward_kernel', 'sr_backward_kernel')), key=lambda k: ktimes[k][0])
         achieved = alg[dom] / (ktimes[dom][0] * 1e-3) / 1e9
         traffic, traffic_src, traffic_stale = measured_traffic(dom, B) if IS == 256 else (None, None, 'PMC passes are taken at 256x256')
         vi = valu_issue(dom, B, ktimes[dom][0]) if IS == 256 else None
@@ -479,7 +538,8 @@ def main():
                        'step_definition': 'face setup + forward kernel (background colour passed as an argument: no pre-fill pass, '
                                           'every element of soft_colors written) + face setup (launches above 200k faces; smaller ones '
                                           'reuse the forward\'s records, as the autograd operator does) + backward kernel (stores every '
-                                          'gradient element: no zero-fill pass) + face->vertex scatter of both gradients '
+                                          'gradient element: no zero-fill pass) + face->vertex reduction of both gradients with the product\'s deterministic '
+                                          'lasr_face_gather_backward + sum over the frames '
                                           '(+ RCCL all-reduce of the [2,V,3] mesh gradient for N > 1); rounds 1 and early 2 '
                                           'also timed the two fill passes the reference caller needs (soft_rasterize.py:50-53, '
                                           ':88-89), which these entry points make unnecessary'},
@@ -496,9 +556,9 @@ def main():
                          'valu_issue': vi},
         }
         if world == 1:
-            # informational: the opt-in relaxed forward arithmetic (lasr_sr_set_forward_math(1), image within ~1e-5 of the
-            # default path; `value` above is the default, reference-faithful arithmetic)
-            h.lasr_sr_set_forward_math(1)
+            # informational: the opt-in relaxed forward arithmetic (per-call flag LASR_SR_RELAXED_MATH, image within ~1e-5 of
+            # the default path; `value` above is the default, reference-faithful arithmetic)
+            job.forward_flags = _lib.SR_RELAXED_MATH
             try:
                 job.step()
                 torch.cuda.synchronize()
@@ -509,7 +569,7 @@ def main():
                 out['relaxed_forward_math'] = {'value': B * min(a.steps, 10) / (time.perf_counter() - t1), 'unit': 'frames/s',
                                                'note': 'opt-in; distance + threshold decision bit-faithful, the rest fp32 rcp/exp'}
             finally:
-                h.lasr_sr_set_forward_math(0)
+                job.forward_flags = 0
         if world == 1 and not a.no_sweep:
             out['sweep'] = sweep_leg(dev, [(1, 256), (4, 256), (16, 256), (64, 256), (64, 512)])
             IS = a.image_size
@@ -519,6 +579,10 @@ def main():
             out['lbs'] = lbs_leg(dev)
         if world == 1 and a.lasr_iters > 0:
             out['optimize_py'] = optimize_leg(dev, a.lasr_iters)
+    dp = optimize_dp_leg(dev, a.lasr_iters, rank, world, dist) if world > 1 and a.lasr_iters > 0 else None     # every rank takes part
+    if rank == 0:
+        if dp is not None:
+            out['optimize_py_dp'] = dp
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -127,7 +127,10 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
 /*
  * Supersets of the entry points above with every option as an argument (no reference counterpart).  channels = 3, 6 or 9 (6 and 9 as
  * for the *_attr variants); near_far_dev: NULL or a device pointer to {near, far} that overrides near / far.
- * forward flags  : LASR_SR_RELAXED_MATH (the per-call form of lasr_sr_set_forward_math below), or LASR_SR_DEFAULT_FLAGS.
+ * forward flags  : 0, or LASR_SR_RELAXED_MATH -- LASR's mode combination only: the point-to-face distance and the
+ *                  `dis >= threshold` decision stay bit-faithful, the sigmoid, alpha product, clip / normalise, depth and
+ *                  softmax weights use fp32 v_rcp / v_exp arithmetic (~15 % faster forward, image within ~3e-5 of the default
+ *                  arithmetic; the north-star bar is 1e-4).  LASR_SR_DEFAULT_FLAGS (-1) is accepted and means 0.
  * backward flags : LASR_SR_RECORDS_VALID -- the caller vouches that `workspace` still holds the per-face records the forward
  *                  pass of the SAME faces / N / F / IS / sigma_val / dist_eps left there (nothing else was run on that
  *                  workspace in between); the backward then skips its own setup launch.  Without the flag every backward
@@ -136,7 +139,7 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
  *                  face is owned by one wavefront), so the caller may pass uninitialised buffers instead of zeroed ones (the
  *                  reference accumulates with atomics into zeroed tensors, soft_rasterize.py:88-89); ignored for surface textures.
  */
-#define LASR_SR_DEFAULT_FLAGS (-1)   /* forward only: use the process-wide default of lasr_sr_set_forward_math */
+#define LASR_SR_DEFAULT_FLAGS (-1)   /* forward only: the default arithmetic (same as 0) */
 #define LASR_SR_RELAXED_MATH  1
 #define LASR_SR_RECORDS_VALID 4
 #define LASR_SR_GRADS_OVERWRITE 8   /* backward, vertex textures: grad_faces / grad_textures need not be zeroed by the caller */
@@ -161,40 +164,49 @@ int lasr_sr_backward_ex(const float* faces, const float* textures, const float* 
                         int flags, void* hip_stream);
 
 /*
- * Optional per-kernel timing for benchmarks (no reference counterpart: the
- * reference has no profiling hooks).  While enabled, every
- * kernel launch of this library is bracketed by hipEvents on its stream;
- * lasr_prof_collect blocks until those launches finished and returns their
- * summed duration and count, then forgets them.
+ * Per-call launch options (no reference counterpart).  The library keeps NO mutable process state: what used to be
+ * process-wide setters in rounds 1-3 (forward arithmetic, kernel-choice thresholds) is an argument now, so two callers in one
+ * process with different settings cannot race.
+ * Which forward kernel a launch of LASR's mode combination takes is decided by its size in 8x8-pixel tiles (frames x tiles
+ * per frame); the output is bit-identical whichever kernel runs (tests/test_forward_kernel_choice_gpu.py runs every one on
+ * the same inputs).  Up to coop8_max_tiles: eight waves share a tile; up to coop_max_tiles: four waves (csrc/sr_forward_coop.h:
+ * latency designs for launches that cannot fill the chip); up to choose_max_tiles: a one-wave kernel estimates the BUSY tiles
+ * from the meshes' pixel bounding boxes on the device and picks four waves per tile (estimate at most coop_max_tiles) or one
+ * wave per tile -- both are launched, the one not chosen returns at once; above: one wave per tile.  A NEGATIVE field takes the
+ * built-in default: 2200 / 14336 / 49152 (six and nine channels: 5/8 of the first two and no device-decided range; measured
+ * on an MI355X, csrc/sr_raster.hip), or the value of LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES /
+ * LASR_SR_CHOOSE_MAX_TILES read ONCE when the library is loaded.
  */
-int         lasr_prof_enable(int on);
+typedef struct lasr_sr_options {
+    long long coop8_max_tiles;
+    long long coop_max_tiles;
+    long long choose_max_tiles;
+} lasr_sr_options;
+/* lasr_sr_forward_bg with options: `background` may be NULL (then soft_colors holds the pre-filled background, as for
+ * lasr_sr_forward_ex), `options` may be NULL (all defaults). */
+int lasr_sr_forward_opt(const float* faces, const float* textures, float* faces_info, float* aggrs_info, float* soft_colors,
+                        void* workspace, size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near,
+                        float far, const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,
+                        float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                        const float* background, int flags, const lasr_sr_options* options, void* hip_stream);
+
+/*
+ * Optional per-kernel timing for benchmarks (no reference counterpart: the reference has no profiling hooks, SURVEY.md
+ * section 5), scoped to a STREAM: while enabled for `hip_stream`, every kernel this library launches on that stream is
+ * bracketed by hipEvents; launches on other streams (another trainer in the same process) are neither timed nor slowed.
+ * lasr_prof_collect blocks until the recorded launches of that stream finished and returns their summed duration and count,
+ * then forgets them.
+ */
+int         lasr_prof_enable(void* hip_stream, int on);
 int         lasr_prof_kernel_count(void);
 const char* lasr_prof_kernel_name(int kernel_id);
-int         lasr_prof_collect(int kernel_id, double* total_ms, long long* launches);
+int         lasr_prof_collect(void* hip_stream, int kernel_id, double* total_ms, long long* launches);
 
 /*
- * Arithmetic of the forward pass for LASR's mode combination (euclidean / softmax / prod / vertex / double-sided),
- * process-wide (no reference counterpart).  0 (default): the reference's rounding sequence, image within ~2.4e-7 of the
- * op-faithful oracle.  1: the point-to-face distance and the `dis >= threshold` decision stay bit-faithful, the sigmoid,
- * alpha product, clip/normalise, depth and softmax weights use fp32 v_rcp / v_exp arithmetic: ~15 % faster forward, image
- * within ~3e-5 of mode 0 (the north-star bar is 1e-4).  Other mode combinations and the backward pass are unaffected.
+ * lasr_sr_peek_choice (test hook, synchronises the stream): what the device-side kernel choice of the LAST forward call on
+ * `workspace` was -- 0 one wave per tile, 1 four waves per tile; meaningful only if that call's size was in the
+ * device-decided range (lasr_sr_options).
  */
-int lasr_sr_set_forward_math(int mode);
-
-/*
- * Which forward kernel a launch of LASR's mode combination takes, by its size in 8x8-pixel tiles (frames x tiles per frame);
- * process-wide, no reference counterpart, the output is bit-identical whichever kernel runs (tests/test_forward_kernel_choice_gpu.py
- * runs every one on the same inputs).  Up to coop8_max_tiles: eight waves share a tile; up to coop_max_tiles: four waves
- * (csrc/sr_forward_coop.h: latency designs for launches that cannot fill the chip); up to choose_max_tiles: a one-wave kernel
- * estimates the BUSY tiles from the meshes' pixel bounding boxes on the device and picks four waves per tile (estimate at most
- * coop_max_tiles) or one wave per tile -- both are launched, the one not chosen returns at once; above: one wave per tile.
- * Defaults 2200 / 14336 / 49152 (six and nine channels: 5/8 of the first two and no device-decided range; measured on an MI355X,
- * csrc/sr_raster.hip), also settable
- * through LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES / LASR_SR_CHOOSE_MAX_TILES.  A negative argument keeps the current value.
- * lasr_sr_peek_choice (test hook, synchronises the stream): what the device-side choice of the LAST forward call on `workspace`
- * was -- 0 one wave per tile, 1 four waves per tile; meaningful only if that call's size was in the device-decided range.
- */
-int lasr_sr_set_launch_thresholds(long long coop8_max_tiles, long long coop_max_tiles, long long choose_max_tiles);
 int lasr_sr_peek_choice(const void* workspace, int N, int F, int* choice, void* hip_stream);
 
 

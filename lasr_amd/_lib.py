@@ -91,20 +91,26 @@ SIGNATURES = {
     'lasr_sr_forward_ex': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_bg': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p, _i, _p]),
     'lasr_sr_backward_ex': (_i, [_p] * 8 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
-    'lasr_sr_set_forward_math': (_i, [_i]),
-    'lasr_sr_set_launch_thresholds': (_i, [ctypes.c_longlong] * 3),
+    'lasr_sr_forward_opt': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p, _i, _p, _p]),
     'lasr_sr_peek_choice': (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _p]),
     'lasr_selftest_div': (_i, [_p, _p, _p, _i, _p]),
     'lasr_selftest_div3': (_i, [_p, _p, _p, _i, _p]),
-    'lasr_prof_enable': (_i, [_i]),
+    'lasr_prof_enable': (_i, [_p, _i]),
     'lasr_prof_kernel_count': (_i, []),
     'lasr_prof_kernel_name': (ctypes.c_char_p, [_i]),
-    'lasr_prof_collect': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
+    'lasr_prof_collect': (_i, [_p, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
 }
 
 # flags of the *_ex entry points (include/lasr_sr.h)
 SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_RECORDS_VALID, SR_GRADS_OVERWRITE = -1, 1, 4, 8
 MEANS_MAX_TERMS, TAIL_MAX_GROUPS = 24, 16          # LASR_MEANS_MAX_TERMS / LASR_TAIL_MAX_GROUPS of include/lasr_ops.h
+
+
+
+class SrOptions(ctypes.Structure):
+    """lasr_sr_options (include/lasr_sr.h): per-call kernel-choice thresholds of the forward pass; a negative field = default."""
+    _fields_ = [('coop8_max_tiles', ctypes.c_longlong), ('coop_max_tiles', ctypes.c_longlong), ('choose_max_tiles', ctypes.c_longlong)]
+
 
 _lib = None
 

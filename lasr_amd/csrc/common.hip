@@ -1,4 +1,5 @@
 // common.hip -- error reporting and the optional per-kernel timing of liblasr_hip.so (host code only).
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -6,10 +7,13 @@
 
 namespace {
 thread_local int g_last_hip_error = 0;
-struct ProfRec { int id; hipEvent_t a, b; };
+// per-kernel timing, scoped to the streams it was switched on for (include/lasr_sr.h): the only state is the set of profiled
+// streams and their pending event pairs; n_on lets the common case (nothing profiled) skip the lock
+struct ProfRec { hipStream_t st; int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
-bool g_prof_on = false;
+std::vector<hipStream_t> g_prof_streams;
+std::atomic<int> g_prof_n_on{0};
 const char* const kKernelNames[K_NUM_KERNELS] = {
     "sr_setup_kernel", "sr_forward_kernel", "sr_backward_kernel",
     "lbs_forward_kernel", "lbs_backward_kernel", "pinhole_forward_kernel", "pinhole_backward_kernel",
@@ -31,12 +35,18 @@ int lasr_launch_ok()
     return LASR_OK;
 }
 
-bool lasr_prof_is_on() { return g_prof_on; }
+bool lasr_prof_is_on(hipStream_t st)
+{
+    if (g_prof_n_on.load(std::memory_order_relaxed) == 0) return false;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (hipStream_t s : g_prof_streams) if (s == st) return true;
+    return false;
+}
 
-void lasr_prof_push(int id, hipEvent_t a, hipEvent_t b)
+void lasr_prof_push(hipStream_t st, int id, hipEvent_t a, hipEvent_t b)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_recs.push_back(ProfRec{id, a, b});
+    g_prof_recs.push_back(ProfRec{st, id, a, b});
 }
 
 extern "C" int lasr_abi_version(void) { return 1; }
@@ -56,10 +66,15 @@ extern "C" const char* lasr_strerror(int code)
     }
 }
 
-extern "C" int lasr_prof_enable(int on)
+extern "C" int lasr_prof_enable(void* hip_stream, int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
+    const hipStream_t st = (hipStream_t)hip_stream;
+    size_t i = 0;
+    while (i < g_prof_streams.size() && g_prof_streams[i] != st) i++;
+    if (on && i == g_prof_streams.size()) g_prof_streams.push_back(st);
+    if (!on && i < g_prof_streams.size()) g_prof_streams.erase(g_prof_streams.begin() + i);
+    g_prof_n_on.store((int)g_prof_streams.size(), std::memory_order_relaxed);
     return LASR_OK;
 }
 
@@ -68,14 +83,14 @@ extern "C" int lasr_prof_kernel_count(void) { return K_NUM_KERNELS; }
 extern "C" const char* lasr_prof_kernel_name(int id) { return id >= 0 && id < K_NUM_KERNELS ? kKernelNames[id] : ""; }
 
 // Sums (and clears) the recorded launches of kernel `id`; blocks until they finished.
-extern "C" int lasr_prof_collect(int id, double* total_ms, long long* launches)
+extern "C" int lasr_prof_collect(void* hip_stream, int id, double* total_ms, long long* launches)
 {
     if (!total_ms || !launches) return LASR_E_BADARG;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double tot = 0; long long n = 0;
     std::vector<ProfRec> keep;
     for (auto& r : g_prof_recs) {
-        if (r.id != id) { keep.push_back(r); continue; }
+        if (r.id != id || r.st != (hipStream_t)hip_stream) { keep.push_back(r); continue; }
         float ms = 0.f;
         (void)hipEventSynchronize(r.b);
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; n++; }

@@ -18,19 +18,19 @@ enum LasrKernelId {
 };
 
 int lasr_launch_ok();                                   // hipGetLastError -> LASR_OK / LASR_E_LAUNCH (records the code)
-bool lasr_prof_is_on();
-void lasr_prof_push(int id, hipEvent_t a, hipEvent_t b);
+bool lasr_prof_is_on(hipStream_t st);
+void lasr_prof_push(hipStream_t st, int id, hipEvent_t a, hipEvent_t b);
 
 // Brackets one kernel launch with hipEvents on its stream when profiling is enabled.
 struct ProfScope {
     hipStream_t st; int id; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(int id_, hipStream_t st_) : st(st_), id(id_), on(lasr_prof_is_on())
+    ProfScope(int id_, hipStream_t st_) : st(st_), id(id_), on(lasr_prof_is_on(st_))
     {
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (on) { (void)hipEventRecord(b, st); lasr_prof_push(id, a, b); }
+        if (on) { (void)hipEventRecord(b, st); lasr_prof_push(st, id, a, b); }
     }
 };
 

@@ -108,7 +108,7 @@ __device__ __forceinline__ UniRecip uni_recip(const RasterArgs& A)
     return U;
 }
 
-// RX = relaxed arithmetic (opt-in, lasr_sr_set_forward_math(1); LASR's mode combination only): the distance and the
+// RX = relaxed arithmetic (opt-in per call, LASR_SR_RELAXED_MATH; LASR's mode combination only): the distance and the
 // `dis >= threshold` decision stay bit-faithful -- that is where the reference is ill-conditioned -- but everything after
 // it (sigmoid, alpha product, clip/normalise, depth, softmax weights) uses fp32 v_rcp / v_exp arithmetic instead of the
 // reference's division / double-promotion sequence.  Rendered image within ~3e-5 of the exact path (bar: 1e-4).
@@ -557,10 +557,9 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     return A;
 }
 
-// process-wide DEFAULT of the forward arithmetic (lasr_sr_set_forward_math); the *_ex entry points take the same choice per
-// call in `flags`, and nothing else in this file is global state
-static int g_forward_math = 0;                               // 0 = reference-faithful (default), 1 = relaxed, see forward_face
-static int default_flags() { return g_forward_math ? LASR_SR_RELAXED_MATH : 0; }
+// nothing in this file is mutable process state: the forward arithmetic is a per-call flag, the kernel-choice thresholds a per-call
+// lasr_sr_options (their built-in defaults below are constants read once at load time)
+static int default_flags() { return 0; }
 
 static long long env_blocks(const char* name, long long dflt)
 {
@@ -588,11 +587,11 @@ static long long env_blocks(const char* name, long long dflt)
 // W1 against four waves per 16x16 tile: 256 frames 2.370 -> 2.163 ms, 64 frames 0.696 -> 0.649, 16 frames 0.284 -> 0.280,
 // 4 frames 0.210 -> 0.221 (profiles/r03_w1_ab.txt): launches that small now take the cooperative kernel, and the four-wave
 // 16x16 kernel is left to the other mode combinations.
-// Environment overrides LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES / LASR_SR_CHOOSE_MAX_TILES, read once, or
-// lasr_sr_set_launch_thresholds; the output is bit-identical whichever kernel runs.
-static long long g_coop8_max_tiles = env_blocks("LASR_SR_COOP8_MAX_TILES", 2200);
-static long long g_coop_max_tiles = env_blocks("LASR_SR_COOP_MAX_TILES", 14336);
-static long long g_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES", 49152);
+// Environment overrides LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES / LASR_SR_CHOOSE_MAX_TILES, read once at load time;
+// per call: lasr_sr_options (lasr_sr_forward_opt).  The output is bit-identical whichever kernel runs.
+static const long long k_coop8_max_tiles = env_blocks("LASR_SR_COOP8_MAX_TILES", 2200);
+static const long long k_coop_max_tiles = env_blocks("LASR_SR_COOP_MAX_TILES", 14336);
+static const long long k_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES", 49152);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -601,8 +600,11 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                         float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps,
                         float gamma_val, int func_id_rgb, int func_id_alpha, int texture_sample_type,
                         int double_side, void* hip_stream, int nch, const float* near_far_dev, int flags,
-                        const float* background = nullptr)
+                        const float* background = nullptr, const lasr_sr_options* opt = nullptr)
 {
+    const long long g_coop8_max_tiles = opt && opt->coop8_max_tiles >= 0 ? opt->coop8_max_tiles : k_coop8_max_tiles;
+    const long long g_coop_max_tiles = opt && opt->coop_max_tiles >= 0 ? opt->coop_max_tiles : k_coop_max_tiles;
+    const long long g_choose_max_tiles = opt && opt->choose_max_tiles >= 0 ? opt->choose_max_tiles : k_choose_max_tiles;
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
     if (rc) return rc;
     if (N == 0 || IS == 0) return LASR_OK;
@@ -842,6 +844,22 @@ extern "C" int lasr_sr_forward_bg(const float* faces, const float* textures, flo
                         texture_sample_type, double_side, hip_stream, channels, near_far_dev, flags, background);
 }
 
+extern "C" int lasr_sr_forward_opt(const float* faces, const float* textures, float* faces_info, float* aggrs_info,
+                                   float* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T,
+                                   int channels, int IS, float near, float far, const float* near_far_dev, float eps,
+                                   float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                                   int func_id_alpha, int texture_sample_type, int double_side, const float* background, int flags,
+                                   const lasr_sr_options* options, void* hip_stream)
+{
+    if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
+    if (flags & ~LASR_SR_RELAXED_MATH) return LASR_E_BADARG;
+    const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
+    if (rc) return rc;
+    return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
+                        far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                        texture_sample_type, double_side, hip_stream, channels, near_far_dev, flags, background, options);
+}
+
 extern "C" int lasr_sr_backward_ex(const float* faces, const float* textures, const float* soft_colors,
                                    const float* aggrs_info, float* grad_faces, float* grad_textures,
                                    const float* grad_soft_colors, void* workspace, size_t workspace_bytes, int N, int F,
@@ -876,14 +894,6 @@ extern "C" int lasr_selftest_div3(const float* a, const float* b, int* mismatche
     return launch_ok();
 }
 
-extern "C" int lasr_sr_set_launch_thresholds(long long coop8_max_tiles, long long coop_max_tiles, long long choose_max_tiles)
-{
-    if (coop8_max_tiles >= 0) g_coop8_max_tiles = coop8_max_tiles;
-    if (coop_max_tiles >= 0) g_coop_max_tiles = coop_max_tiles;
-    if (choose_max_tiles >= 0) g_choose_max_tiles = choose_max_tiles;
-    return LASR_OK;
-}
-
 extern "C" int lasr_sr_peek_choice(const void* workspace, int N, int F, int* choice, void* hip_stream)
 {
     if (!workspace || !choice || N < 0 || F < 0) return LASR_E_BADARG;
@@ -893,11 +903,4 @@ extern "C" int lasr_sr_peek_choice(const void* workspace, int N, int F, int* cho
          align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256);
     if (hipMemcpyAsync(choice, p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)hip_stream) != hipSuccess) return LASR_E_LAUNCH;
     return hipStreamSynchronize((hipStream_t)hip_stream) == hipSuccess ? LASR_OK : LASR_E_LAUNCH;
-}
-
-extern "C" int lasr_sr_set_forward_math(int mode)
-{
-    if (mode != 0 && mode != 1) return LASR_E_BADMODE;
-    g_forward_math = mode;
-    return LASR_OK;
 }

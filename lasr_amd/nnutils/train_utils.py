@@ -279,10 +279,13 @@ class LASRTrainer:
             # hooks do in the reference (nnutils/train_utils.py:104-109, :277), which cannot live inside a capture
             from .. import parallel
             late, early, graph_b = g[4], g[5], g[6]
+            t0 = self._comm_mark()
             work = parallel.allreduce_grads_async([gr for _, gr in late], average=True)
             graph_b.replay()
+            t1 = self._comm_mark()
             parallel.allreduce_grads_([gr for _, gr in early], average=True)
             work()
+            self._comm_done(t0, t1)
             self._dp_reduced = True
         for p, gr in g[3]:
             p.grad = gr
@@ -327,9 +330,37 @@ class LASRTrainer:
             total_loss.mean().backward()
         if getattr(self, 'manual_dp', False) and not self.__dict__.pop('_dp_reduced', False):
             from .. import parallel                        # mean of the ranks' gradients, one flat message over RCCL
+            t0 = self._comm_mark()
             parallel.allreduce_grads_([p.grad for p in m.parameters() if p.grad is not None], average=True)
+            self._comm_done(t0, t0)
         self.step_tail()
         return total_loss.detach(), aux
+
+    # Optional timing of the gradient all-reduce for bench.py (`time_comm = True`): HIP events on the trainer's stream around the
+    # collective(s) of a step.  comm_events holds (start, after_overlapped_compute, end) per step: end - start is the span from
+    # the first collective's enqueue to the last one's completion as this stream sees it; end - after_overlapped_compute is the
+    # part of it that is NOT hidden behind the second graph's replay (equal to the whole span without overlap).
+    time_comm = False
+
+    def _comm_mark(self):
+        if not self.time_comm:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _comm_done(self, t0, t1):
+        if t0 is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.__dict__.setdefault('comm_events', []).append((t0, t1, e))
+
+    def comm_times_ms(self):
+        """[(span_ms, exposed_ms)] of the recorded steps (synchronises); clears the record."""
+        ev = self.__dict__.pop('comm_events', [])
+        if ev:
+            ev[-1][2].synchronize()
+        return [(a.elapsed_time(c), b.elapsed_time(c)) for a, b, c in ev]
 
     def step_tail(self):
         """What follows backward() in the reference loop (nnutils/train_utils.py:282-296): clip the mean-shape gradient to

@@ -25,13 +25,30 @@ _workspaces = {}
 _forward_flags = _lib.SR_DEFAULT_FLAGS
 
 
+_launch_options = None
+
+
 def set_forward_flags(flags):
-    """Forward-kernel flags the autograd operator passes per call: _lib.SR_DEFAULT_FLAGS (default: whatever
-    lasr_sr_set_forward_math set process-wide), 0 or _lib.SR_RELAXED_MATH
-    (include/lasr_sr.h).  Returns the previous value."""
+    """Forward-kernel flags the autograd operator passes per call: 0 / _lib.SR_DEFAULT_FLAGS (default arithmetic) or
+    _lib.SR_RELAXED_MATH (include/lasr_sr.h).  This is the CALLER's setting (a module variable of this Python operator); the
+    native library itself keeps no state.  Returns the previous value."""
     global _forward_flags
     old, _forward_flags = _forward_flags, int(flags)
     return old
+
+
+def set_launch_thresholds(coop8_max_tiles=-1, coop_max_tiles=-1, choose_max_tiles=-1):
+    """Kernel-choice thresholds this operator passes with every forward call (lasr_sr_options; negative = library default,
+    no argument = all defaults).  The output is bit-identical whichever kernel runs; tests force each one through here."""
+    global _launch_options
+    if coop8_max_tiles < 0 and coop_max_tiles < 0 and choose_max_tiles < 0:
+        _launch_options = None
+    else:
+        _launch_options = _lib.SrOptions(int(coop8_max_tiles), int(coop_max_tiles), int(choose_max_tiles))
+
+
+def _options_ref():
+    return ctypes.byref(_launch_options) if _launch_options is not None else None
 
 
 def forward_flags():
@@ -139,10 +156,10 @@ class SoftRasterizeFunction(Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
-            rc = h.lasr_sr_forward_bg(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(), soft_colors.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), N, F, T, C, IS, *ctx.near_far,
-                                      nf.data_ptr() if nf is not None else None, *tail, (ctypes.c_float * C)(*bg[:C]),
-                                      forward_flags(), stream)
+            rc = h.lasr_sr_forward_opt(fv.data_ptr(), tx.data_ptr(), None, aggrs_info.data_ptr(), soft_colors.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), N, F, T, C, IS, *ctx.near_far,
+                                       nf.data_ptr() if nf is not None else None, *tail, (ctypes.c_float * C)(*bg[:C]),
+                                       forward_flags(), _options_ref(), stream)
         _lib.check(rc, 'lasr_sr_forward')
         ctx.records = _new_records(dev, stream)
         ctx.save_for_backward(fv, tx, soft_colors, aggrs_info)
@@ -220,9 +237,11 @@ def soft_rasterize_raw(face_vertices, textures, image_size, background_color, ne
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         ws = _workspace(dev, stream, h.lasr_sr_workspace_bytes(N, F, T, IS))
-        rc = h.lasr_sr_forward(fv.data_ptr(), tx.data_ptr(), faces_info.data_ptr() if want_faces_info else None,
-                               aggrs_info.data_ptr(), soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
-                               N, F, T, IS, *scalars, stream)
+        # (lasr_sr_forward is this call with flags 0 and no options; the raw path takes the operator's settings as well)
+        rc = h.lasr_sr_forward_opt(fv.data_ptr(), tx.data_ptr(), faces_info.data_ptr() if want_faces_info else None,
+                                   aggrs_info.data_ptr(), soft_colors.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   N, F, T, 3, IS, scalars[0], scalars[1], None, *scalars[2:], None, forward_flags(),
+                                   _options_ref(), stream)
     _lib.check(rc, 'lasr_sr_forward')
     _new_records(dev, stream)
     return (soft_colors, aggrs_info, faces_info) if want_faces_info else (soft_colors, aggrs_info)

@@ -98,7 +98,9 @@ def test_fused_operator_argument_validation():
     assert h.lasr_point_mesh_forward(None, None, None, None, None, None, None, 1, 5, 0, 5, None) == -1
     assert h.lasr_cosdist_forward(None, None, None, None, 2, 8, 16, 0, None) == -1                        # rep must be >= 1
     assert h.lasr_cosdist_scratch_floats(4, 1000) >= 16
-    assert h.lasr_sr_set_forward_math(0) == 0 and h.lasr_sr_set_forward_math(7) == -2
+    # unknown forward flag bits are refused before anything is launched
+    assert h.lasr_sr_forward_opt(None, None, None, None, None, None, 0, 1, 1, 3, 3, 8, 1., 2., None, 1e-3, 1e-4, 2, 9.21, 1e-2,
+                                 1, 2, 1, 1, None, 64, None, None) == -1
 
 
 def test_header_constants_match_the_python_mirror():

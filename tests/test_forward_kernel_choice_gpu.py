@@ -2,7 +2,7 @@
 forward_impl): eight or four waves sharing an 8x8 tile for launches that cannot fill the chip (sr_forward_coop.h), one wave per
 8x8 tile for the rest; in between a one-wave kernel estimates the busy tiles ON THE DEVICE and both candidates are launched.
 The kernels evaluate every (pixel, face) pair with the same instruction sequence and visit the faces of a pixel in index
-order, so their outputs must be IDENTICAL bit for bit: this file forces each one in turn (lasr_sr_set_launch_thresholds,
+order, so their outputs must be IDENTICAL bit for bit: this file forces each one in turn (lasr_sr_options through the operator's set_launch_thresholds,
 include/lasr_sr.h) on the same inputs -- ragged image sizes, 3 / 6 / 9 channels, a tile whose list needs more than one round,
 device-resident near/far, an empty mesh -- and compares the raw bits; one of them is also held against the oracle, which pins
 all of them.  The device-side choice is checked against both of its outcomes."""
@@ -25,9 +25,8 @@ DEFAULTS = (2200, 14336, 49152)
 
 @pytest.fixture
 def thresholds():
-    h = _lib.lib()
-    yield lambda name: _lib.check(h.lasr_sr_set_launch_thresholds(*VARIANTS[name]), 'lasr_sr_set_launch_thresholds')
-    h.lasr_sr_set_launch_thresholds(*DEFAULTS)
+    yield lambda name: srf.set_launch_thresholds(*VARIANTS[name])
+    srf.set_launch_thresholds()
 
 
 def render(dev, fv, ft, IS, kw):
@@ -121,7 +120,7 @@ def test_the_device_side_choice_takes_either_kernel_and_the_bits_do_not_change(t
     import ctypes
     seen = {}
     for coop_max in (300, 40):
-        _lib.check(h.lasr_sr_set_launch_thresholds(0, coop_max, BIG), 'thresholds')
+        srf.set_launch_thresholds(0, coop_max, BIG)
         got = render(cuda, fv, ft, 64, kw)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]

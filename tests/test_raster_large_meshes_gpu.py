@@ -42,9 +42,8 @@ SPOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'spot_
 
 @pytest.fixture
 def thresholds():
-    h = _lib.lib()
-    yield lambda name: _lib.check(h.lasr_sr_set_launch_thresholds(*VARIANTS[name]), 'lasr_sr_set_launch_thresholds')
-    h.lasr_sr_set_launch_thresholds(*VARIANTS['default thresholds'])
+    yield lambda name: srf.set_launch_thresholds(*VARIANTS[name])
+    srf.set_launch_thresholds()
 
 
 def hip_forward(dev, fv, ft, IS, kw):

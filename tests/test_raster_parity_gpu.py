@@ -370,28 +370,27 @@ def test_integration_stub_binds_like_the_reference_extension(oracle, cuda):
 
 
 def test_relaxed_forward_math_stays_inside_the_tolerance(oracle, cuda):
-    # lasr_sr_set_forward_math(1): the distance and threshold decision stay bit-faithful, the rest of the pixel pipeline is
-    # fp32 rcp/exp arithmetic; the image must still meet the north-star bar against the op-faithful oracle
+    # LASR_SR_RELAXED_MATH (a per-call flag): the distance and threshold decision stay bit-faithful, the rest of the pixel
+    # pipeline is fp32 rcp/exp arithmetic; the image must still meet the north-star bar against the op-faithful oracle
     from lasr_amd import _lib
-    h = _lib.lib()
+    from lasr_amd.soft_renderer import functional as srf
     worst = 0.0
     try:
         for nu, IS, count in ((4, 64, 2), (8, 128, 2), (11, 256, 1)):
             fv, ft, near, far = synth.raster_batch(nu, 26, count=count)
             kw = dict(synth.LASR_MODES, near=near, far=far)
             ref = oracle.forward(fv, ft, IS, **kw)
-            assert h.lasr_sr_set_forward_math(0) == 0
+            srf.set_forward_flags(0)
             exact, _ = run_hip(cuda, fv, ft, IS, **kw)
-            assert h.lasr_sr_set_forward_math(1) == 0
+            srf.set_forward_flags(_lib.SR_RELAXED_MATH)
             relaxed, gf, _ = run_hip(cuda, fv, ft, IS, g=synth.upstream_grad(count, IS), **kw)
             err = np.abs(relaxed - ref['soft_colors']).max()
             worst = max(worst, err)
             assert err <= IMG_TOL and np.abs(relaxed - exact).max() > 0          # a different (cheaper) rounding sequence
             rgf, _ = oracle.backward(ref, synth.upstream_grad(count, IS), IS, **kw)
             assert np.abs(gf - rgf).max() <= GRAD_REL * np.abs(rgf).max()       # backward reads the relaxed image / aggregates
-        assert h.lasr_sr_set_forward_math(2) != 0
     finally:
-        h.lasr_sr_set_forward_math(0)
+        srf.set_forward_flags(_lib.SR_DEFAULT_FLAGS)
     print('relaxed forward: worst image max-abs error %.2e' % worst)
 
 

@@ -3,7 +3,7 @@ that ratio into the driver's own record: the reference's kernels built with the 
 the reference as it would ship on this GPU; soft_rasterize_cuda_kernel.cu:308-668 behind soft_rasterize_cuda.cpp:59-138, zero
 fills and clones of soft_rasterize.py:41-53,88-89 included, as the reference's own Function does them) and the HIP operator
 (lasr_amd.soft_renderer.functional.soft_rasterize, forward + backward through autograd) are timed on the same GPU, same inputs:
-mesh M2 (2420 faces), LASR modes.  Floors asserted (measured in round 3: 35x / 50x / 56x / 65x); the numbers are printed and
+mesh M2 (2420 faces), LASR modes.  Floors asserted: 25x / 35x / 45x / 40x (measured in round 4: 57x / 69x / 75x / 86x; round 3: 35x / 50x / 56x / 65x); the numbers are printed and
 appended to gpurun_out/reference_ratio.jsonl.
 """
 import json
@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(not sr_ref.available('sr_ref'), reason='oracle/_ref/sr_ref.so not in this snapshot (oracle/build_ref.py)')
-@pytest.mark.parametrize('count,IS,floor', [(16, 256, 20.), (64, 256, 30.), (256, 256, 40.), (16, 512, 30.)])
+@pytest.mark.parametrize('count,IS,floor', [(16, 256, 25.), (64, 256, 35.), (256, 256, 45.), (16, 512, 40.)])
 def test_speedup_over_the_reference_build_on_the_same_gpu(cuda, tmp_path, count, IS, floor):
     fv, ft, near, far = synth.raster_batch(11, 26, count=count)
     kw = dict(synth.LASR_MODES, near=near, far=far)

@@ -16,6 +16,7 @@ from lasr_amd.nnutils import fused_ops                                # noqa: E4
 
 dev = torch.device('cuda:0')
 h = _lib.lib()
+st = torch.cuda.current_stream(dev).cuda_stream      # the stream fused_ops launches on (lasr_prof_* is scoped to a stream)
 N, rep = 32, 8
 out = {'N': N, 'repeat': rep, 'hbm_peak_GBs': 8000.0, 'layers': {}}
 for name, (C, hw) in {'conv1': (64, 63), 'conv2': (192, 31), 'conv3': (384, 15), 'conv4': (256, 15), 'conv5': (256, 15)}.items():
@@ -28,17 +29,17 @@ for name, (C, hw) in {'conv1': (64, 63), 'conv2': (192, 31), 'conv3': (384, 15),
         d.backward(up)
     torch.cuda.synchronize()
     # kernel-only times from the library's own HIP events around each launch (lasr_prof_*): forward = reduction + fold
-    h.lasr_prof_enable(1)
+    h.lasr_prof_enable(st, 1)
     reps = 20
     for _ in range(reps):
         fb.grad = None
         fused_ops.cosine_distance(fa, fb, rep).backward(up)
     torch.cuda.synchronize()
-    h.lasr_prof_enable(0)
+    h.lasr_prof_enable(st, 0)
     t = {}
     for k in range(h.lasr_prof_kernel_count()):
         ms, n = ctypes.c_double(0), ctypes.c_longlong(0)
-        h.lasr_prof_collect(k, ctypes.byref(ms), ctypes.byref(n))
+        h.lasr_prof_collect(st, k, ctypes.byref(ms), ctypes.byref(n))
         if n.value:
             t[h.lasr_prof_kernel_name(k).decode()] = ms.value / reps * 1e3
     fwd, bwd = t['cosdist_forward_kernel'], t['cosdist_backward_kernel']
