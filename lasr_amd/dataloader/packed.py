@@ -54,8 +54,20 @@ class PackedTable:
         arr = ctypes.c_longlong * len(self.keys)
         self._c = (arr(*self.seg_off), arr(*self.seg_len), arr(*self.out_off))
 
-    def gather(self, ids):
-        """ids: int64 tensor [B] on the table's device -> the batch dictionary (the SAME views every call)."""
+    def gather(self, ids, clone=False):
+        """ids: int64 tensor [B] on the table's device -> the batch dictionary.
+
+        ALIASING CONTRACT: by default every call returns the SAME PackedBatch of views into one persistent buffer (that is what
+        lets the trainer's HIP graph read its inputs in place): the previous batch's tensors are overwritten by this call.  A
+        caller that holds two batches at once (prefetching, comparing, accumulating over micro-batches) passes clone=True and
+        gets an independent copy (a plain dict, `persistent` False).  A change of B re-allocates the buffer: views of the old
+        size keep the old storage."""
+        out = self._gather(ids)
+        if clone:
+            return {k: v.clone() for k, v in out.items()}
+        return out
+
+    def _gather(self, ids):
         B = int(ids.shape[0])
         if self._B != B:
             self._alloc(B)

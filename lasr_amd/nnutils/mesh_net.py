@@ -150,7 +150,8 @@ class ResNetConv(nn.Module):
         for i, layer in enumerate(self.layers[:self.n_blocks]):
             x = layer(x)
             if i == self.boundary_after:
-                self.boundary = x          # the trainer cuts the captured backward here (graph-replay data parallelism)
+                self.boundary = x          # the trainer cuts the captured backward here (graph-replay data parallelism); set only
+                                           # while it captures (train_utils._capture_split), so no activation outlives a step
         return x
 
     boundary_after = -1                     # index of the layer whose output is kept in .boundary (-1: none)

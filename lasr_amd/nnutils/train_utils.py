@@ -272,6 +272,10 @@ class LASRTrainer:
             for k, v in batch.items():
                 self._static[k].copy_(v)
         g[0].replay()
+        # the replayed raster calls wrote face records into the operator's workspace behind its bookkeeping: an eager backward
+        # pass still pending on this stream must not reuse "its" forward's records (soft_rasterize.py: invalidate_records)
+        from ..soft_renderer.functional import soft_rasterize as _srz
+        _srz.invalidate_records(self.device)
         if len(g) > 4:
             # graph-replay data parallelism with overlap: the first graph ends when the backward pass reaches the encoder's
             # layer-3 output; the gradients that exist by then (mesh, bones, heads, layer 4: ~80 % of the bytes) are all-reduced
@@ -297,7 +301,19 @@ class LASRTrainer:
         tensor and every parameter above it as inputs), graph B = the backward of the layers below it, seeded with the
         boundary's gradient.  Same kernels, same order, same numbers as the single graph."""
         trunk = self.module.encoder.resnet_conv
+        if trunk.n_blocks < 2:
+            raise ValueError('overlapped all-reduce needs an encoder trunk of at least two residual layers to cut between '
+                             '(--nooverlap_allreduce for n_blocks = %d)' % trunk.n_blocks)
         trunk.boundary_after = min(2, trunk.n_blocks - 2)
+        try:
+            return self._capture_split_at(graph_a, trunk)
+        finally:
+            # the boundary is recorded during the capture only: later eager / eval forwards must not keep an activation (and,
+            # in eager steps, its autograd graph) alive in the module
+            trunk.boundary_after = -1
+            trunk.boundary = None
+
+    def _capture_split_at(self, graph_a, trunk):
         params = [p for p in self.module.parameters() if p.requires_grad]
         early_ids = {id(p) for p in trunk.early_parameters()}
         late = [p for p in params if id(p) not in early_ids]
@@ -390,6 +406,11 @@ class LASRTrainer:
             self._skipped_eager = getattr(self, '_skipped_eager', 0) + 1
         self.optimizer.step()
         self.scheduler.step()
+        # torch.optim advanced the step tensors of the parameters it stepped; the fused tail's cached tables carry their own
+        # shared count (_tail_t), which would now be stale: forget them, the next fused step re-reads the optimizer's counts (and
+        # takes the torch path for good if they have become non-uniform, e.g. a parameter without a gradient this step)
+        if getattr(self, '_tail_shared', None) or getattr(self, '_tail_caches', None):
+            self._tail_reset()
 
     # ---- the same tail as three multi-tensor HIP launches (lasr_tail_step, lasr_amd/csrc/tail.hip) ------------------------
     # Used on a GPU from the second step on: the first step goes through torch.optim.AdamW, which creates the optimizer state
@@ -452,12 +473,20 @@ class LASRTrainer:
         sh = shared.get(skey)
         dev = self.device
         if sh is None:
+            # One step count (_tail_t) serves every cached table, which is only right while they all cover the SAME parameters
+            # (tables that differ in gradient addresses only).  A new parameter / state set -- a parameter without a gradient this
+            # step, an edited optimizer state -- drops the tables of the old one: when that set comes back it re-reads the
+            # optimizer's counts like this one does now (and goes to the torch path if they are no longer uniform).
+            if shared:
+                shared.clear()
+                caches.clear()
             steps = torch.stack([t.reshape(()) for t in key]).cpu()             # the one sync per parameter / state set
             self._tail_syncs = getattr(self, '_tail_syncs', 0) + 1
             if float(steps.min()) != float(steps.max()):                         # tensors at different step counts (a parameter
                 sh = shared[skey] = dict(valid=False)                            # joined later): torch path, decided once
             else:
-                self._tail_t = int(steps[0])                                     # shared by all tables: the optimizer's step count
+                self._tail_t = int(steps[0])                                     # the optimizer's step count
+
                 ch = _lib.lib().lasr_tail_chunk_elems()
                 chunks = [(i, off) for i, r in enumerate(rows) for off in range(0, r[5], ch)]
                 if getattr(self, '_tail_ctl', None) is None:

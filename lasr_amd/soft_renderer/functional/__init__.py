@@ -5,5 +5,5 @@ from .shading import ambient_lighting, directional_lighting
 from .geometry import face_vertices, vertex_normals, surface_normals
 from .obj_io import load_obj, save_obj
 from .soft_rasterize import (soft_rasterize, soft_rasterize_raw, SoftRasterizeFunction, set_forward_flags, forward_flags,
-                             set_launch_thresholds)
+                             set_launch_thresholds, invalidate_records)
 from .load_textures import load_textures

@@ -83,6 +83,16 @@ def _workspace(device, stream, nbytes):
     return ws
 
 
+def invalidate_records(device=None, stream=None):
+    """Tell the operator that something OUTSIDE its eager calls wrote face records into the raster workspace of (device, stream)
+    -- a HIP-graph replay of captured forward / backward calls, or direct C-ABI calls on the same buffer: pending eager backward
+    passes then rebuild their records instead of trusting the forward's (LASR_SR_RECORDS_VALID).  No arguments: every
+    workspace.  LASRTrainer calls this after each graph replay; other users of the workspace must do the same."""
+    for key in list(_records_of):
+        if (device is None or key[0] == torch.device(device).index) and (stream is None or key[1] == stream):
+            _records_of[key] = _records_of.get(key, 0) + 1
+
+
 def _new_records(device, stream):
     key = (device.index, stream)
     _records_of[key] = _records_of.get(key, 0) + 1

@@ -40,6 +40,13 @@ def test_packed_table_layout_on_cpu():
     a = tab.gather(torch.tensor([1, 2]))
     b = tab.gather(torch.tensor([3, 0]))
     assert a is b and a['cams        '].data_ptr() == b['cams        '].data_ptr()      # the same views, refilled
+    # the aliasing contract: the default hands out the persistent views; clone=True gives a batch that survives the next gather
+    keep = tab.gather(torch.tensor([1, 2]), clone=True)
+    nxt = tab.gather(torch.tensor([3, 0]))
+    want = _reference_batch(rows, [1, 2])
+    assert not getattr(keep, 'persistent', False) and keep is not nxt
+    for k in want:
+        assert torch.equal(keep[k], want[k]) and keep[k].data_ptr() != nxt[k].data_ptr(), k
 
 
 @pytest.mark.gpu

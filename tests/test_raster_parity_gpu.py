@@ -550,3 +550,19 @@ def test_autograd_backward_reuses_the_forwards_records_only_while_they_are_there
         assert sr._records_of[key] == before + 1 and torch.equal(v.grad, want_a[0])
     finally:
         sr.REUSE_RECORDS_MAX_FACES = old
+    # records written BEHIND the operator's back -- a HIP-graph replay, a direct C-ABI call on the same workspace -- must be
+    # announced (invalidate_records; LASRTrainer does so after every replay): the pending backward then rebuilds its records
+    from lasr_amd import _lib
+    v, t = leaf(fa), leaf(ta)
+    img = srf.soft_rasterize(v, t, 64, **kw)
+    ws = sr._workspaces[key]
+    fbt, tat = torch.from_numpy(fb).to(cuda).reshape(2, -1, 9).contiguous(), torch.from_numpy(ta).to(cuda).reshape(2, -1, 9).contiguous()
+    scratch_img, scratch_aggr = torch.ones(2, 4, 64, 64, device=cuda), torch.empty(2, 2, 64, 64, device=cuda)
+    _lib.check(_lib.lib().lasr_sr_forward(fbt.data_ptr(), tat.data_ptr(), None, scratch_aggr.data_ptr(), scratch_img.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), 2, fbt.shape[1], 3, 64, float(near), float(far), 1e-3, 1e-4, 2,
+                                          float(np.log(1. / 1e-4 - 1.)), 1e-2, 1, 2, 1, 1, key[1]), 'direct forward')
+    before = sr._records_of[key]
+    srf.invalidate_records(cuda)
+    assert sr._records_of[key] == before + 1
+    img.backward(g)
+    assert sr._records_of[key] == before + 2 and torch.equal(v.grad, want_a[0]) and torch.equal(t.grad, want_a[1])
