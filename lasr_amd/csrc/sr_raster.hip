@@ -453,6 +453,9 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     if (m.alpha == 0) a_out = s.a;
     else if (m.alpha == 1) a_out = s.a / A.F;
     else a_out = (float)(1. - (double)s.a);
+#if defined(LASR_ABL) && LASR_ABL == 4              // measurement build: everything but the output stores (what do they cost?)
+    if (a_out != 12345.678f || s.ssum != 3.25f) return;
+#endif
     colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = a_out;
     if (m.rgb == 0) {
         if (s.fbest != -1 || A.use_bg) {             // no face: the pre-filled background stays -- or is written now
