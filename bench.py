@@ -425,7 +425,27 @@ def sweep_leg(dev, points, steps_budget_ms=150.0):
         torch.cuda.synchronize()
         h.lasr_prof_enable(job.stream, 0)
         kt = collect_kernel_times(h, job.stream)
-        out.append({'frames': B, 'image_size': size, 'frames_per_s': B / dt, 'ms_per_step': dt * 1e3,
+        seg = None
+        if B <= 16:
+            # opt-in LASR_SR_SEGMENTED (a tile's list folded by 4 / 8 waves in parallel, partial states merged: another rounding
+            # sequence, image within 1e-6 of the default): the forward kernel alone and the step, at the launch sizes it is for
+            job.forward_flags = _lib.SR_SEGMENTED
+            for _ in range(3):
+                job.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                job.step()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / steps
+            h.lasr_prof_enable(job.stream, 1)
+            for _ in range(min(steps, 10)):
+                job.step()
+            torch.cuda.synchronize()
+            h.lasr_prof_enable(job.stream, 0)
+            seg = {'frames_per_s': B / dts, 'forward_kernel_ms': round(collect_kernel_times(h, job.stream)['sr_forward_kernel'][0], 5)}
+            job.forward_flags = 0
+        out.append({'frames': B, 'image_size': size, 'frames_per_s': B / dt, 'ms_per_step': dt * 1e3, 'segmented_opt_in': seg,
                     'us_per_frame': dt / B * 1e6, 'steps': steps,
                     'kernel_ms': {k: round(v[0], 5) for k, v in kt.items()},
                     'kernel_us_per_frame': round(sum(v[0] * v[1] for k, v in kt.items()) / min(steps, 10) / B * 1e3, 3)})

@@ -131,6 +131,12 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
  *                  `dis >= threshold` decision stay bit-faithful, the sigmoid, alpha product, clip / normalise, depth and
  *                  softmax weights use fp32 v_rcp / v_exp arithmetic (~15 % faster forward, image within ~3e-5 of the default
  *                  arithmetic; the north-star bar is 1e-4).  LASR_SR_DEFAULT_FLAGS (-1) is accepted and means 0.
+ *                  LASR_SR_SEGMENTED -- LASR's mode combination, launches small enough for the several-waves-per-tile kernels
+ *                  (lasr_sr_options): a tile's face list is split into index-ordered segments folded by 4 or 8 waves in
+ *                  parallel and the partial (alpha product, depth-softmax) states are merged at the end instead of one wave
+ *                  applying every fragment in face order.  Exact arithmetic is unchanged (the aggregates are symmetric in the
+ *                  fragments), the rounding sequence is not: image within ~1e-6 of the default path.  Larger launches and other
+ *                  modes ignore the flag.  The backward pass reads whatever aggregates the forward wrote: no flag needed.
  * backward flags : LASR_SR_RECORDS_VALID -- the caller vouches that `workspace` still holds the per-face records the forward
  *                  pass of the SAME faces / N / F / IS / sigma_val / dist_eps left there (nothing else was run on that
  *                  workspace in between); the backward then skips its own setup launch.  Without the flag every backward
@@ -141,6 +147,7 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
  */
 #define LASR_SR_DEFAULT_FLAGS (-1)   /* forward only: the default arithmetic (same as 0) */
 #define LASR_SR_RELAXED_MATH  1
+#define LASR_SR_SEGMENTED     2   /* forward, LASR's modes, small launches: see below */
 #define LASR_SR_RECORDS_VALID 4
 #define LASR_SR_GRADS_OVERWRITE 8   /* backward, vertex textures: grad_faces / grad_textures need not be zeroed by the caller */
 int lasr_sr_forward_ex(const float* faces, const float* textures, float* faces_info, float* aggrs_info, float* soft_colors,

@@ -102,7 +102,7 @@ SIGNATURES = {
 }
 
 # flags of the *_ex entry points (include/lasr_sr.h)
-SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_RECORDS_VALID, SR_GRADS_OVERWRITE = -1, 1, 4, 8
+SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_SEGMENTED, SR_RECORDS_VALID, SR_GRADS_OVERWRITE = -1, 1, 2, 4, 8
 MEANS_MAX_TERMS, TAIL_MAX_GROUPS = 24, 16          # LASR_MEANS_MAX_TERMS / LASR_TAIL_MAX_GROUPS of include/lasr_ops.h
 
 

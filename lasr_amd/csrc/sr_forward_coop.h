@@ -237,6 +237,9 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
         if (base < 0) base = 0;
         __syncthreads();
         // ---- the walk, software-pipelined over steps of COOP_STEP entries: step k is produced while step k - 1 is consumed
+#if defined(LASR_ABL) && LASR_ABL == 2              // measurement build: tile order + list building + stores, no walk
+        count = 0;
+#endif
         const int steps = (count + COOP_STEP - 1) / COOP_STEP;
         for (int k = 0; k <= steps; k++) {
             if (k < steps) {
@@ -264,7 +267,206 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
     }   // tile meets at least one group
 
     if (!valid || wave != 0) return;
+#if defined(LASR_ABL) && LASR_ABL == 4              // measurement build: everything but the output stores
+    if (s.a != 12345.678f || s.ssum != 3.25f) return;
+#endif
     // ---- finalise (K.cu:458-482)
+    colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = (float)(1. - (double)s.a);
+#pragma unroll
+    for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k] / s.ssum;
+    aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
+    aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Opt-in (LASR_SR_SEGMENTED, include/lasr_sr.h): the SAME small-launch problem attacked from the other side.  The cooperative
+// kernel above keeps the reference's accumulation order, so its ordered part (wave 0: ~50 instructions per entry on a lone wave)
+// stays a serial chain.  Alpha product and depth-softmax are, in exact arithmetic, symmetric in the fragments: a list split into
+// NW index-ordered segments can be folded by NW waves independently -- each with the full per-entry arithmetic of
+// sr_forward_kernel's forward_face, records through the scalar cache, no per-entry hand-over -- and the NW partial states
+// (alpha product, running maximum, rescaled sums) merged in segment order at the end:
+//     a = a_0 a_1 ...;   m = max_w m_w;   sum = SUM_w sum_w exp((m_w - m) / gamma);   c likewise.
+// Only the rounding sequence changes (measured <= 1e-6 on the image against the default path, tests/test_forward_segmented_gpu.py;
+// the north-star bar is 1e-4); the default path stays bit-faithful to the reference's order.  Segment 0 carries the background
+// term (K.cu:354-368); the others start from an empty state (sum 0, maximum -1e30: the first fragment's rescale is exp(-inf) = 0).
+// Measured (profiles/experiments/README.md, round 4): forward 0.0535 -> 0.0445 ms at one frame, 0.0896 -> 0.0838 at four, slower
+// from sixteen on -- a lone wave needs ~4500 cycles per list entry whichever way the entry is evaluated, so the host applies the
+// flag only to launches of at most twice the eight-wave range.
+template <int NCH, int NW>
+__global__ __launch_bounds__(NW * 64) void sr_forward_seg_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
+{
+    constexpr int FIELDS = 3 + NCH;                     // a, smax, ssum, NCH accumulators
+    __shared__ unsigned short s_list[COOP_CAP];
+    __shared__ int s_wcnt[2][NW];
+    __shared__ float s_part[NW][FIELDS][64];
+
+    if (A.choice && *A.choice != CHOICE_COOP) return;
+    const Modes m = Modes{2, 1, 2, 1, 1};
+    if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
+    const int IS = A.IS, P = IS * IS;
+    const int tiles_x = (IS + 7) / 8;
+    int bn, tx, ty;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int qx0 = tx * 8, qy0 = ty * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool valid = px < IS && py < IS;
+    const int pn = py * IS + px;
+    const int pxy = valid ? px | (py << 16) : -1;
+
+    PixState<NCH> s;
+    s.a = 1.f;
+    s.fbest = -1;
+    if (wave == 0) {
+        s.ssum = expf(A.eps / A.gamma); s.smax = A.eps;
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const float bg = A.use_bg ? A.bg[k] : (valid ? colors[((size_t)bn * (NCH + 1) + k) * P + pn] : 1.f);
+            s.c[k] = bg * s.ssum;
+        }
+    } else {
+        s.ssum = 0.f; s.smax = -1e30f;
+#pragma unroll
+        for (int k = 0; k < NCH; k++) s.c[k] = 0.f;
+    }
+
+    const int G = groups_of(A.F);
+    const short4* __restrict__ grects = A.grects + (size_t)bn * G;
+    const int tX1 = qx0 + 7, tY1 = qy0 + 7;
+    unsigned long long gmask;
+    {
+        bool t = false;
+        if (lane < G) {
+            const short4 q = grects[lane];
+            t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
+        }
+        gmask = __ballot(t);
+    }
+    if (gmask != 0 || G > 64) {
+    const float xp = pix_center(px, IS);
+    const float yp = pix_center(IS - 1 - py, IS);
+    const short4* __restrict__ rects = A.rects + (size_t)bn * A.F;
+    const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
+    const float* __restrict__ texs = A.textures + (size_t)bn * A.F * A.T * NCH;
+    const int texstride = A.T * NCH;
+    const UniRecip U = uni_recip(A);
+    const int ok_bit = U.ok ? 32 : 0;
+    const float thr_pad2 = A.thr * 1.10f;
+    const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
+    const float q_yhi = pix_center(IS - 1 - qy0, IS), q_ylo = pix_center(IS - 1 - min(qy0 + 7, IS - 1), IS);
+
+    auto touches_tile = [&](int f) -> bool {          // as in sr_forward_coop_kernel
+        const short4 q = rects[f];
+        bool hit = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
+        if (hit) {
+            const float* R = recs + (size_t)f * REC;
+            if (__float_as_int(R[R_FLAGS]) & 16) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float a = R[R_INV + 3 * k], b = R[R_INV + 3 * k + 1], c = R[R_INV + 3 * k + 2];
+                    const float w00 = a * q_xlo + b * q_ylo + c, w01 = a * q_xhi + b * q_ylo + c;
+                    const float w10 = a * q_xlo + b * q_yhi + c, w11 = a * q_xhi + b * q_yhi + c;
+                    const float wmax = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
+                    if (wmax < 0.f && wmax * wmax * R[R_HK2 + k] > thr_pad2) hit = false;
+                }
+            }
+        }
+        return hit;
+    };
+
+    int g_next = 64, g_mask0 = 0;
+    bool more = true;
+    while (more) {
+        int count = 0, flip = 0, base = -1;
+        for (;;) {                                      // the ordered list of the faces that reach the tile (as above)
+            if (gmask == 0) {
+                if (g_next >= G) { more = false; break; }
+                g_mask0 = g_next;
+                bool t = false;
+                if (g_next + lane < G) {
+                    const short4 q = grects[g_next + lane];
+                    t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
+                }
+                gmask = __ballot(t);
+                g_next += 64;
+                continue;
+            }
+            unsigned long long mm = gmask;
+            int mine_g = -1, last_g = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                if (mm) {
+                    const int bit = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    if (k == wave) mine_g = g_mask0 + bit;
+                    last_g = g_mask0 + bit;
+                }
+            }
+            const int first_g = g_mask0 + __builtin_ctzll(gmask);
+            if (base < 0) base = first_g * GROUP;
+            if (count + NW * 64 > COOP_CAP || (last_g + 1) * GROUP - base > 65536) break;
+            gmask = mm;
+            const int f = mine_g * GROUP + lane;
+            const bool hit = mine_g >= 0 && f < A.F && touches_tile(f);
+            const unsigned long long mask = __ballot(hit);
+            if (lane == 0) s_wcnt[flip][wave] = __popcll(mask);
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int c = s_wcnt[flip][k];
+                if (k < wave) before += c;
+                all += c;
+            }
+            if (hit) s_list[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+            count += all;
+            flip ^= 1;
+        }
+        if (base < 0) base = 0;
+        __syncthreads();
+        // ---- this wave's segment of the round: entries [e0, e1), in list order, straight into its own partial state
+        const int per = (count + NW - 1) / NW;
+        const int e0 = min(wave * per, count), e1 = min(e0 + per, count);
+        for (int e = e0; e < e1; e++) {
+            const int fn = __builtin_amdgcn_readfirstlane(base + (int)s_list[e]);
+            const cptr_t rec = as_const(recs + (size_t)fn * REC);
+            const bool cand = rect_has(__float_as_int(rec[R_BB + 0]), __float_as_int(rec[R_BB + 1]), pxy);
+            float w0, w1, w2;
+            barycentric(rec, xp, yp, w0, w1, w2);
+            const cptr_t tex = as_const(texs + (size_t)fn * texstride);
+            const bool mk = (__float_as_int(rec[R_FLAGS]) & ok_bit) != 0;
+            if (cand) {
+                if (mk) forward_face<true, true, NCH, false>(A, m, rec, tex, fn, 0, xp, yp, w0, w1, w2, s, U);
+                else forward_face<true, false, NCH>(A, m, rec, tex, fn, 0, xp, yp, w0, w1, w2, s, U);
+            }
+        }
+        __syncthreads();                                // the list is rebuilt by the next round
+    }
+    }   // tile meets at least one group
+
+    // ---- merge the partial states in segment order (wave 0), then finalise as K.cu:458-482
+    if (wave != 0) {
+        s_part[wave][0][lane] = s.a; s_part[wave][1][lane] = s.smax; s_part[wave][2][lane] = s.ssum;
+#pragma unroll
+        for (int k = 0; k < NCH; k++) s_part[wave][3 + k][lane] = s.c[k];
+    }
+    __syncthreads();
+    if (!valid || wave != 0) return;
+    const float inv_gamma = 1.f / A.gamma;
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+        const float sw = s_part[w][2][lane];
+        s.a *= s_part[w][0][lane];
+        if (sw > 0.f) {
+            const float mw = s_part[w][1][lane];
+            const float mx = fmaxf(s.smax, mw);
+            const float e_a = __expf((s.smax - mx) * inv_gamma), e_b = __expf((mw - mx) * inv_gamma);
+            s.ssum = s.ssum * e_a + sw * e_b;
+#pragma unroll
+            for (int k = 0; k < NCH; k++) s.c[k] = s.c[k] * e_a + s_part[w][3 + k][lane] * e_b;
+            s.smax = mx;
+        }
+    }
     colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = (float)(1. - (double)s.a);
 #pragma unroll
     for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k] / s.ssum;

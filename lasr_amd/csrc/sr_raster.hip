@@ -653,12 +653,24 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                 hipLaunchKernelGGL(sr_choose_kernel, dim3(1), dim3(64), 0, st, grects, N, groups_of_host(F), IS, coop_max, choice);
                 A.choice = choice;
             }
-            if (plan == 2) {
+            // LASR_SR_SEGMENTED pays up to about twice the eight-wave range (measured: -17 % at one frame, -6 % at four, +8 % at
+            // sixteen, sr_forward_coop.h); beyond that the flag is ignored
+            const bool seg = (flags & LASR_SR_SEGMENTED) != 0 && tiles8 <= 2 * coop8_max;
+            if (seg && plan == 2) {
+                if (nch == 9) hipLaunchKernelGGL((sr_forward_seg_kernel<9, 8>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6) hipLaunchKernelGGL((sr_forward_seg_kernel<6, 8>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_seg_kernel<3, 8>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
+            } else if (seg && (plan == 1 || plan == 3)) {
+                if (nch == 9) hipLaunchKernelGGL((sr_forward_seg_kernel<9, 4>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6) hipLaunchKernelGGL((sr_forward_seg_kernel<6, 4>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_seg_kernel<3, 4>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            }
+            if (!seg && plan == 2) {
                 if (nch == 9) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
                 else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
                 else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 8, 1, 0>), grid8, dim3(512), 0, st, A, aggrs_info, soft_colors);
             }
-            if (plan == 1 || plan == 3) {
+            if (!seg && (plan == 1 || plan == 3)) {
                 if (nch == 9) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 4, 1, 0>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 4, 1, 0>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
@@ -822,7 +834,7 @@ extern "C" int lasr_sr_forward_ex(const float* faces, const float* textures, flo
                                   int func_id_alpha, int texture_sample_type, int double_side, int flags, void* hip_stream)
 {
     if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
-    if (flags & ~LASR_SR_RELAXED_MATH) return LASR_E_BADARG;
+    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) return LASR_E_BADARG;
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
     if (rc) return rc;
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
@@ -839,7 +851,7 @@ extern "C" int lasr_sr_forward_bg(const float* faces, const float* textures, flo
 {
     if (!background) return LASR_E_BADARG;
     if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
-    if (flags & ~LASR_SR_RELAXED_MATH) return LASR_E_BADARG;
+    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) return LASR_E_BADARG;
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
     if (rc) return rc;
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
@@ -855,7 +867,7 @@ extern "C" int lasr_sr_forward_opt(const float* faces, const float* textures, fl
                                    const lasr_sr_options* options, void* hip_stream)
 {
     if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
-    if (flags & ~LASR_SR_RELAXED_MATH) return LASR_E_BADARG;
+    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) return LASR_E_BADARG;
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
     if (rc) return rc;
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
