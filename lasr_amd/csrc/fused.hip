@@ -386,11 +386,13 @@ __global__ __launch_bounds__(256) void flatten_backward_vertex_kernel(const floa
 // ===========================================================================
 // Per-face gather of per-vertex attributes, face_vertices.py:4-22: out[n,f,c,:] = attr[n, faces[n,f,c], :].
 // Backward: a vertex-centric sum without a precomputed incidence structure and without float atomics.  One block owns
-// 64 vertices of one mesh: all threads scan the mesh's 3F corner indices once and file the corners that point into the
+// GATHER_VERTS vertices of one mesh: all threads scan the mesh's 3F corner indices once and file the corners that point into the
 // block's vertex range into per-vertex LDS lists; each list (<= GATHER_CAP entries, mesh valence) is sorted so that the
 // summation order -- ascending corner index -- does not depend on the order the scan happened to fill it in.
 // ===========================================================================
-constexpr int GATHER_VERTS = 64, GATHER_CAP = 30;
+// GV vertices per block: 64 when the launch needs the blocks to fill the chip (LASR's 16 meshes of 642 vertices: 13 us vs 16),
+// 256 when there are plenty (256 meshes of 1212 vertices: 5 instead of 19 scans of each mesh's corner list, 27 us vs 51)
+constexpr int GATHER_CAP = 30;
 
 __global__ __launch_bounds__(256) void face_gather_forward_kernel(const float* __restrict__ attr, const long long* __restrict__ faces,
                                                                   float* __restrict__ out, int V, int F3, int C)
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(256) void face_gather_forward_kernel(const float* _
     for (int k = 0; k < C; k++) dst[k] = src[k];
 }
 
+template <int GATHER_VERTS>
 __global__ __launch_bounds__(256) void face_gather_backward_kernel(const float* __restrict__ gout, const long long* __restrict__ faces,
                                                                    float* __restrict__ gattr, int V, int F3, int C)
 {
@@ -954,8 +957,13 @@ extern "C" int lasr_face_gather_backward(const float* grad_out, const long long*
     if (N == 0 || V == 0) return LASR_OK;
     if (!grad_attr || (F > 0 && (!grad_out || !faces))) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_kernel, dim3((V + GATHER_VERTS - 1) / GATHER_VERTS, N), dim3(256), 0,
-                grad_out, faces, grad_attr, V, 3 * F, C);
+    if ((long long)N * ((V + 63) / 64) >= 2048) {
+        LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_kernel<256>, dim3((V + 255) / 256, N), dim3(256), 0,
+                    grad_out, faces, grad_attr, V, 3 * F, C);
+    } else {
+        LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_kernel<64>, dim3((V + 63) / 64, N), dim3(256), 0,
+                    grad_out, faces, grad_attr, V, 3 * F, C);
+    }
     return launch_ok();
 }
 
