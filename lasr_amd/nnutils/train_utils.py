@@ -274,8 +274,8 @@ class LASRTrainer:
         g[0].replay()
         # the replayed raster calls wrote face records into the operator's workspace behind its bookkeeping: an eager backward
         # pass still pending on this stream must not reuse "its" forward's records (soft_rasterize.py: invalidate_records)
-        from ..soft_renderer.functional import soft_rasterize as _srz
-        _srz.invalidate_records(self.device)
+        from ..soft_renderer import functional as _srf
+        _srf.invalidate_records(self.device)
         if len(g) > 4:
             # graph-replay data parallelism with overlap: the first graph ends when the backward pass reaches the encoder's
             # layer-3 output; the gradients that exist by then (mesh, bones, heads, layer 4: ~80 % of the bytes) are all-reduced
