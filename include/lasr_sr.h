@@ -171,6 +171,26 @@ int lasr_sr_backward_ex(const float* faces, const float* textures, const float* 
                         int flags, void* hip_stream);
 
 /*
+ * float64 tensors (the reference dispatches its kernels on the tensor type, AT_DISPATCH_FLOATING_TYPES at
+ * soft_rasterize_cuda_kernel.cu:701,716,780; the scalar arguments stay float there as here).  Same call shape as
+ * lasr_sr_forward / lasr_sr_backward, three colour channels, every mode combination; `faces_info` [N,F,27] doubles is written
+ * by the forward pass when given (the reference's layout) and then serves the backward pass; when NULL both passes build the
+ * per-face data in `workspace` (lasr_sr_workspace_bytes_f64).  soft_colors holds the background on entry, gradients accumulate
+ * into zeroed buffers, as for the reference.  A brute-force path in the reference's operation order (csrc/sr_fp64.hip): LASR
+ * never renders in double, this exists so that the operator accepts what the reference's accepts.
+ */
+size_t lasr_sr_workspace_bytes_f64(int N, int F);
+int lasr_sr_forward_f64(const double* faces, const double* textures, double* faces_info, double* aggrs_info,
+                        double* soft_colors, void* workspace, size_t workspace_bytes, int N, int F, int T, int IS,
+                        float near, float far, float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                        int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side, void* hip_stream);
+int lasr_sr_backward_f64(const double* faces, const double* textures, const double* soft_colors, const double* faces_info,
+                         const double* aggrs_info, double* grad_faces, double* grad_textures, const double* grad_soft_colors,
+                         void* workspace, size_t workspace_bytes, int N, int F, int T, int IS, float near, float far, float eps,
+                         float sigma_val, int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb, int func_id_alpha,
+                         int texture_sample_type, int double_side, void* hip_stream);
+
+/*
  * Per-call launch options (no reference counterpart).  The library keeps NO mutable process state: what used to be
  * process-wide setters in rounds 1-3 (forward arithmetic, kernel-choice thresholds) is an argument now, so two callers in one
  * process with different settings cannot race.

@@ -92,6 +92,9 @@ SIGNATURES = {
     'lasr_sr_forward_bg': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p, _i, _p]),
     'lasr_sr_backward_ex': (_i, [_p] * 8 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _p]),
     'lasr_sr_forward_opt': (_i, [_p] * 6 + [_sz] + [_i] * 5 + [_f, _f, _p, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p, _i, _p, _p]),
+    'lasr_sr_workspace_bytes_f64': (_sz, [_i, _i]),
+    'lasr_sr_forward_f64': (_i, [_p] * 6 + [_sz] + [_i] * 4 + [_f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),
+    'lasr_sr_backward_f64': (_i, [_p] * 9 + [_sz] + [_i] * 4 + [_f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _p]),
     'lasr_sr_peek_choice': (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _p]),
     'lasr_selftest_div': (_i, [_p, _p, _p, _i, _p]),
     'lasr_selftest_div3': (_i, [_p, _p, _p, _i, _p]),

@@ -131,8 +131,11 @@ class SoftRasterizeFunction(Function):
                 sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
                 gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod',
                 texture_type='surface'):
+        if face_vertices.dtype == torch.float64 and textures.dtype == torch.float64:
+            return _forward_f64(ctx, face_vertices, textures, image_size, background_color, near, far, fill_back, eps, sigma_val,
+                                dist_func, dist_eps, gamma_val, aggr_func_rgb, aggr_func_alpha, texture_type)
         if face_vertices.dtype != torch.float32 or textures.dtype != torch.float32:
-            raise TypeError('lasr_amd soft_rasterize supports float32 tensors only')
+            raise TypeError('lasr_amd soft_rasterize takes float32 tensors (or float64 for both, as the reference dispatches)')
         dev = face_vertices.device
         N, F = face_vertices.shape[:2]
         fv = face_vertices.detach().reshape(N, F, 9).contiguous()
@@ -178,6 +181,8 @@ class SoftRasterizeFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_soft_colors):
+        if getattr(ctx, 'f64', False):
+            return _backward_f64(ctx, grad_soft_colors)
         fv, tx, soft_colors, aggrs_info = ctx.saved_tensors
         N, F, T, IS = ctx.geom
         C, nf, tail = ctx.C, ctx.nf, ctx.tail
@@ -207,6 +212,51 @@ class SoftRasterizeFunction(Function):
         fshape, tshape = ctx.in_shapes
         return (grad_faces.reshape(fshape), grad_textures.reshape(tshape),
                 None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+def _forward_f64(ctx, face_vertices, textures, image_size, background_color, near, far, fill_back, eps, sigma_val, dist_func,
+                 dist_eps, gamma_val, aggr_func_rgb, aggr_func_alpha, texture_type):
+    """float64 tensors (the reference dispatches on the tensor type, soft_rasterize_cuda_kernel.cu:701,716,780): the
+    brute-force double-precision path of csrc/sr_fp64.hip, same call convention as the reference's Function -- faces_info zeroed,
+    soft_colors = background with alpha 1 (soft_rasterize.py:47-53), gradients accumulated into zeroed buffers (:88-89)."""
+    dev = face_vertices.device
+    N, F = face_vertices.shape[:2]
+    fv = face_vertices.detach().reshape(N, F, 9).contiguous()
+    T = _texels(textures)
+    tx = textures.detach().reshape(N, F, T, 3).contiguous()
+    IS = int(image_size)
+    scalars = (_as_float(near), _as_float(far), float(eps), float(sigma_val), _DIST[dist_func], float(math.log(1. / dist_eps - 1.)),
+               float(gamma_val), _RGB[aggr_func_rgb], _ALPHA[aggr_func_alpha], _TEX[texture_type], 1 if fill_back else 0)
+    faces_info = torch.zeros(N, F, 27, dtype=torch.float64, device=dev)
+    aggrs_info = torch.zeros(N, 2, IS, IS, dtype=torch.float64, device=dev)
+    soft_colors = torch.ones(N, 4, IS, IS, dtype=torch.float64, device=dev)
+    for k in range(3):
+        soft_colors[:, k] = float(background_color[k])
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = _lib.lib().lasr_sr_forward_f64(fv.data_ptr(), tx.data_ptr(), faces_info.data_ptr(), aggrs_info.data_ptr(),
+                                            soft_colors.data_ptr(), None, 0, N, F, T, IS, *scalars, stream)
+    _lib.check(rc, 'lasr_sr_forward_f64')
+    ctx.f64, ctx.geom, ctx.scalars = True, (N, F, T, IS), scalars
+    ctx.in_shapes = (face_vertices.shape, textures.shape)
+    ctx.save_for_backward(fv, tx, soft_colors, aggrs_info, faces_info)
+    ctx.mark_non_differentiable(aggrs_info)
+    return soft_colors
+
+
+def _backward_f64(ctx, grad_soft_colors):
+    fv, tx, soft_colors, aggrs_info, faces_info = ctx.saved_tensors
+    N, F, T, IS = ctx.geom
+    grad_faces, grad_textures = torch.zeros_like(fv), torch.zeros_like(tx)
+    g = grad_soft_colors.contiguous().double()
+    with torch.cuda.device(fv.device):
+        stream = torch.cuda.current_stream(fv.device).cuda_stream
+        rc = _lib.lib().lasr_sr_backward_f64(fv.data_ptr(), tx.data_ptr(), soft_colors.data_ptr(), faces_info.data_ptr(),
+                                             aggrs_info.data_ptr(), grad_faces.data_ptr(), grad_textures.data_ptr(), g.data_ptr(),
+                                             None, 0, N, F, T, IS, *ctx.scalars, stream)
+    _lib.check(rc, 'lasr_sr_backward_f64')
+    fshape, tshape = ctx.in_shapes
+    return (grad_faces.reshape(fshape), grad_textures.reshape(tshape)) + (None,) * 13
 
 
 def soft_rasterize(face_vertices, textures, image_size=256,
