@@ -107,15 +107,10 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
         const float zlo = fminf(fminf(z0, z1), z2), zhi = fmaxf(fmaxf(z0, z1), z2);
         depth_safe = zlo > 0.f && zlo * (1.f - 1e-4f) > A.near && zhi * (1.f + 1e-4f) < A.far;
     }
-    // the ten pixel planes this face reads, through buffer descriptors: one 32-bit byte offset per pixel (voffset) and the
-    // plane's offset as a scalar (soffset) instead of a 64-bit address computation per load
-    const unsigned P4 = (unsigned)P * 4u;
-    const __amdgpu_buffer_rsrc_t rs_col = __builtin_amdgcn_make_buffer_rsrc((void*)(colors + (size_t)bn * (NCH + 1) * P), 0, (int)(P4 * (NCH + 1)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_gcol = __builtin_amdgcn_make_buffer_rsrc((void*)(gcolors + (size_t)bn * (NCH + 1) * P), 0, (int)(P4 * (NCH + 1)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_aggr = __builtin_amdgcn_make_buffer_rsrc((void*)(aggrs + (size_t)bn * 2 * P), 0, (int)(P4 * 2), 0x00020000);
-    auto ld_plane = [&](const __amdgpu_buffer_rsrc_t& rs, const float* base, int nplanes, int plane, int pn_) -> float {
-        if (OPT_BWD_MEM && LASR_FAST)
-            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, pn_ * 4, (int)(P4 * (unsigned)plane), 0));
+    // (the ten pixel planes a face reads go through plain 64-bit addressed loads: buffer descriptors with the plane offset as a
+    // scalar -- one 32-bit byte offset per pixel instead of an address computation per load -- were measured 1.5 % SLOWER,
+    // profiles/r04_opt_ab.txt)
+    auto ld_plane = [&](const float* base, int nplanes, int plane, int pn_) -> float {
         return base[((size_t)bn * nplanes + plane) * P + pn_];
     };
 
@@ -172,10 +167,10 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
         const float D = fr.D;
 
         // alpha path (K.cu:583-593); hard alpha: the reference still adds g_alpha into C
-        float Ca = ld_plane(rs_gcol, gcolors, NCH + 1, NCH, pn);
+        float Ca = ld_plane(gcolors, NCH + 1, NCH, pn);
         if (m.alpha == 1) Ca = div_<FM>(Ca, (float)A.F);
         else if (m.alpha == 2) {
-            const float a_out = ld_plane(rs_col, colors, NCH + 1, NCH, pn);
+            const float a_out = ld_plane(colors, NCH + 1, NCH, pn);
             Ca *= div_<FM>(1 - a_out, fmaxf(1 - D, 1e-6f));
         }
         float C = Ca;
@@ -197,10 +192,10 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
 
         float gz0 = 0, gz1 = 0, gz2 = 0;
         if (m.rgb == 0) {
-            if ((float)fn == ld_plane(rs_aggr, aggrs, 2, 1, pn)) {       // K.cu:603
+            if ((float)fn == ld_plane(aggrs, 2, 1, pn)) {       // K.cu:603
                 float g[NCH];
 #pragma unroll
-                for (int k = 0; k < NCH; k++) g[k] = ld_plane(rs_gcol, gcolors, NCH + 1, k, pn);
+                for (int k = 0; k < NCH; k++) g[k] = ld_plane(gcolors, NCH + 1, k, pn);
                 if (vertex_tex) {
 #pragma unroll
                     for (int k = 0; k < NCH; k++) {
@@ -215,13 +210,13 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
                 }
             }
         } else if (front || m.double_side) {                                 // K.cu:611-640
-            const float ssum = ld_plane(rs_aggr, aggrs, 2, 0, pn);
-            const float smax = ld_plane(rs_aggr, aggrs, 2, 1, pn);
+            const float ssum = ld_plane(aggrs, 2, 0, pn);
+            const float smax = ld_plane(aggrs, 2, 1, pn);
             const float zn = div_<FM>(A.far - zp, A.far - A.near);
             const float sm = div_<FM>(D * exp_<FM>(div_<FM>(zn - smax, A.gamma)), ssum);
             float g[NCH];
 #pragma unroll
-            for (int k = 0; k < NCH; k++) g[k] = ld_plane(rs_gcol, gcolors, NCH + 1, k, pn);
+            for (int k = 0; k < NCH; k++) g[k] = ld_plane(gcolors, NCH + 1, k, pn);
             if (vertex_tex) {
 #pragma unroll
                 for (int k = 0; k < NCH; k++) {
@@ -237,7 +232,7 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
             float Crgb = 0.f;
 #pragma unroll
             for (int k = 0; k < NCH; k++)
-                Crgb += g[k] * (sample_colour(tex, w0, w1, w2, A.res, k, m.tex, lim, NCH) - ld_plane(rs_col, colors, NCH + 1, k, pn));
+                Crgb += g[k] * (sample_colour(tex, w0, w1, w2, A.res, k, m.tex, lim, NCH) - ld_plane(colors, NCH + 1, k, pn));
             Crgb *= sm;
             C += div_<FM>(Crgb, D);
             const float Cz = div_<FM>(div_<FM>(Crgb, A.gamma), A.near - A.far) * zp * zp;

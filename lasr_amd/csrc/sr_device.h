@@ -51,7 +51,7 @@ constexpr bool OPT_MED3 = (LASR_OPT & 2) != 0;        // clamps / inside test as
 constexpr bool OPT_NOSCALE = (LASR_OPT & 4) != 0;     // 1/x and the f64 sigmoid division without v_div_scale / v_div_fixup
 constexpr bool OPT_SIGNFOLD = (LASR_OPT & 8) != 0;    // threshold cut inside the outside branch, no float sign
 constexpr bool OPT_SOFTMAX = (LASR_OPT & 16) != 0;    // depth-softmax update with -|zn - smax| and v_max
-constexpr bool OPT_BWD_MEM = (LASR_OPT & 32) != 0;    // backward: pixel planes through buffer descriptors (32-bit offsets)
+// (bit 32, the backward's pixel planes through buffer descriptors, was measured slower and removed)
 constexpr bool OPT_BWD_S1 = (LASR_OPT & 64) != 0;     // backward stage 1: branch-free conservative reject, fused centres
 constexpr bool OPT_BWD_MATH = (LASR_OPT & 128) != 0;
 constexpr bool OPT_EDGESEL = (LASR_OPT & 256) != 0;   // which edge an outside pixel projects to: lane-mask algebra, not a nested if chain  // backward stage 2: record reciprocals, med3, per-face depth-range test

@@ -17,5 +17,5 @@ def test_latest_counter_files_match_the_raster_sources():
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*' + suffix)))
         assert files, 'no profiles/*%s committed' % suffix
         d = json.load(open(files[-1]))
-        assert d.get('source_sha') == sha, ('%s was measured on other raster sources (%s, now %s): run tools/prof/r03_final.sh on '
+        assert d.get('source_sha') == sha, ('%s was measured on other raster sources (%s, now %s): run tools/prof/r04_final.sh on '
                                              'the GPU box and commit its output' % (os.path.basename(files[-1]), d.get('source_sha'), sha))

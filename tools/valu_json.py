@@ -33,7 +33,7 @@ for name, c in k.items():
            tr * COST['transcendental'] + other * COST['other'])
     out['kernels'][name] = {
         'valu_wave_instructions': c['SQ_INSTS_VALU'], 'fp32_mul_add_fma': fp32, 'f64': f64, 'transcendental': tr, 'other': other,
-        'salu': c['SQ_INSTS_SALU'], 'smem': c['SQ_INSTS_SMEM'],
+        'salu': c['SQ_INSTS_SALU'], 'smem': c['SQ_INSTS_SMEM'], 'branch': c.get('SQ_INSTS_BRANCH'),
         'live_lane_fraction': c['SQ_THREAD_CYCLES_VALU'] / (64.0 * c['SQ_ACTIVE_INST_VALU']),
         'wait_any_fraction_of_wave_cycles': c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'],
         'modelled_issue_ms': cyc / SIMDS / (GHZ * 1e6)}
