@@ -65,15 +65,16 @@ def parse():
 class RasterStep:
     """Pre-allocated buffers + one fwd/bwd pass through the C ABI."""
 
-    def __init__(self, dev, B, first_frame, image_size=None):
+    def __init__(self, dev, B, first_frame, image_size=None, sigma=None, n_cycle=None):
         global IS
         IS = image_size or IS
         self.IS = IS
         self.dev, self.B = dev, B
         v, f, tex = synth.blobby_mesh(NU)
         self.V, self.F = v.shape[0], f.shape[0]
-        pv = synth.frame_vertices(v, N_FRAMES_CYCLE, first=first_frame, count=B)
-        self.near, self.far = synth.near_far(synth.frame_vertices(v, N_FRAMES_CYCLE)[:, :, 2])
+        n_cycle = n_cycle or N_FRAMES_CYCLE
+        pv = synth.frame_vertices(v, n_cycle, first=first_frame, count=B)
+        self.near, self.far = synth.near_far(synth.frame_vertices(v, n_cycle)[:, :, 2])
         self.faces_idx = torch.from_numpy(f).to(dev)
         self.fv = torch.from_numpy(np.ascontiguousarray(pv[:, f])).to(dev).reshape(B, self.F, 9).contiguous()
         self.ft = torch.from_numpy(np.ascontiguousarray(tex[f])).to(dev).reshape(1, self.F, 9).repeat(B, 1, 1).contiguous()
@@ -87,7 +88,7 @@ class RasterStep:
         m = synth.LASR_MODES
         self.h = _lib.lib()
         self.ws = torch.empty(self.h.lasr_sr_workspace_bytes(B, self.F, 3, IS), dtype=torch.uint8, device=dev)
-        self.scalars = (float(self.near), float(self.far), float(m['eps']), float(m['sigma_val']), 2,
+        self.scalars = (float(self.near), float(self.far), float(m['eps']), float(sigma if sigma is not None else m['sigma_val']), 2,
                         float(math.log(1. / m['dist_eps'] - 1.)), float(m['gamma_val']), 1, 2, 1, 1)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
         self.white = (ctypes.c_float * 3)(1., 1., 1.)
@@ -397,6 +398,36 @@ def valu_issue(kernel, frames_per_launch, launch_ms):
                     'do not apply to this arithmetic (DESIGN.md section 4)'}
 
 
+def variants_leg(dev, B):
+    """The other points of SURVEY section 8(d) at the headline launch size: sigma = 1e-5 (the last stage of the reference's schedule,
+    scripts/template.sh:32: a 1.2-pixel reject radius instead of 3.9, shorter lists) and Nf = 3 (the 3-frame cycle of syn-spot3f,
+    scripts/render_syn.py:31,35: three distinct poses repeated).  Same step as `value`."""
+    global IS
+    keep = IS
+    out = {}
+    h = _lib.lib()
+    for name, kw in (('sigma_1e-5', dict(sigma=1e-5)), ('nf_3', dict(n_cycle=3))):
+        job = RasterStep(dev, B, 0, image_size=keep, **kw)
+        for _ in range(3):
+            job.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            job.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        h.lasr_prof_enable(job.stream, 1)
+        for _ in range(5):
+            job.step()
+        torch.cuda.synchronize()
+        h.lasr_prof_enable(job.stream, 0)
+        out[name] = {'frames_per_s': B / dt, 'ms_per_step': dt * 1e3,
+                     'kernel_ms': {k: round(v[0], 5) for k, v in collect_kernel_times(h, job.stream).items()}}
+        del job
+    IS = keep
+    return out
+
+
 def sweep_leg(dev, points, steps_budget_ms=150.0):
     """The launch sizes the reference actually uses (N = 2 / 4 / 16 / 96 meshes per render call), through the
     same RasterStep as `value`: frames/s, us per frame and per-kernel ms (library HIP events) at each (frames, image size)."""
@@ -593,6 +624,7 @@ def main():
         if world == 1 and not a.no_sweep:
             out['sweep'] = sweep_leg(dev, [(1, 256), (4, 256), (16, 256), (64, 256), (64, 512)])
             IS = a.image_size
+            out['other_points'] = variants_leg(dev, B)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(F)
         if world == 1 and not a.no_lbs:

@@ -49,12 +49,15 @@ needs_ref_build = pytest.mark.skipif(not sr_ref.available('sr_ref_nofma'),
 
 
 @needs_ref_build
-@pytest.mark.parametrize('nu,n_frames,count,IS,hard', [(11, 26, 64, 256, False), (11, 26, 16, 512, False),
-                                                       (8, 3, 16, 256, False), (11, 26, 26, 256, True),
-                                                       (8, 16, 16, 256, True)])
-def test_live_against_the_reference_build_at_baseline_sizes(cuda, nu, n_frames, count, IS, hard):
+@pytest.mark.parametrize('nu,n_frames,count,IS,hard,sigma', [(11, 26, 64, 256, False, 1e-4), (11, 26, 16, 512, False, 1e-4),
+                                                             (8, 3, 16, 256, False, 1e-4), (11, 26, 26, 256, True, 1e-4),
+                                                             (8, 16, 16, 256, True, 1e-4),
+                                                             # sigma = 1e-5, the last stage of the reference's schedule
+                                                             # (scripts/template.sh:32), at the benchmark size and at 512^2
+                                                             (11, 26, 32, 256, False, 1e-5), (11, 3, 8, 512, False, 1e-5)])
+def test_live_against_the_reference_build_at_baseline_sizes(cuda, nu, n_frames, count, IS, hard, sigma):
     fv, ft, near, far = synth.raster_batch(nu, n_frames, count=count)
-    kw = dict(synth.LASR_MODES, near=near, far=far)
+    kw = dict(synth.LASR_MODES, near=near, far=far, sigma_val=sigma)
     if hard:
         kw.update(dist_func='hard', aggr_func_rgb='hard', aggr_func_alpha='hard')
     tfv = torch.from_numpy(fv).to(cuda)
