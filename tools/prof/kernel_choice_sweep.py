@@ -16,12 +16,18 @@ from lasr_amd.soft_renderer import functional as srf                # noqa: E402
 BIG = 10 ** 12
 FORMS = {'eight': (BIG, BIG, BIG), 'four': (0, BIG, BIG), 'one': (0, 0, 0), 'default': (-1, -1, -1)}
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+FOCAL = float(sys.argv[2]) if len(sys.argv) > 2 else 9.0      # 9: the bench object (a third of the tiles busy); 16: the object fills the frame, as LASR's crops do
 dev = torch.device('cuda:0')
 h = _lib.lib()
 st = torch.cuda.current_stream(dev).cuda_stream
 out = {}
 for n in (1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64):
-    fv, ft, near, far = synth.raster_batch(11, 26, count=n)
+    v, f, tex = synth.blobby_mesh(11)
+    pv = synth.frame_vertices(v, 26, focal=FOCAL, count=n)
+    near, far = synth.near_far(pv[:, :, 2])
+    fv = pv[:, f]
+    import numpy as np
+    ft = np.broadcast_to(tex[f][None], fv.shape).copy()
     kw = dict(synth.LASR_MODES, near=near, far=far)
     a = torch.from_numpy(fv).to(dev)
     b = torch.from_numpy(ft).to(dev)
