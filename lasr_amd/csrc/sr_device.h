@@ -421,21 +421,16 @@ __device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
             // regions per entry): which edge a pixel outside the face projects to follows from the sign pattern of its
             // barycentrics, with the obtuse-corner override; every lane takes exactly one of the three projections
             const bool n0 = w0 <= 0, n1 = w1 <= 0, n2 = w2 <= 0;
-            // Without an obtuse corner the chain of K.cu:113-125 reduces to: edge 1 iff w0 <= 0 < w1; edge 2 iff w1 <= 0 < w2;
-            // edge 0 otherwise (sign patterns (n0 n1 n2) 100, 101 -> 1; 010, 110 -> 2; 000, 001, 011, 111 -> 0).
-            bool e1 = n0 & !n1, e2 = n1 & !n2;
-            if (flags & 7) {                                         // at most one corner of a face is flagged (wave-uniform)
-                bool o0 = false, o1 = false, o2 = false;
+            bool o0 = false, o1 = false, o2 = false;                 // at most one corner of a face is obtuse (wave-uniform flags)
+            if (flags & 7) {
                 if (flags & 1) o0 = (xp - x0) * (x2 - x0) + (yp - y0) * (y2 - y0) > 0;
                 if (flags & 2) o1 = (xp - x1) * (x0 - x1) + (yp - y1) * (y0 - y1) > 0;
                 if (flags & 4) o2 = (xp - x2) * (x1 - x2) + (yp - y2) * (y1 - y2) > 0;
-                // the override moves a corner region to the other edge at that corner: (w1, w2 <= 0) & o0: 0 -> 2;
-                // (w2, w0 <= 0, w1 > 0) & o1: 1 -> 0;  (w0, w1 <= 0, w2 > 0) & o2: 2 -> 1
-                e1 = (e1 & !(n2 & o1)) | (n0 & n1 & !n2 & o2);
-                e2 = (e2 & !(n0 & o2)) | (n1 & n2 & o0);
             }
-            // everything else -- incl. "none <= 0" (the reference indexes [-1] there: UB; pinned to edge 0 like the oracle) -- takes edge 0
-            const bool e0 = !(e1 | e2);
+            const bool c12 = n1 & n2, c20 = n2 & n0 & !n1, c01 = n0 & n1 & !n2;        // two (or three) non-positive: a corner region
+            const bool e1 = (c20 & !o1) | (c01 & o2) | (n0 & !n1 & !n2);
+            const bool e2 = (c01 & !o2) | (c12 & o0) | (n1 & !n0 & !n2);
+            const bool e0 = !(e1 | e2);             // incl. "none <= 0" (the reference indexes [-1] there: UB; pinned to edge 0 like the oracle)
             if (e0) edge_project<0, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
             if (e1) edge_project<1, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
             if (e2) edge_project<2, true, FM, MK, RP, IDEN>(rec, w0, w1, w2, u0, u1, u2);
