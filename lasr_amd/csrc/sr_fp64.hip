@@ -67,14 +67,12 @@ __device__ inline double euclid64(const FaceD& fc, double xp, double yp, const d
     const double* sym = fc.sym;
     if (w[0] > 0 && w[1] > 0 && w[2] > 0 && w[0] < 1 && w[1] < 1 && w[2] < 1) {
         double best = 100000000., bx = 0, by = 0, bt[3] = {0, 0, 0};
-        for (int k = 0; k < 3; k++) {
-            const int v0 = k, v1 = (k + 1) % 3, v2 = (k + 2) % 3;
-            double a0[3], u[3];
-            for (int j = 0; j < 3; j++) a0[j] = sym[3 * v0 + j] - sym[3 * v1 + j];
-            u[v0] = (w[0] * a0[0] + w[1] * a0[1] + w[2] * a0[2] - a0[v1]) / (a0[v0] - a0[v1]);
-            u[v1] = 1 - u[v0];
-            u[v2] = 0;
-            u[0] -= w[0]; u[1] -= w[1]; u[2] -= w[2];
+        for (int ka = 0; ka < 3; ka++) {               // all three edges, unclamped (K.cu:81-95): the nearest one wins
+            const int kb = (ka + 1) % 3, kc = (ka + 2) % 3;
+            double ds[3], u[3];
+            for (int j = 0; j < 3; j++) ds[j] = sym[3 * ka + j] - sym[3 * kb + j];
+            const double along = (w[0] * ds[0] + w[1] * ds[1] + w[2] * ds[2] - ds[kb]) / (ds[ka] - ds[kb]);
+            u[ka] = along - w[ka]; u[kb] = (1 - along) - w[kb]; u[kc] = 0 - w[kc];
             const double qx = u[0] * f[0] + u[1] * f[3] + u[2] * f[6];
             const double qy = u[0] * f[1] + u[1] * f[4] + u[2] * f[7];
             const double d2 = qx * qx + qy * qy;
@@ -83,28 +81,22 @@ __device__ inline double euclid64(const FaceD& fc, double xp, double yp, const d
         dx = bx; dy = by; t[0] = bt[0]; t[1] = bt[1]; t[2] = bt[2];
         return 1.;
     }
-    int v0 = -1;
-    if (w[1] <= 0 && w[2] <= 0) {
-        v0 = 0;
-        if ((fc.obt & 1) && (xp - f[0]) * (f[6] - f[0]) + (yp - f[1]) * (f[7] - f[1]) > 0) v0 = 2;
-    } else if (w[2] <= 0 && w[0] <= 0) {
-        v0 = 1;
-        if ((fc.obt & 2) && (xp - f[3]) * (f[0] - f[3]) + (yp - f[4]) * (f[1] - f[4]) > 0) v0 = 0;
-    } else if (w[0] <= 0 && w[1] <= 0) {
-        v0 = 2;
-        if ((fc.obt & 4) && (xp - f[6]) * (f[3] - f[6]) + (yp - f[7]) * (f[4] - f[7]) > 0) v0 = 1;
-    } else if (w[0] <= 0) v0 = 1;
-    else if (w[1] <= 0) v0 = 2;
-    else if (w[2] <= 0) v0 = 0;
-    if (v0 < 0) v0 = 0;                             // the reference indexes [-1] here (undefined); pinned to edge 0 like the fp32 path
-    const int v1 = (v0 + 1) % 3, v2 = (v0 + 2) % 3;
-    double a0[3];
-    for (int j = 0; j < 3; j++) a0[j] = sym[3 * v0 + j] - sym[3 * v1 + j];
-    t[v0] = (w[0] * a0[0] + w[1] * a0[1] + w[2] * a0[2] - a0[v1]) / (a0[v0] - a0[v1]);
-    t[v1] = 1 - t[v0];
-    t[v2] = 0;
-    t[v0] = fmin(fmax(t[v0], 0.), 1.);
-    t[v1] = fmin(fmax(t[v1], 0.), 1.);
+    // Which edge the pixel projects to (K.cu:113-125), in the form the fp32 kernels use: without an obtuse corner the sign pattern
+    // of the barycentrics decides -- edge 1 iff w0 <= 0 < w1, edge 2 iff w1 <= 0 < w2, edge 0 otherwise (incl. "none <= 0", where
+    // the reference indexes [-1]: undefined there, pinned to edge 0 like the fp32 path and the oracle) -- and beyond a flagged
+    // obtuse corner the pixel goes to the corner's OTHER edge when it lies on that side.
+    const bool n0 = w[0] <= 0, n1 = w[1] <= 0, n2 = w[2] <= 0;
+    int ka = (n0 && !n1) ? 1 : ((n1 && !n2) ? 2 : 0);
+    if (n1 && n2) { if ((fc.obt & 1) && (xp - f[0]) * (f[6] - f[0]) + (yp - f[1]) * (f[7] - f[1]) > 0) ka = 2; }
+    else if (n2 && n0) { if ((fc.obt & 2) && (xp - f[3]) * (f[0] - f[3]) + (yp - f[4]) * (f[1] - f[4]) > 0) ka = 0; }
+    else if (n0 && n1) { if ((fc.obt & 4) && (xp - f[6]) * (f[3] - f[6]) + (yp - f[7]) * (f[4] - f[7]) > 0) ka = 1; }
+    const int kb = (ka + 1) % 3, kc = (ka + 2) % 3;
+    double ds[3];                                   // row ka minus row kb of the Gram matrix: the edge's direction in barycentric space
+    for (int j = 0; j < 3; j++) ds[j] = sym[3 * ka + j] - sym[3 * kb + j];
+    const double along = (w[0] * ds[0] + w[1] * ds[1] + w[2] * ds[2] - ds[kb]) / (ds[ka] - ds[kb]);
+    t[ka] = fmin(fmax(along, 0.), 1.);              // clamped to the segment (the outside branch only, K.cu:141-145)
+    t[kb] = fmin(fmax(1 - along, 0.), 1.);
+    t[kc] = 0;
     t[0] -= w[0]; t[1] -= w[1]; t[2] -= w[2];
     dx = t[0] * f[0] + t[1] * f[3] + t[2] * f[6];
     dy = t[0] * f[1] + t[1] * f[4] + t[2] * f[7];
