@@ -367,6 +367,17 @@ def test_integration_stub_binds_like_the_reference_extension(oracle, cuda):
     assert np.abs(grad_faces.cpu().numpy().reshape(rgf.shape) - rgf).max() <= 1e-3 * scale
     with pytest.raises(RuntimeError):                       # CHECK_INPUT of the pybind layer (soft_rasterize_cuda.cpp:54-56)
         stub.forward_soft_rasterize(faces.cpu(), textures, faces_info, aggrs_info, soft_colors, *scalars)
+    # float64 tensors through the same two functions (the reference dispatches on faces.type(), K.cu:701,716,780)
+    d = [t.double() for t in (faces, textures)]
+    info64, aggr64 = torch.zeros(N, F, 27, dtype=torch.float64, device=cuda), torch.zeros(N, 2, IS, IS, dtype=torch.float64, device=cuda)
+    col64 = torch.ones(N, 4, IS, IS, dtype=torch.float64, device=cuda)
+    stub.forward_soft_rasterize(d[0], d[1], info64, aggr64, col64, *scalars)
+    ref64 = oracle.forward(fv.astype(np.float64), ft.astype(np.float64), IS, dtype=np.float64, **kw)
+    assert np.abs(col64.cpu().numpy() - ref64['soft_colors']).max() <= 1e-9
+    gf64, gt64 = torch.zeros_like(d[0]), torch.zeros_like(d[1])
+    stub.backward_soft_rasterize(d[0], d[1], col64, info64, aggr64, gf64, gt64, torch.from_numpy(g).to(cuda).double(), *scalars)
+    rgf64, _ = oracle.backward(ref64, g.astype(np.float64), IS, dtype=np.float64, **kw)
+    assert np.abs(gf64.cpu().numpy().reshape(rgf64.shape) - rgf64).max() <= 1e-9 * np.abs(rgf64).max()
 
 
 def test_relaxed_forward_math_stays_inside_the_tolerance(oracle, cuda):
