@@ -142,8 +142,8 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
                 barycentric(rec, pix_center_p2(xi, IS, inv_is, pow2), pix_center_p2(IS - 1 - row, IS, inv_is, pow2), w0, w1, w2);
                 keep = !certainly_far(rec, w0, w1, w2, thr_pad);
             }
-            const unsigned long long mask = __ballot(keep);
-            if (keep) ring[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (unsigned)xi | ((unsigned)row << 16);
+            const unsigned long long mask = wave_mask(keep);
+            if (keep) ring[(tail + bits_below_lane(mask)) & (QCAP - 1)] = (unsigned)xi | ((unsigned)row << 16);
             tail += __popcll(mask);
         }
         const int avail = tail - head;

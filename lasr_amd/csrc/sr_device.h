@@ -396,7 +396,7 @@ __device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
 {
 #pragma clang fp contract(off)   // see edge_project
     const float x0 = rec[R_FACE + 0], y0 = rec[R_FACE + 1], x1 = rec[R_FACE + 3], y1 = rec[R_FACE + 4], x2 = rec[R_FACE + 6], y2 = rec[R_FACE + 7];
-    const bool inside = TAME ? ((fminf(fminf(w0, w1), w2) > 0) & (fmaxf(fmaxf(w0, w1), w2) < 1))     // (no short-circuit branch)
+    const bool inside = TAME ? (bool)((int)(fminf(fminf(w0, w1), w2) > 0) & (int)(fmaxf(fmaxf(w0, w1), w2) < 1))     // (no short-circuit branch)
                              : (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1);
     if (inside) {
         float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
@@ -570,6 +570,15 @@ __device__ __forceinline__ float sample_colour(TP tex, float c0, float c1, float
 }
 
 // ---- wave64 helpers ----------------------------------------------------------
+// Lane mask of a per-lane condition, straight from the condition's own mask (HIP's __ballot(int) first turns the bool into a
+// 0 / 1 register and compares it again), and the number of set bits below the calling lane as v_mbcnt_lo / v_mbcnt_hi (two
+// instructions; the shift-and-popcount form needs a per-lane 64-bit mask and four).
+__device__ __forceinline__ unsigned long long wave_mask(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ int bits_below_lane(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic);
 // the total lands in lane 63.
 __device__ __forceinline__ float wave_sum_to_lane63(float v)

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
             const short4 q = grects[lane];
             t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
         }
-        gmask = __ballot(t);
+        gmask = wave_mask(t);
     }
     if (gmask != 0 || G > 64) {
     const float xp = pix_center(px, IS);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
                     const short4 q = grects[g_next + lane];
                     t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
                 }
-                gmask = __ballot(t);
+                gmask = wave_mask(t);
                 g_next += 64;
                 continue;
             }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
             gmask = mm;
             const int f = mine_g * GROUP + lane;
             const bool hit = mine_g >= 0 && f < A.F && touches_tile(f);
-            const unsigned long long mask = __ballot(hit);
+            const unsigned long long mask = wave_mask(hit);
             if (lane == 0) s_wcnt[flip][wave] = __popcll(mask);
             __syncthreads();
             int before = 0, all = 0;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
                 if (k < wave) before += c;
                 all += c;
             }
-            if (hit) s_list[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+            if (hit) s_list[count + before + bits_below_lane(mask)] = (unsigned short)(f - base);
             count += all;
             flip ^= 1;
         }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_seg_kernel(RasterArgs A, f
             const short4 q = grects[lane];
             t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
         }
-        gmask = __ballot(t);
+        gmask = wave_mask(t);
     }
     if (gmask != 0 || G > 64) {
     const float xp = pix_center(px, IS);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_seg_kernel(RasterArgs A, f
                     const short4 q = grects[g_next + lane];
                     t = !(q.x > tX1 || q.y < qx0 || q.z > tY1 || q.w < qy0);
                 }
-                gmask = __ballot(t);
+                gmask = wave_mask(t);
                 g_next += 64;
                 continue;
             }
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_seg_kernel(RasterArgs A, f
             gmask = mm;
             const int f = mine_g * GROUP + lane;
             const bool hit = mine_g >= 0 && f < A.F && touches_tile(f);
-            const unsigned long long mask = __ballot(hit);
+            const unsigned long long mask = wave_mask(hit);
             if (lane == 0) s_wcnt[flip][wave] = __popcll(mask);
             __syncthreads();
             int before = 0, all = 0;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_seg_kernel(RasterArgs A, f
                 if (k < wave) before += c;
                 all += c;
             }
-            if (hit) s_list[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+            if (hit) s_list[count + before + bits_below_lane(mask)] = (unsigned short)(f - base);
             count += all;
             flip ^= 1;
         }

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
             const short4 q = grects[lane];
             t = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
         }
-        gmask = __ballot(t);
+        gmask = wave_mask(t);
     }
     if (gmask != 0 || G > 64) {
     const float xp = pix_center(px, IS);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                     const short4 q = grects[g_next + lane];
                     t = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
                 }
-                gmask = __ballot(t);
+                gmask = wave_mask(t);
                 g_next += 64;
                 continue;
             }
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 gmask &= gmask - 1;
                 const int f = g * GROUP + lane;
                 const bool hit = f < A.F && touches_quadrant(f);
-                const unsigned long long mask = __ballot(hit);
-                if (hit) mine[count + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+                const unsigned long long mask = wave_mask(hit);
+                if (hit) mine[count + bits_below_lane(mask)] = (unsigned short)(f - base);
                 count += __popcll(mask);
                 continue;
             }
@@ -384,12 +384,12 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 const short4 q = rects[f];
                 hit = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
             }
-            const unsigned long long mask = __ballot(hit);
+            const unsigned long long mask = wave_mask(hit);
             if (lane == 0) s_wcnt[flip][wave] = __popcll(mask);
             __syncthreads();
             const int c0 = s_wcnt[flip][0], c1 = s_wcnt[flip][1], c2 = s_wcnt[flip][2], c3 = s_wcnt[flip][3];
             const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-            if (hit) s_all[count + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(f - base);
+            if (hit) s_all[count + before + bits_below_lane(mask)] = (unsigned short)(f - base);
             count += c0 + c1 + c2 + c3;
             flip ^= 1;
             (void)taken;
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
                 e = s_all[i0 + lane];
                 hit = touches_quadrant(base + e);
             }
-            const unsigned long long mask = __ballot(hit);
-            if (hit) mine[n_mine + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)e;
+            const unsigned long long mask = wave_mask(hit);
+            if (hit) mine[n_mine + bits_below_lane(mask)] = (unsigned short)e;
             n_mine += __popcll(mask);
         }
         } else n_mine = count;
