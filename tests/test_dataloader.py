@@ -214,3 +214,18 @@ def test_image_ops_on_analytic_cases_of_the_opencv_definitions():
     assert abs(dt[4, 7] - 3) < 1e-9 and abs(dt[1, 0] - 5) < 1e-9 and dt[4, 4] == 0
     b = iu.compute_dt_barrier(m, k=50)
     assert b[4, 4] < 0.5 < b[4, 5] and abs(b[0, 0] - 1 / (1 + np.exp(-50 * np.hypot(4, 4) / 9))) < 1e-9
+
+
+def test_resize_linear_against_an_independent_bilinear_sampler():
+    # a second opinion on the cv2.resize(INTER_LINEAR) restatement: scipy's own bilinear sampler (map_coordinates, order=1,
+    # mode='nearest' = replicated border) evaluated at OpenCV's documented source positions (dst + 0.5) * scale - 0.5
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(3)
+    for (h, w), (H, W) in (((17, 23), (40, 31)), ((64, 48), (25, 25)), ((9, 9), (9, 20)), ((5, 7), (256, 256))):
+        src = rng.uniform(-1, 1, (h, w))
+        yy = (np.arange(H) + 0.5) * (h / H) - 0.5
+        xx = (np.arange(W) + 0.5) * (w / W) - 0.5
+        ref = map_coordinates(src, np.meshgrid(yy, xx, indexing='ij'), order=1, mode='nearest')
+        assert np.abs(iu.resize_linear(src, W, H) - ref).max() < 1e-12
+        near = iu.resize_nearest(src, W, H)
+        assert np.array_equal(near, src[np.minimum((np.arange(H) * (h / H)).astype(int), h - 1)][:, np.minimum((np.arange(W) * (w / W)).astype(int), w - 1)])
