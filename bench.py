@@ -43,7 +43,7 @@ MFMA_F32_PEAK_TF = 157.3       # dense fp32-input MFMA peak (same guide)
 IS = 256
 NU = 11                        # mesh M2
 N_FRAMES_CYCLE = 26            # yaw positions ("~26 frames" of BASELINE configs)
-REBUILD_RECORDS = -1            # -1: what the autograd operator does (reuse the forward's records up to 200k faces per launch)
+REBUILD_RECORDS = -1            # -1: what the autograd operator does (reuse the forward's records)
 
 
 def parse():
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument('--image-size', type=int, default=256, help='256 = the headline metric; 512 = BASELINE configs[2] (camel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rebuild-records', type=int, default=-1, help='1: the backward rebuilds the per-face records, 0: it reuses the '
-                    'forward\'s (LASR_SR_RECORDS_VALID), -1 (default): as the autograd operator does -- reuse up to 200k faces per launch')
+                    'forward\'s (LASR_SR_RECORDS_VALID), -1 (default): as the autograd operator does -- reuse')
     ap.add_argument('--no-lbs', action='store_true', help='skip the LBS (MFMA) micro-benchmark block')
     ap.add_argument('--no-sweep', action='store_true', help='skip the launch-size sweep (N = 1/4/16/64 at 256^2, 64 at 512^2)')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
@@ -107,10 +107,9 @@ class RasterStep:
                                   self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                                   B, F, 3, 3, IS, near, far, None, *tail, self.white, self.forward_flags, self.stream)
         _lib.check(rc, 'lasr_sr_forward_bg')
-        # the per-face records in the backward, as the autograd operator handles them (soft_rasterize.py: _records_of): launches
-        # up to 200k faces reuse the forward's (one launch less on a latency-bound step), larger ones rebuild them (records written
-        # a few microseconds earlier are warmer in L2 than the forward's, profiles/r02e_records_reuse.txt)
-        rebuild = REBUILD_RECORDS if REBUILD_RECORDS >= 0 else (B * F > 200000)
+        # the per-face records in the backward, as the autograd operator handles them (soft_rasterize.py: _records_of): the
+        # forward's are reused, one launch less (profiles/r04_flag_sweep.txt; --rebuild-records 1 times the other way)
+        rebuild = REBUILD_RECORDS > 0
         rc = h.lasr_sr_backward_ex(self.fv.data_ptr(), self.ft.data_ptr(), self.colors.data_ptr(), self.aggrs.data_ptr(),
                                    self.gf.data_ptr(), self.gt.data_ptr(), self.g.data_ptr(), self.ws.data_ptr(),
                                    self.ws.numel(), B, F, 3, 3, IS, near, far, None, *tail,
@@ -587,8 +586,8 @@ def main():
                        'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
                        'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world,
                        'step_definition': 'face setup + forward kernel (background colour passed as an argument: no pre-fill pass, '
-                                          'every element of soft_colors written) + face setup (launches above 200k faces; smaller ones '
-                                          'reuse the forward\'s records, as the autograd operator does) + backward kernel (stores every '
+                                          'every element of soft_colors written) + backward kernel on the forward\'s face records, as the autograd operator '
+                                          'runs it (--rebuild-records 1: a second face setup first) (stores every '
                                           'gradient element: no zero-fill pass) + face->vertex reduction of both gradients with the product\'s deterministic '
                                           'lasr_face_gather_backward + sum over the frames '
                                           '(+ RCCL all-reduce of the [2,V,3] mesh gradient for N > 1); rounds 1 and early 2 '

@@ -65,11 +65,11 @@ def _texels(textures):
 
 # Whose per-face records does a workspace hold?  Every call that writes records into it (a forward, or a backward that rebuilds
 # them) takes the next number; a backward may skip its setup launch (LASR_SR_RECORDS_VALID) exactly when the number its forward
-# took is still the current one.  Worth it for launches that are latency bound -- measured on an MI355X, mesh M2 at 256x256,
-# fwd+bwd frames/s with rebuilt -> reused records: 1 frame 9.6 k -> 10.2 k, 4 frames 24.7 k -> 25.7 k, 16 frames 42.3 k -> 43.4 k,
-# 64 frames 58.6 k -> 59.3 k -- and not for large ones, where freshly written records are warmer in L2 / Infinity Cache when the
-# face-major backward reads them than the forward's (256 frames: 1.88 ms with reuse vs 1.83 ms, profiles/r02e_records_reuse.txt).
-REUSE_RECORDS_MAX_FACES = int(os.environ.get('LASR_SR_REUSE_RECORDS_MAX_FACES', 200000))     # 0 = the backward always rebuilds
+# took is still the current one.  Measured on an MI355X, mesh M2 at 256x256 (profiles/r04_flag_sweep.txt), step ms with rebuilt ->
+# reused records: 64 frames 0.961 -> 0.952, 256 frames 3.353 -> 3.343 (the forward's records are colder in L2 / Infinity Cache when
+# the face-major backward reads them: +19 us, the second setup launch: 33 us); in round 2 the sign at 256 frames was the other way
+# (profiles/r02e_records_reuse.txt) and launches above 200k faces rebuilt.  The limit stays as a knob.
+REUSE_RECORDS_MAX_FACES = int(os.environ.get('LASR_SR_REUSE_RECORDS_MAX_FACES', 1 << 40))   # 0 = the backward always rebuilds
 _records_of = {}
 
 
