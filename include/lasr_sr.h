@@ -203,11 +203,22 @@ int lasr_sr_backward_f64(const double* faces, const double* textures, const doub
  * built-in default: 2200 / 14336 / 49152 (six and nine channels: 5/8 of the first two and no device-decided range; measured
  * on an MI355X, csrc/sr_raster.hip), or the value of LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES /
  * LASR_SR_CHOOSE_MAX_TILES read ONCE when the library is loaded.
+ * order_max_tiles: launches of LASR's mode combination with a multiple of 8 frames and at most this many tiles issue their
+ * tiles HEAVIEST FIRST -- two small kernels (sr_tile_weight_kernel, one workgroup per image; sr_order_kernel, one per XCD)
+ * count, from the setup kernel's pixel rects, the faces that touch each 8x8 tile of this batch and write the block -> tile
+ * table the forward kernels then follow, instead of the fixed centre-out order.  Which block renders a tile does not change
+ * the tile's arithmetic: output bit-identical; forward + order kernels are 8-15 % faster at 8-128 frames, even at 256
+ * (profiles/r04_tile_order_ab.txt).  For such launches four waves share a tile up to 4/7 of coop_max_tiles, the device-decided
+ * range ends at 7/16 of choose_max_tiles, and the device decides on the count of non-empty tiles (at most 3/8 of
+ * coop_max_tiles: four waves) instead of the bounding-box estimate.  Default (negative): no limit but the kernels' capacity
+ * (images up to 1016 pixels a side, 61440 tiles per XCD = 480 frames at 256x256; LASR_SR_ORDER_MAX_TILES at load time); 0
+ * switches it off.
  */
 typedef struct lasr_sr_options {
     long long coop8_max_tiles;
     long long coop_max_tiles;
     long long choose_max_tiles;
+    long long order_max_tiles;
 } lasr_sr_options;
 /* lasr_sr_forward_bg with options: `background` may be NULL (then soft_colors holds the pre-filled background, as for
  * lasr_sr_forward_ex), `options` may be NULL (all defaults). */
@@ -230,9 +241,11 @@ const char* lasr_prof_kernel_name(int kernel_id);
 int         lasr_prof_collect(void* hip_stream, int kernel_id, double* total_ms, long long* launches);
 
 /*
- * lasr_sr_peek_choice (test hook, synchronises the stream): what the device-side kernel choice of the LAST forward call on
- * `workspace` was -- 0 one wave per tile, 1 four waves per tile; meaningful only if that call's size was in the
- * device-decided range (lasr_sr_options).
+ * lasr_sr_peek_choice (test hook, synchronises the stream): the device-side choice word of the LAST forward call on
+ * `workspace`, meaningful only if that call's size was in the device-decided range (lasr_sr_options).  Launches in the fixed
+ * tile order: sr_choose_kernel's decision, 0 one wave per tile, 1 four waves per tile.  Launches in their own tile order
+ * (multiples of 8 frames): the number of non-empty tiles sr_order_kernel counted, which the forward kernels compare with
+ * 3/8 of coop_max_tiles themselves.
  */
 int lasr_sr_peek_choice(const void* workspace, int N, int F, int* choice, void* hip_stream);
 

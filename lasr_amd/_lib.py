@@ -111,8 +111,10 @@ MEANS_MAX_TERMS, TAIL_MAX_GROUPS = 24, 16          # LASR_MEANS_MAX_TERMS / LASR
 
 
 class SrOptions(ctypes.Structure):
-    """lasr_sr_options (include/lasr_sr.h): per-call kernel-choice thresholds of the forward pass; a negative field = default."""
-    _fields_ = [('coop8_max_tiles', ctypes.c_longlong), ('coop_max_tiles', ctypes.c_longlong), ('choose_max_tiles', ctypes.c_longlong)]
+    """lasr_sr_options (include/lasr_sr.h): per-call kernel-choice thresholds of the forward pass and the size limit of the
+    heaviest-first tile order; a negative field = default."""
+    _fields_ = [('coop8_max_tiles', ctypes.c_longlong), ('coop_max_tiles', ctypes.c_longlong), ('choose_max_tiles', ctypes.c_longlong),
+                ('order_max_tiles', ctypes.c_longlong)]
 
 
 _lib = None

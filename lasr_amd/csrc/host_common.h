@@ -13,7 +13,7 @@ enum LasrKernelId {
     K_FLOW_REPROJECT_FORWARD, K_FLOW_REPROJECT_BACKWARD, K_QUAT_FORWARD, K_QUAT_BACKWARD, K_SKIN_FORWARD, K_SKIN_BACKWARD,
     K_FLATTEN_FORWARD, K_FLATTEN_BACKWARD, K_FACE_GATHER_FORWARD, K_FACE_GATHER_BACKWARD,
     K_NEAREST_POINT, K_POINT_MESH_FORWARD, K_POINT_MESH_BACKWARD, K_COSDIST_FORWARD, K_COSDIST_BACKWARD,
-    K_LOAD_TEXTURES, K_GEODESIC_FORWARD, K_GEODESIC_BACKWARD, K_WEIGHTED_MEANS, K_INTRINSICS, K_BONE_FIXUP, K_CHAMFER, K_MEAN_SHAPE, K_OBS_PAIR, K_TAIL, K_FILL_PLANES, K_GATHER_ROWS, K_RENDER_TABLES_FORWARD, K_RENDER_TABLES_BACKWARD, K_RASTER_INPUTS,
+    K_LOAD_TEXTURES, K_GEODESIC_FORWARD, K_GEODESIC_BACKWARD, K_WEIGHTED_MEANS, K_INTRINSICS, K_BONE_FIXUP, K_CHAMFER, K_MEAN_SHAPE, K_OBS_PAIR, K_TAIL, K_FILL_PLANES, K_GATHER_ROWS, K_RENDER_TABLES_FORWARD, K_RENDER_TABLES_BACKWARD, K_RASTER_INPUTS, K_SR_ORDER,
     K_NUM_KERNELS
 };
 

@@ -19,10 +19,18 @@ struct RasterArgs {
     int use_bg;                               // forward: the background colour comes from bg[] instead of the pre-filled soft_colors
     const int* __restrict__ choice;           // forward, optional: device word written by sr_choose_kernel; a forward kernel whose
                                               // id (CHOICE_*) differs returns at once (both candidates are launched)
+    int choice_max;                           // < 0: *choice is the id; else *choice is the launch's number of non-empty tiles
+                                              // (sr_order_kernel) and the id is CHOICE_COOP iff it is at most this
+    const int* __restrict__ order;            // forward, optional: block -> (image, 8x8 tile) table written by sr_order_kernel
     float bg[9];
 };
 
 constexpr int CHOICE_ONE_WAVE = 0, CHOICE_COOP = 1;
+__device__ __forceinline__ int chosen_kernel(const RasterArgs& A)
+{
+    const int w = *A.choice;
+    return A.choice_max < 0 ? w : (w <= A.choice_max ? CHOICE_COOP : CHOICE_ONE_WAVE);
+}
 
 // Block -> (image, tile) with all tiles of an image kept on one XCD (block b runs
 // on XCD b % 8; an image's records are then fetched into a single L2).

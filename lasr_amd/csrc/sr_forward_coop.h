@@ -60,13 +60,13 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
     __shared__ int s_wcnt[2][NW];
     __shared__ float s_buf[2][COOP_STEP][FIELDS][64];
 
-    if (A.choice && *A.choice != CHOICE_COOP) return;   // the launch was left to sr_choose_kernel, which took the other kernel
+    if (A.choice && chosen_kernel(A) != CHOICE_COOP) return;   // the launch was left to the device, which took the other kernel
     const Modes m = Modes{2, 1, 2, 1, 1};               // LASR's configuration: euclidean, softmax, prod, vertex, double-sided
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
     const int IS = A.IS, P = IS * IS;
     const int tiles_x = (IS + 7) / 8;
     int bn, tx, ty;
-    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty);
+    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, A.order);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int qx0 = tx * 8, qy0 = ty * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -300,13 +300,13 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_seg_kernel(RasterArgs A, f
     __shared__ int s_wcnt[2][NW];
     __shared__ float s_part[NW][FIELDS][64];
 
-    if (A.choice && *A.choice != CHOICE_COOP) return;
+    if (A.choice && chosen_kernel(A) != CHOICE_COOP) return;
     const Modes m = Modes{2, 1, 2, 1, 1};
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
     const int IS = A.IS, P = IS * IS;
     const int tiles_x = (IS + 7) / 8;
     int bn, tx, ty;
-    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty);
+    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, A.order);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int qx0 = tx * 8, qy0 = ty * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);

@@ -88,6 +88,151 @@ __global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------
 // Per-pixel forward state (K.cu:354-368)
+// ---------------------------------------------------------------------------
+// Block -> tile order of ONE launch, heaviest tiles first.  A tile's walk length is the number of faces whose pixel rect touches
+// it (0 to ~200 on LASR's crops); the fixed centre-out spiral of tile_of_block starts crowded tiles early but knows nothing of
+// THIS batch, and with 8-128 frames per launch (every call LASR makes: nnutils/mesh_net.py:318-363) a SIMD holds only a handful
+// of crowded tiles, so the launch ends when the unluckiest SIMD does.  Issued in descending weight the hardware's round-robin
+// placement deals every SIMD one tile of each weight class: forward kernel -15 % at 16 frames, -18 % at 64, -2 % at 256
+// (profiles/r04_tile_order_ab.txt).  Which block renders which tile does not change any tile's arithmetic: bit-identical output.
+//
+// sr_tile_weight_kernel, one workgroup per image: every face adds its tile rectangle to a 2-D difference array in LDS (four
+// atomics per face, whatever the rect's size); a prefix pass along the rows and one down the columns turn it into the per-tile
+// counts, stored as min(count, 255).
+// sr_order_kernel, one workgroup per XCD: block b of the forward runs on XCD b % 8 and takes entry b / 8 of that XCD's list; the
+// XCD keeps the m = N / 8 images whose records it already fetches (tile_of_block's partition).  Counting sort of the m x tiles
+// keys (staged in LDS), descending; the empty tiles (three quarters of a LASR crop) are counted per wave, not per lane; ties
+// land in atomic order (any order is correct).  Table: [8][m x tiles], image << 16 | tile row << 8 | tile column.
+// Needs N % 8 == 0, at most ORDER_MAX_SIDE tiles per side and at most ORDER_MAX_ENTRIES tiles per XCD.
+// (Measured and dropped, 16 / 64 frames: weights by one atomic per (face, tile) pair -- neighbouring faces hit the same counters
+// -- 26 / 84 us; both steps in the per-XCD workgroups, eight CUs doing all the work: 16 / 36 us; one launch with the sort done by
+// the last workgroup of each XCD to finish, a device-scope fence per workgroup: 21 / 46 us; weights from the 64-face group rects
+// only: 10 / 18 us but half of the forward's gain lost.)
+constexpr int ORDER_MAX_SIDE = 127;           // (side + 1)^2 ints of LDS: image sizes up to 1016 pixels
+constexpr int ORDER_MAX_ENTRIES = 61440;      // 60 KB of keys per XCD: 480 frames at 256x256, 120 at 512x512
+constexpr int ORDER_THREADS = 1024;
+
+// e / d for 0 <= e < 2^23 with inv = 1.f / d (wave-uniform divisors: no integer division sequence per element)
+__device__ __forceinline__ int div_small(int e, int d, float inv)
+{
+    int q = (int)((float)e * inv);
+    const int r = e - q * d;
+    q += r >= d ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
+
+__global__ __launch_bounds__(512) void sr_tile_weight_kernel(const short4* __restrict__ rects, int F, int t8,
+                                                             unsigned char* __restrict__ keys, int* __restrict__ busy)
+{
+    __shared__ int s_d[(ORDER_MAX_SIDE + 1) * (ORDER_MAX_SIDE + 1)];
+    const int bn = blockIdx.x, S = t8 + 1, tiles = t8 * t8;
+    if (busy && bn == 0 && threadIdx.x == 0) *busy = 0;                          // sr_order_kernel adds up the non-empty tiles
+    for (int i = threadIdx.x; i < S * S; i += 512) s_d[i] = 0;
+    __syncthreads();
+    const short4* __restrict__ mine = rects + (size_t)bn * F;
+    for (int i = threadIdx.x; i < F; i += 4 * 512) {
+        short4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = i + k * 512 < F ? mine[i + k * 512] : make_short4(1, 0, 1, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (r[k].y < r[k].x || r[k].w < r[k].z) continue;                   // empty rect (culled face)
+            const int tx0 = r[k].x >> 3, tx1 = min((int)r[k].y >> 3, t8 - 1) + 1;
+            const int ty0 = r[k].z >> 3, ty1 = min((int)r[k].w >> 3, t8 - 1) + 1;
+            atomicAdd(&s_d[ty0 * S + tx0], 1);
+            atomicAdd(&s_d[ty0 * S + tx1], -1);
+            atomicAdd(&s_d[ty1 * S + tx0], -1);
+            atomicAdd(&s_d[ty1 * S + tx1], 1);
+        }
+    }
+    __syncthreads();
+    // prefix along the rows, then down the columns: one thread per row / column, eight cells fetched ahead of the running sum
+    for (int pass = 0; pass < 2; pass++) {
+        if ((int)threadIdx.x < t8) {
+            const int step = pass == 0 ? 1 : S;
+            int* const p = s_d + (pass == 0 ? threadIdx.x * S : threadIdx.x);
+            int run = 0;
+            for (int c = 0; c < t8; c += 8) {
+                int v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = c + k < t8 ? p[(c + k) * step] : 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { run += v[k]; if (c + k < t8) p[(c + k) * step] = run; }
+            }
+        }
+        __syncthreads();
+    }
+    unsigned char* __restrict__ out = keys + (size_t)bn * tiles;
+    const float inv_t8 = 1.f / (float)t8;
+    for (int t = threadIdx.x; t < tiles; t += 512) {
+        const int ty = div_small(t, t8, inv_t8);
+        out[t] = (unsigned char)min(s_d[ty * S + (t - ty * t8)], 255);
+    }
+}
+
+__global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned char* __restrict__ keys, int N, int t8,
+                                                                 int* __restrict__ order, int* __restrict__ busy)
+{
+    extern __shared__ unsigned char s_key[];
+    __shared__ unsigned s_hist[256], s_base[256], s_wave[4];
+    const int x = blockIdx.x, m = N >> 3, tiles = t8 * t8, entries = m * tiles;
+    const int lane = threadIdx.x & 63;
+    const unsigned char* __restrict__ mine = keys + (size_t)x * entries;
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
+    if ((entries & 3) == 0) {                                                    // every XCD's slice starts on a word
+        const unsigned* __restrict__ w = (const unsigned*)mine;
+        for (int i = threadIdx.x; i < entries >> 2; i += ORDER_THREADS) ((unsigned*)s_key)[i] = w[i];
+    } else {
+        for (int i = threadIdx.x; i < entries; i += ORDER_THREADS) s_key[i] = mine[i];
+    }
+    __syncthreads();
+    for (int e0 = threadIdx.x - lane; e0 < entries; e0 += ORDER_THREADS) {       // wave-uniform trip count
+        const int e = e0 + lane;
+        const int key = e < entries ? (int)s_key[e] : -1;
+        const unsigned long long empty = wave_mask(key == 0);
+        if (key > 0) atomicAdd(&s_hist[key], 1u);
+        if (lane == 0 && empty) atomicAdd(&s_hist[0], (unsigned)__popcll(empty));
+    }
+    __syncthreads();
+    // first position of key k = number of entries with a larger key: suffix sums of the 256 counts, 64 per wave
+    unsigned incl = 0;
+    if (threadIdx.x < 256) {
+        incl = s_hist[threadIdx.x];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned up = __shfl_down(incl, d);
+            if (lane + d < 64) incl += up;
+        }
+        if (lane == 0) s_wave[threadIdx.x >> 6] = incl;                          // this wave's total
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        unsigned above = incl - s_hist[threadIdx.x];
+        for (int w = (threadIdx.x >> 6) + 1; w < 4; w++) above += s_wave[w];
+        s_base[threadIdx.x] = above;
+    }
+    if (busy && threadIdx.x == 0) atomicAdd(busy, entries - (int)s_hist[0]);    // the launch's non-empty tiles: the forward kernels' choice
+    __syncthreads();
+    int* __restrict__ out = order + (size_t)x * entries;
+    const float inv_tiles = 1.f / (float)tiles, inv_t8 = 1.f / (float)t8;
+    for (int e0 = threadIdx.x - lane; e0 < entries; e0 += ORDER_THREADS) {
+        const int e = e0 + lane;
+        const int key = e < entries ? (int)s_key[e] : -1;
+        const unsigned long long empty = wave_mask(key == 0);
+        unsigned pos = 0;
+        if (key > 0) pos = atomicAdd(&s_base[key], 1u);
+        unsigned first = 0;
+        if (lane == 0 && empty) first = atomicAdd(&s_base[0], (unsigned)__popcll(empty));
+        first = __builtin_amdgcn_readfirstlane(first);
+        if (key == 0) pos = first + bits_below_lane(empty);
+        if (key >= 0) {
+            const int img = div_small(e, tiles, inv_tiles), t = e - img * tiles, ty = div_small(t, t8, inv_t8);
+            out[pos] = ((x * m + img) << 16) | (ty << 8) | (t - ty * t8);
+        }
+    }
+}
+
 template <int NCH>
 struct PixState {
     float c[NCH];         // colour / attribute accumulators (3 = RGB; 6 = two attribute triples in one pass)
@@ -179,8 +324,13 @@ __device__ __forceinline__ void forward_face(const RasterArgs& A, const Modes m,
 // border tiles fill the tail of the launch.  With few frames per launch the crowded tiles' serial walks are the critical
 // path (0.2 ms for ONE frame); starting them last cost up to 40 % of a 16-frame launch.  Any order is correct; odd tile
 // counts or frame counts that do not divide over the XCDs keep the plain row-major order.
-__device__ __forceinline__ void tile_of_block(int b, int total, int tiles_x, int& bn, int& tx, int& ty)
+__device__ __forceinline__ void tile_of_block(int b, int total, int tiles_x, int& bn, int& tx, int& ty, const int* __restrict__ order = nullptr)
 {
+    if (order) {                                    // the launch's own order (sr_order_kernel): image << 16 | tile row << 8 | tile column
+        const int e = __builtin_amdgcn_readfirstlane(order[(b & 7) * (total >> 3) + (b >> 3)]);
+        bn = e >> 16; ty = (e >> 8) & 255; tx = e & 255;
+        return;
+    }
     const int tiles = tiles_x * tiles_x;
     const int per = total >> 3;
 #ifndef LASR_ORDER
@@ -243,7 +393,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     __shared__ unsigned short s_mine[NW][CAP];        // per wave: the subset touching its 8x8 quadrant, index order
     __shared__ int s_wcnt[2][4];
 
-    if (W1 && A.choice && *A.choice != CHOICE_ONE_WAVE) return;      // sr_choose_kernel took the cooperative kernel for this launch
+    if (W1 && A.choice && chosen_kernel(A) != CHOICE_ONE_WAVE) return;      // the device took the cooperative kernel for this launch
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
@@ -251,7 +401,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const int IS = A.IS, P = IS * IS;
     const int tiles_x = (IS + TW - 1) / TW;
     int bn, tx, ty;
-    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty);
+    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, W1 ? A.order : nullptr);
     const int tid = threadIdx.x, wave = W1 ? 0 : tid >> 6, lane = tid & 63;
 
     const int qx0 = tx * TW + (wave & 1) * 8, qy0 = ty * TW + (wave >> 1) * 8;       // this wave's quadrant
@@ -522,11 +672,13 @@ static inline int groups_of_host(int F) { return (F + GROUP - 1) / GROUP; }
 
 extern "C" size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS)
 {
-    (void)T; (void)IS;
+    (void)T;
     if (N < 0 || F < 0) return 0;
     const size_t nf = (size_t)N * (size_t)F;
     const size_t ng = (size_t)N * (size_t)((F + GROUP - 1) / GROUP);
-    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) + align_up(ng * sizeof(short4), 256) + 256 /* sr_choose_kernel's word */ + 256;
+    const size_t t8 = IS > 0 ? (size_t)(IS + 7) / 8 : 0;
+    return align_up(nf * REC * sizeof(float), 256) + align_up(nf * sizeof(short4), 256) + align_up(ng * sizeof(short4), 256) + 256 /* sr_choose_kernel's word */
+           + align_up((size_t)N * t8 * t8 * sizeof(int), 256) /* sr_order_kernel's table */ + align_up((size_t)N * t8 * t8, 256) /* tile weights */ + 256;
 }
 
 static int check_common(int N, int F, int T, int IS, int dist, int rgb, int alpha, int tex)
@@ -557,6 +709,8 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     A.overwrite_grads = 0;
     A.use_bg = 0;
     A.choice = nullptr;
+    A.choice_max = -1;
+    A.order = nullptr;
     return A;
 }
 
@@ -595,6 +749,8 @@ static long long env_blocks(const char* name, long long dflt)
 static const long long k_coop8_max_tiles = env_blocks("LASR_SR_COOP8_MAX_TILES", 2200);
 static const long long k_coop_max_tiles = env_blocks("LASR_SR_COOP_MAX_TILES", 14336);
 static const long long k_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES", 49152);
+// launches of up to this many 8x8 tiles (and N % 8 == 0) issue their tiles heaviest first
+static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES", 1ll << 40);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -608,6 +764,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const long long g_coop8_max_tiles = opt && opt->coop8_max_tiles >= 0 ? opt->coop8_max_tiles : k_coop8_max_tiles;
     const long long g_coop_max_tiles = opt && opt->coop_max_tiles >= 0 ? opt->coop_max_tiles : k_coop_max_tiles;
     const long long g_choose_max_tiles = opt && opt->choose_max_tiles >= 0 ? opt->choose_max_tiles : k_choose_max_tiles;
+    const long long g_order_max_tiles = opt && opt->order_max_tiles >= 0 ? opt->order_max_tiles : k_order_max_tiles;
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
     if (rc) return rc;
     if (N == 0 || IS == 0) return LASR_OK;
@@ -623,6 +780,12 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
         for (int k = 0; k < nch; k++) A.bg[k] = background[k];
     }
     const int total = N * F;
+    // the 8x8-tile kernels, multiples of 8 frames: this launch's own tile order (sr_order_kernel)
+    const int t8o = (IS + 7) / 8;
+    const long long tiles8o = (long long)N * t8o * t8o;
+    const bool use_order = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && (N & 7) == 0 && tiles8o <= g_order_max_tiles &&
+                           t8o <= ORDER_MAX_SIDE && tiles8o <= 8ll * ORDER_MAX_ENTRIES && N < 32768;
+    char* const slot = (char*)grects + align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256);   // [0] sr_choose_kernel's word
     if (total > 0) {
         {
             ProfScope ps(K_SR_SETUP, st);
@@ -634,22 +797,43 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     }
     const int tiles_x = (IS + TILE - 1) / TILE;
     const dim3 grid((unsigned)(N * tiles_x * tiles_x));
+    // which of the 8x8-tile kernels (LASR's mode combination; six / nine channels).  0: one wave per tile, 1: four waves, 2: eight
+    // waves, 3: four waves AND one wave are launched and the device chooses.
+    // (six / nine channels are LASR.forward's render: its frames are cropped around the object and nearly every tile is busy, so
+    // the launch size itself is the estimate and the extra launches of the device-side choice are saved)
+    // With the launch's own tile order the one-wave kernel catches up earlier (tools/prof/kernel_choice_sweep.py, forward + order
+    // kernels, ms, four waves | one wave: bench object, a third of the tiles busy, 8 frames .115 | .211, 16: .182 | .228, 24:
+    // .264 | .237, 32: .339 | .289; object filling the frame, 8: .151 | .154, 16: .275 | .217): four waves up to 4/7 of
+    // coop_max_tiles, the device decides up to 7/16 of choose_max_tiles -- on the launch's count of NON-EMPTY tiles, which
+    // sr_order_kernel has anyway (at most 3/8 of coop_max_tiles: four waves), not on sr_choose_kernel's bounding-box estimate.
+    const bool tile_kernels = nch > 3 || is_lasr_fast(A.m);
+    const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
+    const long long coop8_max = nch > 3 ? g_coop8_max_tiles / 8 * 5 : g_coop8_max_tiles;
+    const long long coop_max_plain = nch > 3 ? g_coop_max_tiles / 8 * 5 : g_coop_max_tiles;
+    const long long coop_max = use_order ? coop_max_plain / 7 * 4 : coop_max_plain;
+    const long long choose_max = nch > 3 ? coop_max : use_order ? g_choose_max_tiles / 16 * 7 : g_choose_max_tiles;
+    const int plan = !tile_kernels || rx ? 0 : tiles8o <= coop8_max ? 2 : tiles8o <= coop_max ? 1 :
+                     (tiles8o <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;
+    if (use_order) {
+        int* order = (int*)(slot + 256);
+        unsigned char* keys = (unsigned char*)order + align_up((size_t)tiles8o * sizeof(int), 256);
+        int* busy = plan == 3 ? (int*)slot : nullptr;
+        ProfScope po(K_SR_ORDER, st);
+        hipLaunchKernelGGL(sr_tile_weight_kernel, dim3((unsigned)N), dim3(512), 0, st, rects, F, t8o, keys, busy);
+        hipLaunchKernelGGL(sr_order_kernel, dim3(8), dim3(ORDER_THREADS), align_up((size_t)(tiles8o / 8), 16), st, keys, N, t8o, order, busy);
+        A.order = order;
+        if (plan == 3) {
+            A.choice = busy;
+            A.choice_max = (int)std::min<long long>(coop_max_plain / 8 * 3, 0x7fffffff);
+        }
+    }
     {
         ProfScope ps(K_SR_FORWARD, st);
-        const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
-        if (nch > 3 || is_lasr_fast(A.m)) {
-            const int t8 = (IS + 7) / 8;
-            const long long tiles8 = (long long)N * t8 * t8;
+        if (tile_kernels) {
+            const long long tiles8 = tiles8o;
             const dim3 grid8((unsigned)tiles8);
-            const long long coop8_max = nch > 3 ? g_coop8_max_tiles / 8 * 5 : g_coop8_max_tiles;
-            const long long coop_max = nch > 3 ? g_coop_max_tiles / 8 * 5 : g_coop_max_tiles;
-            // (six / nine channels are LASR.forward's render: its frames are cropped around the object and nearly every tile is
-            // busy, so the launch size itself is the estimate and the two extra launches of the device-side choice are saved)
-            const long long choose_max = nch > 3 ? coop_max : g_choose_max_tiles;
-            // 0: one wave per tile, 1: four waves, 2: eight waves, 3: four waves AND one wave, the device chooses
-            const int plan = rx ? 0 : tiles8 <= coop8_max ? 2 : tiles8 <= coop_max ? 1 : (tiles8 <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;
-            if (plan == 3) {
-                int* choice = (int*)((char*)grects + align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256));
+            if (plan == 3 && !use_order) {
+                int* choice = (int*)slot;
                 hipLaunchKernelGGL(sr_choose_kernel, dim3(1), dim3(64), 0, st, grects, N, groups_of_host(F), IS, coop_max, choice);
                 A.choice = choice;
             }

@@ -138,3 +138,119 @@ def test_default_thresholds_pick_by_launch_size(cuda):
     batch = render(cuda, fv, ft, 256, kw)
     one = render(cuda, fv[5:6], ft[5:6], 256, kw)
     assert np.array_equal(batch[5:6], one)
+
+
+# ---- this launch's own tile order (sr_order_kernel): multiples of 8 frames issue their 8x8 tiles heaviest first
+
+def _order_table(cuda, N, F, IS):
+    """The block -> tile table the last forward call left in the operator's workspace, and the setup kernel's pixel rects."""
+    import importlib
+    sr_mod = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
+    ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
+    up = lambda v: (v + 255) // 256 * 256
+    base = (-ws.data_ptr()) % 256
+    o_rects = base + up(N * F * 48 * 4)
+    o_grects = o_rects + up(N * F * 8)
+    o_order = o_grects + up(N * ((F + 63) // 64) * 8) + 256
+    t8 = (IS + 7) // 8
+    rects = ws[o_rects:o_rects + N * F * 8].view(torch.int16).reshape(N, F, 4).cpu().numpy().astype(np.int64)
+    table = ws[o_order:o_order + N * t8 * t8 * 4].view(torch.int32).cpu().numpy()
+    return table, rects, t8
+
+
+@pytest.mark.parametrize('count,IS,channels', [(8, 64, 3), (16, 100, 3), (8, 256, 3), (16, 72, 9), (24, 48, 6)])
+def test_heaviest_first_tile_order_gives_the_same_bits_in_every_kernel(cuda, count, IS, channels):
+    fv, ft, near, far = synth.raster_batch(4 if IS < 256 else 8, 5, count=count)
+    rng = np.random.default_rng(count)
+    if channels > 3:
+        ft = np.concatenate([ft] + [rng.uniform(-2, 2, ft.shape).astype(np.float32) for _ in range(channels // 3 - 1)], -1)
+    kw = dict(synth.LASR_MODES, near=near, far=far, background_color=[0.125 * k for k in range(channels)])
+    try:
+        out = {}
+        for name, th in VARIANTS.items():
+            for order_max in (0, BIG):
+                srf.set_launch_thresholds(*th, order_max)
+                out[name, order_max] = render(cuda, fv, ft, IS, kw)
+        first = out[next(iter(out))]
+        for key, img in out.items():
+            assert np.array_equal(img.view(np.uint32), first.view(np.uint32)), key
+    finally:
+        srf.set_launch_thresholds()
+
+
+def test_the_tile_order_is_a_permutation_sorted_by_the_faces_that_touch_each_tile(cuda):
+    N, IS = 16, 104                                            # 13 x 13 tiles per frame, the last column / row cut by the image edge
+    fv, ft, near, far = synth.raster_batch(4, 7, count=N)
+    fv[3] += np.array([0.45, -0.3, 0.], np.float32)            # one object off-centre: the fixed spiral would start in its empty middle
+    F = fv.shape[1]
+    try:
+        srf.set_launch_thresholds(-1, -1, -1, BIG)
+        render(cuda, fv, ft, IS, dict(synth.LASR_MODES, near=near, far=far))
+    finally:
+        srf.set_launch_thresholds()
+    table, rects, t8 = _order_table(cuda, N, F, IS)
+    bn, ty, tx = table >> 16, (table >> 8) & 255, table & 255
+    assert sorted(zip(bn.tolist(), ty.tolist(), tx.tolist())) == [(n, y, x) for n in range(N) for y in range(t8) for x in range(t8)]
+    w = np.zeros((N, t8, t8), np.int64)
+    for n in range(N):
+        for x0, x1, y0, y1 in rects[n]:
+            if x1 >= x0 and y1 >= y0:
+                w[n, y0 >> 3:(y1 >> 3) + 1, x0 >> 3:(x1 >> 3) + 1] += 1
+    assert w.max() > 20
+    m = N // 8
+    per = m * t8 * t8
+    for x in range(8):                                          # block b runs on XCD b % 8 and takes entry b // 8 of its list
+        mine = slice(x * per, (x + 1) * per)
+        assert ((bn[mine] >= x * m) & (bn[mine] < (x + 1) * m)).all()
+        key = np.minimum(w[bn[mine], ty[mine], tx[mine]], 255)
+        assert (np.diff(key) <= 0).all(), 'XCD %d: tiles not in descending weight' % x
+
+
+def test_launches_the_tile_order_does_not_cover_fall_back_to_the_fixed_order(cuda):
+    # 12 frames (not a multiple of 8) and order_max_tiles below the launch size: no table, same bits as with it switched off
+    for count, order_max in ((12, BIG), (16, 100)):
+        fv, ft, near, far = synth.raster_batch(4, 5, count=count)
+        kw = dict(synth.LASR_MODES, near=near, far=far)
+        try:
+            srf.set_launch_thresholds(-1, -1, -1, order_max)
+            a = render(cuda, fv, ft, 64, kw)
+            srf.set_launch_thresholds(-1, -1, -1, 0)
+            b = render(cuda, fv, ft, 64, kw)
+        finally:
+            srf.set_launch_thresholds()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_ordered_launches_choose_on_the_count_of_non_empty_tiles(cuda):
+    # 8 frames of 64x64 = 512 tiles.  coop_max x 4/7 below the launch size and choose_max x 7/16 above it: both kernels are launched
+    # and decide on the device from sr_order_kernel's count of tiles that meet at least one face (<= coop_max x 3/8: four waves).
+    import ctypes
+    import importlib
+    sr_mod = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
+    N, IS = 8, 64
+    fv, ft, near, far = synth.raster_batch(4, 5, count=N)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    h = _lib.lib()
+    try:
+        srf.set_launch_thresholds(0, 0, 0, 0)
+        want = render(cuda, fv, ft, IS, kw)
+        seen = {}
+        for coop_max in (880, 160):                                     # x 3/8 = 330 and 60 non-empty tiles
+            srf.set_launch_thresholds(0, coop_max, BIG, BIG)
+            got = render(cuda, fv, ft, IS, kw)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
+            c = ctypes.c_int(-1)
+            _lib.check(h.lasr_sr_peek_choice(ws.data_ptr(), N, fv.shape[1], ctypes.byref(c), None), 'peek')
+            seen[coop_max] = c.value
+    finally:
+        srf.set_launch_thresholds()
+    table, rects, t8 = _order_table(cuda, N, fv.shape[1], IS)
+    w = np.zeros((N, t8, t8), np.int64)
+    for n in range(N):
+        for x0, x1, y0, y1 in rects[n]:
+            if x1 >= x0 and y1 >= y0:
+                w[n, y0 >> 3:(y1 >> 3) + 1, x0 >> 3:(x1 >> 3) + 1] += 1
+    busy = int((w > 0).sum())
+    assert 60 < busy <= 330, busy                                       # so the two settings took different kernels
+    assert seen == {880: busy, 160: busy}, (seen, busy)

@@ -21,7 +21,7 @@ dev = torch.device('cuda:0')
 h = _lib.lib()
 st = torch.cuda.current_stream(dev).cuda_stream
 out = {}
-for n in (1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64):
+for n in (1, 2, 4, 6, 8, 12, 16, 24, 32, 40, 48, 64, 96):
     v, f, tex = synth.blobby_mesh(11)
     pv = synth.frame_vertices(v, 26, focal=FOCAL, count=n)
     near, far = synth.near_far(pv[:, :, 2])
@@ -49,8 +49,8 @@ for n in (1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64):
         tot = 0.0
         for k in range(h.lasr_prof_kernel_count()):
             h.lasr_prof_collect(st, k, ctypes.byref(ms), ctypes.byref(cnt))
-            if h.lasr_prof_kernel_name(k).decode() == 'sr_forward_kernel':
-                tot = ms.value / 20
+            if h.lasr_prof_kernel_name(k).decode() in ('sr_forward_kernel', 'sr_order_kernel'):   # multiples of 8 frames: + the tile order
+                tot += ms.value / 20
         row[name] = round(tot, 5)
     out[n] = row
     print(n, row, flush=True)
