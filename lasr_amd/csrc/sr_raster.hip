@@ -783,8 +783,12 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     // the 8x8-tile kernels, multiples of 8 frames: this launch's own tile order (sr_order_kernel)
     const int t8o = (IS + 7) / 8;
     const long long tiles8o = (long long)N * t8o * t8o;
+    // (an XCD then walks the crowded tiles of ALL its N / 8 images at once: while their records fit about twice its 4 MB L2 that
+    // costs little -- 128 frames of 2420 faces, 7.4 MB per XCD: forward -8 % -- beyond it the record fetch multiplies for nothing:
+    // 256 frames, 14.9 MB: FETCH_SIZE 172 MB -> 1.18 GB per launch for -2 % in the kernel and +32 us of order kernels)
     const bool use_order = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && (N & 7) == 0 && tiles8o <= g_order_max_tiles &&
-                           t8o <= ORDER_MAX_SIDE && tiles8o <= 8ll * ORDER_MAX_ENTRIES && N < 32768;
+                           t8o <= ORDER_MAX_SIDE && tiles8o <= 8ll * ORDER_MAX_ENTRIES && N < 32768 &&
+                           (long long)(N >> 3) * F * REC * (long long)sizeof(float) <= (8ll << 20);
     char* const slot = (char*)grects + align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256);   // [0] sr_choose_kernel's word
     if (total > 0) {
         {
