@@ -203,15 +203,15 @@ int lasr_sr_backward_f64(const double* faces, const double* textures, const doub
  * built-in default: 2200 / 14336 / 49152 (six and nine channels: 5/8 of the first two and no device-decided range; measured
  * on an MI355X, csrc/sr_raster.hip), or the value of LASR_SR_COOP8_MAX_TILES / LASR_SR_COOP_MAX_TILES /
  * LASR_SR_CHOOSE_MAX_TILES read ONCE when the library is loaded.
- * order_max_tiles: launches of LASR's mode combination with a multiple of 8 frames and at most this many tiles issue their
+ * order_max_tiles: launches of LASR's mode combination with five frames or more (tile total a multiple of 8) and at most this many tiles issue their
  * tiles HEAVIEST FIRST -- two small kernels (sr_tile_weight_kernel, one workgroup per image; sr_order_kernel, one per XCD)
  * count, from the setup kernel's pixel rects, the faces that touch each 8x8 tile of this batch and write the block -> tile
  * table the forward kernels then follow, instead of the fixed centre-out order.  Which block renders a tile does not change
- * the tile's arithmetic: output bit-identical; forward + order kernels are 8-15 % faster at 8-128 frames, even at 256
+ * the tile's arithmetic: output bit-identical; forward + order kernels are 6-25 % faster at 6-128 frames, even at 256; below five frames the two order launches (12 us) cost more than they gain
  * (profiles/r04_tile_order_ab.txt).  For such launches four waves share a tile up to 4/7 of coop_max_tiles, the device-decided
  * range ends at 7/16 of choose_max_tiles, and the device decides on the count of non-empty tiles (at most 3/8 of
  * coop_max_tiles: four waves) instead of the bounding-box estimate.  Default (negative): no limit but the kernels' capacity
- * (images up to 1016 pixels a side, 61440 tiles per XCD) and the rule that the face records of an XCD's N / 8 images stay within
+ * (images up to 1016 pixels a side, 61440 tiles per XCD) and the rule that the face records of an XCD's ceil(N / 8) images stay within
  * 8 MB, twice its L2 (2420 faces: up to 136 frames; beyond that the interleaved walk of all those images' crowded tiles
  * multiplies the record fetch -- 256 frames: 172 MB -> 1.18 GB per launch -- for a 2 % shorter kernel);
  * LASR_SR_ORDER_MAX_TILES at load time; 0 switches it off.
@@ -246,7 +246,7 @@ int         lasr_prof_collect(void* hip_stream, int kernel_id, double* total_ms,
  * lasr_sr_peek_choice (test hook, synchronises the stream): the device-side choice word of the LAST forward call on
  * `workspace`, meaningful only if that call's size was in the device-decided range (lasr_sr_options).  Launches in the fixed
  * tile order: sr_choose_kernel's decision, 0 one wave per tile, 1 four waves per tile.  Launches in their own tile order
- * (multiples of 8 frames): the number of non-empty tiles sr_order_kernel counted, which the forward kernels compare with
+ * (lasr_sr_options order_max_tiles): the number of non-empty tiles sr_order_kernel counted, which the forward kernels compare with
  * 3/8 of coop_max_tiles themselves.
  */
 int lasr_sr_peek_choice(const void* workspace, int N, int F, int* choice, void* hip_stream);

@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 // Block -> tile order of ONE launch, heaviest tiles first.  A tile's walk length is the number of faces whose pixel rect touches
 // it (0 to ~200 on LASR's crops); the fixed centre-out spiral of tile_of_block starts crowded tiles early but knows nothing of
-// THIS batch, and with 8-128 frames per launch (every call LASR makes: nnutils/mesh_net.py:318-363) a SIMD holds only a handful
+// THIS batch, and with 5-128 frames per launch (most calls LASR makes: nnutils/mesh_net.py:318-363) a SIMD holds only a handful
 // of crowded tiles, so the launch ends when the unluckiest SIMD does.  Issued in descending weight the hardware's round-robin
-// placement deals every SIMD one tile of each weight class: forward kernel -15 % at 16 frames, -18 % at 64, -2 % at 256
+// placement deals every SIMD one tile of each weight class: forward kernel -18 % at 16 frames, -18 % at 64, -2 % at 256
 // (profiles/r04_tile_order_ab.txt).  Which block renders which tile does not change any tile's arithmetic: bit-identical output.
 //
 // sr_tile_weight_kernel, one workgroup per image: every face adds its tile rectangle to a 2-D difference array in LDS (four
@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void sr_setup_kernel(const float* __restrict__
 // sr_order_kernel, one workgroup per XCD: block b of the forward runs on XCD b % 8 and takes entry b / 8 of that XCD's list; the
 // XCD keeps the m = N / 8 images whose records it already fetches (tile_of_block's partition).  Counting sort of the m x tiles
 // keys (staged in LDS), descending; the empty tiles (three quarters of a LASR crop) are counted per wave, not per lane; ties
-// land in atomic order (any order is correct).  Table: [8][m x tiles], image << 16 | tile row << 8 | tile column.
-// Needs N % 8 == 0, at most ORDER_MAX_SIDE tiles per side and at most ORDER_MAX_ENTRIES tiles per XCD.
+// land in atomic order (any order is correct).  Table: [8][N x tiles / 8], image << 16 | tile row << 8 | tile column.  A frame
+// count that is not a multiple of 8 gives every XCD the same share of the (image, tile) list, an image split between two neighbours.
+// Needs N x tiles % 8 == 0, at most ORDER_MAX_SIDE tiles per side and at most ORDER_MAX_ENTRIES tiles per XCD.
 // (Measured and dropped, 16 / 64 frames: weights by one atomic per (face, tile) pair -- neighbouring faces hit the same counters
 // -- 26 / 84 us; both steps in the per-XCD workgroups, eight CUs doing all the work: 16 / 36 us; one launch with the sort done by
 // the last workgroup of each XCD to finish, a device-scope fence per workgroup: 21 / 46 us; weights from the 64-face group rects
@@ -176,9 +177,11 @@ __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned 
 {
     extern __shared__ unsigned char s_key[];
     __shared__ unsigned s_hist[256], s_base[256], s_wave[4];
-    const int x = blockIdx.x, m = N >> 3, tiles = t8 * t8, entries = m * tiles;
+    // this XCD's slice of the (image, tile) keys: N / 8 whole images, or -- frame counts that are not a multiple of 8 -- the same
+    // share of the list with an image split between two neighbours (its records are then fetched into both L2s)
+    const int x = blockIdx.x, tiles = t8 * t8, entries = (int)(((long long)N * tiles) >> 3), e_first = x * entries;
     const int lane = threadIdx.x & 63;
-    const unsigned char* __restrict__ mine = keys + (size_t)x * entries;
+    const unsigned char* __restrict__ mine = keys + e_first;
     if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
     if ((entries & 3) == 0) {                                                    // every XCD's slice starts on a word
         const unsigned* __restrict__ w = (const unsigned*)mine;
@@ -227,8 +230,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned 
         first = __builtin_amdgcn_readfirstlane(first);
         if (key == 0) pos = first + bits_below_lane(empty);
         if (key >= 0) {
-            const int img = div_small(e, tiles, inv_tiles), t = e - img * tiles, ty = div_small(t, t8, inv_t8);
-            out[pos] = ((x * m + img) << 16) | (ty << 8) | (t - ty * t8);
+            const int img = div_small(e_first + e, tiles, inv_tiles), t = e_first + e - img * tiles, ty = div_small(t, t8, inv_t8);
+            out[pos] = (img << 16) | (ty << 8) | (t - ty * t8);
         }
     }
 }
@@ -749,7 +752,7 @@ static long long env_blocks(const char* name, long long dflt)
 static const long long k_coop8_max_tiles = env_blocks("LASR_SR_COOP8_MAX_TILES", 2200);
 static const long long k_coop_max_tiles = env_blocks("LASR_SR_COOP_MAX_TILES", 14336);
 static const long long k_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES", 49152);
-// launches of up to this many 8x8 tiles (and N % 8 == 0) issue their tiles heaviest first
+// launches of up to this many 8x8 tiles (five frames and more, tile total a multiple of 8) issue their tiles heaviest first
 static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES", 1ll << 40);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
@@ -780,15 +783,17 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
         for (int k = 0; k < nch; k++) A.bg[k] = background[k];
     }
     const int total = N * F;
-    // the 8x8-tile kernels, multiples of 8 frames: this launch's own tile order (sr_order_kernel)
+    // the 8x8-tile kernels, five frames and more: this launch's own tile order (sr_order_kernel)
     const int t8o = (IS + 7) / 8;
     const long long tiles8o = (long long)N * t8o * t8o;
     // (an XCD then walks the crowded tiles of ALL its N / 8 images at once: while their records fit about twice its 4 MB L2 that
     // costs little -- 128 frames of 2420 faces, 7.4 MB per XCD: forward -8 % -- beyond it the record fetch multiplies for nothing:
     // 256 frames, 14.9 MB: FETCH_SIZE 172 MB -> 1.18 GB per launch for -2 % in the kernel and +32 us of order kernels)
-    const bool use_order = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && (N & 7) == 0 && tiles8o <= g_order_max_tiles &&
-                           t8o <= ORDER_MAX_SIDE && tiles8o <= 8ll * ORDER_MAX_ENTRIES && N < 32768 &&
-                           (long long)(N >> 3) * F * REC * (long long)sizeof(float) <= (8ll << 20);
+    // (below 5 frames the two order launches, 12 us, cost more than the order gains: 4 frames forward .089 -> .081 ms, step .153 -> .155)
+    static const int order_min_frames = (int)env_blocks("LASR_SR_ORDER_MIN_FRAMES", 5);
+    const bool use_order = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && N >= order_min_frames && (tiles8o & 7) == 0 &&
+                           tiles8o <= g_order_max_tiles && t8o <= ORDER_MAX_SIDE && tiles8o <= 8ll * ORDER_MAX_ENTRIES && N < 32768 &&
+                           (long long)((N + 7) >> 3) * F * REC * (long long)sizeof(float) <= (8ll << 20);
     char* const slot = (char*)grects + align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256);   // [0] sr_choose_kernel's word
     if (total > 0) {
         {
@@ -814,7 +819,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const bool rx = (flags & LASR_SR_RELAXED_MATH) && is_lasr_fast(A.m);
     const long long coop8_max = nch > 3 ? g_coop8_max_tiles / 8 * 5 : g_coop8_max_tiles;
     const long long coop_max_plain = nch > 3 ? g_coop_max_tiles / 8 * 5 : g_coop_max_tiles;
-    const long long coop_max = use_order ? coop_max_plain / 7 * 4 : coop_max_plain;
+    const long long coop_max = use_order && nch == 3 ? coop_max_plain / 7 * 4 : coop_max_plain;      // (nine channels, 6 | 8 | 12 frames: .146 | .164 | .238 four, .165 | .167 | .200 one)
     const long long choose_max = nch > 3 ? coop_max : use_order ? g_choose_max_tiles / 16 * 7 : g_choose_max_tiles;
     const int plan = !tile_kernels || rx ? 0 : tiles8o <= coop8_max ? 2 : tiles8o <= coop_max ? 1 :
                      (tiles8o <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;

@@ -120,7 +120,7 @@ def test_the_device_side_choice_takes_either_kernel_and_the_bits_do_not_change(t
     import ctypes
     seen = {}
     for coop_max in (300, 40):
-        srf.set_launch_thresholds(0, coop_max, BIG)
+        srf.set_launch_thresholds(0, coop_max, BIG, 0)           # fixed tile order: sr_choose_kernel's bounding-box estimate decides
         got = render(cuda, fv, ft, 64, kw)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
@@ -140,7 +140,7 @@ def test_default_thresholds_pick_by_launch_size(cuda):
     assert np.array_equal(batch[5:6], one)
 
 
-# ---- this launch's own tile order (sr_order_kernel): multiples of 8 frames issue their 8x8 tiles heaviest first
+# ---- this launch's own tile order (sr_order_kernel): five frames and more issue their 8x8 tiles heaviest first
 
 def _order_table(cuda, N, F, IS):
     """The block -> tile table the last forward call left in the operator's workspace, and the setup kernel's pixel rects."""
@@ -158,7 +158,7 @@ def _order_table(cuda, N, F, IS):
     return table, rects, t8
 
 
-@pytest.mark.parametrize('count,IS,channels', [(8, 64, 3), (16, 100, 3), (8, 256, 3), (16, 72, 9), (24, 48, 6)])
+@pytest.mark.parametrize('count,IS,channels', [(8, 64, 3), (16, 100, 3), (8, 256, 3), (16, 72, 9), (24, 48, 6), (12, 64, 3), (7, 64, 9)])
 def test_heaviest_first_tile_order_gives_the_same_bits_in_every_kernel(cuda, count, IS, channels):
     fv, ft, near, far = synth.raster_batch(4 if IS < 256 else 8, 5, count=count)
     rng = np.random.default_rng(count)
@@ -178,8 +178,9 @@ def test_heaviest_first_tile_order_gives_the_same_bits_in_every_kernel(cuda, cou
         srf.set_launch_thresholds()
 
 
-def test_the_tile_order_is_a_permutation_sorted_by_the_faces_that_touch_each_tile(cuda):
-    N, IS = 16, 104                                            # 13 x 13 tiles per frame, the last column / row cut by the image edge
+@pytest.mark.parametrize('N,IS', [(16, 104), (12, 96), (5, 64)])
+def test_the_tile_order_is_a_permutation_sorted_by_the_faces_that_touch_each_tile(cuda, N, IS):
+    # 104: 13 x 13 tiles per frame, the last column / row cut by the image edge; 12 and 5 frames: an image split between two XCDs
     fv, ft, near, far = synth.raster_batch(4, 7, count=N)
     fv[3] += np.array([0.45, -0.3, 0.], np.float32)            # one object off-centre: the fixed spiral would start in its empty middle
     F = fv.shape[1]
@@ -197,25 +198,26 @@ def test_the_tile_order_is_a_permutation_sorted_by_the_faces_that_touch_each_til
             if x1 >= x0 and y1 >= y0:
                 w[n, y0 >> 3:(y1 >> 3) + 1, x0 >> 3:(x1 >> 3) + 1] += 1
     assert w.max() > 20
-    m = N // 8
-    per = m * t8 * t8
-    for x in range(8):                                          # block b runs on XCD b % 8 and takes entry b // 8 of its list
-        mine = slice(x * per, (x + 1) * per)
-        assert ((bn[mine] >= x * m) & (bn[mine] < (x + 1) * m)).all()
+    per = N * t8 * t8 // 8
+    entry = (bn * t8 + ty) * t8 + tx                            # position in the image-major (image, row, column) list
+    for x in range(8):                                          # block b runs on XCD b % 8 and takes entry b // 8 of its list:
+        mine = slice(x * per, (x + 1) * per)                    # the XCD's share of that list, an image possibly split with a neighbour
+        assert ((entry[mine] >= x * per) & (entry[mine] < (x + 1) * per)).all()
         key = np.minimum(w[bn[mine], ty[mine], tx[mine]], 255)
         assert (np.diff(key) <= 0).all(), 'XCD %d: tiles not in descending weight' % x
 
 
 def test_launches_the_tile_order_does_not_cover_fall_back_to_the_fixed_order(cuda):
-    # 12 frames (not a multiple of 8) and order_max_tiles below the launch size: no table, same bits as with it switched off
-    for count, order_max in ((12, BIG), (16, 100)):
+    # 4 frames (below the 5 the order pays from), 12 frames of 5 x 5 tiles (300 tiles do not divide over the 8 XCDs), and
+    # order_max_tiles below the launch size: no table, same bits as with it switched off
+    for count, IS, order_max in ((4, 64, BIG), (12, 40, BIG), (16, 64, 100)):
         fv, ft, near, far = synth.raster_batch(4, 5, count=count)
         kw = dict(synth.LASR_MODES, near=near, far=far)
         try:
             srf.set_launch_thresholds(-1, -1, -1, order_max)
-            a = render(cuda, fv, ft, 64, kw)
+            a = render(cuda, fv, ft, IS, kw)
             srf.set_launch_thresholds(-1, -1, -1, 0)
-            b = render(cuda, fv, ft, 64, kw)
+            b = render(cuda, fv, ft, IS, kw)
         finally:
             srf.set_launch_thresholds()
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
