@@ -36,7 +36,11 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     const int lane = threadIdx.x & 63;
     unsigned int* ring = s_ring[threadIdx.x >> 6];
     // blocks of one image stay on one XCD (block b runs on XCD b % 8): its 10 pixel planes (2.6 MB at 256x256) then
-    // live in a single 4 MB L2 instead of being fetched by all eight
+    // live in a single 4 MB L2 instead of being fetched by all eight.  Every XCD walks its faces LAST TO FIRST: the backward
+    // pass follows the forward pass, whose most recently written images are the ones still in L2 / Infinity Cache (measured,
+    // same box, first-to-last -> last-to-first: backward 1.292 -> 1.262 ms at 256 frames, 0.318 -> 0.310 at 64, 0.099 -> 0.092
+    // at 16, 0.998 -> 0.961 at 64 frames of 512x512; profiles/r04_tile_order_ab.txt).  A face's gradients are written by its
+    // own wave: the walk order does not enter the result.
 #if defined(LASR_BWD_ORDER) && LASR_BWD_ORDER == 1      // measurement build: the XCD's images interleaved face by face
     int blk = xcd_remap(blockIdx.x, gridDim.x);
     {
@@ -46,8 +50,14 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
             blk = ((blockIdx.x & 7) * m + (i - rank * m)) * A.F + rank;
         }
     }
-#else
+#elif defined(LASR_BWD_ORDER) && LASR_BWD_ORDER == 3    // measurement build: first to last (rounds 2-4 until this change)
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
+#else
+    int blk;
+    {
+        const int total = gridDim.x, per = total >> 3;
+        blk = (total & 7) == 0 ? (blockIdx.x & 7) * per + (per - 1 - (blockIdx.x >> 3)) : total - 1 - blockIdx.x;
+    }
 #endif
     const int gw = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
     if (gw >= A.N * A.F) return;
