@@ -585,8 +585,7 @@ def main():
                                    '(euclidean/softmax/prod/vertex, sigma=1e-4, gamma=1e-2)' % (IS, IS),
                        'frames_per_gpu_per_step': B, 'image_size': IS, 'faces': F, 'vertices': job.V,
                        'parallelism': 'dp%d (frames sharded, mesh-gradient all-reduce)' % world,
-                       'step_definition': 'face setup + [5 frames and more whose records stay within 8 MB per XCD -- not the 256-frame '
-                                          'headline launch: the launch\'s own tile order, sr_tile_weight_kernel + sr_order_kernel] + '
+                       'step_definition': 'face setup + [5 frames and more: the launch\'s own tile order, sr_tile_weight_kernel + sr_order_kernel] + '
                                           'forward kernel (background colour passed as an argument: no pre-fill pass, '
                                           'every element of soft_colors written) + backward kernel on the forward\'s face records, as the autograd operator '
                                           'runs it (--rebuild-records 1: a second face setup first) (stores every '

@@ -210,11 +210,11 @@ int lasr_sr_backward_f64(const double* faces, const double* textures, const doub
  * the tile's arithmetic: output bit-identical; forward + order kernels are 6-25 % faster at 6-128 frames, even at 256; below five frames the two order launches (12 us) cost more than they gain
  * (profiles/r04_tile_order_ab.txt).  For such launches four waves share a tile up to 4/7 of coop_max_tiles, the device-decided
  * range ends at 7/16 of choose_max_tiles, and the device decides on the count of non-empty tiles (at most 3/8 of
- * coop_max_tiles: four waves) instead of the bounding-box estimate.  Default (negative): no limit but the kernels' capacity
- * (images up to 1016 pixels a side, 61440 tiles per XCD) and the rule that the face records of an XCD's ceil(N / 8) images stay within
- * 8 MB, twice its L2 (2420 faces: up to 136 frames; beyond that the interleaved walk of all those images' crowded tiles
- * multiplies the record fetch -- 256 frames: 172 MB -> 1.18 GB per launch -- for a 2 % shorter kernel);
- * LASR_SR_ORDER_MAX_TILES at load time; 0 switches it off.
+ * coop_max_tiles: four waves) instead of the bounding-box estimate.  An XCD sorts all of its ceil(N / 8) images together while
+ * their face records stay within 8 MB, twice its L2 (2420 faces: up to 136 frames); larger launches (multiples of 8 frames) sort
+ * and issue them four images at a time (all 32 images of an XCD at once, 256 frames: record fetch 172 MB -> 1.18 GB per launch).
+ * Default (negative): no limit but the kernels' capacity (images up to 1016 pixels a side); LASR_SR_ORDER_MAX_TILES at load time;
+ * 0 switches it off.
  */
 typedef struct lasr_sr_options {
     long long coop8_max_tiles;

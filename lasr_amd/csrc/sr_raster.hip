@@ -179,7 +179,9 @@ __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned 
     __shared__ unsigned s_hist[256], s_base[256], s_wave[4];
     // this XCD's slice of the (image, tile) keys: N / 8 whole images, or -- frame counts that are not a multiple of 8 -- the same
     // share of the list with an image split between two neighbours (its records are then fetched into both L2s)
-    const int x = blockIdx.x, tiles = t8 * t8, entries = (int)(((long long)N * tiles) >> 3), e_first = x * entries;
+    // (large launches: the XCD's images in G groups, one workgroup each, sorted and issued one group after the other)
+    const int G = gridDim.x >> 3, x = blockIdx.x / G, grp = blockIdx.x - x * G, tiles = t8 * t8;
+    const int entries = (int)(((long long)N * tiles) >> 3) / G, e_first = (x * G + grp) * entries;
     const int lane = threadIdx.x & 63;
     const unsigned char* __restrict__ mine = keys + e_first;
     if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned 
     }
     if (busy && threadIdx.x == 0) atomicAdd(busy, entries - (int)s_hist[0]);    // the launch's non-empty tiles: the forward kernels' choice
     __syncthreads();
-    int* __restrict__ out = order + (size_t)x * entries;
+    int* __restrict__ out = order + e_first;
     const float inv_tiles = 1.f / (float)tiles, inv_t8 = 1.f / (float)t8;
     for (int e0 = threadIdx.x - lane; e0 < entries; e0 += ORDER_THREADS) {
         const int e = e0 + lane;
@@ -786,14 +788,19 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     // the 8x8-tile kernels, five frames and more: this launch's own tile order (sr_order_kernel)
     const int t8o = (IS + 7) / 8;
     const long long tiles8o = (long long)N * t8o * t8o;
-    // (an XCD then walks the crowded tiles of ALL its N / 8 images at once: while their records fit about twice its 4 MB L2 that
-    // costs little -- 128 frames of 2420 faces, 7.4 MB per XCD: forward -8 % -- beyond it the record fetch multiplies for nothing:
-    // 256 frames, 14.9 MB: FETCH_SIZE 172 MB -> 1.18 GB per launch for -2 % in the kernel and +32 us of order kernels)
+    // (an XCD walks the crowded tiles of ALL its N / 8 images at once while their records fit about twice its 4 MB L2 -- 128 frames of
+    // 2420 faces, 7.4 MB per XCD: forward -8 % -- beyond that the record fetch multiplies for nothing: 256 frames, 14.9 MB: FETCH_SIZE
+    // 172 MB -> 1.18 GB per launch.  Larger launches sort and issue the XCD's images four at a time, the interleave of the fixed
+    // order: 256 frames, forward 1.964 -> 1.915 ms + 15 us of order kernels; groups of 2 / 16: 1.924 / 1.925)
     // (below 5 frames the two order launches, 12 us, cost more than the order gains: 4 frames forward .089 -> .081 ms, step .153 -> .155)
     static const int order_min_frames = (int)env_blocks("LASR_SR_ORDER_MIN_FRAMES", 5);
+    static const int order_group_images = (int)env_blocks("LASR_SR_ORDER_GROUP_IMAGES", 4);
+    int order_groups = 1;
+    if ((long long)((N + 7) >> 3) * F * REC * (long long)sizeof(float) > (8ll << 20) || tiles8o > 8ll * ORDER_MAX_ENTRIES)
+        order_groups = (N & 7) == 0 && order_group_images > 0 && (N >> 3) % order_group_images == 0 ? (N >> 3) / order_group_images : 0;
     const bool use_order = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && N >= order_min_frames && (tiles8o & 7) == 0 &&
-                           tiles8o <= g_order_max_tiles && t8o <= ORDER_MAX_SIDE && tiles8o <= 8ll * ORDER_MAX_ENTRIES && N < 32768 &&
-                           (long long)((N + 7) >> 3) * F * REC * (long long)sizeof(float) <= (8ll << 20);
+                           tiles8o <= g_order_max_tiles && t8o <= ORDER_MAX_SIDE && order_groups > 0 &&
+                           tiles8o <= 8ll * order_groups * ORDER_MAX_ENTRIES && N < 32768;
     char* const slot = (char*)grects + align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256);   // [0] sr_choose_kernel's word
     if (total > 0) {
         {
@@ -829,7 +836,8 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
         int* busy = plan == 3 ? (int*)slot : nullptr;
         ProfScope po(K_SR_ORDER, st);
         hipLaunchKernelGGL(sr_tile_weight_kernel, dim3((unsigned)N), dim3(512), 0, st, rects, F, t8o, keys, busy);
-        hipLaunchKernelGGL(sr_order_kernel, dim3(8), dim3(ORDER_THREADS), align_up((size_t)(tiles8o / 8), 16), st, keys, N, t8o, order, busy);
+        hipLaunchKernelGGL(sr_order_kernel, dim3(8 * order_groups), dim3(ORDER_THREADS), align_up((size_t)(tiles8o / 8 / order_groups), 16), st,
+                           keys, N, t8o, order, busy);
         A.order = order;
         if (plan == 3) {
             A.choice = busy;
