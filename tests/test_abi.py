@@ -119,3 +119,21 @@ def test_header_constants_match_the_python_mirror():
     assert define(sr, 'LASR_SR_RELAXED_MATH') == _lib.SR_RELAXED_MATH
     assert define(sr, 'LASR_SR_RECORDS_VALID') == _lib.SR_RECORDS_VALID
     assert define(sr, 'LASR_SR_GRADS_OVERWRITE') == _lib.SR_GRADS_OVERWRITE
+
+
+def test_options_struct_of_the_python_mirror_is_the_header_s():
+    # lasr_sr_options (include/lasr_sr.h) <-> _lib.SrOptions: same fields, same order, all `long long`; the workspace size the
+    # library asks for depends on the image size (the forward's tile-order table lives there)
+    import ctypes
+    import re
+    from lasr_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sr = open(os.path.join(root, 'include', 'lasr_sr.h')).read()
+    body = re.search(r'typedef struct lasr_sr_options \{(.*?)\} lasr_sr_options;', sr, re.S).group(1)
+    fields = re.findall(r'long long\s+(\w+);', body)
+    assert fields == [n for n, _ in _lib.SrOptions._fields_] == ['coop8_max_tiles', 'coop_max_tiles', 'choose_max_tiles', 'order_max_tiles']
+    assert all(t is ctypes.c_longlong for _, t in _lib.SrOptions._fields_) and ctypes.sizeof(_lib.SrOptions) == 8 * len(fields)
+    h = _lib.lib()
+    small, large = h.lasr_sr_workspace_bytes(8, 100, 3, 64), h.lasr_sr_workspace_bytes(8, 100, 3, 256)
+    assert large - small >= 8 * (32 * 32 - 8 * 8) * 4                      # 4 bytes per (image, 8x8 tile) at least
+    assert h.lasr_sr_workspace_bytes(8, 100, 3, 0) <= small
