@@ -137,3 +137,28 @@ def test_options_struct_of_the_python_mirror_is_the_header_s():
     small, large = h.lasr_sr_workspace_bytes(8, 100, 3, 64), h.lasr_sr_workspace_bytes(8, 100, 3, 256)
     assert large - small >= 8 * (32 * 32 - 8 * 8) * 4                      # 4 bytes per (image, 8x8 tile) at least
     assert h.lasr_sr_workspace_bytes(8, 100, 3, 0) <= small
+
+
+def test_operator_launch_options_are_per_call_arguments_not_library_state():
+    # the operator keeps its lasr_sr_options struct on the Python side and passes it with every forward call (the library has
+    # no setters since round 4); no arguments = NULL = every default
+    import importlib
+    sr_mod = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
+    from lasr_amd.soft_renderer import functional as srf
+    h = __import__('lasr_amd._lib', fromlist=['lib']).lib()
+    assert not hasattr(h, 'lasr_sr_set_launch_thresholds') and not hasattr(h, 'lasr_sr_set_forward_math')
+    try:
+        assert sr_mod._options_ref() is None
+        srf.set_launch_thresholds(0, 10, 20, 0)
+        o = sr_mod._launch_options
+        assert (o.coop8_max_tiles, o.coop_max_tiles, o.choose_max_tiles, o.order_max_tiles) == (0, 10, 20, 0)
+        assert sr_mod._options_ref() is not None
+        srf.set_launch_thresholds(order_max_tiles=0)                # only the tile order switched off: the rest stay defaults
+        o = sr_mod._launch_options
+        assert (o.coop8_max_tiles, o.coop_max_tiles, o.choose_max_tiles, o.order_max_tiles) == (-1, -1, -1, 0)
+    finally:
+        srf.set_launch_thresholds()
+    assert sr_mod._options_ref() is None
+    old = srf.set_forward_flags(srf.SR_SEGMENTED) if hasattr(srf, 'SR_SEGMENTED') else None
+    if old is not None:
+        srf.set_forward_flags(old)
