@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--no-lbs', action='store_true', help='skip the LBS (MFMA) micro-benchmark block')
     ap.add_argument('--no-sweep', action='store_true', help='skip the launch-size sweep (N = 1/4/16/64 at 256^2, 64 at 512^2)')
     ap.add_argument('--lasr-iters', type=int, default=20, help='optimize.py-style iterations timed at N=1 (0 = skip)')
+    ap.add_argument('--no-step-profile', action='store_true', help='skip the in_scope_step block (a rocprofv3 kernel trace of one '
+                    'optimisation iteration per configuration, taken in a child process)')
+    ap.add_argument('--step-worker', default='', help=argparse.SUPPRESS)       # child mode of the in_scope_step block
     return ap.parse_args()
 
 
@@ -322,6 +325,183 @@ def optimize_dp_leg(dev, iters, rank, world, dist):
     return out
 
 
+STEP_CONFIGS = {
+    # scripts/spot3.sh:24 -- stage 0: 1 pair per GPU, 8 hypotheses, 21 bones, icosphere-3, 256x256: 16 meshes per render
+    'spot3_s0': dict(flags=['--only_mean_sym', '--subdivide', '3', '--n_bones', '21', '--n_hypo', '8', '--batch_size', '1'],
+                     note='spot3 stage 0 (scripts/spot3.sh:24): B=1 pair, H=8, K=21, V=642/F=1280, 256x256, 16 meshes per render'),
+    # scripts/template.sh:30 -- last stage of the camel schedule: 2 pairs per GPU, 1 hypothesis, 36 bones, 2560 faces, 512x512,
+    # symmetry constraint dropped (the mesh comes out of the stage hand-off's exact-count re-mesh)
+    'camel_s4': dict(flags=['--nosymmetric', '--noonly_mean_sym', '--subdivide', '3', '--n_bones', '36', '--n_hypo', '1', '--batch_size', '2',
+                            '--img_size', '512', '--n_faces', '2560', '--n_frames', '8'],
+                     stage_before=['--subdivide', '3', '--n_bones', '1', '--n_hypo', '1', '--batch_size', '1', '--img_size', '512',
+                                   '--n_frames', '8'],
+                     note='camel stage 4 (scripts/template.sh:30, BASELINE configs[2]): B=2 pairs, H=1, K=36, V=1282/F=2560 (re-meshed), '
+                          '512x512, 4 meshes per render'),
+}
+RASTER_KERNELS = ('sr_forward_kernel', 'sr_backward_kernel', 'sr_setup_kernel', 'sr_tile_weight_kernel', 'sr_order_kernel',
+                  'sr_forward_coop_kernel', 'sr_forward_head_kernel')
+
+
+def step_worker(name):
+    """Child process of in_scope_step_leg (run under rocprofv3 --kernel-trace): a few optimisation iterations of one
+    configuration, forward + backward replayed as a HIP graph like optimize.py runs them."""
+    import tempfile
+    import optimize
+    from lasr_amd.nnutils import train_utils
+    cfg = STEP_CONFIGS[name]
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    common = ['--nouse_gtpose', '--num_epochs', '5', '--opt_tex', 'yes', '--iters_per_epoch', '40', '--use_graph']
+    extra = []
+    with tempfile.TemporaryDirectory() as tmp:
+        if 'stage_before' in cfg:                      # the previous stage's checkpoint for the hand-off (train_utils.load_network)
+            o = optimize.parse_flags(['--name', 'prev', '--checkpoint_dir', tmp] + common + cfg['stage_before'])
+            o.local_rank = 0
+            torch.manual_seed(0)
+            tr0 = train_utils.LASRTrainer(o).init_training()
+            tr0.epoch_nscore = torch.zeros(o.n_hypo, device=dev)
+            tr0.save('latest')
+            extra = ['--model_path', os.path.join(tr0.save_dir, 'pred_net_latest.pth')]
+            del tr0
+        opts = optimize.parse_flags(['--name', 'bench', '--checkpoint_dir', ''] + common + cfg['flags'] + extra)
+        opts.local_rank = 0
+        torch.manual_seed(0)
+        tr = train_utils.LASRTrainer(opts).init_training()
+    tr.model.train()
+    tr.reinit_bones()
+    n = len(tr.dataloader)
+    for i in range(18):                                # iteration 0: eager (part render); then capture; then replays
+        tr.module.iters = i
+        tr.train_step(tr.set_input(tr.dataloader[i % n]))
+    torch.cuda.synchronize()
+    print('step-worker %s done' % name, flush=True)
+
+
+def _demangled_base(name):
+    """'_ZN4lasr17sr_forward_kernelILb1E...' / 'void lasr::sr_forward_kernel<...>(...)' -> ('sr_forward_kernel', in_library)."""
+    import re
+    m = re.match(r'_ZN4lasr(\d+)', name)
+    if m:
+        k = int(m.group(1))
+        return name[m.end():m.end() + k], True
+    m = re.match(r'_Z(\d+)', name)
+    if m:
+        k = int(m.group(1))
+        base = name[m.end():m.end() + k]
+        return base, base == 'gather_rows_kernel'
+    m = re.search(r'lasr::([A-Za-z0-9_]+)', name)
+    if m:
+        return m.group(1), True
+    if 'gather_rows_kernel' in name:
+        return 'gather_rows_kernel', True
+    return name.split('(')[0][:60], False
+
+
+def step_trace_summary(db_path, cfg_name):
+    """One steady-state iteration (between two tail_adamw launches) of a rocprofv3 rocpd kernel trace -> per-kernel us of the
+    library's kernels, grouped raster / tail / other, and what remains (MIOpen convolutions, torch glue of the networks)."""
+    import sqlite3
+    c = sqlite3.connect(db_path)
+    rows = list(c.execute('select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d '
+                          'join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start'))
+    ends = [i for i, r in enumerate(rows) if 'tail_adamw' in r[0]]
+    if len(ends) < 3:
+        raise RuntimeError('the trace holds %d optimisation steps' % len(ends))
+    per = {}
+    n_iters = min(5, len(ends) - 1)                    # average over the last few iterations
+    for j in range(n_iters):
+        for name, t0, t1 in rows[ends[-2 - j] + 1:ends[-1 - j] + 1]:
+            base, ours = _demangled_base(name)
+            e = per.setdefault(base, [0.0, 0, ours])
+            e[0] += (t1 - t0) / 1e3
+            e[1] += 1
+    groups = {'raster': {}, 'tail': {}, 'other_in_scope': {}}
+    out_scope_us, out_scope_n = 0.0, 0
+    for base, (us, cnt, ours) in per.items():
+        us, cnt = us / n_iters, cnt / n_iters
+        if not ours:
+            out_scope_us += us
+            out_scope_n += cnt
+            continue
+        g = 'raster' if base in RASTER_KERNELS else ('tail' if base.startswith('tail_') else 'other_in_scope')
+        groups[g][base] = {'us': round(us, 2), 'launches': round(cnt, 2)}
+    seq = rows[ends[-2] + 1:ends[-1] + 1]
+    res = {'config': STEP_CONFIGS[cfg_name]['note'], 'iterations_averaged': n_iters,
+           'kernels_per_iteration': len(seq), 'wall_us': round((seq[-1][2] - seq[0][1]) / 1e3, 1)}
+    for g, ks in groups.items():
+        res[g + '_us'] = round(sum(k['us'] for k in ks.values()), 1)
+        res[g + '_launches'] = round(sum(k['launches'] for k in ks.values()), 1)
+        res[g] = dict(sorted(ks.items(), key=lambda kv: -kv[1]['us']))
+    res['out_of_scope_us'] = round(out_scope_us, 1)
+    res['out_of_scope_launches'] = round(out_scope_n, 1)
+    return res
+
+
+def loss_reduction_figures(step, I, H, P, feat_shapes):
+    """GB/s of the loss-reduction kernels north_star names, from the same trace: algorithmic bytes (silhouette 12 P,
+    flow 24 P, texture 40 P bytes per rendered image = 76 P for the fused table kernels; the backward reads the same planes again
+    and writes the ten gradient planes: 116 P; perceptual reduction 2 / 3 x N C P x 4 per layer, fused.hip) / kernel time."""
+    N = I * H
+    ks = step['other_in_scope']
+    out = {}
+
+    def add(name, kernels, nbytes):
+        us = sum(ks[k]['us'] for k in kernels if k in ks)
+        if us > 0:
+            out[name] = {'kernels': [k for k in kernels if k in ks], 'us': round(us, 2), 'algorithmic_bytes': int(nbytes),
+                         'GBs': round(nbytes / us / 1e3, 1), 'frac_of_hbm_peak': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+    add('render_tables_forward', ['render_tables_forward_kernel', 'render_tables_flow_kernel', 'render_tables_fold_kernel',
+                                  'render_tables_flow_fold_kernel'], 76 * P * N)
+    add('render_tables_backward', ['render_tables_backward_kernel', 'render_tables_intrinsics_fold_kernel'], 116 * P * N)
+    cp = sum(c * p for c, p in feat_shapes)
+    add('cosdist_forward', ['cosdist_multi_forward_kernel', 'cosdist_forward_kernel', 'cosdist_fold_kernel'], 2 * 2 * N * cp * 4)
+    add('cosdist_backward', ['cosdist_multi_backward_kernel', 'cosdist_backward_kernel'], 3 * 2 * N * cp * 4)
+    return out
+
+
+def in_scope_step_leg():
+    """where the optimisation step's in-scope time goes at the sizes LASR launches.  For each configuration a
+    child process runs a few graph-replayed iterations under `rocprofv3 --kernel-trace`; the trace's dispatch timestamps (what
+    profiles/r05_optimize_step_kernel_stats.txt is built from) give per-kernel us of one iteration.  In-library HIP events cannot
+    time kernels inside a graph replay, and around eager launches they add the launch gap to every few-us kernel."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    out = {'source': 'rocprofv3 --kernel-trace of `bench.py --step-worker <config>` (child process), dispatch end - start per kernel, '
+                     'mean of the last iterations; groups: raster = sr_* kernels, tail = clip / NaN guard / AdamW, other_in_scope = '
+                     'every other kernel of liblasr_hip.so; out_of_scope = MIOpen / rocBLAS / ATen kernels of the encoder and AlexNet'}
+    if shutil.which('rocprofv3') is None:
+        out['error'] = 'rocprofv3 not on PATH'
+        return out
+    shapes = {'spot3_s0': (2, 8, 256 * 256), 'camel_s4': (4, 1, 512 * 512)}
+    for name in STEP_CONFIGS:
+        tmp = tempfile.mkdtemp(prefix='lasr_step_', dir='/tmp')
+        try:
+            env = dict(os.environ, TMPDIR='/tmp')
+            cmd = ['rocprofv3', '--kernel-trace', '-d', tmp, '-o', 't', '--', sys.executable, os.path.abspath(__file__), '--step-worker', name]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            dbs = glob.glob(os.path.join(tmp, '**', '*.db'), recursive=True)
+            if r.returncode != 0 or not dbs:
+                out[name] = {'error': 'rc %d: %s' % (r.returncode, r.stdout.decode(errors='replace')[-400:])}
+                continue
+            step = step_trace_summary(dbs[0], name)
+            I, H, P = shapes[name]
+            side = int(P ** 0.5)
+            f = lambda n, k, s_, p_: (n + 2 * p_ - k) // s_ + 1                     # noqa: E731
+            c1 = f(side, 11, 4, 2)
+            c2 = f(c1, 3, 2, 0)
+            c3 = f(c2, 3, 2, 0)
+            step['loss_reductions'] = loss_reduction_figures(step, I, H, P, [(64, c1 * c1), (192, c2 * c2), (384, c3 * c3),
+                                                                             (256, c3 * c3), (256, c3 * c3)])
+            out[name] = step
+        except Exception as e:                       # the headline line must not depend on the profiler
+            out[name] = {'error': repr(e)[:400]}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 RASTER_SOURCES = ('sr_raster.hip', 'sr_forward_coop.h', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
 VALU_PEAK_LANE_OPS = 1024 * 32 * 2.4e9      # 256 CUs x 4 SIMDs, 32 fp32 lanes per SIMD per clock (a wave64 op issues in 2), 2.4 GHz
 
@@ -487,6 +667,8 @@ def sweep_leg(dev, points, steps_budget_ms=150.0):
 def main():
     global IS, REBUILD_RECORDS
     a = parse()
+    if a.step_worker:
+        return step_worker(a.step_worker)
     IS = a.image_size
     REBUILD_RECORDS = a.rebuild_records
     rank = int(os.environ.get('RANK', 0))
@@ -631,6 +813,10 @@ def main():
             out['lbs'] = lbs_leg(dev)
         if world == 1 and a.lasr_iters > 0:
             out['optimize_py'] = optimize_leg(dev, a.lasr_iters)
+        if world == 1 and a.lasr_iters > 0 and not a.no_step_profile:
+            # after every timed leg: the child process shares this GPU while it runs
+            torch.cuda.synchronize()
+            out['in_scope_step'] = in_scope_step_leg()
     dp = optimize_dp_leg(dev, a.lasr_iters, rank, world, dist) if world > 1 and a.lasr_iters > 0 else None     # every rank takes part
     if rank == 0:
         if dp is not None:

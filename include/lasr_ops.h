@@ -32,12 +32,16 @@ int lasr_lbs_forward(const float* verts, const float* Rmat, const float* Tmat, c
 int lasr_lbs_forward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out_cam,
                           float* out_blend, int N, int V, int K, void* hip_stream);
 size_t lasr_lbs_backward_scratch_floats(int N, int V, int K);     /* chunk partials of the transform gradients */
+/* Backward.  ticket: one zeroed device word (left zero) -> ONE launch with all three contractions (blended transform, g_skin,
+ * the transposed g_RT) on v_mfma_f32_16x16x4_f32 and the chunk fold done by the launch's last block; NULL (or K > 65) -> the
+ * two-launch VALU path of ABI version 1. */
 int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                       const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
-                      float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream);
+                      float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam, void* hip_stream);
 int lasr_lbs_backward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                            const float* grad_out_cam, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
-                           float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, void* hip_stream);
+                           float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K,
+                           void* hip_stream);
 
 /*
  * Pinhole projection, nnutils/geom_utils.py:27-34 (pinhole_cam), with pp / fl already expanded per mesh:
@@ -120,6 +124,25 @@ int lasr_laplacian_forward(const float* x, const int* row_ptr, const int* col, f
                            void* hip_stream);
 int lasr_laplacian_backward(const float* x, const int* row_ptr, const int* col, const float* grad_loss,
                             float* grad_x, float* scratch_lx /*[N,V,3]*/, int N, int V, void* hip_stream);
+
+/*
+ * The three shape regularisers of a step in ONE launch each way (nnutils/mesh_net.py:449-459 Laplacian + flatten on the mean shape
+ * x [N,V,3]; :494-497 ARAP between the two frames' deformed shapes arap_dx / arap_x [NA,V,3]); the same arithmetic and summation
+ * orders as lasr_laplacian_* / lasr_flatten_* / lasr_arap_*, results bit-identical to calling those one by one:
+ *   lap_loss [N], flat_loss [N], arap_loss [NA];  lap_coords [N,V,3] = the Laplacian coordinates, kept by the caller for the backward.
+ * Index buffers as for the separate entry points (CSR adjacency of the Laplacian and of ARAP, quads [E,4], incidence CSR of the
+ * flatten backward).  Backward: grad_x [N,V,3] = Laplacian part + flatten part (overwritten), grad_arap_dx / grad_arap_x [NA,V,3]
+ * (either may be NULL).  N or NA may be 0.
+ */
+int lasr_mesh_regularisers_forward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
+                                   const int* lap_col, const int* arap_row_ptr, const int* arap_col, const int* quads,
+                                   float* lap_loss, float* lap_coords, float* flat_loss, float* arap_loss, int N, int NA, int V,
+                                   int E, void* hip_stream);
+int lasr_mesh_regularisers_backward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
+                                    const int* lap_col, const int* arap_row_ptr, const int* arap_col, const int* quads,
+                                    const int* inc_ptr, const int* inc, const float* lap_coords, const float* grad_lap,
+                                    const float* grad_flat, const float* grad_arap, float* grad_x, float* grad_arap_dx,
+                                    float* grad_arap_x, int N, int NA, int V, int E, void* hip_stream);
 
 /*
  * Flow reprojection, nnutils/mesh_net.py:93-104 (the tail of render_flow_soft_2 after the render).
@@ -236,6 +259,21 @@ int lasr_cosdist_forward(const float* feat_obs, const float* feat_rnd, float* di
                          int rep, void* hip_stream);
 int lasr_cosdist_backward(const float* feat_obs, const float* feat_rnd, const float* grad_dist, float* grad_rnd, int N,
                           int C, int P, int rep, void* hip_stream);
+
+/*
+ * The same reduction over ALL feature layers of the perceptual network in one launch each way (the sum over layers of
+ * models/networks_basic.py:51-64): dist[n] = sum_l (1 - mean_p cos_l[n,p]), layers added in list order, each layer's value
+ * bit-identical to lasr_cosdist_forward's.  feat_obs / feat_rnd / grad_rnd: HOST arrays of n_layers device pointers
+ * ([N/rep, C_l, P_l] / [N, C_l, P_l]); C, P: host arrays; n_layers <= LASR_COSDIST_MAX_LAYERS.
+ * scratch: lasr_cosdist_multi_scratch_floats floats.  ticket: one device word, ZERO on entry, left zero (the launch's last
+ * block folds the tile partials; see "tickets" below).  Backward: every grad_rnd[l] overwritten.
+ */
+#define LASR_COSDIST_MAX_LAYERS 8
+size_t lasr_cosdist_multi_scratch_floats(const int* P, int n_layers, int N);
+int lasr_cosdist_multi_forward(const float* const* feat_obs, const float* const* feat_rnd, const int* C, const int* P,
+                               int n_layers, float* dist, float* scratch, unsigned int* ticket, int N, int rep, void* hip_stream);
+int lasr_cosdist_multi_backward(const float* const* feat_obs, const float* const* feat_rnd, const int* C, const int* P,
+                                int n_layers, const float* grad_dist, float* const* grad_rnd, int N, int rep, void* hip_stream);
 
 /*
  * Texture atlas -> per-face surface textures, replaces `soft_renderer.cuda.load_textures`
@@ -374,6 +412,28 @@ int lasr_raster_inputs_forward(const float* verts_cam, const float* tex, const f
 int lasr_raster_inputs_backward(const float* verts_cam, const float* fl, const float* grad_verts_pre, const float* grad_attrs,
                                 float* grad_verts_cam, float* grad_tex, float* grad_pp, float* grad_fl, int N, int V,
                                 void* hip_stream);
+
+/*
+ * The same stage per FACE CORNER, one launch each way (what the rasteriser consumes; replaces, for LASR.forward's own render,
+ * lasr_raster_inputs_forward + the camera stage's `vertices - eye` (third_party/softras/soft_renderer/functional/look_at.py:6-62
+ * with a constant eye on the -z axis, rotation = identity) + two lasr_face_gather_forward calls, and their three backward
+ * launches):
+ *   face_vertices[n,f,c,:] = ((pinhole(verts_cam[n, faces[f,c]]) + eye) * (1,-1,1)) - eye          [N,F,3,3]
+ *   face_attrs[n,f,c,:]    = (tex | verts_cam | verts_cam of mesh (n + N/2) % N) at that vertex      [N,F,3,9]
+ *   near_far               = as lasr_raster_inputs_forward
+ * faces: int64 [N,F,3], or [1,F,3] with faces_shared = 1 (all meshes share the connectivity).  Backward: the vertex-centric sums
+ * run over a CSR incidence structure the caller builds once per connectivity: inc_ptr int32 [N or 1, V+1], inc int32 [N or 1, 3F] =
+ * corner ids (3 f + c) grouped by vertex, ASCENDING inside a vertex (the summation order of lasr_face_gather_backward).
+ * scratch: lasr_raster_faces_scratch_floats(N, V, F) floats (either direction).  ticket: one zeroed device word, left zero.
+ */
+size_t lasr_raster_faces_scratch_floats(int N, int V, int F);
+int lasr_raster_faces_forward(const float* verts_cam, const float* tex, const float* pp, const float* fl, const float* eye,
+                              const long long* faces, int faces_shared, float* face_vertices, float* face_attrs, float* near_far,
+                              float* scratch, unsigned int* ticket, int N, int V, int F, void* hip_stream);
+int lasr_raster_faces_backward(const float* verts_cam, const float* fl, const int* inc_ptr, const int* inc, int faces_shared,
+                               const float* grad_face_vertices, const float* grad_face_attrs, float* grad_verts_cam,
+                               float* grad_tex, float* grad_pp, float* grad_fl, float* scratch, unsigned int* ticket, int N, int V,
+                               int F, void* hip_stream);
 
 #define LASR_GATHER_MAX_KEYS 24
 int lasr_gather_rows(const float* table, long long W, int pairs, const long long* ids, int B, int n_keys,

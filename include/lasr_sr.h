@@ -39,6 +39,16 @@ extern "C" {
 #define LASR_E_LAUNCH     (-4)   /* HIP reported an error at launch (see lasr_last_hip_error) */
 #define LASR_E_NODEVICE   (-5)   /* no gfx950 device / code object not loadable       */
 
+/* Version of THIS header.  A caller built against it checks `lasr_abi_version() == LASR_ABI_VERSION` after loading the library
+ * (lasr_amd/_lib.py and the INTEGRATION.md stub do); the number moves whenever an exported signature or a size contract changes.
+ *   1  rounds 1-3.
+ *   2  round 4: lasr_prof_enable(void* stream, int on) / lasr_prof_collect(void* stream, ...) (were process-wide),
+ *      lasr_sr_set_forward_math / lasr_sr_set_launch_thresholds removed (per-call lasr_sr_options / flags instead),
+ *      lasr_sr_workspace_bytes grows with IS (tile-order table).
+ *   3  round 5: lasr_lbs_backward / lasr_lbs_backward_both take a ticket word; lasr_skin_weights_backward ignores its scratch;
+ *      lasr_render_tables_* run 2 + 1 launches (same signatures, the scratch's last 16 floats hold block tickets);
+ *      new: lasr_cosdist_multi_*, lasr_raster_faces_*, lasr_mesh_regularisers_*. */
+#define LASR_ABI_VERSION 3
 int         lasr_abi_version(void);
 const char* lasr_strerror(int code);
 int         lasr_last_hip_error(void);      /* hipError_t of the most recent LASR_E_LAUNCH on this thread */

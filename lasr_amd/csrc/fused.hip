@@ -15,6 +15,7 @@
 
 #include "../../include/lasr_ops.h"
 #include "ops_common.h"
+#include "mesh_losses.h"
 
 namespace lasr {
 
@@ -189,39 +190,46 @@ __device__ __forceinline__ void load_bones(Bone* bones, const float* ts, const f
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void skin_forward_kernel(const float* __restrict__ ts, const float* __restrict__ rs,
-                                                           const float* __restrict__ lc, const float* __restrict__ verts,
-                                                           float* __restrict__ skin, int V, int J)
+// One wave per block (V = 642 x 8 hypotheses: 88 blocks instead of 24 -- the launch is a latency chain, not bandwidth); the
+// logits of all bones are evaluated ONCE into registers when they fit (J <= MAXJ; LASR: 20 or 35 part bones), the max / sum /
+// normalise passes then run on registers.  Same expressions in the same order as the three-pass form (MAXJ = 0, kept for
+// larger bone counts): bit-identical weights.
+template <int MAXJ>
+__global__ __launch_bounds__(64) void skin_forward_kernel(const float* __restrict__ ts, const float* __restrict__ rs,
+                                                          const float* __restrict__ lc, const float* __restrict__ verts,
+                                                          float* __restrict__ skin, int V, int J)
 {
     __shared__ Bone bones[SKIN_MAX_BONES];
-    const int h = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y, v = blockIdx.x * 64 + threadIdx.x;
     load_bones(bones, ts, rs, lc, h, J);
     if (v >= V) return;
     const float* p = verts + ((size_t)h * V + v) * 3;
     const float vx = p[0], vy = p[1], vz = p[2];
     float r[3], mx = -INFINITY;
+    if (MAXJ > 0) {
+        float lg[MAXJ > 0 ? MAXJ : 1];
+#pragma unroll
+        for (int k = 0; k < MAXJ; k++) if (k < J) { lg[k] = bone_logit(bones[k], vx, vy, vz, r); mx = fmaxf(mx, lg[k]); }
+        float z = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXJ; k++) if (k < J) { lg[k] = expf(lg[k] - mx); z += lg[k]; }
+#pragma unroll
+        for (int k = 0; k < MAXJ; k++) if (k < J) skin[((size_t)h * J + k) * V + v] = lg[k] / z;
+        return;
+    }
     for (int k = 0; k < J; k++) mx = fmaxf(mx, bone_logit(bones[k], vx, vy, vz, r));
     float z = 0.f;
     for (int k = 0; k < J; k++) z += expf(bone_logit(bones[k], vx, vy, vz, r) - mx);
     for (int k = 0; k < J; k++) skin[((size_t)h * J + k) * V + v] = expf(bone_logit(bones[k], vx, vy, vz, r) - mx) / z;
 }
 
-// backward, stage 1: dot[h,v] = sum_k skin * gskin (the softmax Jacobian's common term)
-__global__ __launch_bounds__(256) void skin_backward_dot_kernel(const float* __restrict__ skin, const float* __restrict__ gskin,
-                                                                float* __restrict__ dot, int V, int J)
-{
-    const int h = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    float d = 0.f;
-    for (int k = 0; k < J; k++) { const size_t i = ((size_t)h * J + k) * V + v; d += skin[i] * gskin[i]; }
-    dot[(size_t)h * V + v] = d;
-}
-
-// backward, stage 2: one block per (h, bone): sums over the vertices, then the quaternion / log-scale chain
+// backward: one block per (h, bone): sums over the vertices, then the quaternion / log-scale chain.  The softmax Jacobian's
+// common term dot[h,v] = sum_k skin * gskin is formed by each block for the vertices it walks (J coalesced loads per vertex
+// from L2, bones in order: the value the former separate skin_backward_dot_kernel launch wrote, 10 us of launch saved).
 __global__ __launch_bounds__(256) void skin_backward_kernel(const float* __restrict__ ts, const float* __restrict__ rs,
                                                             const float* __restrict__ lc, const float* __restrict__ verts,
                                                             const float* __restrict__ skin, const float* __restrict__ gskin,
-                                                            const float* __restrict__ dot, float* __restrict__ gts,
+                                                            float* __restrict__ gts,
                                                             float* __restrict__ grs, float* __restrict__ glc, int V, int J)
 {
     __shared__ float red[4];
@@ -236,7 +244,9 @@ __global__ __launch_bounds__(256) void skin_backward_kernel(const float* __restr
     for (int v = threadIdx.x; v < V; v += 256) {
         const float* p = verts + ((size_t)h * V + v) * 3;
         const size_t i = (size_t)hk * V + v;
-        const float ge = -10.f * (skin[i] * (gskin[i] - dot[(size_t)h * V + v]));     // d loss / d (sum_d w_d r_d^2)
+        float dot = 0.f;
+        for (int k = 0; k < J; k++) { const size_t e = ((size_t)h * J + k) * V + v; dot += skin[e] * gskin[e]; }
+        const float ge = -10.f * (skin[i] * (gskin[i] - dot));                        // d loss / d (sum_d w_d r_d^2)
         float r[3];
         const float d0 = b.t[0] - p[0], d1 = b.t[1] - p[1], d2 = b.t[2] - p[2];
         r[0] = d0 * b.R[0] + d1 * b.R[3] + d2 * b.R[6];
@@ -269,101 +279,27 @@ __global__ __launch_bounds__(256) void skin_backward_kernel(const float* __restr
 //   loss[n] = sum_e (cos_e + 1)^2, cos_e = the cosine between the components of (v2-v0), (v3-v0) orthogonal to (v1-v0)
 // quads [E,4] int32 (v0,v1,v2,v3), x [N,V,3] -> loss [N].
 // ===========================================================================
-constexpr float FLAT_EPS = 1e-6f;
-
-struct FlatSide { float b[3], cb[3], bl1, ab, den, cosb, sinb, t, nb; };
-
-__device__ __forceinline__ void flat_side(const float* a, float al2, float sq_al2, const float* v0, const float* vb, FlatSide& s)
-{
-    float bl2 = 0.f; s.ab = 0.f;
-#pragma unroll
-    for (int d = 0; d < 3; d++) { s.b[d] = vb[d] - v0[d]; bl2 += s.b[d] * s.b[d]; s.ab += a[d] * s.b[d]; }
-    s.bl1 = sqrtf(bl2 + FLAT_EPS);
-    s.den = sq_al2 * s.bl1 + FLAT_EPS;
-    s.cosb = s.ab / s.den;
-    s.sinb = sqrtf(1.f - s.cosb * s.cosb + FLAT_EPS);
-    s.t = s.ab / (al2 + FLAT_EPS);
-#pragma unroll
-    for (int d = 0; d < 3; d++) s.cb[d] = s.b[d] - a[d] * s.t;
-    s.nb = s.bl1 * s.sinb;
-}
-
-struct FlatEdge { float a[3], al2, sq_al2; FlatSide s1, s2; float S, D, cos; };
-
-__device__ __forceinline__ void flat_edge(const float* x, const int* q, FlatEdge& e)
-{
-    const float* v0 = x + 3 * (size_t)q[0];
-    const float* v1 = x + 3 * (size_t)q[1];
-    e.al2 = 0.f;
-#pragma unroll
-    for (int d = 0; d < 3; d++) { e.a[d] = v1[d] - v0[d]; e.al2 += e.a[d] * e.a[d]; }
-    e.sq_al2 = sqrtf(e.al2 + FLAT_EPS);
-    flat_side(e.a, e.al2, e.sq_al2, v0, x + 3 * (size_t)q[2], e.s1);
-    flat_side(e.a, e.al2, e.sq_al2, v0, x + 3 * (size_t)q[3], e.s2);
-    e.S = e.s1.cb[0] * e.s2.cb[0] + e.s1.cb[1] * e.s2.cb[1] + e.s1.cb[2] * e.s2.cb[2];
-    e.D = e.s1.nb * e.s2.nb + FLAT_EPS;
-    e.cos = e.S / e.D;
-}
-
 __global__ __launch_bounds__(256) void flatten_forward_kernel(const float* __restrict__ x, const int* __restrict__ quads,
                                                               float* __restrict__ loss, int V, int E)
 {
     __shared__ float red[4];
     const int n = blockIdx.x;
-    const float* xn = x + (size_t)n * V * 3;
-    float acc = 0.f;
-    for (int e = threadIdx.x; e < E; e += 256) {
-        FlatEdge fe;
-        flat_edge(xn, quads + 4 * (size_t)e, fe);
-        acc += (fe.cos + 1.f) * (fe.cos + 1.f);
-    }
-    acc = block_sum(acc, red);
+    const float acc = flatten_forward_block(x + (size_t)n * V * 3, quads, E, red);
     if (threadIdx.x == 0) loss[n] = acc;
 }
 
 // per-edge gradients w.r.t. its four vertices -> gedge [N,E,4,3]
-__device__ __forceinline__ void flat_side_backward(const FlatEdge& e, const FlatSide& s, const float* g_cb, float g_n,
-                                                   float* g_a, float* g_b)
-{
-    float g_bl1 = g_n * s.sinb;
-    const float g_cosb = (g_n * s.bl1) * (-s.cosb / s.sinb);
-    float a_gcb = 0.f;
-#pragma unroll
-    for (int d = 0; d < 3; d++) a_gcb += e.a[d] * g_cb[d];
-    const float g_t = -a_gcb;
-    const float al2e = e.al2 + FLAT_EPS;
-    const float g_ab = g_t / al2e + g_cosb / s.den;
-    const float g_den = -g_cosb * s.ab / (s.den * s.den);
-    float g_al2 = -g_t * s.ab / (al2e * al2e) + (g_den * s.bl1) / (2.f * e.sq_al2);
-    g_bl1 += g_den * e.sq_al2;
-    const float g_bl2 = g_bl1 / (2.f * s.bl1);
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        g_b[d] = g_cb[d] + 2.f * s.b[d] * g_bl2 + e.a[d] * g_ab;
-        g_a[d] += -s.t * g_cb[d] + s.b[d] * g_ab + 2.f * e.a[d] * g_al2;
-    }
-}
-
 __global__ __launch_bounds__(256) void flatten_backward_edge_kernel(const float* __restrict__ x, const int* __restrict__ quads,
                                                                     const float* __restrict__ gloss, float* __restrict__ gedge,
                                                                     int V, int E)
 {
     const int n = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
-    FlatEdge fe;
-    flat_edge(x + (size_t)n * V * 3, quads + 4 * (size_t)e, fe);
-    const float gcos = 2.f * (fe.cos + 1.f) * gloss[n];
-    const float gD = -gcos * fe.S / (fe.D * fe.D);
-    float g_cb1[3], g_cb2[3], g_a[3] = {0.f, 0.f, 0.f}, g_b1[3], g_b2[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) { g_cb1[d] = gcos / fe.D * fe.s2.cb[d]; g_cb2[d] = gcos / fe.D * fe.s1.cb[d]; }
-    flat_side_backward(fe, fe.s1, g_cb1, gD * fe.s2.nb, g_a, g_b1);
-    flat_side_backward(fe, fe.s2, g_cb2, gD * fe.s1.nb, g_a, g_b2);
+    float g[12];
+    flatten_edge_gradient(x + (size_t)n * V * 3, quads + 4 * (size_t)e, gloss[n], g);
     float* o = gedge + ((size_t)n * E + e) * 12;
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        o[d] = -(g_a[d] + g_b1[d] + g_b2[d]); o[3 + d] = g_a[d]; o[6 + d] = g_b1[d]; o[9 + d] = g_b2[d];
-    }
+    for (int d = 0; d < 12; d++) o[d] = g[d];
 }
 
 // vertex-centric gather of the edge gradients: inc_ptr [V+1], inc [nnz] = edge * 4 + slot, ascending (deterministic)
@@ -736,6 +672,138 @@ __global__ __launch_bounds__(256) void cosdist_backward_kernel(const float* __re
     }
 }
 
+// ---- all feature layers of the perceptual term in one launch each way ---------------------------------------------------------
+// LASR's perceptual distance sums the cosine distance over the five AlexNet feature maps (networks_basic.py:51-64): with one
+// operator call per layer that is 5 x (reduce + fold) + 5 backward launches per step, each 5-16 us for a few MB, plus the
+// eager adds between them.  Here a block still owns one 32-pixel tile of one image of ONE layer (same arithmetic, same tile
+// partials as cosdist_forward_kernel / cosdist_backward_kernel<CPT>), but the grid's second dimension runs over the tiles of
+// every layer, and the last block of the forward launch folds the tile partials exactly like cosdist_fold_kernel does (lane-
+// strided, DPP tree) and adds the layers in list order: dist[n] = sum_l (1 - mean_l) is bit-identical to the per-layer calls
+// added up by the caller.
+struct CosLayers {
+    const float* fa[LASR_COSDIST_MAX_LAYERS];
+    const float* fb[LASR_COSDIST_MAX_LAYERS];
+    float* gfb[LASR_COSDIST_MAX_LAYERS];
+    int C[LASR_COSDIST_MAX_LAYERS], P[LASR_COSDIST_MAX_LAYERS];
+    int tile0[LASR_COSDIST_MAX_LAYERS + 1];          // first global tile of each layer; tile0[n_layers] = tiles per image
+    int n_layers, rep;
+};
+
+__device__ __forceinline__ int cos_layer_of(const CosLayers& L, int tile)
+{
+    int l = 0;
+    while (l + 1 < L.n_layers && tile >= L.tile0[l + 1]) l++;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void cosdist_multi_forward_kernel(CosLayers L, float* __restrict__ part, float* __restrict__ d,
+                                                                    unsigned int* __restrict__ cnt, int N)
+{
+    __shared__ float red[3][COS_CG][COS_TP];
+    __shared__ int s_last;
+    const int n = blockIdx.x, pxl = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int l = cos_layer_of(L, blockIdx.y), C = L.C[l], P = L.P[l], ntile = L.tile0[L.n_layers];
+    const int p = (blockIdx.y - L.tile0[l]) * COS_TP + pxl;
+    float dot = 0.f, na = 0.f, nb = 0.f;
+    if (p < P) {
+        const float* a = L.fa[l] + (size_t)(n / L.rep) * C * P + p;
+        const float* b = L.fb[l] + (size_t)n * C * P + p;
+#pragma unroll 8
+        for (int c = cg; c < C; c += COS_CG) {
+            const float x = a[(size_t)c * P], y = b[(size_t)c * P];
+            dot += x * y; na += x * x; nb += y * y;
+        }
+    }
+    cos_exchange(red, cg, pxl, dot, na, nb);
+    if (cg == 0) {                                             // lanes 0..31 of wave 0 finish the tile
+        float cosv = p < P ? dot / ((sqrtf(na) + COS_EPS) * (sqrtf(nb) + COS_EPS)) : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) cosv += __shfl_xor(cosv, o, 32);
+        if (pxl == 0) part[(size_t)n * ntile + blockIdx.y] = cosv;
+    }
+    // ticket; the last block folds every image (a wave per image, cosdist_fold_kernel's order) and adds the layers in order
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int t = atomicAdd(cnt, 1u);
+        s_last = (t == gridDim.x * gridDim.y - 1u);
+        if (s_last) { *cnt = 0u; __threadfence(); }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = wave; m < N; m += 4) {
+        float acc = 0.f;
+        for (int k = 0; k < L.n_layers; k++) {
+            const int t0 = L.tile0[k], nt = L.tile0[k + 1] - t0;
+            float sm = 0.f;
+            for (int j = lane; j < nt; j += 64) sm += ((const volatile float*)part)[(size_t)m * ntile + t0 + j];
+            sm = wave_sum_to_lane63(sm);
+            acc = acc + (1.f - sm / (float)L.P[k]);
+        }
+        if (lane == 63) d[m] = acc;
+    }
+}
+
+template <int CPT>
+__device__ __forceinline__ void cosdist_backward_tile(const float* __restrict__ fa, const float* __restrict__ fb, float gdn,
+                                                      float* __restrict__ gfb, int n, int tile, int C, int P, int rep,
+                                                      float (*red)[COS_CG][COS_TP])
+{
+    const int pxl = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int p = tile * COS_TP + pxl;
+    const bool in = p < P;
+    const float* a = fa + (size_t)(n / rep) * C * P + (in ? p : 0);
+    const float* b = fb + (size_t)n * C * P + (in ? p : 0);
+    float* g = gfb + (size_t)n * C * P + p;
+    float xa[CPT > 0 ? CPT : 1], xb[CPT > 0 ? CPT : 1];
+    float dot = 0.f, na = 0.f, nb = 0.f;
+    if (CPT > 0) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg + COS_CG * i;
+            xa[i] = in ? a[(size_t)c * P] : 0.f;
+            xb[i] = in ? b[(size_t)c * P] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; i++) { dot += xa[i] * xb[i]; na += xa[i] * xa[i]; nb += xb[i] * xb[i]; }
+    } else if (in) {
+#pragma unroll 8
+        for (int c = cg; c < C; c += COS_CG) {
+            const float x = a[(size_t)c * P], y = b[(size_t)c * P];
+            dot += x * y; na += x * x; nb += y * y;
+        }
+    }
+    cos_exchange(red, cg, pxl, dot, na, nb);
+    if (!in) return;
+    const float A = sqrtf(na) + COS_EPS, nbr = sqrtf(nb), B = nbr + COS_EPS;
+    const float k = -gdn / (float)P;                         // d = 1 - mean cos
+    const float ka = k / (A * B);
+    const float kb = nbr > 0.f ? k * dot / (A * nbr * B * B) : 0.f;
+    if (CPT > 0) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) g[(size_t)(cg + COS_CG * i) * P] = ka * xa[i] - kb * xb[i];
+    } else {
+#pragma unroll 8
+        for (int c = cg; c < C; c += COS_CG) g[(size_t)c * P] = ka * a[(size_t)c * P] - kb * b[(size_t)c * P];
+    }
+}
+
+__global__ __launch_bounds__(256) void cosdist_multi_backward_kernel(CosLayers L, const float* __restrict__ gd)
+{
+    __shared__ float red[3][COS_CG][COS_TP];
+    const int n = blockIdx.x;
+    const int l = cos_layer_of(L, blockIdx.y), C = L.C[l], P = L.P[l], tile = blockIdx.y - L.tile0[l];
+    const float g = gd[n];                                   // every layer's distance enters the sum with weight 1
+    switch (C % COS_CG == 0 ? C / COS_CG : 0) {              // block-uniform: AlexNet's 64 / 192 / 384 / 256 channels in registers
+        case 8:  cosdist_backward_tile<8>(L.fa[l], L.fb[l], g, L.gfb[l], n, tile, C, P, L.rep, red); break;
+        case 24: cosdist_backward_tile<24>(L.fa[l], L.fb[l], g, L.gfb[l], n, tile, C, P, L.rep, red); break;
+        case 32: cosdist_backward_tile<32>(L.fa[l], L.fb[l], g, L.gfb[l], n, tile, C, P, L.rep, red); break;
+        case 48: cosdist_backward_tile<48>(L.fa[l], L.fb[l], g, L.gfb[l], n, tile, C, P, L.rep, red); break;
+        default: cosdist_backward_tile<0>(L.fa[l], L.fb[l], g, L.gfb[l], n, tile, C, P, L.rep, red);
+    }
+}
+
 // ===========================================================================
 // Texture atlas -> per-face surface texels, third_party/softras/soft_renderer/cuda/load_textures_cuda_kernel.cu:8-66:
 // texel (w_x, w_y) of an R x R face texture sits at barycentric ((w_x + 1/3)/R, (w_y + 1/3)/R) of the lower triangle of
@@ -883,8 +951,10 @@ extern "C" int lasr_skin_weights_forward(const float* ctl_ts, const float* ctl_r
     if (H == 0 || J == 0 || V == 0) return LASR_OK;
     if (!ctl_ts || !ctl_rs || !log_ctl || !verts || !skin) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_SKIN_FORWARD, skin_forward_kernel, dim3((V + 255) / 256, H), dim3(256), 0, ctl_ts, ctl_rs, log_ctl, verts,
-                skin, V, J);
+    const dim3 grid((V + 63) / 64, H);
+    if (J <= 24)      LASR_LAUNCH(K_SKIN_FORWARD, skin_forward_kernel<24>, grid, dim3(64), 0, ctl_ts, ctl_rs, log_ctl, verts, skin, V, J);
+    else if (J <= 40) LASR_LAUNCH(K_SKIN_FORWARD, skin_forward_kernel<40>, grid, dim3(64), 0, ctl_ts, ctl_rs, log_ctl, verts, skin, V, J);
+    else              LASR_LAUNCH(K_SKIN_FORWARD, skin_forward_kernel<0>, grid, dim3(64), 0, ctl_ts, ctl_rs, log_ctl, verts, skin, V, J);
     return launch_ok();
 }
 
@@ -895,17 +965,12 @@ extern "C" int lasr_skin_weights_backward(const float* ctl_ts, const float* ctl_
 {
     if (H < 0 || J < 0 || V < 0 || J > SKIN_MAX_BONES) return LASR_E_BADARG;
     if (H == 0 || J == 0) return LASR_OK;
-    if (!ctl_ts || !ctl_rs || !log_ctl || !verts || !skin || !grad_skin || !grad_ts || !grad_rs || !grad_log_ctl || !scratch)
+    if (!ctl_ts || !ctl_rs || !log_ctl || !verts || !skin || !grad_skin || !grad_ts || !grad_rs || !grad_log_ctl)
         return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    if (V > 0) {
-        LASR_LAUNCH(K_SKIN_BACKWARD, skin_backward_dot_kernel, dim3((V + 255) / 256, H), dim3(256), 0, skin, grad_skin,
-                    scratch, V, J);
-        int rc = launch_ok();
-        if (rc) return rc;
-    }
+    (void)scratch;                                       // rounds 1-4: the dot[h,v] table of a separate first launch
     LASR_LAUNCH(K_SKIN_BACKWARD, skin_backward_kernel, dim3(H * J), dim3(256), 0, ctl_ts, ctl_rs, log_ctl, verts, skin,
-                grad_skin, scratch, grad_ts, grad_rs, grad_log_ctl, V, J);
+                grad_skin, grad_ts, grad_rs, grad_log_ctl, V, J);
     return launch_ok();
 }
 
@@ -1051,6 +1116,61 @@ extern "C" int lasr_cosdist_backward(const float* feat_obs, const float* feat_rn
         default: LASR_COS_BWD(0);
     }
 #undef LASR_COS_BWD
+    return launch_ok();
+}
+
+static int cos_layers(CosLayers& L, const float* const* feat_obs, const float* const* feat_rnd, float* const* grad_rnd, const int* C,
+                      const int* P, int n_layers, int rep)
+{
+    if (n_layers < 1 || n_layers > LASR_COSDIST_MAX_LAYERS || rep < 1 || !feat_obs || !feat_rnd || !C || !P) return LASR_E_BADARG;
+    L.n_layers = n_layers; L.rep = rep;
+    L.tile0[0] = 0;
+    for (int l = 0; l < n_layers; l++) {
+        if (C[l] < 1 || P[l] < 1 || !feat_obs[l] || !feat_rnd[l] || (grad_rnd && !grad_rnd[l])) return LASR_E_BADARG;
+        L.fa[l] = feat_obs[l]; L.fb[l] = feat_rnd[l]; L.gfb[l] = grad_rnd ? grad_rnd[l] : nullptr;
+        L.C[l] = C[l]; L.P[l] = P[l];
+        L.tile0[l + 1] = L.tile0[l] + (P[l] + COS_TP - 1) / COS_TP;
+        if (L.tile0[l + 1] > 65535) return LASR_E_BADARG;             // grid.y
+    }
+    return LASR_OK;
+}
+
+extern "C" size_t lasr_cosdist_multi_scratch_floats(const int* P, int n_layers, int N)
+{
+    if (!P || n_layers < 1 || n_layers > LASR_COSDIST_MAX_LAYERS || N < 0) return 0;
+    size_t tiles = 0;
+    for (int l = 0; l < n_layers; l++) tiles += (size_t)((P[l] > 0 ? P[l] : 0) + COS_TP - 1) / COS_TP;
+    return (size_t)N * tiles + 4;                                       // tile partials
+}
+
+extern "C" int lasr_cosdist_multi_forward(const float* const* feat_obs, const float* const* feat_rnd, const int* C, const int* P,
+                                          int n_layers, float* dist, float* scratch, unsigned int* ticket, int N, int rep,
+                                          void* hip_stream)
+{
+    if (N < 0) return LASR_E_BADARG;
+    CosLayers L;
+    int rc = cos_layers(L, feat_obs, feat_rnd, nullptr, C, P, n_layers, rep);
+    if (rc) return rc;
+    if (N == 0) return LASR_OK;
+    if (!dist || !scratch || !ticket) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int ntile = L.tile0[n_layers];
+    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_multi_forward_kernel, dim3(N, ntile), dim3(256), 0, L, scratch, dist, ticket, N);
+    return launch_ok();
+}
+
+extern "C" int lasr_cosdist_multi_backward(const float* const* feat_obs, const float* const* feat_rnd, const int* C, const int* P,
+                                           int n_layers, const float* grad_dist, float* const* grad_rnd, int N, int rep,
+                                           void* hip_stream)
+{
+    if (N < 0 || !grad_rnd) return LASR_E_BADARG;
+    CosLayers L;
+    int rc = cos_layers(L, feat_obs, feat_rnd, grad_rnd, C, P, n_layers, rep);
+    if (rc) return rc;
+    if (N == 0) return LASR_OK;
+    if (!grad_dist) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_COSDIST_BACKWARD, cosdist_multi_backward_kernel, dim3(N, L.tile0[n_layers]), dim3(256), 0, L, grad_dist);
     return launch_ok();
 }
 

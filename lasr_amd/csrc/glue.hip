@@ -57,33 +57,37 @@ struct MeansArgs {
     int terms, groups;
 };
 
-// One workgroup of 1024 threads walks the terms in order; out[0..groups) = group totals, out[groups] = total,
-// accumulated in term order by one thread (deterministic).
+// One workgroup of 1024 threads.  Every thread strides over every term (all the loads of all the terms are in flight
+// together), the 16 wave totals of each term meet in LDS, ONE barrier, then thread t folds term t's wave totals in wave order
+// and thread 0 accumulates the weighted means in term order: out[0..groups) = group totals, out[groups] = total.  The order
+// of every sum is the one of the round-1..4 kernel (which walked the terms one at a time, two barriers each: 10 us for LASR's
+// dozen tiny tensors), so the numbers are bit-identical.
 __global__ __launch_bounds__(1024) void weighted_means_kernel(MeansArgs A, float* __restrict__ out)
 {
-    __shared__ float red[16];
-    __shared__ float acc[LASR_MEANS_MAX_TERMS + 1];
+    __shared__ float red[LASR_MEANS_MAX_TERMS][16];
+    __shared__ float val[LASR_MEANS_MAX_TERMS];
     const int tid = threadIdx.x;
-    if (tid <= A.groups) acc[tid] = 0.f;
     for (int t = 0; t < A.terms; t++) {
         const float* __restrict__ x = A.x[t];
         float s = 0.f;
         for (int i = tid; i < A.n[t]; i += 1024) s += x[i];
         s = wave_sum_to_lane63(s);
-        __syncthreads();
-        if ((tid & 63) == 63) red[tid >> 6] = s;
-        __syncthreads();
-        if (tid == 0) {
-            float tot = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; k++) tot += red[k];
-            const float v = A.w[t] * (A.n[t] > 0 ? tot / (float)A.n[t] : 0.f);
-            acc[A.g[t]] += v;
-            acc[A.groups] += v;
-        }
+        if ((tid & 63) == 63) red[t][tid >> 6] = s;
     }
     __syncthreads();
-    if (tid <= A.groups) out[tid] = acc[tid];
+    if (tid < A.terms) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) tot += red[tid][k];
+        val[tid] = A.w[tid] * (A.n[tid] > 0 ? tot / (float)A.n[tid] : 0.f);
+    }
+    __syncthreads();
+    if (tid <= A.groups) {                                   // thread g: its group's terms in term order; thread `groups`: all
+        float acc = 0.f;
+        for (int t = 0; t < A.terms; t++)
+            if (tid == A.groups || A.g[t] == tid) acc += val[t];
+        out[tid] = acc;
+    }
 }
 
 struct MeansCoef { float c[LASR_MEANS_MAX_TERMS]; int terms; };
@@ -573,17 +577,22 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     long long row = ids[b];
     row = row < 0 ? 0 : (row >= pairs ? pairs - 1 : row);          // ids are produced by the loader itself; never read out of bounds
     const float* __restrict__ src = table + row * W;
+    // the row's keys form one run of 16-byte quads (or of floats when a segment is not 16-byte aligned); block y of gridDim.y
+    // takes every gridDim.y-th group of 256 of them, across the key boundaries, so the blocks stay evenly loaded whatever the
+    // mix of segment lengths (image planes next to 2-float principal points)
+    long long base = 0;
+    const long long step = (long long)gridDim.y * 256, first = (long long)blockIdx.y * 256 + threadIdx.x;
     for (int k = 0; k < K.n; k++) {
         const long long len = K.seg_len[k];
         const float* __restrict__ s = src + K.seg_off[k];
         float* __restrict__ d = out + K.out_off[k] + (long long)b * len;
-        if (((K.seg_off[k] | len | K.out_off[k] | W) & 3) == 0) {   // 16-B aligned segment: float4 copies
-            const long long n4 = len >> 2;
-            for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < n4; i += (long long)gridDim.y * 256)
-                reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
-        } else {
-            for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len; i += (long long)gridDim.y * 256) d[i] = s[i];
-        }
+        const bool quad = ((K.seg_off[k] | len | K.out_off[k] | W) & 3) == 0;
+        const long long units = quad ? len >> 2 : len;
+        // first unit of this key owned by this thread: the smallest i >= 0 with (base + i) % step == first
+        long long i = (first - base % step + step) % step;
+        if (quad) for (; i < units; i += step) reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+        else      for (; i < units; i += step) d[i] = s[i];
+        base += units;
     }
 }
 
@@ -596,14 +605,19 @@ extern "C" int lasr_gather_rows(const float* table, long long W, int pairs, cons
     if (!table || !ids || !seg_off || !seg_len || !out_off || !out || pairs == 0) return LASR_E_BADARG;
     GatherKeys K;
     K.n = n_keys;
-    long long longest = 0;
     for (int k = 0; k < n_keys; k++) {
         if (seg_off[k] < 0 || seg_len[k] < 0 || out_off[k] < 0 || seg_off[k] + seg_len[k] > W) return LASR_E_BADARG;
         K.seg_off[k] = seg_off[k]; K.seg_len[k] = seg_len[k]; K.out_off[k] = out_off[k];
-        longest = seg_len[k] > longest ? seg_len[k] : longest;
     }
     hipStream_t st = (hipStream_t)hip_stream;
-    const unsigned chunks = (unsigned)(longest / (4 * 256 * 8) + 1 > 64 ? 64 : longest / (4 * 256 * 8) + 1);
+    // one 16-byte quad per thread and pass; at least ~4 blocks per CU when the rows are long enough (rounds 1-4 capped the
+    // grid at 64 blocks per row: 22 us for the 6.6 MB batch of the spot3 configuration, 0.3 TB/s)
+    long long quads = 0;
+    for (int k = 0; k < n_keys; k++) quads += (seg_len[k] + 3) / 4;
+    long long want = (quads + 256 * 4 - 1) / (256 * 4);                  // ~4 quads per thread
+    const long long cap = (4 * 256 + B - 1) / B > 1 ? (4 * 256 + B - 1) / B : 1;
+    want = want < 1 ? 1 : (want > cap ? cap : want);
+    const unsigned chunks = (unsigned)want;
     LASR_LAUNCH(K_GATHER_ROWS, gather_rows_kernel, dim3((unsigned)B, chunks), dim3(256), 0, table, W, ids, K, out, pairs);
     return launch_ok();
 }

@@ -13,6 +13,7 @@
 #include "host_common.h"
 #include "sr_device.h"
 #include "ops_common.h"
+#include "mesh_losses.h"
 
 namespace lasr {
 
@@ -188,6 +189,175 @@ __global__ __launch_bounds__(256) void lbs_backward_fold_kernel(const float* __r
         const int k = i / 12, c = i - k * 12;
         if (c < 9) { if (gR) gR[((size_t)n * K + k) * 9 + c] = a; }
         else if (gT) gT[((size_t)n * K + k) * 3 + (c - 9)] = a;
+    }
+}
+
+// ---- backward on the matrix cores, one launch ----------------------------------------------------------------------------------
+// Rounds 1-4 ran the kernel above: a per-thread loop over the bones for M and g_skin, and the transposed contraction
+// g_RT[k][c] = sum_v skin[k][v] G[v][c] as one thread per (bone, column) walking 256 vertices serially -- 48 workgroups and
+// 18 us per call at LASR's 16 x 642 x 21, plus the fold launch.  Here a block owns 64 vertices of one mesh (4 waves x 16: 176
+// blocks at that size) and all three contractions run on v_mfma_f32_16x16x4_f32 from LDS-staged operands:
+//   M      [16 v x 12]   = skin^T [16 v x nb]   x RT [nb x 12]        (the forward's product; needed for g_verts and g_R0)
+//   g_skin [16 v x nb]   = G      [16 v x 12]   x RT^T [12 x nb]
+//   g_RT   [nb x 12]    += skin   [nb x 16 v]   x G  [16 v x 12]      (per wave; the four waves' tiles meet in LDS, wave order)
+// with G[v] = (v_i * h_j | h_j), h = d loss / d blended vertex.  The per-vertex pieces (h, G, g_verts, the body transform's
+// outer products) are thread-per-vertex code around them.  Chunk partials of the transform gradients go to scratch; the
+// launch's last block (device-scope ticket) folds them in chunk order.  No atomics on data, fixed orders throughout.
+constexpr int LBSB_VERTS = 64;
+constexpr int LBSB_MAX_K = 65;          // nb <= 64 part bones: Ss / Cs tiles of at most 64 rows
+
+__global__ __launch_bounds__(256) void lbs_backward_mfma_kernel(const float* __restrict__ verts, const float* __restrict__ Rmat,
+                                                                const float* __restrict__ Tmat, const float* __restrict__ skin,
+                                                                const float* __restrict__ gout, float* __restrict__ gverts,
+                                                                float* __restrict__ gskin, float* __restrict__ partial,
+                                                                int N, int V, int K, int tocam, const float* __restrict__ gout_blend,
+                                                                float* __restrict__ gR, float* __restrict__ gT,
+                                                                unsigned int* __restrict__ ticket)
+{
+    extern __shared__ float lds[];
+    __shared__ int s_last;
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, tid = threadIdx.x, nb = K - 1;
+    const int nbp = (nb + 15) & ~15;                        // bones padded to whole 16-row MFMA tiles
+    float* RT = lds;                                         // [K][12], k = 0 body
+    float* Gs = RT + ((K * 12 + 3) & ~3);                    // [64][16]  G rows (12 live columns), later the body-transform products
+    float* Ms = Gs + LBSB_VERTS * 16;                        // [64][16]  blended transform per vertex
+    float* Ss = Ms + LBSB_VERTS * 16;                        // [nbp][64] skin tile, zero padded
+    float* Cs = Ss + nbp * LBSB_VERTS;                       // [4][nbp][16] per-wave g_RT tiles
+    const int lane = tid & 63, wave = tid >> 6, col = lane & 15, kc = lane >> 4;
+    const int v0 = chunk * LBSB_VERTS;
+    for (int i = tid; i < K * 12; i += 256) {
+        const int k = i / 12, c = i - k * 12;
+        RT[i] = c < 9 ? Rmat[((size_t)n * K + k) * 9 + c] : Tmat[((size_t)n * K + k) * 3 + (c - 9)];
+    }
+    for (int i = tid; i < nbp * LBSB_VERTS; i += 256) {       // coalesced rows of 64 vertices
+        const int k = i >> 6, u = i & 63;
+        Ss[i] = (k < nb && v0 + u < V) ? skin[((size_t)n * nb + k) * V + v0 + u] : 0.f;
+    }
+    __syncthreads();
+    // ---- per vertex, part 1 (wave 0, thread = vertex): h and G
+    const int v = v0 + tid;
+    const bool mine = tid < LBSB_VERTS && v < V;
+    float px = 0.f, py = 0.f, pz = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f;
+    if (tid < LBSB_VERTS) {
+        if (mine) {
+            const size_t o = ((size_t)n * V + v) * 3;
+            px = verts[o]; py = verts[o + 1]; pz = verts[o + 2];
+            g0 = gout[o]; g1 = gout[o + 1]; g2 = gout[o + 2];
+            h0 = g0; h1 = g1; h2 = g2;
+            if (tocam) {                         // g_vs = g_out @ R0^T
+                h0 = g0 * RT[0] + g1 * RT[1] + g2 * RT[2];
+                h1 = g0 * RT[3] + g1 * RT[4] + g2 * RT[5];
+                h2 = g0 * RT[6] + g1 * RT[7] + g2 * RT[8];
+            }
+            if (gout_blend) { h0 += gout_blend[o]; h1 += gout_blend[o + 1]; h2 += gout_blend[o + 2]; }
+        }
+        float* G = Gs + tid * 16;
+        G[0] = px * h0; G[1] = px * h1; G[2] = px * h2; G[3] = py * h0; G[4] = py * h1; G[5] = py * h2;
+        G[6] = pz * h0; G[7] = pz * h1; G[8] = pz * h2; G[9] = h0; G[10] = h1; G[11] = h2;
+        G[12] = G[13] = G[14] = G[15] = 0.f;
+    }
+    __syncthreads();
+    // ---- the three contractions; wave w owns vertices vw .. vw + 15 of the block
+    const int vw = wave * 16;
+    if (nb > 0) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < nb; kk += 4) {                  // M = skin^T x RT
+            const int k = kk + kc;
+            const float a = k < nb ? Ss[k * LBSB_VERTS + vw + col] : 0.f;
+            const float b = (k < nb && col < 12) ? RT[(k + 1) * 12 + col] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) Ms[(vw + kc * 4 + r) * 16 + col] = acc[r];
+        for (int bb = 0; bb < nbp; bb += 16) {
+            const int bone = bb + col;
+            if (gskin) {                                      // g_skin = G x RT^T
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 12; s4 += 4) {
+                    const float a = Gs[(vw + col) * 16 + s4 + kc];
+                    const float b = bone < nb ? RT[(bone + 1) * 12 + s4 + kc] : 0.f;
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, d, 0, 0, 0);
+                }
+                if (bone < nb) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int vv = v0 + vw + kc * 4 + r;
+                        if (vv < V) gskin[((size_t)n * nb + bone) * V + vv] = d[r];
+                    }
+                }
+            }
+            f32x4 c4 = {0.f, 0.f, 0.f, 0.f};                  // g_RT tile of this wave = skin x G
+#pragma unroll
+            for (int s4 = 0; s4 < 16; s4 += 4) {
+                const float a = Ss[(bb + col) * LBSB_VERTS + vw + s4 + kc];
+                const float b = Gs[(vw + s4 + kc) * 16 + col];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) Cs[((size_t)wave * nbp + bb + kc * 4 + r) * 16 + col] = c4[r];
+        }
+    }
+    __syncthreads();
+    float* P = partial + ((size_t)n * nchunks + chunk) * K * 12;
+    for (int i = tid; i < nb * 12; i += 256) {               // part bones: the four waves' tiles in wave order
+        const int k = i / 12, c = i - k * 12;
+        const float* t = Cs + (size_t)k * 16 + c;
+        P[(k + 1) * 12 + c] = ((t[0] + t[(size_t)nbp * 16]) + t[(size_t)2 * nbp * 16]) + t[(size_t)3 * nbp * 16];
+    }
+    // ---- per vertex, part 2: g_verts and the body transform's products (into Gs, free now)
+    float q[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (mine) {
+        float M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        if (nb > 0) {
+#pragma unroll
+            for (int c = 0; c < 12; c++) M[c] = Ms[tid * 16 + c];
+        }
+        const size_t o = ((size_t)n * V + v) * 3;
+        if (gverts) {                        // g_v = g_vs @ M^T
+            gverts[o] = h0 * M[0] + h1 * M[1] + h2 * M[2];
+            gverts[o + 1] = h0 * M[3] + h1 * M[4] + h2 * M[5];
+            gverts[o + 2] = h0 * M[6] + h1 * M[7] + h2 * M[8];
+        }
+        if (tocam) {                         // body transform: g_R0 += vs^T g_out, g_T0 += g_out
+            const float s0 = px * M[0] + py * M[3] + pz * M[6] + M[9];
+            const float s1 = px * M[1] + py * M[4] + pz * M[7] + M[10];
+            const float s2 = px * M[2] + py * M[5] + pz * M[8] + M[11];
+            q[0] = s0 * g0; q[1] = s0 * g1; q[2] = s0 * g2;
+            q[3] = s1 * g0; q[4] = s1 * g1; q[5] = s1 * g2;
+            q[6] = s2 * g0; q[7] = s2 * g1; q[8] = s2 * g2;
+            q[9] = g0; q[10] = g1; q[11] = g2;
+        }
+    }
+    __syncthreads();                                         // every wave is done reading Gs
+    if (tid < LBSB_VERTS) {
+#pragma unroll
+        for (int c = 0; c < 12; c++) Gs[tid * 16 + c] = q[c];
+    }
+    __syncthreads();
+    if (tid < 12) {                                          // vertex order
+        float t = 0.f;
+        for (int u = 0; u < LBSB_VERTS; u++) t += Gs[u * 16 + tid];
+        P[tid] = tocam ? t : 0.f;
+    }
+    // ---- the last block folds the chunk partials of every mesh in chunk order (the former lbs_backward_fold_kernel launch)
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const unsigned int tk = atomicAdd(ticket, 1u);
+        s_last = (tk == gridDim.x * gridDim.y - 1u);
+        if (s_last) { *ticket = 0u; __threadfence(); }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int per = K * 12;
+    for (int i = tid; i < N * per; i += 256) {
+        const int m = i / per, j = i - m * per;
+        float a = 0.f;
+        for (int ch = 0; ch < nchunks; ch++) a += ((const volatile float*)partial)[((size_t)m * nchunks + ch) * per + j];
+        const int k = j / 12, c = j - k * 12;
+        if (c < 9) { if (gR) gR[((size_t)m * K + k) * 9 + c] = a; }
+        else if (gT) gT[((size_t)m * K + k) * 3 + (c - 9)] = a;
     }
 }
 
@@ -473,20 +643,7 @@ __global__ __launch_bounds__(256) void arap_forward_kernel(const float* __restri
 {
     __shared__ float red[4];
     const int n = blockIdx.x;
-    const float* X = x + (size_t)n * V * 3;
-    const float* D = dx + (size_t)n * V * 3;
-    float s = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) {
-        const float a0 = X[3 * v], a1 = X[3 * v + 1], a2 = X[3 * v + 2];
-        const float b0 = D[3 * v], b1 = D[3 * v + 1], b2 = D[3 * v + 2];
-        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
-            const int u = col[e];
-            const float p0 = X[3 * u] - a0, p1 = X[3 * u + 1] - a1, p2 = X[3 * u + 2] - a2;
-            const float q0 = D[3 * u] - b0, q1 = D[3 * u + 1] - b1, q2 = D[3 * u + 2] - b2;
-            s += fabsf((p0 * p0 + p1 * p1 + p2 * p2) - (q0 * q0 + q1 * q1 + q2 * q2));
-        }
-    }
-    s = block_sum(s, red);
+    const float s = arap_forward_block(x + (size_t)n * V * 3, dx + (size_t)n * V * 3, row_ptr, col, V, red);
     if (threadIdx.x == 0) loss[n] = s / (float)row_ptr[V];
 }
 
@@ -496,25 +653,11 @@ __global__ __launch_bounds__(256) void arap_backward_kernel(const float* __restr
                                                             float* __restrict__ gx, int V)
 {
     const int n = blockIdx.x;
-    const float* X = x + (size_t)n * V * 3;
-    const float* D = dx + (size_t)n * V * 3;
-    // each undirected edge appears as (v,u) and (u,v) with the same value: 2 * d|e|/dx_v = 4 sign(e) (x_v - x_u)
     const float k = 4.f * gloss[n] / (float)row_ptr[V];
     for (int v = threadIdx.x; v < V; v += 256) {
-        const float a0 = X[3 * v], a1 = X[3 * v + 1], a2 = X[3 * v + 2];
-        const float b0 = D[3 * v], b1 = D[3 * v + 1], b2 = D[3 * v + 2];
-        float gx0 = 0, gx1 = 0, gx2 = 0, gd0 = 0, gd1 = 0, gd2 = 0;
-        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
-            const int u = col[e];
-            const float p0 = a0 - X[3 * u], p1 = a1 - X[3 * u + 1], p2 = a2 - X[3 * u + 2];
-            const float q0 = b0 - D[3 * u], q1 = b1 - D[3 * u + 1], q2 = b2 - D[3 * u + 2];
-            const float sg = sgn((p0 * p0 + p1 * p1 + p2 * p2) - (q0 * q0 + q1 * q1 + q2 * q2));
-            gx0 += sg * p0; gx1 += sg * p1; gx2 += sg * p2;
-            gd0 -= sg * q0; gd1 -= sg * q1; gd2 -= sg * q2;
-        }
         const size_t o = ((size_t)n * V + v) * 3;
-        if (gx) { gx[o] = k * gx0; gx[o + 1] = k * gx1; gx[o + 2] = k * gx2; }
-        if (gdx) { gdx[o] = k * gd0; gdx[o + 1] = k * gd1; gdx[o + 2] = k * gd2; }
+        arap_backward_vertex(x + (size_t)n * V * 3, dx + (size_t)n * V * 3, row_ptr, col, k, v, gx ? gx + o : nullptr,
+                             gdx ? gdx + o : nullptr);
     }
 }
 
@@ -525,21 +668,7 @@ __global__ __launch_bounds__(256) void laplacian_forward_kernel(const float* __r
 {
     __shared__ float red[4];
     const int n = blockIdx.x;
-    const float* X = x + (size_t)n * V * 3;
-    float s = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) {
-        const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
-        float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-        if (e1 > e0) {
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-            for (int e = e0; e < e1; e++) { const int u = col[e]; m0 += X[3 * u]; m1 += X[3 * u + 1]; m2 += X[3 * u + 2]; }
-            const float inv = 1.f / (float)(e1 - e0);
-            l0 = X[3 * v] - m0 * inv; l1 = X[3 * v + 1] - m1 * inv; l2 = X[3 * v + 2] - m2 * inv;
-        }
-        if (lx_out) { const size_t o = ((size_t)n * V + v) * 3; lx_out[o] = l0; lx_out[o + 1] = l1; lx_out[o + 2] = l2; }
-        s += l0 * l0 + l1 * l1 + l2 * l2;
-    }
-    s = block_sum(s, red);
+    const float s = laplacian_forward_block(x + (size_t)n * V * 3, row_ptr, col, lx_out ? lx_out + (size_t)n * V * 3 : nullptr, V, red);
     if (threadIdx.x == 0 && loss) loss[n] = s;
 }
 
@@ -549,17 +678,12 @@ __global__ __launch_bounds__(256) void laplacian_backward_kernel(const float* __
                                                                  float* __restrict__ gx, int V)
 {
     const int n = blockIdx.x;
-    const float* L = lx + (size_t)n * V * 3;
     const float k = 2.f * gloss[n];
     for (int v = threadIdx.x; v < V; v += 256) {
-        float a0 = L[3 * v], a1 = L[3 * v + 1], a2 = L[3 * v + 2];
-        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
-            const int u = col[e];
-            const float inv = 1.f / (float)(row_ptr[u + 1] - row_ptr[u]);
-            a0 -= L[3 * u] * inv; a1 -= L[3 * u + 1] * inv; a2 -= L[3 * u + 2] * inv;
-        }
+        float a[3];
+        laplacian_backward_vertex(lx + (size_t)n * V * 3, row_ptr, col, k, v, a);
         const size_t o = ((size_t)n * V + v) * 3;
-        gx[o] = k * a0; gx[o + 1] = k * a1; gx[o + 2] = k * a2;
+        gx[o] = a[0]; gx[o + 1] = a[1]; gx[o + 2] = a[2];
     }
 }
 
@@ -598,39 +722,53 @@ extern "C" int lasr_lbs_forward_both(const float* verts, const float* Rmat, cons
 extern "C" size_t lasr_lbs_backward_scratch_floats(int N, int V, int K)
 {
     if (N < 0 || V < 0 || K < 1) return 0;
-    return (size_t)N * ((V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1) * K * 12;
+    const size_t chunks = (size_t)(V + LBSB_VERTS - 1) / LBSB_VERTS > 0 ? (size_t)(V + LBSB_VERTS - 1) / LBSB_VERTS : 1;   // >= the 256-vertex chunks
+    return (size_t)N * chunks * K * 12;
 }
 
 static int lbs_backward_impl(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                              const float* grad_out, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
-                             float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream);
+                             float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam,
+                             void* hip_stream);
 
 extern "C" int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                                  const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
-                                 float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream)
+                                 float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam,
+                                 void* hip_stream)
 {
     return lbs_backward_impl(verts, Rmat, Tmat, skin, grad_out, nullptr, grad_verts, grad_Rmat, grad_Tmat, grad_skin, scratch,
-                             N, V, K, tocam, hip_stream);
+                             ticket, N, V, K, tocam, hip_stream);
 }
 
 extern "C" int lasr_lbs_backward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                                       const float* grad_out_cam, const float* grad_out_blend, float* grad_verts,
-                                      float* grad_Rmat, float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K,
-                                      void* hip_stream)
+                                      float* grad_Rmat, float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket,
+                                      int N, int V, int K, void* hip_stream)
 {
     if (!grad_out_blend) return LASR_E_BADARG;
     return lbs_backward_impl(verts, Rmat, Tmat, skin, grad_out_cam, grad_out_blend, grad_verts, grad_Rmat, grad_Tmat, grad_skin,
-                             scratch, N, V, K, 1, hip_stream);
+                             scratch, ticket, N, V, K, 1, hip_stream);
 }
 
 static int lbs_backward_impl(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                              const float* grad_out, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
-                             float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream)
+                             float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam,
+                             void* hip_stream)
 {
     if (N < 0 || V < 0 || K < 1 || K > 1024) return LASR_E_BADARG;
     if (N == 0) return LASR_OK;
     if (!verts || !Rmat || !Tmat || !grad_out || !scratch || (K > 1 && !skin)) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
+    if (ticket && K <= LBSB_MAX_K) {
+        // one launch: matrix-core contractions, last-block fold (ticket: a zeroed device word, left zero)
+        const int nchunks = (V + LBSB_VERTS - 1) / LBSB_VERTS > 0 ? (V + LBSB_VERTS - 1) / LBSB_VERTS : 1;
+        const int nbp = (K - 1 + 15) & ~15;
+        const size_t lds = (size_t)(((K * 12 + 3) & ~3) + 2 * LBSB_VERTS * 16 + nbp * LBSB_VERTS + 4 * nbp * 16) * sizeof(float);
+        LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_mfma_kernel, dim3(nchunks, N), dim3(256), lds, verts, Rmat, Tmat, skin, grad_out,
+                    grad_verts, grad_skin, scratch, N, V, K, tocam, grad_out_blend, grad_Rmat, grad_Tmat, ticket);
+        return launch_ok();
+    }
+    // no ticket word (or more than 64 part bones): the two-launch VALU path of rounds 1-4
     const int nchunks = (V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1;
     const size_t lds = (size_t)(K * 12 + LBS_CHUNK * 13 + 4) * sizeof(float);
     LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_kernel, dim3(nchunks, N), dim3(256), lds, verts, Rmat, Tmat, skin, grad_out,

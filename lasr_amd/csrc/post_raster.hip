@@ -11,7 +11,13 @@
 // slices) and its backward writes every plane of grad_px itself (no split / cat / accumulate kernels of autograd).
 // Arithmetic, chunking and fold order are those of the separate kernels, so the tables are bit-identical to theirs.
 //
-// Scratch (floats): part[N][nch][8] | tot[N][8] | img[I][4] | part2[N][nch][4] | part3[N][nch][4]
+// Scratch (floats): part[N][nch][8] | tot[N][8] | img[I][4] | part2[N][nch][4] | part3[N][nch][4] | 2 block counters (uint)
+//
+// Launches: forward = 2 (the pass over the render; the flow pass, whose blocks fold the first pass' chunk partials themselves
+// in the fixed chunk order and whose last block folds the flow partials), backward = 1 (its last block folds the intrinsics'
+// partials).  "Last block" = the one whose ticket from a device-scope counter is the grid size: it reads what the others
+// published before their ticket (threadfence on both sides); the FOLD ORDER is fixed, so the tables do not depend on which
+// block that is.  Rounds 1-4 ran the three folds as separate one-wave launches (20 + 5 + 5 us per step at LASR's sizes).
 #include <hip/hip_runtime.h>
 
 #include "../../include/lasr_ops.h"
@@ -22,7 +28,7 @@ namespace lasr {
 constexpr int PR_PX_PER_BLOCK = 2048;
 __host__ __device__ inline int pr_nch(int P) { int n = (P + PR_PX_PER_BLOCK - 1) / PR_PX_PER_BLOCK; return n < 1 ? 1 : (n > 64 ? 64 : n); }
 
-struct PrScratch { float *part, *tot, *img, *part2, *part3; };
+struct PrScratch { float *part, *tot, *img, *part2, *part3; unsigned int* cnt; };
 __host__ __device__ inline PrScratch pr_scratch(float* base, int I, int H, int P)
 {
     const size_t N = (size_t)I * H, nch = (size_t)pr_nch(P);
@@ -32,6 +38,7 @@ __host__ __device__ inline PrScratch pr_scratch(float* base, int I, int H, int P
     s.img = s.tot + N * 8;
     s.part2 = s.img + (size_t)I * 4;
     s.part3 = s.part2 + N * nch * 4;
+    s.cnt = reinterpret_cast<unsigned int*>(s.part3 + N * nch * 4);
     return s;
 }
 
@@ -59,10 +66,12 @@ struct PrArgs {
 
 // ---- forward pass 1: everything that needs one look at the render ------------------------------------------------------------
 __global__ __launch_bounds__(256) void render_tables_forward_kernel(PrArgs A, float2* __restrict__ flow, unsigned char* __restrict__ bg,
-                                                                    float* __restrict__ rndpair, float* __restrict__ part)
+                                                                    float* __restrict__ rndpair, float* __restrict__ part,
+                                                                    unsigned int* __restrict__ cnt)
 {
     __shared__ float red[4];
     const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, N = A.I * A.H;
+    if (ij == 0 && ch == 0 && threadIdx.x == 0) { cnt[0] = 0u; cnt[1] = 0u; }      // tickets of the two later launches
     const float* q = A.px + (size_t)ij * 10 * P;
     const float* m = A.masks + (size_t)i * P;
     const float* oc = A.occ + (size_t)i * P;
@@ -110,52 +119,79 @@ __global__ __launch_bounds__(256) void render_tables_forward_kernel(PrArgs A, fl
     }
 }
 
-// one block per image i, thread j = hypothesis: fold the chunk partials in chunk order, form the silhouette / texture tables, and
-// the image's flow weight statistics over (j, chunk) in that order (== flow_loss_stats_fold_kernel)
-__global__ __launch_bounds__(64) void render_tables_fold_kernel(const float* __restrict__ part, float* __restrict__ tot, float* __restrict__ img,
-                                                                float* __restrict__ mask_tab, float* __restrict__ tex_tab, int H, int nch,
-                                                                float tex_scale)
+// Ticket of a block that has published its partials: true for the block that drew the last one (all threads get the answer).
+// The caller's stores are fenced before the ticket; the last block fences again before it reads the others' partials.
+__device__ __forceinline__ bool pr_last_block(unsigned int* counter, unsigned int total, int* flag)
 {
-    const int i = blockIdx.x;
-    for (int j = threadIdx.x; j < H; j += 64) {
-        const int ij = i * H + j;
-        float a = 0.f, c = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < nch; k++) {
-            const float* o = part + ((size_t)ij * nch + k) * 8;
-            a += o[0]; c += o[1]; s1 += o[2]; s2 += o[3];
-        }
-        float* t = tot + (size_t)ij * 8;
-        t[0] = a; t[1] = c; t[2] = s1; t[3] = s2;
-        mask_tab[ij] = 0.5f * (a / c);                      // NaN when empty, like torch (mesh_net.py:388)
-        tex_tab[ij] = (s1 / c + s2 / c) * tex_scale;        // 2 * wt * (mean1 + mean2)
-    }
+    __syncthreads();                                     // every thread's partial stores of this block are issued
     if (threadIdx.x == 0) {
-        float s = 0.f, c = 0.f;
-        for (int j = 0; j < H; j++)
-            for (int k = 0; k < nch; k++) {
-                const float* o = part + (((size_t)i * H + j) * nch + k) * 8;
-                s += o[4]; c += o[5];
-            }
-        img[4 * i] = s; img[4 * i + 1] = c;
+        __threadfence();
+        const unsigned int t = atomicAdd(counter, 1u);
+        *flag = (t == total - 1u);
+        if (t == total - 1u) { *counter = 0u; __threadfence(); }     // ready for the next launch that shares the scratch
     }
+    __syncthreads();
+    return *flag != 0;
 }
 
 // ---- forward pass 2: the flow loss needs the image's mean weight first (== flow_loss_forward_kernel) ----------------------------
+// Prologue (the former render_tables_fold_kernel, 20 us as its own one-wave launch): every block folds the (sum, count) of
+// sigmoid(-occ) over its image's (hypothesis, chunk) partials IN THAT ORDER -- staged through LDS by all threads, added up by
+// one -- so the mean weight it uses is bit-identical to the value the fold kernel used to leave in img[]; the chunk-0 block of
+// each (image, hypothesis) also folds that row's silhouette / texture partials (chunk order) into tot[] and the two tables,
+// and the chunk-0 block of hypothesis 0 records img[].  Epilogue: the last block of the launch folds the flow partials.
+constexpr int PR_FOLD_TILE = 1024;
 __global__ __launch_bounds__(256) void render_tables_flow_kernel(PrArgs A, const float2* __restrict__ flow, const unsigned char* __restrict__ bg,
-                                                                 const float* __restrict__ img, float* __restrict__ part2,
-                                                                 float* __restrict__ fmap, unsigned char* __restrict__ vis)
+                                                                 const float* __restrict__ part, float* __restrict__ tot,
+                                                                 float* __restrict__ img, float* __restrict__ mask_tab,
+                                                                 float* __restrict__ tex_tab, float tex_scale,
+                                                                 float* __restrict__ part2, float* __restrict__ fmap,
+                                                                 unsigned char* __restrict__ vis, float* __restrict__ flow_tab,
+                                                                 unsigned int* __restrict__ cnt)
 {
     __shared__ float red[4];
-    const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P;
+    __shared__ float2 stage[PR_FOLD_TILE];
+    __shared__ float s_img[2];
+    __shared__ int s_last;
+    const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, H = A.H, nch = A.nch, tid = threadIdx.x;
+    {
+        const float* pi = part + (size_t)i * H * nch * 8;            // the image's H * nch partial rows, (j, chunk) order
+        const int rows = H * nch;
+        float s = 0.f, c = 0.f;
+        for (int r0 = 0; r0 < rows; r0 += PR_FOLD_TILE) {
+            const int m = min(PR_FOLD_TILE, rows - r0);
+            __syncthreads();
+            for (int r = tid; r < m; r += 256) stage[r] = make_float2(pi[(size_t)(r0 + r) * 8 + 4], pi[(size_t)(r0 + r) * 8 + 5]);
+            __syncthreads();
+            if (tid == 0)
+                for (int r = 0; r < m; r++) { s += stage[r].x; c += stage[r].y; }
+        }
+        if (tid == 0) {
+            s_img[0] = s; s_img[1] = c;
+            if (ch == 0 && ij == i * H) { img[4 * i] = s; img[4 * i + 1] = c; }
+        }
+        if (ch == 0 && tid == 64) {                                   // another wave: this row's silhouette / texture totals
+            float a = 0.f, cc = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < nch; k++) {
+                const float* o = part + ((size_t)ij * nch + k) * 8;
+                a += o[0]; cc += o[1]; s1 += o[2]; s2 += o[3];
+            }
+            float* t = tot + (size_t)ij * 8;
+            t[0] = a; t[1] = cc; t[2] = s1; t[3] = s2;
+            mask_tab[ij] = 0.5f * (a / cc);                     // NaN when empty, like torch (mesh_net.py:388)
+            tex_tab[ij] = (s1 / cc + s2 / cc) * tex_scale;      // 2 * wt * (mean1 + mean2)
+        }
+        __syncthreads();
+    }
     const float* oc = A.occ + (size_t)i * P;
     const float* m = A.masks + (size_t)i * P;
     const float* ox = A.obs + (size_t)i * A.obs_stride;
     const float* oy = ox + P;
-    const float wmean = img[4 * i] / img[4 * i + 1];
+    const float wmean = s_img[0] / s_img[1];
     int p0, p1;
-    pr_range(P, A.nch, ch, p0, p1);
+    pr_range(P, nch, ch, p0, p1);
     float s = 0.f, c = 0.f;
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    for (int p = p0 + tid; p < p1; p += 256) {
         const float2 f = flow[(size_t)ij * P + p];
         const float dx = f.x - ox[p], dy = f.y - oy[p];
         const float e = sqrtf(dx * dx + dy * dy) * (pr_sigmoid(-oc[p]) / wmean);
@@ -165,18 +201,18 @@ __global__ __launch_bounds__(256) void render_tables_flow_kernel(PrArgs A, const
         if (sel) { s += e; c += 1.f; }
     }
     s = block_sum(s, red); c = block_sum(c, red);
-    if (threadIdx.x == 0) { float* o = part2 + ((size_t)ij * A.nch + ch) * 4; o[0] = s; o[1] = c; o[2] = 0.f; o[3] = 0.f; }
-}
-
-__global__ __launch_bounds__(256) void render_tables_flow_fold_kernel(const float* __restrict__ part2, float* __restrict__ tot,
-                                                                      float* __restrict__ flow_tab, int N, int nch)
-{
-    const int ij = blockIdx.x * 256 + threadIdx.x;
-    if (ij >= N) return;
-    float s = 0.f, c = 0.f;
-    for (int k = 0; k < nch; k++) { s += part2[((size_t)ij * nch + k) * 4]; c += part2[((size_t)ij * nch + k) * 4 + 1]; }
-    tot[(size_t)ij * 8 + 4] = s; tot[(size_t)ij * 8 + 5] = c;
-    flow_tab[ij] = c > 0.f ? 0.5f * (s / c) : 0.f;          // 0 when nothing is selected (mesh_net.py:412)
+    if (tid == 0) { float* o = part2 + ((size_t)ij * nch + ch) * 4; o[0] = s; o[1] = c; o[2] = 0.f; o[3] = 0.f; }
+    if (!pr_last_block(cnt, gridDim.x * gridDim.y, &s_last)) return;
+    const int N = A.I * H;                                          // the former render_tables_flow_fold_kernel
+    for (int n = tid; n < N; n += 256) {
+        float fs = 0.f, fc = 0.f;
+        for (int k = 0; k < nch; k++) {
+            const volatile float* o = part2 + ((size_t)n * nch + k) * 4;
+            fs += o[0]; fc += o[1];
+        }
+        tot[(size_t)n * 8 + 4] = fs; tot[(size_t)n * 8 + 5] = fc;
+        flow_tab[n] = fc > 0.f ? 0.5f * (fs / fc) : 0.f;          // 0 when nothing is selected (mesh_net.py:412)
+    }
 }
 
 // ---- backward: every plane of grad_px in one pass --------------------------------------------------------------------------------
@@ -185,9 +221,12 @@ __global__ __launch_bounds__(256) void render_tables_flow_fold_kernel(const floa
 __global__ __launch_bounds__(256) void render_tables_backward_kernel(PrArgs A, const float* __restrict__ tot, const float* __restrict__ img,
                                                                      const float* __restrict__ g_mask, const float* __restrict__ g_flow,
                                                                      const float* __restrict__ g_tex, const float* __restrict__ g_rndpair,
-                                                                     float wt, float* __restrict__ gpx, float* __restrict__ part3)
+                                                                     float wt, float* __restrict__ gpx, float* __restrict__ part3,
+                                                                     float* __restrict__ gpp, float* __restrict__ gfl,
+                                                                     unsigned int* __restrict__ cnt)
 {
     __shared__ float red[4];
+    __shared__ int s_last;
     const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, N = A.I * A.H;
     const float* q = A.px + (size_t)ij * 10 * P;
     float* g = gpx + (size_t)ij * 10 * P;
@@ -266,21 +305,18 @@ __global__ __launch_bounds__(256) void render_tables_backward_kernel(PrArgs A, c
         float* o = part3 + ((size_t)ij * A.nch + ch) * 4;
         o[0] = sx; o[1] = sy; o[2] = sf; o[3] = 0.f;
     }
-}
-
-// image n's sums belong to the intrinsics of image (n + half) % N
-__global__ __launch_bounds__(256) void render_tables_intrinsics_fold_kernel(const float* __restrict__ part3, float* __restrict__ gpp,
-                                                                            float* __restrict__ gfl, int N, int nch, int half)
-{
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float a = 0.f, b = 0.f, c = 0.f;
-    for (int k = 0; k < nch; k++) {
-        const float* o = part3 + ((size_t)n * nch + k) * 4;
-        a += o[0]; b += o[1]; c += o[2];
+    // the last block folds the chunk partials in chunk order (the former render_tables_intrinsics_fold_kernel): image n's sums
+    // belong to the intrinsics of image (n + half) % N
+    if (!pr_last_block(cnt + 1, gridDim.x * gridDim.y, &s_last)) return;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int k = 0; k < A.nch; k++) {
+            const volatile float* o = part3 + ((size_t)n * A.nch + k) * 4;
+            a += o[0]; b += o[1]; c += o[2];
+        }
+        const int o2 = (n + A.half) % N;
+        gpp[2 * o2] = a; gpp[2 * o2 + 1] = b; gfl[o2] = c;
     }
-    const int other = (n + half) % N;
-    gpp[2 * other] = a; gpp[2 * other + 1] = b; gfl[other] = c;
 }
 
 // =====================================================================================================================
@@ -365,9 +401,203 @@ __global__ __launch_bounds__(256) void raster_inputs_backward_kernel(RiArgs A, c
     if (tid == 0) { g_pp[2 * n] = sx; g_pp[2 * n + 1] = sy; g_fl[n] = sf; }
 }
 
+
+// =====================================================================================================================
+// The same stage written PER FACE CORNER: what the rasteriser actually consumes is face_vertices [N,F,3,3] and the per-face
+// attribute stack [N,F,3,9]; via raster_inputs_forward_kernel they take five launches (that kernel, its near / far fold, the
+// camera stage's `vertices - eye`, two face gathers) and three on the way back (two vertex-centric gathers, the kernel above).
+// Here one launch each way:
+//   forward : corner c of face f of mesh n reads its vertex once and writes the projected, eye-shifted position
+//             ((pinhole + eye) * (1,-1,1)) - eye  -- the expression of raster_inputs_forward_kernel followed by look_at's
+//             subtraction (soft_renderer/functional/look_at.py:6-62 with LASR's constant eye on the -z axis: R = I), bit for bit --
+//             and the nine attributes; blocks also take min / max depth of a 256-vertex slice, and the launch's last block
+//             (device-scope ticket) folds them into near / far (mesh_net.py:304-311).
+//   backward: 16 lanes per vertex walk the vertex' incident corners (CSR built once per connectivity, corners ascending: the
+//             summation order of face_gather_backward_kernel) -- 3 position sums, 6 own-attribute sums, 3 sums of the position
+//             attribute this vertex lends to the other frame's mesh -- then one lane per vertex applies the projection's
+//             Jacobian; d pp / d fl: block partials in LDS order, folded by the last block in block order.
+// faces: [Nf,F,3] int64 with Nf = N, or Nf = 1 when all meshes share the connectivity (LASR: always); same for the CSR.
+struct RfArgs {
+    const float* verts_cam; const float* tex; const float* pp; const float* fl;
+    const long long* faces; int faces_shared;
+    int N, V, F3, half; float ex, ey, ez;
+};
+
+__global__ __launch_bounds__(256) void raster_faces_forward_kernel(RfArgs A, float* __restrict__ fv, float* __restrict__ fa,
+                                                                   float* __restrict__ zpart, float* __restrict__ near_far,
+                                                                   unsigned int* __restrict__ ticket)
+{
+    __shared__ float red[8];
+    __shared__ int s_last;
+    const int n = blockIdx.y, tid = threadIdx.x, V = A.V;
+    const int other = (n + A.half) % A.N;
+    const int c = blockIdx.x * 256 + tid;
+    if (c < A.F3) {
+        const long long vi = A.faces[(A.faces_shared ? (size_t)0 : (size_t)n * A.F3) + c];
+        const size_t i = (size_t)n * V + (size_t)vi, o = (size_t)other * V + (size_t)vi;
+        const float f = A.fl[n], cx = A.pp[2 * n], cy = A.pp[2 * n + 1];
+        const float x = A.verts_cam[3 * i], y = A.verts_cam[3 * i + 1], z = A.verts_cam[3 * i + 2];
+        const float px = cx + x * f / z, py = cy + y * f / z;           // geom_utils.py:32-33
+        float* q = fv + ((size_t)n * A.F3 + c) * 3;
+        q[0] = (px + A.ex) * 1.f - A.ex;                                  // (+ eye) * (1,-1,1), then look_at's - eye
+        q[1] = (py + A.ey) * -1.f - A.ey;
+        q[2] = (z + A.ez) * 1.f - A.ez;
+        float* a = fa + ((size_t)n * A.F3 + c) * 9;
+        a[0] = A.tex[3 * i]; a[1] = A.tex[3 * i + 1]; a[2] = A.tex[3 * i + 2];
+        a[3] = x; a[4] = y; a[5] = z;
+        a[6] = A.verts_cam[3 * o]; a[7] = A.verts_cam[3 * o + 1]; a[8] = A.verts_cam[3 * o + 2];
+    }
+    // depth range over the VERTICES (referenced by a face or not, like the reference's min / max over the projected batch)
+    float zmin = 3.4e38f, zmax = -3.4e38f;
+    if (c < V) { const float z = A.verts_cam[3 * ((size_t)n * V + c) + 2]; zmin = z; zmax = z; }
+    for (int d = 32; d >= 1; d >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, d)); zmax = fmaxf(zmax, __shfl_xor(zmax, d)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = zmin; red[4 + (tid >> 6)] = zmax; }
+    __syncthreads();
+    const int nblk = gridDim.x;
+    if (tid == 0) {
+        float* zp = zpart + 2 * ((size_t)n * nblk + blockIdx.x);
+        zp[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        zp[1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    }
+    if (!pr_last_block(ticket, gridDim.x * gridDim.y, &s_last)) return;
+    zmin = 3.4e38f; zmax = -3.4e38f;
+    for (int k = tid; k < A.N * nblk; k += 256) {
+        zmin = fminf(zmin, ((const volatile float*)zpart)[2 * k]);
+        zmax = fmaxf(zmax, ((const volatile float*)zpart)[2 * k + 1]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, d)); zmax = fmaxf(zmax, __shfl_xor(zmax, d)); }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = zmin; red[4 + (tid >> 6)] = zmax; }
+    __syncthreads();
+    if (tid == 0) {
+        zmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        zmax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        const float half_range = (zmax - zmin) / 2.f;              // mesh_net.py:306-311
+        near_far[0] = zmin - half_range;
+        near_far[1] = zmax + half_range;
+    }
+}
+
+constexpr int RF_VPB = 16;            // vertices per block of the backward (16 lanes each)
+__global__ __launch_bounds__(256) void raster_faces_backward_kernel(RfArgs A, const int* __restrict__ inc_ptr, const int* __restrict__ inc,
+                                                                    const float* __restrict__ g_fv, const float* __restrict__ g_fa,
+                                                                    float* __restrict__ g_cam, float* __restrict__ g_tex,
+                                                                    float* __restrict__ part, float* __restrict__ g_pp,
+                                                                    float* __restrict__ g_fl, unsigned int* __restrict__ ticket)
+{
+    __shared__ float sums[RF_VPB][16];
+    __shared__ float bsum[RF_VPB][3];
+    __shared__ int s_last;
+    const int n = blockIdx.y, tid = threadIdx.x, V = A.V, F3 = A.F3;
+    const int other = (n + A.half) % A.N;              // the mesh whose attributes 6..8 are THIS mesh's positions
+    const int vl = tid >> 4, lane = tid & 15, v = blockIdx.x * RF_VPB + vl;
+    // lane 0-2: d verts_pre; 3-8: own attributes 0..5 (colour, own position); 9-11: attributes 6..8 of mesh `other`
+    float acc = 0.f;
+    if (v < V && lane < 12) {
+        const size_t inc_base = A.faces_shared ? 0 : (size_t)n;
+        const int* ptr = inc_ptr + inc_base * (V + 1);
+        const int* lst = inc + inc_base * F3;
+        const float* src; int stride, off;
+        if (lane < 3) { src = g_fv + (size_t)n * F3 * 3; stride = 3; off = lane; }
+        else if (lane < 9) { src = g_fa + (size_t)n * F3 * 9; stride = 9; off = lane - 3; }
+        else { src = g_fa + (size_t)other * F3 * 9; stride = 9; off = lane - 3; }
+        if (lane >= 9 && !A.faces_shared) {                // the other mesh's own incidence lists
+            ptr = inc_ptr + (size_t)other * (V + 1);
+            lst = inc + (size_t)other * F3;
+        }
+        const int e0 = ptr[v], e1 = ptr[v + 1];
+        for (int e = e0; e < e1; e += 4) {                 // corner ids first, then the four gathers: two latency levels per round
+            int cid[4]; float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) cid[j] = e + j < e1 ? lst[e + j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) g[j] = cid[j] >= 0 ? src[(size_t)cid[j] * stride + off] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (cid[j] >= 0) acc += g[j];          // ascending corner order
+        }
+    }
+    sums[vl][lane] = acc;
+    __syncthreads();
+    if (lane == 0) {
+        float sx = 0.f, sy = 0.f, sf = 0.f;
+        if (v < V) {
+            const size_t i = (size_t)n * V + v;
+            const float f = A.fl[n];
+            const float x = A.verts_cam[3 * i], y = A.verts_cam[3 * i + 1], z = A.verts_cam[3 * i + 2];
+            const float* S = sums[vl];
+            const float gx = S[0], gy = -S[1], gz = S[2];
+            const float iz = 1.f / z, xz = x * iz, yz = y * iz;                   // == raster_inputs_backward_kernel
+            g_cam[3 * i] = gx * f * iz + S[6] + S[9];
+            g_cam[3 * i + 1] = gy * f * iz + S[7] + S[10];
+            g_cam[3 * i + 2] = gz - (gx * xz + gy * yz) * f * iz + S[8] + S[11];
+            g_tex[3 * i] = S[3]; g_tex[3 * i + 1] = S[4]; g_tex[3 * i + 2] = S[5];
+            sx = gx; sy = gy; sf = gx * xz + gy * yz;
+        }
+        bsum[vl][0] = sx; bsum[vl][1] = sy; bsum[vl][2] = sf;
+    }
+    __syncthreads();
+    const int nblk = gridDim.x;
+    if (tid < 3) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < RF_VPB; k++) t += bsum[k][tid];                          // vertex order
+        part[((size_t)n * nblk + blockIdx.x) * 4 + tid] = t;
+    }
+    if (!pr_last_block(ticket, gridDim.x * gridDim.y, &s_last)) return;
+    for (int k = tid; k < A.N * 3; k += 256) {
+        const int m = k / 3, comp = k - 3 * m;
+        float t = 0.f;
+        for (int b = 0; b < nblk; b++) t += ((const volatile float*)part)[((size_t)m * nblk + b) * 4 + comp];   // block order
+        if (comp < 2) g_pp[2 * m + comp] = t; else g_fl[m] = t;
+    }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
+
+extern "C" size_t lasr_raster_faces_scratch_floats(int N, int V, int F)
+{
+    if (N < 0 || V < 0 || F < 0) return 0;
+    const size_t cov = (size_t)(3 * F > V ? 3 * F : V);
+    const size_t fwd = 2 * (size_t)N * ((cov + 255) / 256);
+    const size_t bwd = 4 * (size_t)N * (((size_t)V + RF_VPB - 1) / RF_VPB);
+    return (fwd > bwd ? fwd : bwd) + 4;
+}
+
+extern "C" int lasr_raster_faces_forward(const float* verts_cam, const float* tex, const float* pp, const float* fl, const float* eye,
+                                         const long long* faces, int faces_shared, float* face_vertices, float* face_attrs,
+                                         float* near_far, float* scratch, unsigned int* ticket, int N, int V, int F, void* hip_stream)
+{
+    if (N < 0 || V < 0 || F < 0 || (N % 2)) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!verts_cam || !tex || !pp || !fl || !eye || !near_far || !scratch || !ticket) return LASR_E_BADARG;
+    if (F > 0 && (!faces || !face_vertices || !face_attrs)) return LASR_E_BADARG;
+    if ((long long)3 * F > 0x7fffffffLL) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    RfArgs A{verts_cam, tex, pp, fl, faces, faces_shared, N, V, 3 * F, N / 2, eye[0], eye[1], eye[2]};
+    const int cov = 3 * F > V ? 3 * F : V;
+    LASR_LAUNCH(K_RASTER_FACES, raster_faces_forward_kernel, dim3((cov + 255) / 256, N), dim3(256), 0, A, face_vertices, face_attrs,
+                scratch, near_far, ticket);
+    return launch_ok();
+}
+
+extern "C" int lasr_raster_faces_backward(const float* verts_cam, const float* fl, const int* inc_ptr, const int* inc,
+                                          int faces_shared, const float* grad_face_vertices, const float* grad_face_attrs,
+                                          float* grad_verts_cam, float* grad_tex, float* grad_pp, float* grad_fl, float* scratch,
+                                          unsigned int* ticket, int N, int V, int F, void* hip_stream)
+{
+    if (N < 0 || V < 0 || F < 0 || (N % 2)) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!verts_cam || !fl || !inc_ptr || !grad_verts_cam || !grad_tex || !grad_pp || !grad_fl || !scratch || !ticket) return LASR_E_BADARG;
+    if (F > 0 && (!inc || !grad_face_vertices || !grad_face_attrs)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    RfArgs A{verts_cam, nullptr, nullptr, fl, nullptr, faces_shared, N, V, 3 * F, N / 2, 0.f, 0.f, 0.f};
+    LASR_LAUNCH(K_RASTER_FACES, raster_faces_backward_kernel, dim3((V + RF_VPB - 1) / RF_VPB, N), dim3(256), 0, A, inc_ptr, inc,
+                grad_face_vertices, grad_face_attrs, grad_verts_cam, grad_tex, scratch, grad_pp, grad_fl, ticket);
+    return launch_ok();
+}
+
 
 extern "C" int lasr_raster_inputs_forward(const float* verts_cam, const float* tex, const float* pp, const float* fl, const float* eye,
                                           float* verts_pre, float* attrs, float* near_far, float* scratch, int N, int V,
@@ -432,16 +662,10 @@ extern "C" int lasr_render_tables_forward(const float* px, const float* masks, c
     const PrScratch S = pr_scratch(scratch, I, H, P);
     const int N = I * H;
     LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_forward_kernel, dim3(N, A.nch), dim3(256), 0, A, (float2*)flow_rd, bgmask,
-                rndpair, S.part);
+                rndpair, S.part, S.cnt);
     if ((rc = launch_ok())) return rc;
-    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_fold_kernel, dim3(I), dim3(64), 0, S.part, S.tot, S.img, mask_tab, tex_tab, H,
-                A.nch, 2.f * l1tex_wt);
-    if ((rc = launch_ok())) return rc;
-    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_flow_kernel, dim3(N, A.nch), dim3(256), 0, A, (const float2*)flow_rd, bgmask,
-                S.img, S.part2, flow_map, vis_mask);
-    if ((rc = launch_ok())) return rc;
-    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_flow_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part2, S.tot, flow_tab,
-                N, A.nch);
+    LASR_LAUNCH(K_RENDER_TABLES_FLOW, render_tables_flow_kernel, dim3(N, A.nch), dim3(256), 0, A, (const float2*)flow_rd, bgmask,
+                S.part, S.tot, S.img, mask_tab, tex_tab, 2.f * l1tex_wt, S.part2, flow_map, vis_mask, flow_tab, S.cnt);
     return launch_ok();
 }
 
@@ -460,9 +684,6 @@ extern "C" int lasr_render_tables_backward(const float* px, const float* masks, 
     const PrScratch S = pr_scratch(const_cast<float*>(scratch), I, H, P);
     const int N = I * H;
     LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_backward_kernel, dim3(N, A.nch), dim3(256), 0, A, S.tot, S.img, grad_mask_tab,
-                grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3);
-    if ((rc = launch_ok())) return rc;
-    LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_intrinsics_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part3, grad_pp,
-                grad_fl, N, A.nch, A.half);
+                grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3, grad_pp, grad_fl, S.cnt);
     return launch_ok();
 }

@@ -224,6 +224,79 @@ def raster_inputs(verts_cam, tex, pp, fl, eye):
     return _RasterInputs.apply(verts_cam, tex, pp, fl, eye)
 
 
+def face_incidence(faces, num_vertices):
+    """CSR vertex -> incident corners of a face tensor [N,F,3] (or [1,F,3]): (inc_ptr int32 [N,V+1], inc int32 [N,3F]) with the
+    corner ids (3 f + c) of a vertex in ASCENDING order -- the order lasr_face_gather_backward sums in.  Built with a handful of
+    torch ops; callers cache it per connectivity (LASR.forward: with its repeated face tensor)."""
+    N = faces.shape[0]
+    flat = faces.reshape(N, -1).long()
+    order = torch.argsort(flat, dim=1, stable=True)                  # stable: ascending corner id inside a vertex
+    counts = torch.zeros(N, num_vertices, dtype=torch.long, device=faces.device)
+    counts.scatter_add_(1, flat, torch.ones_like(flat))
+    ptr = torch.zeros(N, num_vertices + 1, dtype=torch.long, device=faces.device)
+    ptr[:, 1:] = counts.cumsum(1)
+    return ptr.int().contiguous(), order.int().contiguous()
+
+
+class _RasterFaces(Function):
+    @staticmethod
+    def forward(ctx, verts_cam, tex, pp, fl, eye, faces, inc_ptr, inc):
+        import ctypes
+        _lib.need_cuda(verts_cam, tex, pp, fl, faces, inc_ptr, inc)
+        N, V = verts_cam.shape[:2]
+        verts_cam, tex = verts_cam.contiguous().float(), tex.contiguous().float()
+        pp, fl = pp.contiguous().float(), fl.contiguous().float()
+        faces = faces.contiguous().long()
+        shared = int(faces.shape[0] == 1 and N != 1)
+        if faces.shape[0] not in (1, N) or inc_ptr.shape[0] != faces.shape[0] or inc.shape[0] != faces.shape[0]:
+            raise ValueError('faces / incidence must be [N,...] or [1,...] (shared connectivity)')
+        F_ = faces.shape[1]
+        dev = verts_cam.device
+        h = _lib.lib()
+        fv = torch.empty(N, F_, 3, 3, dtype=torch.float32, device=dev)
+        fa = torch.empty(N, F_, 3, 9, dtype=torch.float32, device=dev)
+        nf = torch.empty(2, dtype=torch.float32, device=dev)
+        scratch = torch.empty(h.lasr_raster_faces_scratch_floats(N, V, F_), dtype=torch.float32, device=dev)
+        guard, st = _lib.stream_of(verts_cam)
+        with guard:
+            rc = h.lasr_raster_faces_forward(verts_cam.data_ptr(), tex.data_ptr(), pp.data_ptr(), fl.data_ptr(),
+                                             (ctypes.c_float * 3)(*[float(e) for e in eye]), faces.data_ptr(), shared,
+                                             fv.data_ptr(), fa.data_ptr(), nf.data_ptr(), scratch.data_ptr(),
+                                             _lib.ticket(dev, _lib.TICKET_RASTER_INPUTS), N, V, F_, st)
+        _lib.check(rc, 'lasr_raster_faces_forward')
+        ctx.save_for_backward(verts_cam, fl, inc_ptr, inc)
+        ctx.dims = (N, V, F_, shared)
+        ctx.mark_non_differentiable(nf)
+        return fv, fa, nf
+
+    @staticmethod
+    def backward(ctx, g_fv, g_fa, _g_nf=None):
+        verts_cam, fl, inc_ptr, inc = ctx.saved_tensors
+        N, V, F_, shared = ctx.dims
+        dev = verts_cam.device
+        g_fv = g_fv.contiguous().float() if g_fv is not None else torch.zeros(N, F_, 3, 3, device=dev)
+        g_fa = g_fa.contiguous().float() if g_fa is not None else torch.zeros(N, F_, 3, 9, device=dev)
+        g_cam, g_tex = torch.empty_like(verts_cam), torch.empty_like(verts_cam)
+        g_pp, g_fl = torch.empty(N, 2, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        scratch = torch.empty(h.lasr_raster_faces_scratch_floats(N, V, F_), dtype=torch.float32, device=dev)
+        guard, st = _lib.stream_of(verts_cam)
+        with guard:
+            rc = h.lasr_raster_faces_backward(verts_cam.data_ptr(), fl.data_ptr(), inc_ptr.data_ptr(), inc.data_ptr(), shared,
+                                              g_fv.data_ptr(), g_fa.data_ptr(), g_cam.data_ptr(), g_tex.data_ptr(),
+                                              g_pp.data_ptr(), g_fl.data_ptr(), scratch.data_ptr(),
+                                              _lib.ticket(dev, _lib.TICKET_RASTER_INPUTS), N, V, F_, st)
+        _lib.check(rc, 'lasr_raster_faces_backward')
+        return g_cam, g_tex, g_pp, g_fl, None, None, None, None
+
+
+def raster_faces(verts_cam, tex, pp, fl, eye, faces, incidence):
+    """raster_inputs + the camera stage's eye shift + both face gathers in one launch each way: verts_cam / tex [N,V,3], pp [N,2],
+    fl [N], eye (3 floats, the constant look_at eye: rotation = identity), faces int64 [N,F,3] or [1,F,3] (shared), incidence =
+    face_incidence(faces, V) -> (face_vertices [N,F,3,3] ready for soft_rasterize, face_attrs [N,F,3,9], near_far [2])."""
+    return _RasterFaces.apply(verts_cam, tex, pp, fl, eye, faces, incidence[0], incidence[1])
+
+
 def flow_reproject_planes(pos6, pp0, pp1, fl0, fl1):
     """flow_reproject on the six position planes [N,6,IS,IS] of a wider render (a channel slice of the [N,10,IS,IS] output of the
     9-attribute pass: consecutive images further apart than 6 planes) -> flow [N,IS,IS,2], bgmask [N,IS,IS] bool."""
@@ -337,6 +410,57 @@ def flatten_loss(x, quads, inc_ptr, inc):
     return _Flatten.apply(x, quads, inc_ptr, inc)
 
 
+class _MeshReg(Function):
+    @staticmethod
+    def forward(ctx, x, dx, ax, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc):
+        _lib.need_cuda(x, dx, ax, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc)
+        x, dx, ax = x.contiguous().float(), dx.contiguous().float(), ax.contiguous().float()
+        N, V = x.shape[:2]
+        NA, E = dx.shape[0], quads.shape[0]
+        if dx.shape != ax.shape or (NA and dx.shape[1] != V):
+            raise ValueError('the ARAP pair must be two [NA,V,3] tensors on the same vertex set')
+        dev = x.device
+        out = torch.empty(2 * N + NA, dtype=torch.float32, device=dev)
+        lx = torch.empty_like(x)
+        guard, st = _lib.stream_of(x)
+        with guard:
+            rc = _lib.lib().lasr_mesh_regularisers_forward(x.data_ptr(), dx.data_ptr(), ax.data_ptr(), lap_ptr.data_ptr(), lap_col.data_ptr(),
+                                                           arap_ptr.data_ptr(), arap_col.data_ptr(), quads.data_ptr(), out.data_ptr(),
+                                                           lx.data_ptr(), out[N:].data_ptr(), out[2 * N:].data_ptr(), N, NA, V, E, st)
+        _lib.check(rc, 'lasr_mesh_regularisers_forward')
+        ctx.save_for_backward(x, dx, ax, lx, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc)
+        return out[:N], out[N:2 * N], out[2 * N:]
+
+    @staticmethod
+    def backward(ctx, g_lap, g_flat, g_arap):
+        x, dx, ax, lx, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc = ctx.saved_tensors
+        N, V = x.shape[:2]
+        NA, E = dx.shape[0], quads.shape[0]
+        g_lap, g_flat, g_arap = g_lap.contiguous().float(), g_flat.contiguous().float(), g_arap.contiguous().float()
+        gx, gdx, gax = torch.empty_like(x), torch.empty_like(dx), torch.empty_like(ax)
+        guard, st = _lib.stream_of(x)
+        with guard:
+            rc = _lib.lib().lasr_mesh_regularisers_backward(x.data_ptr(), dx.data_ptr(), ax.data_ptr(), lap_ptr.data_ptr(), lap_col.data_ptr(),
+                                                            arap_ptr.data_ptr(), arap_col.data_ptr(), quads.data_ptr(), inc_ptr.data_ptr(),
+                                                            inc.data_ptr(), lx.data_ptr(), g_lap.data_ptr(), g_flat.data_ptr(),
+                                                            g_arap.data_ptr(), gx.data_ptr(), gdx.data_ptr(), gax.data_ptr(), N, NA, V, E, st)
+        _lib.check(rc, 'lasr_mesh_regularisers_backward')
+        return (gx, gdx, gax) + (None,) * 7
+
+
+def mesh_regularisers(x, arap_dx, arap_x, laplacian, flatten, arap):
+    """(laplacian(x), flatten(x), arap(arap_dx, arap_x)) for the criteria LaplacianLoss / FlattenLoss / ARAPLoss of
+    nnutils/loss_utils.py (average = False), in one launch each way instead of three forward and five backward launches; values and
+    gradients bit-identical to the three calls (/root/reference/nnutils/mesh_net.py:449-459, :494-497)."""
+    V = x.shape[1]
+    dev = x.device
+    ptr = flatten.inc_ptr
+    if ptr.numel() < V + 1:                                           # trailing vertices no face refers to
+        ptr = torch.cat([ptr, ptr[-1:].repeat(V + 1 - ptr.numel())])
+    return _MeshReg.apply(x, arap_dx, arap_x, laplacian.row_ptr.to(dev), laplacian.col.to(dev), arap.row_ptr.to(dev), arap.col.to(dev),
+                          flatten.quads.to(dev), ptr.to(dev), flatten.inc.to(dev))
+
+
 def nearest_point(a, b):
     """a [N,P,3], b [N,Q,3] -> (squared distance [N,P], index [N,P] int64) of the nearest b point; not differentiable
     (chamfer3D's dist1/idx1, /root/reference/nnutils/mesh_net.py:477)."""
@@ -437,6 +561,64 @@ def cosine_distance(feat_obs, feat_rnd, repeat=1):
     util/util.py:71-83, models/networks_basic.py:51-52): feat_obs [N/repeat,C,h,w] (no gradient), feat_rnd [N,C,h,w]
     -> [N]."""
     return _CosDist.apply(feat_obs, feat_rnd, repeat)
+
+
+class _CosDistMulti(Function):
+    """lasr_cosdist_multi_*: every feature layer in one launch each way (see cosine_distance_layers)."""
+
+    @staticmethod
+    def forward(ctx, rep, *feats):
+        import ctypes
+        L = len(feats) // 2
+        _lib.need_cuda(*feats)
+        fa = [f.detach().contiguous().float() for f in feats[:L]]
+        fb = [f.contiguous().float() for f in feats[L:]]
+        N = fb[0].shape[0]
+        Cs = (ctypes.c_int * L)(*[f.shape[1] for f in fb])
+        Ps = (ctypes.c_int * L)(*[f[0, 0].numel() for f in fb])
+        for a, b in zip(fa, fb):
+            if b.shape[0] != N or a.shape[0] * rep != N or a.shape[1:] != b.shape[1:]:
+                raise ValueError('feature maps must be [N/rep,C,h,w] / [N,C,h,w] per layer')
+        h = _lib.lib()
+        dev = fb[0].device
+        d = torch.empty(N, dtype=torch.float32, device=dev)
+        scratch = torch.empty(h.lasr_cosdist_multi_scratch_floats(Ps, L, N), dtype=torch.float32, device=dev)
+        pa = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fa])
+        pb = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fb])
+        guard, st = _lib.stream_of(fb[0])
+        with guard:
+            rc = h.lasr_cosdist_multi_forward(pa, pb, Cs, Ps, L, d.data_ptr(), scratch.data_ptr(),
+                                              _lib.ticket(dev, _lib.TICKET_COSDIST), N, rep, st)
+        _lib.check(rc, 'lasr_cosdist_multi_forward')
+        ctx.save_for_backward(*fa, *fb)
+        ctx.rep, ctx.dims = rep, (Cs, Ps, L, N)
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        Cs, Ps, L, N = ctx.dims
+        fa, fb = ctx.saved_tensors[:L], ctx.saved_tensors[L:]
+        g = g.contiguous().float()
+        gb = [torch.empty_like(f) for f in fb]
+        pa = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fa])
+        pb = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fb])
+        pg = (ctypes.c_void_p * L)(*[f.data_ptr() for f in gb])
+        guard, st = _lib.stream_of(fb[0])
+        with guard:
+            rc = _lib.lib().lasr_cosdist_multi_backward(pa, pb, Cs, Ps, L, g.data_ptr(), pg, N, ctx.rep, st)
+        _lib.check(rc, 'lasr_cosdist_multi_backward')
+        return (None,) + (None,) * L + tuple(gb)
+
+
+def cosine_distance_layers(feats_obs, feats_rnd, repeat=1):
+    """sum over the feature layers of cosine_distance(feats_obs[l], feats_rnd[l], repeat) -> [N]: the perceptual distance of
+    /root/reference/third_party/PerceptualSimilarity/models/networks_basic.py:51-64 (unweighted layers) as ONE launch each way
+    instead of one reduce + one fold + one backward launch per layer.  Each layer's value, and the left-to-right sum of the
+    layers, are bit-identical to the per-layer calls."""
+    if len(feats_obs) != len(feats_rnd) or not 1 <= len(feats_rnd) <= 8:
+        raise ValueError('1..8 feature layers, the same number on both sides')
+    return _CosDistMulti.apply(int(repeat), *feats_obs, *feats_rnd)
 
 
 # ---- small-tensor glue of LASR.forward (lasr_amd/csrc/glue.hip): one launch where the reference runs a chain of tiny ops --------

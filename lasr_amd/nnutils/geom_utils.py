@@ -42,7 +42,7 @@ class _LBS(Function):
             rc = h.lasr_lbs_backward(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(),
                                      skin.data_ptr() if K > 1 else None, gout.data_ptr(), gv.data_ptr(),
                                      gR.data_ptr(), gT.data_ptr(), gs.data_ptr() if K > 1 else None,
-                                     scratch.data_ptr(), N, V, K, 1 if tocam else 0, st)
+                                     scratch.data_ptr(), _lib.ticket(verts.device, _lib.TICKET_LBS), N, V, K, 1 if tocam else 0, st)
         _lib.check(rc, 'lasr_lbs_backward')
         return gv, gR, gT, gs, None, None
 
@@ -81,7 +81,8 @@ class _LBSBoth(Function):
         with guard:
             rc = h.lasr_lbs_backward_both(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(), skin.data_ptr() if K > 1 else None,
                                           gcam.data_ptr(), gblend.data_ptr(), gv.data_ptr(), gR.data_ptr(), gT.data_ptr(),
-                                          gs.data_ptr() if K > 1 else None, scratch.data_ptr(), N, V, K, st)
+                                          gs.data_ptr() if K > 1 else None, scratch.data_ptr(),
+                                          _lib.ticket(verts.device, _lib.TICKET_LBS), N, V, K, st)
         _lib.check(rc, 'lasr_lbs_backward_both')
         return gv, gR, gT, gs, None
 

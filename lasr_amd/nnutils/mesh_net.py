@@ -369,8 +369,12 @@ class PerceptualDistance(nn.Module):
     def forward_pair(self, a, b, repeat=1, unit_range=False):
         """Distance between a[i // repeat] and b[i]: `a` holds each observed image once where the reference feeds the
         network `repeat` identical copies of it (one per hypothesis, mesh_net.py:436-441).  unit_range: see _feats."""
+        feats_a, feats_b = self._feats(a, unit_range), self._feats(b, unit_range)
+        if all(f.is_cuda for f in feats_b) and not any(f.requires_grad for f in feats_a):
+            # all five layers: normalise + dot + spatial mean + the sum over the layers in one launch (one more in the backward)
+            return fused_ops.cosine_distance_layers(feats_a, feats_b, repeat)
         d = 0
-        for fa, fb in zip(self._feats(a, unit_range), self._feats(b, unit_range)):
+        for fa, fb in zip(feats_a, feats_b):
             if fb.is_cuda and not fa.requires_grad:
                 d = d + fused_ops.cosine_distance(fa, fb, repeat)            # normalise + dot + spatial mean: one kernel
                 continue
@@ -470,7 +474,7 @@ class MeshNet(nn.Module):
         n2 = 2 * local_batch_size
         key = (n2, self.faces.data_ptr(), tuple(self.faces.shape), self.faces._version)       # _version: in-place edits count too
         if getattr(self, '_faces_key', None) != key:                         # connectivity is fixed: repeat it once, not per step
-            self._faces_key, self._faces_n2, self._faces_rep = key, self.faces[None].repeat(n2, 1, 1), None
+            self._faces_key, self._faces_n2, self._faces_rep, self._faces_inc = key, self.faces[None].repeat(n2, 1, 1), None, None
         faces = self._faces_n2
         if self.mean_v.is_cuda:                                                # symmetrise + sigmoid + tile: one kernel
             sym = self.symmetric
@@ -504,6 +508,23 @@ def render_flow_soft_2(renderer_soft, verts, faces, verts_pos0, verts_pos1, pp0,
     fgmask = px[:, -1]
     flow, bgmask = fused_ops.flow_reproject(px, pp0, pp1, proj_cam0[:, :1], proj_cam1[:, :1])      # (:93-104)
     return flow, bgmask, fgmask
+
+
+def _plain_camera(renderer, device):
+    """True when `renderer`'s stages in front of the rasteriser reduce to `vertices - eye` on the geometry and nothing on the
+    attributes: constant look_at eye whose rotation is exactly the identity, orthographic with unit scale, ambient-only white
+    light, no anti-aliasing -- the configuration of LASR's five renderers (mesh_net.py:132-149).  LASR.forward then forms the
+    rasteriser's inputs per face corner in one launch (fused_ops.raster_faces) instead of going through sr.Mesh."""
+    from ..soft_renderer.functional import cameras
+    t = renderer.transform
+    tr = t.transformer
+    if t.camera_mode != 'look_at' or tr.perspective or tr.viewing_scale != 1 or renderer.rasterizer.anti_aliasing:
+        return False
+    if not isinstance(tr._eye, (list, tuple)) or len(tr._eye) != 3:
+        return False
+    if renderer.lighting._constant_light() != [1.0, 1.0, 1.0]:
+        return False
+    return cameras._const_look_at(tr._eye, [0, 0, 0], [0, 1, 0], device)[1] is None
 
 
 class LASR(MeshNet):
@@ -540,7 +561,7 @@ class LASR(MeshNet):
         # repeated copies forward() caches, whatever the key says
         if name == 'faces':
             self.__dict__.pop('_faces_key', None)
-            self.__dict__['_faces_n2'] = self.__dict__['_faces_rep'] = None
+            self.__dict__['_faces_n2'] = self.__dict__['_faces_rep'] = self.__dict__['_faces_inc'] = None
         super().__setattr__(name, value)
 
     def schedule_scalars(self):
@@ -641,8 +662,25 @@ class LASR(MeshNet):
         N, BH = n2 * H, B * H
         pp_all = ppoint[:, None].repeat(1, H, 1).view(N, 2)
         sc_all = scale.reshape(N)
-        verts_pre, attrs, near_far = fused_ops.raster_inputs(verts_cam, tex, pp_all, sc_all,
-                                                             self.renderer_softtex.transform.transformer._eye)
+        r_tex = self.renderer_softtex
+        eye = r_tex.transform.transformer._eye
+        faces_rep = self._faces_rep                                             # reset by get_mean_shape when the key changes
+        if faces_rep is None:
+            faces_rep = self._faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
+            self._faces_inc = None
+        r_tex.rasterizer.background_color = [1, 1, 1, 0, 0, 0, 0, 0, 0]
+        part_now = K > 1 and self.iters == 0
+        fast = verts_cam.is_cuda and not part_now and _plain_camera(r_tex, verts_cam.device)
+        if fast:
+            # the same values per FACE CORNER in one launch each way: projection, eye shift of the camera stage, both face gathers
+            # and the near / far fold (fused_ops.raster_faces); the connectivity is shared by the batch, its incidence lists are
+            # built once per face tensor
+            if getattr(self, '_faces_inc', None) is None:
+                self._faces_inc = (faces[:1].contiguous(),) + fused_ops.face_incidence(faces[:1], verts_cam.shape[1])
+            f1, inc_ptr, inc = self._faces_inc
+            fv, fattr, near_far = fused_ops.raster_faces(verts_cam, tex, pp_all, sc_all, eye, f1, (inc_ptr, inc))
+        else:
+            verts_pre, attrs, near_far = fused_ops.raster_inputs(verts_cam, tex, pp_all, sc_all, eye)
         near, far = near_far[0], near_far[1]                                     # views of one 2-float device tensor
         for r in (self.renderer_softflf, self.renderer_softflb, self.renderer_softtex):
             r.rasterizer.near, r.rasterizer.far = near, far
@@ -657,11 +695,13 @@ class LASR(MeshNet):
         # All three rasterise the same 2B*H meshes with the same settings, so one 9-attribute pass (colour, own position, the
         # other frame's position; background white / black / black) yields the same images -- channels are blended
         # independently -- for one distance / sigmoid / depth evaluation per fragment instead of two.
-        faces_rep = self._faces_rep                                             # reset by get_mean_shape when the key changes
-        if faces_rep is None:
-            faces_rep = self._faces_rep = faces[:, None].repeat(1, H, 1, 1).view(-1, faces.shape[1], 3)
-        self.renderer_softtex.rasterizer.background_color = [1, 1, 1, 0, 0, 0, 0, 0, 0]
-        px = self.renderer_softtex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=attrs, texture_type='vertex'))
+        if fast:
+            rz = r_tex.rasterizer
+            px = sr.functional.soft_rasterize(fv, fattr, rz.image_size, rz.background_color, rz.near, rz.far, rz.fill_back, rz.eps,
+                                              rz.sigma_val, rz.dist_func, rz.dist_eps, rz.gamma_val, rz.aggr_func_rgb,
+                                              rz.aggr_func_alpha, 'vertex')
+        else:
+            px = r_tex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=attrs, texture_type='vertex'))
         self.texture_render, alpha = px[:, :3], px[:, 9]                         # views of the wide render
         self.mask_pred = alpha
         obspair = fused_ops.obs_pair(self.imgs, self.masks)                     # observed object on black | on white (:364-366)
@@ -703,8 +743,24 @@ class LASR(MeshNet):
         # 4) shape smoothness (:449-459)
         # a device scalar the trainer refreshes (schedule_scalars), so that one captured graph serves every epoch
         factor = 1 if H > 1 else self.reg_factor
-        tri = self.triangle_loss_fn_sr(pred_v) * (factor * (0.005 * (4 ** opts.subdivide) / 64.))
-        tri = tri + self.flatten_loss(pred_v) * (factor * (5e-4 * (2 ** opts.subdivide / 8.0)))
+        from . import loss_utils
+        stock = (pred_v.is_cuda and type(self.triangle_loss_fn_sr) is loss_utils.LaplacianLoss and not self.triangle_loss_fn_sr.average
+                 and type(self.flatten_loss) is loss_utils.FlattenLoss and not self.flatten_loss.average
+                 and (K == 1 or type(self.arap_loss_fn) is loss_utils.ARAPLoss))
+        arap_l = None
+        if stock:
+            # Laplacian + flatten on the mean shape and ARAP between the two frames' shapes: one launch each way
+            # (fused_ops.mesh_regularisers), values and gradients bit-identical to the three criteria called one by one
+            if K > 1:
+                dv0, dv1 = self.deform_v.reshape(2, B * H, -1, 3).unbind(0)
+            else:
+                dv0 = dv1 = pred_v.new_empty(0, pred_v.shape[1], 3)
+            lap_l, flat_l, arap_l = fused_ops.mesh_regularisers(pred_v, dv0, dv1, self.triangle_loss_fn_sr, self.flatten_loss,
+                                                               self.arap_loss_fn if K > 1 else self.triangle_loss_fn_sr)
+        else:
+            lap_l, flat_l = self.triangle_loss_fn_sr(pred_v), self.flatten_loss(pred_v)
+        tri = lap_l * (factor * (0.005 * (4 ** opts.subdivide) / 64.))
+        tri = tri + flat_l * (factor * (5e-4 * (2 ** opts.subdivide / 8.0)))
         self.triangle_loss_sub = tri.view(n2, H)
         terms.append((self.triangle_loss_sub, 1., G_TRI))
         if (not opts.symmetric) and opts.symmetric_loss:                          # symmetry (:461-478)
@@ -722,8 +778,10 @@ class LASR(MeshNet):
             if torch.is_tensor(factor):                                          # H == 1: the schedule's device scalar (else 1)
                 self.lmotion_loss_sub = factor * self.lmotion_loss_sub
             terms.append((self.lmotion_loss_sub, 1., G_LMOTION))
-            dv0, dv1 = self.deform_v.reshape(2, B * H, -1, 3).unbind(0)
-            terms.append((self.arap_loss_fn(dv0, dv1), (4 ** opts.subdivide) / 64., G_ARAP))
+            if arap_l is None:
+                dv0, dv1 = self.deform_v.reshape(2, B * H, -1, 3).unbind(0)
+                arap_l = self.arap_loss_fn(dv0, dv1)
+            terms.append((arap_l, (4 ** opts.subdivide) / 64., G_ARAP))
             if opts.symmetric_loss:                                              # bone symmetry (:500-503)
                 ca = self.ctl_ts.view(H, -1, 3)
                 terms.append((fused_ops.chamfer(ca, ca * sr.functional.const_tensor([-1, 1, 1], ca.device)), 0.1, G_BONESYM))

@@ -89,8 +89,14 @@ def invalidate_records(device=None, stream=None):
     -- a HIP-graph replay of captured forward / backward calls, or direct C-ABI calls on the same buffer: pending eager backward
     passes then rebuild their records instead of trusting the forward's (LASR_SR_RECORDS_VALID).  No arguments: every
     workspace.  LASRTrainer calls this after each graph replay; other users of the workspace must do the same."""
+    index = None
+    if device is not None:
+        d = torch.device(device)
+        if d.type != 'cuda':
+            raise ValueError('invalidate_records: %r is not a HIP device' % (device,))
+        index = d.index if d.index is not None else torch.cuda.current_device()      # 'cuda' = the current device
     for key in list(_records_of):
-        if (device is None or key[0] == torch.device(device).index) and (stream is None or key[1] == stream):
+        if (device is None or key[0] == index) and (stream is None or key[1] == stream):
             _records_of[key] = _records_of.get(key, 0) + 1
 
 

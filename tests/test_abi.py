@@ -32,7 +32,10 @@ def test_library_is_built_and_exports_every_declared_symbol():
 def test_no_compute_entry_points_without_gpu_but_metadata_calls_work():
     from lasr_amd import _lib
     h = _lib.lib()
-    assert h.lasr_abi_version() >= 1
+    # the header's number, the library's and the binding's agree (signatures changed under a constant version 1)
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'lasr_sr.h')).read()
+    assert h.lasr_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define\s+LASR_ABI_VERSION\s+(\d+)', hdr).group(1))
     assert h.lasr_strerror(0) == b'ok'
     assert b'workspace' in h.lasr_strerror(-3)
     n = h.lasr_sr_workspace_bytes(2, 100, 3, 64)

@@ -1,0 +1,166 @@
+"""Round-5 launch fusions of the optimisation step: each one must give what the launches it replaces gave.
+
+  cosine_distance_layers   == the per-layer cosine_distance calls added up (bit-identical, values and gradients)
+  raster_faces             == raster_inputs -> `vertices - eye` -> two face gathers (values bit-identical; the intrinsics'
+                              gradients are the same sums in another association)
+  LBS backward on MFMA     == the two-launch VALU backward (fp32 round-off: the contractions reassociate)
+  mesh_regularisers        == LaplacianLoss / FlattenLoss / ARAPLoss called one by one
+References for the composed operators themselves (reference file:line) are in the tests of those operators
+(tests/test_ops_gpu.py, tests/test_render_tables_gpu.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from lasr_amd import _lib, synth
+from lasr_amd.nnutils import fused_ops, geom_utils, loss_utils
+from lasr_amd.soft_renderer import functional as srf
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
+
+
+@pytest.mark.parametrize('N,rep,sizes', [(32, 8, ((64, 63), (192, 31), (384, 15), (256, 15), (256, 15))),      # AlexNet at 256x256, S0
+                                         (6, 3, ((8, 5), (40, 9), (7, 33))),                                   # odd channel counts / tiles
+                                         (2, 1, ((64, 4),))])
+def test_all_layers_in_one_launch_equal_the_per_layer_calls(cuda, N, rep, sizes):
+    g = torch.Generator().manual_seed(N + len(sizes))
+    fa = [torch.relu(torch.randn(N // rep, C, h, h, generator=g)).to(cuda) for C, h in sizes]
+    fb = [torch.relu(torch.randn(N, C, h, h, generator=g)).to(cuda) for C, h in sizes]
+    fb[0][0, :, 0, 0] = 0                                            # a dead pixel
+    gout = torch.randn(N, generator=g).to(cuda)
+    one = [b.clone().requires_grad_(True) for b in fb]
+    d = 0
+    for a, b in zip(fa, one):
+        d = d + fused_ops.cosine_distance(a, b, rep)
+    (d * gout).sum().backward()
+    many = [b.clone().requires_grad_(True) for b in fb]
+    m = fused_ops.cosine_distance_layers(fa, many, rep)
+    (m * gout).sum().backward()
+    assert torch.equal(m.detach(), d.detach())
+    for x, y in zip(many, one):
+        assert torch.equal(x.grad, y.grad)
+    # twice in a row: the ticket word is left zero
+    assert torch.equal(fused_ops.cosine_distance_layers(fa, fb, rep), d.detach())
+
+
+@pytest.mark.parametrize('n2,H,level', [(2, 8, 3), (4, 1, 2), (2, 2, 1)])
+def test_raster_faces_equals_the_five_launches_it_replaces(cuda, n2, H, level):
+    v, f = synth.geodesic_sphere(2 ** level)
+    V, N = v.shape[0], n2 * H
+    g = torch.Generator().manual_seed(level * 10 + H)
+    cam = (torch.from_numpy(v)[None] * 0.5 + 0.05 * torch.randn(N, V, 3, generator=g))
+    cam[:, :, 2] += 8
+    tex = torch.rand(N, V, 3, generator=g)
+    pp = torch.randn(N, 2, generator=g) * 0.1
+    fl = torch.rand(N, generator=g) + 8
+    eye = [0.0, 0.0, -2.732]
+    faces = torch.from_numpy(np.asarray(f, np.int64))[None].repeat(N, 1, 1).to(cuda)
+    up_v = torch.randn(N, faces.shape[1], 3, 3, generator=g).to(cuda)
+    up_a = torch.randn(N, faces.shape[1], 3, 9, generator=g).to(cuda)
+
+    a = [t.clone().to(cuda).requires_grad_(True) for t in (cam, tex, pp, fl)]
+    pre, attrs, nf = fused_ops.raster_inputs(*a, eye)
+    fv0 = srf.face_vertices(srf.look_at(pre, eye), faces)
+    fa0 = srf.face_vertices(attrs, faces)
+    ((fv0 * up_v).sum() + (fa0 * up_a).sum()).backward()
+
+    b = [t.clone().to(cuda).requires_grad_(True) for t in (cam, tex, pp, fl)]
+    inc = fused_ops.face_incidence(faces[:1], V)
+    fv1, fa1, nf1 = fused_ops.raster_faces(*b, eye, faces[:1].contiguous(), inc)
+    ((fv1 * up_v).sum() + (fa1 * up_a).sum()).backward()
+    assert torch.equal(fv1.detach(), fv0.detach()) and torch.equal(fa1.detach(), fa0.detach()) and torch.equal(nf1, nf)
+    assert torch.equal(b[0].grad, a[0].grad) and torch.equal(b[1].grad, a[1].grad)        # same corner order, same expressions
+    assert rel(b[2].grad, a[2].grad) <= 2e-5 and rel(b[3].grad, a[3].grad) <= 2e-5          # block sums in another association
+
+    # per-mesh connectivity (not shared): a permutation of the faces of every second mesh
+    perm = torch.randperm(faces.shape[1], generator=g).to(cuda)
+    faces2 = faces.clone()
+    faces2[1::2] = faces[1::2][:, perm]
+    c = [t.clone().to(cuda).requires_grad_(True) for t in (cam, tex, pp, fl)]
+    pre, attrs, _ = fused_ops.raster_inputs(*c, eye)
+    ((srf.face_vertices(srf.look_at(pre, eye), faces2) * up_v).sum() + (srf.face_vertices(attrs, faces2) * up_a).sum()).backward()
+    e = [t.clone().to(cuda).requires_grad_(True) for t in (cam, tex, pp, fl)]
+    fv2, fa2, _ = fused_ops.raster_faces(*e, eye, faces2, fused_ops.face_incidence(faces2, V))
+    ((fv2 * up_v).sum() + (fa2 * up_a).sum()).backward()
+    assert torch.equal(e[0].grad, c[0].grad) and torch.equal(e[1].grad, c[1].grad)
+
+
+@pytest.mark.parametrize('N,V,K,tocam', [(16, 642, 21, 1), (6, 1282, 36, 1), (2, 37, 2, 0), (4, 70, 1, 1), (3, 200, 66, 1)])
+def test_lbs_backward_on_the_matrix_cores_equals_the_valu_backward(cuda, N, V, K, tocam):
+    g = torch.Generator().manual_seed(N * K)
+    h = _lib.lib()
+    verts = torch.randn(N, V, 3, generator=g).to(cuda)
+    R = torch.randn(N * K, 9, generator=g).to(cuda)
+    T = torch.randn(N * K, 3, generator=g).to(cuda)
+    skin = torch.softmax(torch.randn(N, max(K - 1, 1), V, generator=g), 1).to(cuda)
+    gout, gblend = torch.randn(N, V, 3, generator=g).to(cuda), torch.randn(N, V, 3, generator=g).to(cuda)
+    st = torch.cuda.current_stream(cuda).cuda_stream
+    scratch = torch.empty(h.lasr_lbs_backward_scratch_floats(N, V, K), device=cuda)
+    outs = []
+    for ticket in (None, _lib.ticket(cuda, _lib.TICKET_LBS)):
+        gv, gR, gT = torch.full_like(verts, 7.), torch.full_like(R, 7.), torch.full_like(T, 7.)
+        gs = torch.full_like(skin, 7.)
+        sk, gsk = (skin.data_ptr(), gs.data_ptr()) if K > 1 else (None, None)
+        if tocam:
+            rc = h.lasr_lbs_backward_both(verts.data_ptr(), R.data_ptr(), T.data_ptr(), sk, gout.data_ptr(), gblend.data_ptr(),
+                                          gv.data_ptr(), gR.data_ptr(), gT.data_ptr(), gsk, scratch.data_ptr(), ticket, N, V, K, st)
+        else:
+            rc = h.lasr_lbs_backward(verts.data_ptr(), R.data_ptr(), T.data_ptr(), sk, gout.data_ptr(), gv.data_ptr(), gR.data_ptr(),
+                                     gT.data_ptr(), gsk, scratch.data_ptr(), ticket, N, V, K, 0, st)
+        _lib.check(rc, 'lasr_lbs_backward')
+        torch.cuda.synchronize()
+        outs.append((gv, gR, gT, gs if K > 1 else None))
+    for name, a, b in zip(('g_verts', 'g_R', 'g_T', 'g_skin'), outs[1], outs[0]):
+        if a is not None:
+            assert rel(a, b) <= 2e-5, name
+    assert int(_lib._tickets[(cuda.index, st)].abs().sum()) == 0            # every ticket word is left zero
+
+
+def test_lbs_operator_gradients_still_match_autograd_of_the_reference_formula(cuda):
+    # geom_utils.py:45-71 restated with torch ops (K-1 blended transforms, then the body transform), autograd as the reference
+    N, V, K = 4, 300, 9
+    g = torch.Generator().manual_seed(3)
+    leaves = [torch.randn(N, V, 3, generator=g), torch.randn(N * K, 3, 3, generator=g), torch.randn(N * K, 1, 3, generator=g),
+              torch.softmax(torch.randn(N, K - 1, V, 1, generator=g), 1)]
+    up = torch.randn(N, V, 3, generator=g)
+
+    def ref(v, R, T, s):
+        Rk, Tk = R.view(N, K, 3, 3), T.view(N, K, 1, 3)
+        vs = (s * (v[:, None] @ Rk[:, 1:] + Tk[:, 1:])).sum(1)
+        return vs @ Rk[:, 0] + Tk[:, 0]
+    a = [t.clone().double().requires_grad_(True) for t in leaves]
+    (ref(*a) * up.double()).sum().backward()
+    b = [t.clone().to(cuda).requires_grad_(True) for t in leaves]
+    (geom_utils.obj_to_cam(b[0], b[1], b[2], K, 1, b[3]) * up.to(cuda)).sum().backward()
+    for name, x, y in zip(('verts', 'Rmat', 'Tmat', 'skin'), b, a):
+        assert rel(x.grad.cpu().double(), y.grad) <= 2e-5, name
+
+
+@pytest.mark.parametrize('level,N,NA', [(3, 16, 8), (2, 4, 2), (1, 2, 1)])
+def test_mesh_regularisers_in_one_launch_equal_the_three_criteria(cuda, level, N, NA):
+    v, f = synth.geodesic_sphere(2 ** level)
+    V = v.shape[0]
+    g = torch.Generator().manual_seed(level)
+    faces = torch.from_numpy(np.asarray(f, np.int64))
+    lap = loss_utils.LaplacianLoss(torch.from_numpy(v), faces).to(cuda)
+    arap = loss_utils.ARAPLoss(torch.from_numpy(v), faces).to(cuda)
+    flat = loss_utils.FlattenLoss(faces).to(cuda)
+    x = (torch.from_numpy(v)[None] + 0.05 * torch.randn(N, V, 3, generator=g)).to(cuda)
+    d0 = (torch.from_numpy(v)[None] + 0.05 * torch.randn(NA, V, 3, generator=g)).to(cuda)
+    d1 = (torch.from_numpy(v)[None] + 0.05 * torch.randn(NA, V, 3, generator=g)).to(cuda)
+    ups = [torch.randn(n, generator=g).to(cuda) for n in (N, N, NA)]
+
+    a = [t.clone().requires_grad_(True) for t in (x, d0, d1)]
+    l0, f0, a0 = lap(a[0]), flat(a[0]), arap(a[1], a[2])
+    ((l0 * ups[0]).sum() + (f0 * ups[1]).sum() + (a0 * ups[2]).sum()).backward()
+    b = [t.clone().requires_grad_(True) for t in (x, d0, d1)]
+    l1, f1, a1 = fused_ops.mesh_regularisers(b[0], b[1], b[2], lap, flat, arap)
+    ((l1 * ups[0]).sum() + (f1 * ups[1]).sum() + (a1 * ups[2]).sum()).backward()
+    assert torch.equal(l1.detach(), l0.detach()) and torch.equal(f1.detach(), f0.detach()) and torch.equal(a1.detach(), a0.detach())
+    assert torch.equal(b[1].grad, a[1].grad) and torch.equal(b[2].grad, a[2].grad)
+    assert rel(b[0].grad, a[0].grad) <= 1e-6            # Laplacian + flatten parts added inside the kernel
