@@ -32,16 +32,15 @@ int lasr_lbs_forward(const float* verts, const float* Rmat, const float* Tmat, c
 int lasr_lbs_forward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin, float* out_cam,
                           float* out_blend, int N, int V, int K, void* hip_stream);
 size_t lasr_lbs_backward_scratch_floats(int N, int V, int K);     /* chunk partials of the transform gradients */
-/* Backward.  ticket: one zeroed device word (left zero) -> ONE launch with all three contractions (blended transform, g_skin,
- * the transposed g_RT) on v_mfma_f32_16x16x4_f32 and the chunk fold done by the launch's last block; NULL (or K > 65) -> the
- * two-launch VALU path of ABI version 1. */
+/* Backward.  The three contractions (blended transform, g_skin, the transposed g_RT) run on v_mfma_f32_16x16x4_f32 (K <= 65;
+ * more bones: the VALU kernel of ABI version 1); a second small launch folds the chunk partials of grad_Rmat / grad_Tmat.  With
+ * grad_Rmat == grad_Tmat == NULL that contraction and the fold are skipped (scratch may then be NULL). */
 int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                       const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
-                      float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam, void* hip_stream);
+                      float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream);
 int lasr_lbs_backward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                            const float* grad_out_cam, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
-                           float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K,
-                           void* hip_stream);
+                           float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, void* hip_stream);
 
 /*
  * Pinhole projection, nnutils/geom_utils.py:27-34 (pinhole_cam), with pp / fl already expanded per mesh:
@@ -238,8 +237,10 @@ int lasr_nearest_point(const float* a, const float* b, float* d2, int* idx, int 
  * as the means produce), writes grad_tri [N,F,3,3] (per face corner; reduce to vertices with lasr_face_gather_backward)
  * and grad_points [N,P,3].  d d2/d p = 2 (p - q), d d2/d corner_i = -2 w_i (p - q) for the closest point q = sum w_i corner_i.
  */
+size_t lasr_point_mesh_scratch_floats(int N, int F, int P);            /* per-chunk minima of the two-launch forward */
 int lasr_point_mesh_forward(const float* verts, const long long* faces, const float* points, float* dmin_point,
-                            int* arg_point, float* dmin_face, int* arg_face, int N, int V, int F, int P, void* hip_stream);
+                            int* arg_point, float* dmin_face, int* arg_face, float* scratch, int N, int V, int F, int P,
+                            void* hip_stream);
 int lasr_point_mesh_backward(const float* verts, const long long* faces, const float* points, const int* arg_point,
                              const int* arg_face, float grad_point_term, float grad_face_term, float* grad_tri,
                              float* grad_points, int N, int V, int F, int P, void* hip_stream);
@@ -265,13 +266,13 @@ int lasr_cosdist_backward(const float* feat_obs, const float* feat_rnd, const fl
  * models/networks_basic.py:51-64): dist[n] = sum_l (1 - mean_p cos_l[n,p]), layers added in list order, each layer's value
  * bit-identical to lasr_cosdist_forward's.  feat_obs / feat_rnd / grad_rnd: HOST arrays of n_layers device pointers
  * ([N/rep, C_l, P_l] / [N, C_l, P_l]); C, P: host arrays; n_layers <= LASR_COSDIST_MAX_LAYERS.
- * scratch: lasr_cosdist_multi_scratch_floats floats.  ticket: one device word, ZERO on entry, left zero (the launch's last
- * block folds the tile partials; see "tickets" below).  Backward: every grad_rnd[l] overwritten.
+ * scratch: lasr_cosdist_multi_scratch_floats floats (tile partials; a second one-wave-per-image launch folds them).
+ * Backward: every grad_rnd[l] overwritten.
  */
 #define LASR_COSDIST_MAX_LAYERS 8
 size_t lasr_cosdist_multi_scratch_floats(const int* P, int n_layers, int N);
 int lasr_cosdist_multi_forward(const float* const* feat_obs, const float* const* feat_rnd, const int* C, const int* P,
-                               int n_layers, float* dist, float* scratch, unsigned int* ticket, int N, int rep, void* hip_stream);
+                               int n_layers, float* dist, float* scratch, int N, int rep, void* hip_stream);
 int lasr_cosdist_multi_backward(const float* const* feat_obs, const float* const* feat_rnd, const int* C, const int* P,
                                 int n_layers, const float* grad_dist, float* const* grad_rnd, int N, int rep, void* hip_stream);
 
@@ -424,16 +425,17 @@ int lasr_raster_inputs_backward(const float* verts_cam, const float* fl, const f
  * faces: int64 [N,F,3], or [1,F,3] with faces_shared = 1 (all meshes share the connectivity).  Backward: the vertex-centric sums
  * run over a CSR incidence structure the caller builds once per connectivity: inc_ptr int32 [N or 1, V+1], inc int32 [N or 1, 3F] =
  * corner ids (3 f + c) grouped by vertex, ASCENDING inside a vertex (the summation order of lasr_face_gather_backward).
- * scratch: lasr_raster_faces_scratch_floats(N, V, F) floats (either direction).  ticket: one zeroed device word, left zero.
+ * scratch: lasr_raster_faces_scratch_floats(N, V, F) floats (either direction; block partials of the depth range / of the
+ * intrinsics' gradients, folded by a second small launch).
  */
 size_t lasr_raster_faces_scratch_floats(int N, int V, int F);
 int lasr_raster_faces_forward(const float* verts_cam, const float* tex, const float* pp, const float* fl, const float* eye,
                               const long long* faces, int faces_shared, float* face_vertices, float* face_attrs, float* near_far,
-                              float* scratch, unsigned int* ticket, int N, int V, int F, void* hip_stream);
+                              float* scratch, int N, int V, int F, void* hip_stream);
 int lasr_raster_faces_backward(const float* verts_cam, const float* fl, const int* inc_ptr, const int* inc, int faces_shared,
                                const float* grad_face_vertices, const float* grad_face_attrs, float* grad_verts_cam,
-                               float* grad_tex, float* grad_pp, float* grad_fl, float* scratch, unsigned int* ticket, int N, int V,
-                               int F, void* hip_stream);
+                               float* grad_tex, float* grad_pp, float* grad_fl, float* scratch, int N, int V, int F,
+                               void* hip_stream);
 
 #define LASR_GATHER_MAX_KEYS 24
 int lasr_gather_rows(const float* table, long long W, int pairs, const long long* ids, int B, int n_keys,

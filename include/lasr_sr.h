@@ -45,9 +45,10 @@ extern "C" {
  *   2  round 4: lasr_prof_enable(void* stream, int on) / lasr_prof_collect(void* stream, ...) (were process-wide),
  *      lasr_sr_set_forward_math / lasr_sr_set_launch_thresholds removed (per-call lasr_sr_options / flags instead),
  *      lasr_sr_workspace_bytes grows with IS (tile-order table).
- *   3  round 5: lasr_lbs_backward / lasr_lbs_backward_both take a ticket word; lasr_skin_weights_backward ignores its scratch;
- *      lasr_render_tables_* run 2 + 1 launches (same signatures, the scratch's last 16 floats hold block tickets);
- *      new: lasr_cosdist_multi_*, lasr_raster_faces_*, lasr_mesh_regularisers_*. */
+ *   3  round 5: lasr_lbs_backward* skip the transform gradients when both pointers are NULL; lasr_skin_weights_backward ignores its
+ *      scratch; lasr_render_tables_* run 3 + 2 launches (same signatures and scratch size);
+ *      new: lasr_cosdist_multi_*, lasr_raster_faces_*, lasr_mesh_regularisers_*, lasr_point_mesh_scratch_floats (+ a scratch
+ *      argument of lasr_point_mesh_forward). */
 #define LASR_ABI_VERSION 3
 int         lasr_abi_version(void);
 const char* lasr_strerror(int code);

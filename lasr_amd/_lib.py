@@ -24,9 +24,9 @@ SIGNATURES = {
     # include/lasr_ops.h
     'lasr_lbs_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_lbs_forward_both': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    'lasr_lbs_backward_both': (_i, [_p] * 12 + [_i, _i, _i, _p]),
+    'lasr_lbs_backward_both': (_i, [_p] * 11 + [_i, _i, _i, _p]),
     'lasr_lbs_backward_scratch_floats': (_sz, [_i, _i, _i]),
-    'lasr_lbs_backward': (_i, [_p] * 11 + [_i, _i, _i, _i, _p]),
+    'lasr_lbs_backward': (_i, [_p] * 10 + [_i, _i, _i, _i, _p]),
     'lasr_pinhole_forward': (_i, [_p, _p, _p, _p, _i, _i, _p]),
     'lasr_pinhole_backward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_loss_scratch_floats': (_sz, [_i, _i, _i]),
@@ -57,13 +57,14 @@ SIGNATURES = {
     'lasr_face_gather_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_face_gather_backward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_nearest_point': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
-    'lasr_point_mesh_forward': (_i, [_p] * 7 + [_i, _i, _i, _i, _p]),
+    'lasr_point_mesh_scratch_floats': (_sz, [_i, _i, _i]),
+    'lasr_point_mesh_forward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),
     'lasr_point_mesh_backward': (_i, [_p] * 5 + [_f, _f, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_cosdist_scratch_floats': (_sz, [_i, _i]),
     'lasr_cosdist_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_cosdist_backward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_cosdist_multi_scratch_floats': (_sz, [_p, _i, _i]),
-    'lasr_cosdist_multi_forward': (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
+    'lasr_cosdist_multi_forward': (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
     'lasr_cosdist_multi_backward': (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
     'lasr_load_textures': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     # lasr_amd/csrc/glue.hip
@@ -87,8 +88,8 @@ SIGNATURES = {
     'lasr_raster_inputs_forward': (_i, [_p] * 9 + [_i, _i, _p]),
     'lasr_raster_inputs_backward': (_i, [_p] * 8 + [_i, _i, _p]),
     'lasr_raster_faces_scratch_floats': (_sz, [_i, _i, _i]),
-    'lasr_raster_faces_forward': (_i, [_p] * 6 + [_i] + [_p] * 5 + [_i, _i, _i, _p]),
-    'lasr_raster_faces_backward': (_i, [_p] * 4 + [_i] + [_p] * 8 + [_i, _i, _i, _p]),
+    'lasr_raster_faces_forward': (_i, [_p] * 6 + [_i] + [_p] * 4 + [_i, _i, _i, _p]),
+    'lasr_raster_faces_backward': (_i, [_p] * 4 + [_i] + [_p] * 7 + [_i, _i, _i, _p]),
     'lasr_gather_rows': (_i, [_p, ctypes.c_longlong, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
     'lasr_mean_shape_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_mean_shape_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
@@ -170,26 +171,6 @@ def stream_of(t):
     """(device-guard context, raw hipStream_t) for the tensor's device: kernels go on torch's current stream."""
     import torch
     return torch.cuda.device(t.device), torch.cuda.current_stream(t.device).cuda_stream
-
-
-_tickets = {}
-TICKET_COSDIST, TICKET_LBS, TICKET_RASTER_INPUTS, TICKET_SLOTS = 0, 1, 2, 16
-
-
-def ticket(device, slot):
-    """Address of one zeroed device word for kernels whose last block folds the launch's partials (include/lasr_ops.h,
-    "tickets"): zero on entry, left zero by the kernel.  One small tensor per (device, stream), allocated once -- outside any
-    graph capture that later reads it -- and a slot per operator so that two operators never share a word."""
-    import torch
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
-    t = _tickets.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            # allocated inside a capture the words would live in the graph's private pool, zeroed by a memset node of that graph only
-            raise LasrNativeError('the ticket words of stream %#x do not exist yet: run the operator sequence once eagerly on this '
-                                  'stream before capturing it (the trainer warms up twice)' % key[1])
-        t = _tickets[key] = torch.zeros(TICKET_SLOTS, dtype=torch.int32, device=device)
-    return t.data_ptr() + 4 * slot
 
 
 def need_cuda(*tensors):

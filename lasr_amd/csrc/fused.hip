@@ -241,28 +241,43 @@ __global__ __launch_bounds__(256) void skin_backward_kernel(const float* __restr
     float acc[15];                                   // g_ts[3] | g_lc[3] | g_R[9]
 #pragma unroll
     for (int i = 0; i < 15; i++) acc[i] = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) {
-        const float* p = verts + ((size_t)h * V + v) * 3;
-        const size_t i = (size_t)hk * V + v;
-        float dot = 0.f;
-        for (int k = 0; k < J; k++) { const size_t e = ((size_t)h * J + k) * V + v; dot += skin[e] * gskin[e]; }
-        const float ge = -10.f * (skin[i] * (gskin[i] - dot));                        // d loss / d (sum_d w_d r_d^2)
-        float r[3];
-        const float d0 = b.t[0] - p[0], d1 = b.t[1] - p[1], d2 = b.t[2] - p[2];
-        r[0] = d0 * b.R[0] + d1 * b.R[3] + d2 * b.R[6];
-        r[1] = d0 * b.R[1] + d1 * b.R[4] + d2 * b.R[7];
-        r[2] = d0 * b.R[2] + d1 * b.R[5] + d2 * b.R[8];
-        float gr[3];
+    constexpr int VPT = 4;                           // vertices per thread and pass: 2 x VPT x 5 independent loads in flight
+    for (int vb = threadIdx.x; vb < V; vb += 256 * VPT) {
+        float dot[VPT];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            acc[3 + d] += ge * b.w[d] * (r[d] * r[d]);           // d/d log_ctl: w = exp(log_ctl)
-            gr[d] = 2.f * ge * b.w[d] * r[d];
+        for (int u = 0; u < VPT; u++) dot[u] = 0.f;
+#pragma unroll 5
+        for (int k = 0; k < J; k++) {                // bones in order: the value of the former dot kernel
+#pragma unroll
+            for (int u = 0; u < VPT; u++) {
+                const int v = vb + 256 * u;
+                if (v < V) { const size_t e = ((size_t)h * J + k) * V + v; dot[u] += skin[e] * gskin[e]; }
+            }
         }
-        acc[0] += gr[0] * b.R[0] + gr[1] * b.R[1] + gr[2] * b.R[2];
-        acc[1] += gr[0] * b.R[3] + gr[1] * b.R[4] + gr[2] * b.R[5];
-        acc[2] += gr[0] * b.R[6] + gr[1] * b.R[7] + gr[2] * b.R[8];
 #pragma unroll
-        for (int c = 0; c < 3; c++) { acc[6 + c] += d0 * gr[c]; acc[9 + c] += d1 * gr[c]; acc[12 + c] += d2 * gr[c]; }
+        for (int u = 0; u < VPT; u++) {
+            const int v = vb + 256 * u;
+            if (v >= V) continue;
+            const float* p = verts + ((size_t)h * V + v) * 3;
+            const size_t i = (size_t)hk * V + v;
+            const float ge = -10.f * (skin[i] * (gskin[i] - dot[u]));                     // d loss / d (sum_d w_d r_d^2)
+            float r[3];
+            const float d0 = b.t[0] - p[0], d1 = b.t[1] - p[1], d2 = b.t[2] - p[2];
+            r[0] = d0 * b.R[0] + d1 * b.R[3] + d2 * b.R[6];
+            r[1] = d0 * b.R[1] + d1 * b.R[4] + d2 * b.R[7];
+            r[2] = d0 * b.R[2] + d1 * b.R[5] + d2 * b.R[8];
+            float gr[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                acc[3 + d] += ge * b.w[d] * (r[d] * r[d]);           // d/d log_ctl: w = exp(log_ctl)
+                gr[d] = 2.f * ge * b.w[d] * r[d];
+            }
+            acc[0] += gr[0] * b.R[0] + gr[1] * b.R[1] + gr[2] * b.R[2];
+            acc[1] += gr[0] * b.R[3] + gr[1] * b.R[4] + gr[2] * b.R[5];
+            acc[2] += gr[0] * b.R[6] + gr[1] * b.R[7] + gr[2] * b.R[8];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { acc[6 + c] += d0 * gr[c]; acc[9 + c] += d1 * gr[c]; acc[12 + c] += d2 * gr[c]; }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 15; i++) acc[i] = block_sum(acc[i], red);
@@ -460,64 +475,103 @@ __device__ __forceinline__ void load_tri(const float* verts, const long long* f,
     for (int d = 0; d < 3; d++) { a[d] = verts[3 * f[0] + d]; b[d] = verts[3 * f[1] + d]; c[d] = verts[3 * f[2] + d]; }
 }
 
-// for each point the nearest face: dmin_p [B,P], arg_p [B,P]
-__global__ __launch_bounds__(256) void pmf_point_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
-                                                        const float* __restrict__ pts, float* __restrict__ dmin,
-                                                        int* __restrict__ arg, int V, int F, int P)
-{
-    __shared__ float tri[128 * 9];
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    const float* vn = verts + (size_t)n * V * 3;
-    float q[3] = {0.f, 0.f, 0.f};
-    if (p < P) { const float* s = pts + ((size_t)n * P + p) * 3; q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; }
-    float best = INFINITY; int barg = 0;
-    for (int f0 = 0; f0 < F; f0 += 128) {
-        const int m = min(128, F - f0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < m * 9; i += 256) {
-            const int f = i / 9, r = i - 9 * f;
-            tri[i] = vn[3 * faces[(size_t)(f0 + f) * 3 + r / 3] + r % 3];
-        }
-        __syncthreads();
-        for (int j = 0; j < m; j++) {
-            const Closest c = point_triangle(q, tri + 9 * j, tri + 9 * j + 3, tri + 9 * j + 6);
-            if (c.d2 < best) { best = c.d2; barg = f0 + j; }
-        }
-    }
-    if (p < P) { dmin[(size_t)n * P + p] = best; arg[(size_t)n * P + p] = barg; }
-}
+// Forward, two launches.  Rounds 1-4 ran one thread per point over ALL faces and one thread per face over ALL points: 6 and 10
+// workgroups for the 1282-point / 2560-face mesh of the camel schedule's last stage, 3.4 ms per step.  Now the other set is cut
+// into chunks of PMF tile size and a block owns (256 points, one face chunk) or (256 faces, one point chunk): hundreds of blocks,
+// the same candidate order inside a chunk; per-chunk minima go to scratch and pmf_fold_kernel takes the minimum over the chunks
+// in chunk order with a strict `<` -- the lowest index wins ties exactly as the single scan did.
+__host__ __device__ inline int pmf_tile(int n) { int t = 32; while ((n + t - 1) / t > 64) t *= 2; return t; }
 
-// for each face the nearest point: dmin_f [B,F], arg_f [B,F]
-__global__ __launch_bounds__(256) void pmf_face_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
-                                                       const float* __restrict__ pts, float* __restrict__ dmin,
-                                                       int* __restrict__ arg, int V, int F, int P)
+struct PmfArgs {
+    const float* verts; const long long* faces; const float* pts;
+    float* part_pd; int* part_pa;       // [N][FC][P]  per face chunk: nearest face of every point
+    float* part_fd; int* part_fa;       // [N][PC][F]  per point chunk: nearest point of every face
+    int V, F, P, FT, PT, FC, PC;
+};
+
+__global__ __launch_bounds__(256) void pmf_partial_kernel(PmfArgs A)
 {
-    __shared__ float tile[256 * 3];
-    const int n = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float tile[128 * 9];
+    const int n = blockIdx.z, tid = threadIdx.x;
+    const float* vn = A.verts + (size_t)n * A.V * 3;
+    if ((int)blockIdx.y < A.FC) {                                   // ---- points against one chunk of faces
+        const int p = blockIdx.x * 256 + tid;
+        if (blockIdx.x * 256 >= A.P) return;
+        const int fbeg = blockIdx.y * A.FT, fend = min(A.F, fbeg + A.FT);
+        float q[3] = {0.f, 0.f, 0.f};
+        if (p < A.P) { const float* s = A.pts + ((size_t)n * A.P + p) * 3; q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; }
+        float best = INFINITY; int barg = fbeg;
+        for (int f0 = fbeg; f0 < fend; f0 += 128) {
+            const int m = min(128, fend - f0);
+            __syncthreads();
+            for (int i = tid; i < m * 9; i += 256) {
+                const int f = i / 9, r = i - 9 * f;
+                tile[i] = vn[3 * A.faces[(size_t)(f0 + f) * 3 + r / 3] + r % 3];
+            }
+            __syncthreads();
+            for (int j = 0; j < m; j++) {
+                const Closest c = point_triangle(q, tile + 9 * j, tile + 9 * j + 3, tile + 9 * j + 6);
+                if (c.d2 < best) { best = c.d2; barg = f0 + j; }
+            }
+        }
+        if (p < A.P) {
+            const size_t o = ((size_t)n * A.FC + blockIdx.y) * A.P + p;
+            A.part_pd[o] = best; A.part_pa[o] = barg;
+        }
+        return;
+    }
+    const int f = blockIdx.x * 256 + tid;                           // ---- faces against one chunk of points
+    if (blockIdx.x * 256 >= A.F) return;
+    const int pc = blockIdx.y - A.FC, pbeg = pc * A.PT, pend = min(A.P, pbeg + A.PT);
     float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f};
-    if (f < F) load_tri(verts + (size_t)n * V * 3, faces + (size_t)f * 3, a, b, c);
-    float best = INFINITY; int barg = 0;
-    for (int p0 = 0; p0 < P; p0 += 256) {
-        const int m = min(256, P - p0);
+    if (f < A.F) load_tri(vn, A.faces + (size_t)f * 3, a, b, c);
+    float best = INFINITY; int barg = pbeg;
+    for (int p0 = pbeg; p0 < pend; p0 += 256) {
+        const int m = min(256, pend - p0);
         __syncthreads();
-        for (int i = threadIdx.x; i < m * 3; i += 256) tile[i] = pts[((size_t)n * P + p0) * 3 + i];
+        for (int i = tid; i < m * 3; i += 256) tile[i] = A.pts[((size_t)n * A.P + p0) * 3 + i];
         __syncthreads();
         for (int j = 0; j < m; j++) {
             const Closest cl = point_triangle(tile + 3 * j, a, b, c);
             if (cl.d2 < best) { best = cl.d2; barg = p0 + j; }
         }
     }
-    if (f < F) { dmin[(size_t)n * F + f] = best; arg[(size_t)n * F + f] = barg; }
+    if (f < A.F) {
+        const size_t o = ((size_t)n * A.PC + pc) * A.F + f;
+        A.part_fd[o] = best; A.part_fa[o] = barg;
+    }
 }
 
-// Backward, face side: gtri[n,f,corner,:] = sum of the contributions of every pair this face takes part in:
-// its own nearest point (weight gf) and every point whose nearest face it is (weight gp), in ascending point order.
+__global__ __launch_bounds__(256) void pmf_fold_kernel(PmfArgs A, float* __restrict__ dmin_p, int* __restrict__ arg_p,
+                                                       float* __restrict__ dmin_f, int* __restrict__ arg_f)
+{
+    const int n = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    const bool face_side = blockIdx.y == 1;
+    const int count = face_side ? A.F : A.P, chunks = face_side ? A.PC : A.FC;
+    if (i >= count) return;
+    const float* pd = face_side ? A.part_fd : A.part_pd;
+    const int* pa = face_side ? A.part_fa : A.part_pa;
+    float best = INFINITY; int barg = 0;
+    for (int k = 0; k < chunks; k++) {                               // chunk order + strict `<`: the lowest index wins ties
+        const size_t o = ((size_t)n * chunks + k) * count + i;
+        const float d = pd[o];
+        if (d < best) { best = d; barg = pa[o]; }
+    }
+    (face_side ? dmin_f : dmin_p)[(size_t)n * count + i] = best;
+    (face_side ? arg_f : arg_p)[(size_t)n * count + i] = barg;
+}
+
+// Backward.  A WAVE per face (per point): its lanes scan the other set's nearest-index table 64 entries at a time and the matches
+// of a ballot are processed in ascending order by the whole wave (uniform arithmetic, lane 0 stores) -- the contributions and
+// their order are those of the single-thread scans of rounds 1-4 (own nearest element first, then ascending index), which took
+// 10 and 6 workgroups and 0.8 ms per step at the camel sizes.
+// Face side: gtri[n,f,corner,:] = its own nearest point (weight gf) + every point whose nearest face it is (weight gp).
 __global__ __launch_bounds__(256) void pmf_backward_face_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
                                                                 const float* __restrict__ pts, const int* __restrict__ arg_p,
                                                                 const int* __restrict__ arg_f, float gp, float gf,
                                                                 float* __restrict__ gtri, int V, int F, int P)
 {
-    const int n = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y, f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f >= F) return;
     float a[3], b[3], c[3], acc[9];
     load_tri(verts + (size_t)n * V * 3, faces + (size_t)f * 3, a, b, c);
@@ -533,20 +587,29 @@ __global__ __launch_bounds__(256) void pmf_backward_face_kernel(const float* __r
         }
     };
     if (P > 0) add(arg_f[(size_t)n * F + f], gf);
-    for (int p = 0; p < P; p++)
-        if (arg_p[(size_t)n * P + p] == f) add(p, gp);
-    float* o = gtri + ((size_t)n * F + f) * 9;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        const int p = p0 + lane;
+        unsigned long long hits = __ballot(p < P && arg_p[(size_t)n * P + p] == f);
+        while (hits) {
+            const int j = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            add(p0 + j, gp);
+        }
+    }
+    if (lane == 0) {
+        float* o = gtri + ((size_t)n * F + f) * 9;
 #pragma unroll
-    for (int i = 0; i < 9; i++) o[i] = acc[i];
+        for (int i = 0; i < 9; i++) o[i] = acc[i];
+    }
 }
 
-// Backward, point side: gpts[n,p,:] = own nearest face (weight gp) + every face whose nearest point it is (weight gf)
+// Point side: gpts[n,p,:] = own nearest face (weight gp) + every face whose nearest point it is (weight gf)
 __global__ __launch_bounds__(256) void pmf_backward_point_kernel(const float* __restrict__ verts, const long long* __restrict__ faces,
                                                                  const float* __restrict__ pts, const int* __restrict__ arg_p,
                                                                  const int* __restrict__ arg_f, float gp, float gf,
                                                                  float* __restrict__ gpts, int V, int F, int P)
 {
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= P) return;
     const float* vn = verts + (size_t)n * V * 3;
     const float* q = pts + ((size_t)n * P + p) * 3;
@@ -559,10 +622,19 @@ __global__ __launch_bounds__(256) void pmf_backward_point_kernel(const float* __
         for (int d = 0; d < 3; d++) acc[d] += 2.f * wgt * (q[d] - (cl.w[0] * a[d] + cl.w[1] * b[d] + cl.w[2] * c[d]));
     };
     if (F > 0) add(arg_p[(size_t)n * P + p], gp);
-    for (int f = 0; f < F; f++)
-        if (arg_f[(size_t)n * F + f] == p) add(f, gf);
-    float* o = gpts + ((size_t)n * P + p) * 3;
-    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    for (int f0 = 0; f0 < F; f0 += 64) {
+        const int f = f0 + lane;
+        unsigned long long hits = __ballot(f < F && arg_f[(size_t)n * F + f] == p);
+        while (hits) {
+            const int j = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            add(f0 + j, gf);
+        }
+    }
+    if (lane == 0) {
+        float* o = gpts + ((size_t)n * P + p) * 3;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
 }
 
 // ===========================================================================
@@ -677,9 +749,10 @@ __global__ __launch_bounds__(256) void cosdist_backward_kernel(const float* __re
 // operator call per layer that is 5 x (reduce + fold) + 5 backward launches per step, each 5-16 us for a few MB, plus the
 // eager adds between them.  Here a block still owns one 32-pixel tile of one image of ONE layer (same arithmetic, same tile
 // partials as cosdist_forward_kernel / cosdist_backward_kernel<CPT>), but the grid's second dimension runs over the tiles of
-// every layer, and the last block of the forward launch folds the tile partials exactly like cosdist_fold_kernel does (lane-
+// every layer, and ONE fold launch (a wave per image) folds the tile partials exactly like cosdist_fold_kernel does (lane-
 // strided, DPP tree) and adds the layers in list order: dist[n] = sum_l (1 - mean_l) is bit-identical to the per-layer calls
-// added up by the caller.
+// added up by the caller.  (Folding by the reduce launch's last block -- ticket + __threadfence per block -- was measured at
+// 224 us for the 5760 blocks of the spot3 sizes: every fence writes the XCD's L2 back.)
 struct CosLayers {
     const float* fa[LASR_COSDIST_MAX_LAYERS];
     const float* fb[LASR_COSDIST_MAX_LAYERS];
@@ -696,11 +769,9 @@ __device__ __forceinline__ int cos_layer_of(const CosLayers& L, int tile)
     return l;
 }
 
-__global__ __launch_bounds__(256) void cosdist_multi_forward_kernel(CosLayers L, float* __restrict__ part, float* __restrict__ d,
-                                                                    unsigned int* __restrict__ cnt, int N)
+__global__ __launch_bounds__(256) void cosdist_multi_forward_kernel(CosLayers L, float* __restrict__ part)
 {
     __shared__ float red[3][COS_CG][COS_TP];
-    __shared__ int s_last;
     const int n = blockIdx.x, pxl = threadIdx.x & 31, cg = threadIdx.x >> 5;
     const int l = cos_layer_of(L, blockIdx.y), C = L.C[l], P = L.P[l], ntile = L.tile0[L.n_layers];
     const int p = (blockIdx.y - L.tile0[l]) * COS_TP + pxl;
@@ -721,28 +792,21 @@ __global__ __launch_bounds__(256) void cosdist_multi_forward_kernel(CosLayers L,
         for (int o = 16; o > 0; o >>= 1) cosv += __shfl_xor(cosv, o, 32);
         if (pxl == 0) part[(size_t)n * ntile + blockIdx.y] = cosv;
     }
-    // ticket; the last block folds every image (a wave per image, cosdist_fold_kernel's order) and adds the layers in order
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int t = atomicAdd(cnt, 1u);
-        s_last = (t == gridDim.x * gridDim.y - 1u);
-        if (s_last) { *cnt = 0u; __threadfence(); }
+}
+
+// a wave per image: cosdist_fold_kernel's order inside a layer, the layers added in list order
+__global__ __launch_bounds__(64) void cosdist_multi_fold_kernel(CosLayers L, const float* __restrict__ part, float* __restrict__ d)
+{
+    const int m = blockIdx.x, lane = threadIdx.x, ntile = L.tile0[L.n_layers];
+    float acc = 0.f;
+    for (int k = 0; k < L.n_layers; k++) {
+        const int t0 = L.tile0[k], nt = L.tile0[k + 1] - t0;
+        float sm = 0.f;
+        for (int j = lane; j < nt; j += 64) sm += part[(size_t)m * ntile + t0 + j];
+        sm = wave_sum_to_lane63(sm);
+        acc = acc + (1.f - sm / (float)L.P[k]);
     }
-    __syncthreads();
-    if (!s_last) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int m = wave; m < N; m += 4) {
-        float acc = 0.f;
-        for (int k = 0; k < L.n_layers; k++) {
-            const int t0 = L.tile0[k], nt = L.tile0[k + 1] - t0;
-            float sm = 0.f;
-            for (int j = lane; j < nt; j += 64) sm += ((const volatile float*)part)[(size_t)m * ntile + t0 + j];
-            sm = wave_sum_to_lane63(sm);
-            acc = acc + (1.f - sm / (float)L.P[k]);
-        }
-        if (lane == 63) d[m] = acc;
-    }
+    if (lane == 63) d[m] = acc;
 }
 
 template <int CPT>
@@ -1042,20 +1106,40 @@ extern "C" int lasr_nearest_point(const float* a, const float* b, float* d2, int
     return launch_ok();
 }
 
+static void pmf_layout(int F, int P, int& FT, int& PT, int& FC, int& PC)
+{
+    FT = pmf_tile(F); PT = pmf_tile(P);
+    FC = (F + FT - 1) / FT; PC = (P + PT - 1) / PT;
+}
+
+extern "C" size_t lasr_point_mesh_scratch_floats(int N, int F, int P)
+{
+    if (N < 0 || F < 1 || P < 1) return 0;
+    int FT, PT, FC, PC;
+    pmf_layout(F, P, FT, PT, FC, PC);
+    return 2 * (size_t)N * ((size_t)FC * P + (size_t)PC * F) + 4;        // per-chunk minima (float) and their indices (int)
+}
+
 extern "C" int lasr_point_mesh_forward(const float* verts, const long long* faces, const float* points, float* dmin_point,
-                                       int* arg_point, float* dmin_face, int* arg_face, int N, int V, int F, int P,
+                                       int* arg_point, float* dmin_face, int* arg_face, float* scratch, int N, int V, int F, int P,
                                        void* hip_stream)
 {
     if (N < 0 || V < 0 || F < 1 || P < 1) return LASR_E_BADARG;
     if (N == 0) return LASR_OK;
-    if (!verts || !faces || !points || !dmin_point || !arg_point || !dmin_face || !arg_face) return LASR_E_BADARG;
+    if (!verts || !faces || !points || !dmin_point || !arg_point || !dmin_face || !arg_face || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_point_kernel, dim3((P + 255) / 256, N), dim3(256), 0, verts, faces, points, dmin_point,
-                arg_point, V, F, P);
+    PmfArgs A;
+    A.verts = verts; A.faces = faces; A.pts = points; A.V = V; A.F = F; A.P = P;
+    pmf_layout(F, P, A.FT, A.PT, A.FC, A.PC);
+    const size_t np = (size_t)N * A.FC * P, nf = (size_t)N * A.PC * F;
+    A.part_pd = scratch; A.part_fd = scratch + np;
+    A.part_pa = reinterpret_cast<int*>(scratch + np + nf); A.part_fa = A.part_pa + np;
+    const int gx = ((P > F ? P : F) + 255) / 256;
+    if (A.FC + A.PC > 65535 || N > 65535) return LASR_E_BADARG;
+    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_partial_kernel, dim3(gx, A.FC + A.PC, N), dim3(256), 0, A);
     int rc = launch_ok();
     if (rc) return rc;
-    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_face_kernel, dim3((F + 255) / 256, N), dim3(256), 0, verts, faces, points, dmin_face,
-                arg_face, V, F, P);
+    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_fold_kernel, dim3(gx, 2, N), dim3(256), 0, A, dmin_point, arg_point, dmin_face, arg_face);
     return launch_ok();
 }
 
@@ -1067,11 +1151,11 @@ extern "C" int lasr_point_mesh_backward(const float* verts, const long long* fac
     if (N == 0) return LASR_OK;
     if (!verts || !faces || !points || !arg_point || !arg_face || !grad_tri || !grad_points) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    LASR_LAUNCH(K_POINT_MESH_BACKWARD, pmf_backward_face_kernel, dim3((F + 255) / 256, N), dim3(256), 0, verts, faces, points,
+    LASR_LAUNCH(K_POINT_MESH_BACKWARD, pmf_backward_face_kernel, dim3((F + 3) / 4, N), dim3(256), 0, verts, faces, points,
                 arg_point, arg_face, grad_point_term, grad_face_term, grad_tri, V, F, P);
     int rc = launch_ok();
     if (rc) return rc;
-    LASR_LAUNCH(K_POINT_MESH_BACKWARD, pmf_backward_point_kernel, dim3((P + 255) / 256, N), dim3(256), 0, verts, faces, points,
+    LASR_LAUNCH(K_POINT_MESH_BACKWARD, pmf_backward_point_kernel, dim3((P + 3) / 4, N), dim3(256), 0, verts, faces, points,
                 arg_point, arg_face, grad_point_term, grad_face_term, grad_points, V, F, P);
     return launch_ok();
 }
@@ -1144,18 +1228,19 @@ extern "C" size_t lasr_cosdist_multi_scratch_floats(const int* P, int n_layers, 
 }
 
 extern "C" int lasr_cosdist_multi_forward(const float* const* feat_obs, const float* const* feat_rnd, const int* C, const int* P,
-                                          int n_layers, float* dist, float* scratch, unsigned int* ticket, int N, int rep,
-                                          void* hip_stream)
+                                          int n_layers, float* dist, float* scratch, int N, int rep, void* hip_stream)
 {
     if (N < 0) return LASR_E_BADARG;
     CosLayers L;
     int rc = cos_layers(L, feat_obs, feat_rnd, nullptr, C, P, n_layers, rep);
     if (rc) return rc;
     if (N == 0) return LASR_OK;
-    if (!dist || !scratch || !ticket) return LASR_E_BADARG;
+    if (!dist || !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
     const int ntile = L.tile0[n_layers];
-    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_multi_forward_kernel, dim3(N, ntile), dim3(256), 0, L, scratch, dist, ticket, N);
+    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_multi_forward_kernel, dim3(N, ntile), dim3(256), 0, L, scratch);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_COSDIST_FORWARD, cosdist_multi_fold_kernel, dim3(N), dim3(64), 0, L, (const float*)scratch, dist);
     return launch_ok();
 }
 

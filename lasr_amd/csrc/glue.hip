@@ -568,7 +568,8 @@ extern "C" int lasr_obs_pair(const float* imgs, const float* masks, float* out, 
 // A batch of B pairs is `out`, key-major: key k's segment is [B, len_k] (pair-major = the interleaved layout set_input
 // produces, train_utils.py:179-180) at out_off[k].  The reference collates B samples on the host and copies ~15 tensors per
 // iteration; the torch version of this gather was 15 index_select launches + 15 copies into the HIP graph's static inputs.
-struct GatherKeys { int n; long long seg_off[LASR_GATHER_MAX_KEYS], seg_len[LASR_GATHER_MAX_KEYS], out_off[LASR_GATHER_MAX_KEYS]; };
+struct GatherKeys { int n; long long seg_off[LASR_GATHER_MAX_KEYS], seg_len[LASR_GATHER_MAX_KEYS], out_off[LASR_GATHER_MAX_KEYS];
+                    int phase[LASR_GATHER_MAX_KEYS]; };   // phase[k] = (units of the keys before k) % (gridDim.y * 256), from the host
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, long long W, const long long* __restrict__ ids,
                                                           GatherKeys K, float* __restrict__ out, int pairs)
@@ -580,19 +581,17 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     // the row's keys form one run of 16-byte quads (or of floats when a segment is not 16-byte aligned); block y of gridDim.y
     // takes every gridDim.y-th group of 256 of them, across the key boundaries, so the blocks stay evenly loaded whatever the
     // mix of segment lengths (image planes next to 2-float principal points)
-    long long base = 0;
-    const long long step = (long long)gridDim.y * 256, first = (long long)blockIdx.y * 256 + threadIdx.x;
+    const int step = (int)gridDim.y * 256, first = (int)blockIdx.y * 256 + threadIdx.x;
     for (int k = 0; k < K.n; k++) {
         const long long len = K.seg_len[k];
         const float* __restrict__ s = src + K.seg_off[k];
         float* __restrict__ d = out + K.out_off[k] + (long long)b * len;
         const bool quad = ((K.seg_off[k] | len | K.out_off[k] | W) & 3) == 0;
         const long long units = quad ? len >> 2 : len;
-        // first unit of this key owned by this thread: the smallest i >= 0 with (base + i) % step == first
-        long long i = (first - base % step + step) % step;
-        if (quad) for (; i < units; i += step) reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
-        else      for (; i < units; i += step) d[i] = s[i];
-        base += units;
+        int i0 = first - K.phase[k];                   // first unit of this key owned by this thread (no 64-bit division here)
+        if (i0 < 0) i0 += step;
+        if (quad) for (long long i = i0; i < units; i += step) reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+        else      for (long long i = i0; i < units; i += step) d[i] = s[i];
     }
 }
 
@@ -618,6 +617,12 @@ extern "C" int lasr_gather_rows(const float* table, long long W, int pairs, cons
     const long long cap = (4 * 256 + B - 1) / B > 1 ? (4 * 256 + B - 1) / B : 1;
     want = want < 1 ? 1 : (want > cap ? cap : want);
     const unsigned chunks = (unsigned)want;
+    long long base = 0;
+    for (int k = 0; k < n_keys; k++) {
+        const bool quad = ((seg_off[k] | seg_len[k] | out_off[k] | W) & 3) == 0;
+        K.phase[k] = (int)(base % ((long long)chunks * 256));
+        base += quad ? seg_len[k] >> 2 : seg_len[k];
+    }
     LASR_LAUNCH(K_GATHER_ROWS, gather_rows_kernel, dim3((unsigned)B, chunks), dim3(256), 0, table, W, ids, K, out, pairs);
     return launch_ok();
 }

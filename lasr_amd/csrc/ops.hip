@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void lbs_backward_fold_kernel(const float* __r
 //   g_skin [16 v x nb]   = G      [16 v x 12]   x RT^T [12 x nb]
 //   g_RT   [nb x 12]    += skin   [nb x 16 v]   x G  [16 v x 12]      (per wave; the four waves' tiles meet in LDS, wave order)
 // with G[v] = (v_i * h_j | h_j), h = d loss / d blended vertex.  The per-vertex pieces (h, G, g_verts, the body transform's
-// outer products) are thread-per-vertex code around them.  Chunk partials of the transform gradients go to scratch; the
-// launch's last block (device-scope ticket) folds them in chunk order.  No atomics on data, fixed orders throughout.
+// outer products) are thread-per-vertex code around them.  Chunk partials of the transform gradients go to scratch and
+// lbs_backward_fold_kernel folds them in chunk order; a caller that needs no transform / skin gradients (LASR's joint and
+// control-point call: only the points receive gradient) passes NULL and the contractions and the fold are skipped.
 constexpr int LBSB_VERTS = 64;
 constexpr int LBSB_MAX_K = 65;          // nb <= 64 part bones: Ss / Cs tiles of at most 64 rows
 
@@ -210,12 +211,9 @@ __global__ __launch_bounds__(256) void lbs_backward_mfma_kernel(const float* __r
                                                                 const float* __restrict__ Tmat, const float* __restrict__ skin,
                                                                 const float* __restrict__ gout, float* __restrict__ gverts,
                                                                 float* __restrict__ gskin, float* __restrict__ partial,
-                                                                int N, int V, int K, int tocam, const float* __restrict__ gout_blend,
-                                                                float* __restrict__ gR, float* __restrict__ gT,
-                                                                unsigned int* __restrict__ ticket)
+                                                                int N, int V, int K, int tocam, const float* __restrict__ gout_blend)
 {
     extern __shared__ float lds[];
-    __shared__ int s_last;
     const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, tid = threadIdx.x, nb = K - 1;
     const int nbp = (nb + 15) & ~15;                        // bones padded to whole 16-row MFMA tiles
     float* RT = lds;                                         // [K][12], k = 0 body
@@ -287,20 +285,22 @@ __global__ __launch_bounds__(256) void lbs_backward_mfma_kernel(const float* __r
                     }
                 }
             }
-            f32x4 c4 = {0.f, 0.f, 0.f, 0.f};                  // g_RT tile of this wave = skin x G
+            if (partial) {
+                f32x4 c4 = {0.f, 0.f, 0.f, 0.f};              // g_RT tile of this wave = skin x G
 #pragma unroll
-            for (int s4 = 0; s4 < 16; s4 += 4) {
-                const float a = Ss[(bb + col) * LBSB_VERTS + vw + s4 + kc];
-                const float b = Gs[(vw + s4 + kc) * 16 + col];
-                c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c4, 0, 0, 0);
+                for (int s4 = 0; s4 < 16; s4 += 4) {
+                    const float a = Ss[(bb + col) * LBSB_VERTS + vw + s4 + kc];
+                    const float b = Gs[(vw + s4 + kc) * 16 + col];
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c4, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) Cs[((size_t)wave * nbp + bb + kc * 4 + r) * 16 + col] = c4[r];
             }
-#pragma unroll
-            for (int r = 0; r < 4; r++) Cs[((size_t)wave * nbp + bb + kc * 4 + r) * 16 + col] = c4[r];
         }
     }
     __syncthreads();
-    float* P = partial + ((size_t)n * nchunks + chunk) * K * 12;
-    for (int i = tid; i < nb * 12; i += 256) {               // part bones: the four waves' tiles in wave order
+    float* P = partial ? partial + ((size_t)n * nchunks + chunk) * K * 12 : nullptr;
+    for (int i = tid; P && i < nb * 12; i += 256) {          // part bones: the four waves' tiles in wave order
         const int k = i / 12, c = i - k * 12;
         const float* t = Cs + (size_t)k * 16 + c;
         P[(k + 1) * 12 + c] = ((t[0] + t[(size_t)nbp * 16]) + t[(size_t)2 * nbp * 16]) + t[(size_t)3 * nbp * 16];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void lbs_backward_mfma_kernel(const float* __r
             gverts[o + 1] = h0 * M[3] + h1 * M[4] + h2 * M[5];
             gverts[o + 2] = h0 * M[6] + h1 * M[7] + h2 * M[8];
         }
-        if (tocam) {                         // body transform: g_R0 += vs^T g_out, g_T0 += g_out
+        if (tocam && P) {                    // body transform: g_R0 += vs^T g_out, g_T0 += g_out
             const float s0 = px * M[0] + py * M[3] + pz * M[6] + M[9];
             const float s1 = px * M[1] + py * M[4] + pz * M[7] + M[10];
             const float s2 = px * M[2] + py * M[5] + pz * M[8] + M[11];
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void lbs_backward_mfma_kernel(const float* __r
             q[9] = g0; q[10] = g1; q[11] = g2;
         }
     }
+    if (!P) return;                                          // block-uniform
     __syncthreads();                                         // every wave is done reading Gs
     if (tid < LBSB_VERTS) {
 #pragma unroll
@@ -339,25 +340,6 @@ __global__ __launch_bounds__(256) void lbs_backward_mfma_kernel(const float* __r
         float t = 0.f;
         for (int u = 0; u < LBSB_VERTS; u++) t += Gs[u * 16 + tid];
         P[tid] = tocam ? t : 0.f;
-    }
-    // ---- the last block folds the chunk partials of every mesh in chunk order (the former lbs_backward_fold_kernel launch)
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        const unsigned int tk = atomicAdd(ticket, 1u);
-        s_last = (tk == gridDim.x * gridDim.y - 1u);
-        if (s_last) { *ticket = 0u; __threadfence(); }
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const int per = K * 12;
-    for (int i = tid; i < N * per; i += 256) {
-        const int m = i / per, j = i - m * per;
-        float a = 0.f;
-        for (int ch = 0; ch < nchunks; ch++) a += ((const volatile float*)partial)[((size_t)m * nchunks + ch) * per + j];
-        const int k = j / 12, c = j - k * 12;
-        if (c < 9) { if (gR) gR[((size_t)m * K + k) * 9 + c] = a; }
-        else if (gT) gT[((size_t)m * K + k) * 3 + (c - 9)] = a;
     }
 }
 
@@ -728,54 +710,55 @@ extern "C" size_t lasr_lbs_backward_scratch_floats(int N, int V, int K)
 
 static int lbs_backward_impl(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                              const float* grad_out, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
-                             float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam,
-                             void* hip_stream);
+                             float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream);
 
 extern "C" int lasr_lbs_backward(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                                  const float* grad_out, float* grad_verts, float* grad_Rmat, float* grad_Tmat,
-                                 float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam,
-                                 void* hip_stream)
+                                 float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream)
 {
     return lbs_backward_impl(verts, Rmat, Tmat, skin, grad_out, nullptr, grad_verts, grad_Rmat, grad_Tmat, grad_skin, scratch,
-                             ticket, N, V, K, tocam, hip_stream);
+                             N, V, K, tocam, hip_stream);
 }
 
 extern "C" int lasr_lbs_backward_both(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                                       const float* grad_out_cam, const float* grad_out_blend, float* grad_verts,
-                                      float* grad_Rmat, float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket,
-                                      int N, int V, int K, void* hip_stream)
+                                      float* grad_Rmat, float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K,
+                                      void* hip_stream)
 {
     if (!grad_out_blend) return LASR_E_BADARG;
     return lbs_backward_impl(verts, Rmat, Tmat, skin, grad_out_cam, grad_out_blend, grad_verts, grad_Rmat, grad_Tmat, grad_skin,
-                             scratch, ticket, N, V, K, 1, hip_stream);
+                             scratch, N, V, K, 1, hip_stream);
 }
 
 static int lbs_backward_impl(const float* verts, const float* Rmat, const float* Tmat, const float* skin,
                              const float* grad_out, const float* grad_out_blend, float* grad_verts, float* grad_Rmat,
-                             float* grad_Tmat, float* grad_skin, float* scratch, unsigned int* ticket, int N, int V, int K, int tocam,
-                             void* hip_stream)
+                             float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, int tocam, void* hip_stream)
 {
     if (N < 0 || V < 0 || K < 1 || K > 1024) return LASR_E_BADARG;
     if (N == 0) return LASR_OK;
-    if (!verts || !Rmat || !Tmat || !grad_out || !scratch || (K > 1 && !skin)) return LASR_E_BADARG;
+    if (!verts || !Rmat || !Tmat || !grad_out || (K > 1 && !skin)) return LASR_E_BADARG;
+    const bool want_rt = grad_Rmat || grad_Tmat;
+    if (want_rt && !scratch) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    if (ticket && K <= LBSB_MAX_K) {
-        // one launch: matrix-core contractions, last-block fold (ticket: a zeroed device word, left zero)
-        const int nchunks = (V + LBSB_VERTS - 1) / LBSB_VERTS > 0 ? (V + LBSB_VERTS - 1) / LBSB_VERTS : 1;
+    int nchunks;
+    if (K <= LBSB_MAX_K) {
+        // the three contractions on the matrix cores; the transposed one (and the fold launch) only when a transform gradient is wanted
+        nchunks = (V + LBSB_VERTS - 1) / LBSB_VERTS > 0 ? (V + LBSB_VERTS - 1) / LBSB_VERTS : 1;
         const int nbp = (K - 1 + 15) & ~15;
         const size_t lds = (size_t)(((K * 12 + 3) & ~3) + 2 * LBSB_VERTS * 16 + nbp * LBSB_VERTS + 4 * nbp * 16) * sizeof(float);
         LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_mfma_kernel, dim3(nchunks, N), dim3(256), lds, verts, Rmat, Tmat, skin, grad_out,
-                    grad_verts, grad_skin, scratch, N, V, K, tocam, grad_out_blend, grad_Rmat, grad_Tmat, ticket);
-        return launch_ok();
+                    grad_verts, grad_skin, want_rt ? scratch : nullptr, N, V, K, tocam, grad_out_blend);
+    } else {
+        // more than 64 part bones: the VALU kernel of rounds 1-4 (256-vertex chunks, per-thread bone loop)
+        if (!scratch) return LASR_E_BADARG;
+        nchunks = (V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1;
+        const size_t lds = (size_t)(K * 12 + LBS_CHUNK * 13 + 4) * sizeof(float);
+        LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_kernel, dim3(nchunks, N), dim3(256), lds, verts, Rmat, Tmat, skin, grad_out,
+                    grad_verts, grad_skin, scratch, N, V, K, tocam, grad_out_blend);
     }
-    // no ticket word (or more than 64 part bones): the two-launch VALU path of rounds 1-4
-    const int nchunks = (V + LBS_CHUNK - 1) / LBS_CHUNK > 0 ? (V + LBS_CHUNK - 1) / LBS_CHUNK : 1;
-    const size_t lds = (size_t)(K * 12 + LBS_CHUNK * 13 + 4) * sizeof(float);
-    LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_kernel, dim3(nchunks, N), dim3(256), lds, verts, Rmat, Tmat, skin, grad_out,
-                grad_verts, grad_skin, scratch, N, V, K, tocam, grad_out_blend);
     int rc = launch_ok();
-    if (rc) return rc;
-    LASR_LAUNCH(K_LBS_BACKWARD, lbs_backward_fold_kernel, dim3(N), dim3(256), 0, scratch, grad_Rmat, grad_Tmat, K, nchunks);
+    if (rc || !want_rt) return rc;
+    LASR_LAUNCH(K_LBS_BACKWARD_FOLD, lbs_backward_fold_kernel, dim3(N), dim3(256), 0, scratch, grad_Rmat, grad_Tmat, K, nchunks);
     return launch_ok();
 }
 

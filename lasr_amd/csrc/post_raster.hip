@@ -11,13 +11,13 @@
 // slices) and its backward writes every plane of grad_px itself (no split / cat / accumulate kernels of autograd).
 // Arithmetic, chunking and fold order are those of the separate kernels, so the tables are bit-identical to theirs.
 //
-// Scratch (floats): part[N][nch][8] | tot[N][8] | img[I][4] | part2[N][nch][4] | part3[N][nch][4] | 2 block counters (uint)
+// Scratch (floats): part[N][nch][8] | tot[N][8] | img[I][4] | part2[N][nch][4] | part3[N][nch][4]
 //
-// Launches: forward = 2 (the pass over the render; the flow pass, whose blocks fold the first pass' chunk partials themselves
-// in the fixed chunk order and whose last block folds the flow partials), backward = 1 (its last block folds the intrinsics'
-// partials).  "Last block" = the one whose ticket from a device-scope counter is the grid size: it reads what the others
-// published before their ticket (threadfence on both sides); the FOLD ORDER is fixed, so the tables do not depend on which
-// block that is.  Rounds 1-4 ran the three folds as separate one-wave launches (20 + 5 + 5 us per step at LASR's sizes).
+// Launches: forward = 3 (the pass over the render; the flow pass, whose blocks fold the first pass' chunk partials themselves in
+// the fixed chunk order -- rounds 1-4 ran that fold as a one-wave launch of 20 us; a 256-thread fold of the flow partials),
+// backward = 2 (the pass back + the fold of the intrinsics' partials).  Folding inside the producing launch by its LAST block
+// (device-scope ticket + __threadfence) was built and measured in round 5: with 512 blocks the L2 write-back of every block's
+// fence costs 20-26 us per launch on this part (8 XCD-private L2s) -- a 5 us fold launch is cheaper (profiles/experiments/).
 #include <hip/hip_runtime.h>
 
 #include "../../include/lasr_ops.h"
@@ -28,7 +28,7 @@ namespace lasr {
 constexpr int PR_PX_PER_BLOCK = 2048;
 __host__ __device__ inline int pr_nch(int P) { int n = (P + PR_PX_PER_BLOCK - 1) / PR_PX_PER_BLOCK; return n < 1 ? 1 : (n > 64 ? 64 : n); }
 
-struct PrScratch { float *part, *tot, *img, *part2, *part3; unsigned int* cnt; };
+struct PrScratch { float *part, *tot, *img, *part2, *part3; };
 __host__ __device__ inline PrScratch pr_scratch(float* base, int I, int H, int P)
 {
     const size_t N = (size_t)I * H, nch = (size_t)pr_nch(P);
@@ -38,7 +38,6 @@ __host__ __device__ inline PrScratch pr_scratch(float* base, int I, int H, int P
     s.img = s.tot + N * 8;
     s.part2 = s.img + (size_t)I * 4;
     s.part3 = s.part2 + N * nch * 4;
-    s.cnt = reinterpret_cast<unsigned int*>(s.part3 + N * nch * 4);
     return s;
 }
 
@@ -66,12 +65,10 @@ struct PrArgs {
 
 // ---- forward pass 1: everything that needs one look at the render ------------------------------------------------------------
 __global__ __launch_bounds__(256) void render_tables_forward_kernel(PrArgs A, float2* __restrict__ flow, unsigned char* __restrict__ bg,
-                                                                    float* __restrict__ rndpair, float* __restrict__ part,
-                                                                    unsigned int* __restrict__ cnt)
+                                                                    float* __restrict__ rndpair, float* __restrict__ part)
 {
     __shared__ float red[4];
     const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, N = A.I * A.H;
-    if (ij == 0 && ch == 0 && threadIdx.x == 0) { cnt[0] = 0u; cnt[1] = 0u; }      // tickets of the two later launches
     const float* q = A.px + (size_t)ij * 10 * P;
     const float* m = A.masks + (size_t)i * P;
     const float* oc = A.occ + (size_t)i * P;
@@ -119,40 +116,23 @@ __global__ __launch_bounds__(256) void render_tables_forward_kernel(PrArgs A, fl
     }
 }
 
-// Ticket of a block that has published its partials: true for the block that drew the last one (all threads get the answer).
-// The caller's stores are fenced before the ticket; the last block fences again before it reads the others' partials.
-__device__ __forceinline__ bool pr_last_block(unsigned int* counter, unsigned int total, int* flag)
-{
-    __syncthreads();                                     // every thread's partial stores of this block are issued
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int t = atomicAdd(counter, 1u);
-        *flag = (t == total - 1u);
-        if (t == total - 1u) { *counter = 0u; __threadfence(); }     // ready for the next launch that shares the scratch
-    }
-    __syncthreads();
-    return *flag != 0;
-}
-
 // ---- forward pass 2: the flow loss needs the image's mean weight first (== flow_loss_forward_kernel) ----------------------------
 // Prologue (the former render_tables_fold_kernel, 20 us as its own one-wave launch): every block folds the (sum, count) of
 // sigmoid(-occ) over its image's (hypothesis, chunk) partials IN THAT ORDER -- staged through LDS by all threads, added up by
 // one -- so the mean weight it uses is bit-identical to the value the fold kernel used to leave in img[]; the chunk-0 block of
 // each (image, hypothesis) also folds that row's silhouette / texture partials (chunk order) into tot[] and the two tables,
-// and the chunk-0 block of hypothesis 0 records img[].  Epilogue: the last block of the launch folds the flow partials.
+// and the chunk-0 block of hypothesis 0 records img[].
 constexpr int PR_FOLD_TILE = 1024;
 __global__ __launch_bounds__(256) void render_tables_flow_kernel(PrArgs A, const float2* __restrict__ flow, const unsigned char* __restrict__ bg,
                                                                  const float* __restrict__ part, float* __restrict__ tot,
                                                                  float* __restrict__ img, float* __restrict__ mask_tab,
                                                                  float* __restrict__ tex_tab, float tex_scale,
                                                                  float* __restrict__ part2, float* __restrict__ fmap,
-                                                                 unsigned char* __restrict__ vis, float* __restrict__ flow_tab,
-                                                                 unsigned int* __restrict__ cnt)
+                                                                 unsigned char* __restrict__ vis)
 {
     __shared__ float red[4];
     __shared__ float2 stage[PR_FOLD_TILE];
     __shared__ float s_img[2];
-    __shared__ int s_last;
     const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, H = A.H, nch = A.nch, tid = threadIdx.x;
     {
         const float* pi = part + (size_t)i * H * nch * 8;            // the image's H * nch partial rows, (j, chunk) order
@@ -202,17 +182,17 @@ __global__ __launch_bounds__(256) void render_tables_flow_kernel(PrArgs A, const
     }
     s = block_sum(s, red); c = block_sum(c, red);
     if (tid == 0) { float* o = part2 + ((size_t)ij * nch + ch) * 4; o[0] = s; o[1] = c; o[2] = 0.f; o[3] = 0.f; }
-    if (!pr_last_block(cnt, gridDim.x * gridDim.y, &s_last)) return;
-    const int N = A.I * H;                                          // the former render_tables_flow_fold_kernel
-    for (int n = tid; n < N; n += 256) {
-        float fs = 0.f, fc = 0.f;
-        for (int k = 0; k < nch; k++) {
-            const volatile float* o = part2 + ((size_t)n * nch + k) * 4;
-            fs += o[0]; fc += o[1];
-        }
-        tot[(size_t)n * 8 + 4] = fs; tot[(size_t)n * 8 + 5] = fc;
-        flow_tab[n] = fc > 0.f ? 0.5f * (fs / fc) : 0.f;          // 0 when nothing is selected (mesh_net.py:412)
-    }
+}
+
+__global__ __launch_bounds__(256) void render_tables_flow_fold_kernel(const float* __restrict__ part2, float* __restrict__ tot,
+                                                                      float* __restrict__ flow_tab, int N, int nch)
+{
+    const int ij = blockIdx.x * 256 + threadIdx.x;
+    if (ij >= N) return;
+    float s = 0.f, c = 0.f;
+    for (int k = 0; k < nch; k++) { s += part2[((size_t)ij * nch + k) * 4]; c += part2[((size_t)ij * nch + k) * 4 + 1]; }
+    tot[(size_t)ij * 8 + 4] = s; tot[(size_t)ij * 8 + 5] = c;
+    flow_tab[ij] = c > 0.f ? 0.5f * (s / c) : 0.f;          // 0 when nothing is selected (mesh_net.py:412)
 }
 
 // ---- backward: every plane of grad_px in one pass --------------------------------------------------------------------------------
@@ -221,12 +201,9 @@ __global__ __launch_bounds__(256) void render_tables_flow_kernel(PrArgs A, const
 __global__ __launch_bounds__(256) void render_tables_backward_kernel(PrArgs A, const float* __restrict__ tot, const float* __restrict__ img,
                                                                      const float* __restrict__ g_mask, const float* __restrict__ g_flow,
                                                                      const float* __restrict__ g_tex, const float* __restrict__ g_rndpair,
-                                                                     float wt, float* __restrict__ gpx, float* __restrict__ part3,
-                                                                     float* __restrict__ gpp, float* __restrict__ gfl,
-                                                                     unsigned int* __restrict__ cnt)
+                                                                     float wt, float* __restrict__ gpx, float* __restrict__ part3)
 {
     __shared__ float red[4];
-    __shared__ int s_last;
     const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, N = A.I * A.H;
     const float* q = A.px + (size_t)ij * 10 * P;
     float* g = gpx + (size_t)ij * 10 * P;
@@ -305,18 +282,21 @@ __global__ __launch_bounds__(256) void render_tables_backward_kernel(PrArgs A, c
         float* o = part3 + ((size_t)ij * A.nch + ch) * 4;
         o[0] = sx; o[1] = sy; o[2] = sf; o[3] = 0.f;
     }
-    // the last block folds the chunk partials in chunk order (the former render_tables_intrinsics_fold_kernel): image n's sums
-    // belong to the intrinsics of image (n + half) % N
-    if (!pr_last_block(cnt + 1, gridDim.x * gridDim.y, &s_last)) return;
-    for (int n = threadIdx.x; n < N; n += 256) {
-        float a = 0.f, b = 0.f, c = 0.f;
-        for (int k = 0; k < A.nch; k++) {
-            const volatile float* o = part3 + ((size_t)n * A.nch + k) * 4;
-            a += o[0]; b += o[1]; c += o[2];
-        }
-        const int o2 = (n + A.half) % N;
-        gpp[2 * o2] = a; gpp[2 * o2 + 1] = b; gfl[o2] = c;
+}
+
+// image n's sums belong to the intrinsics of image (n + half) % N
+__global__ __launch_bounds__(256) void render_tables_intrinsics_fold_kernel(const float* __restrict__ part3, float* __restrict__ gpp,
+                                                                            float* __restrict__ gfl, int N, int nch, int half)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int k = 0; k < nch; k++) {
+        const float* o = part3 + ((size_t)n * nch + k) * 4;
+        a += o[0]; b += o[1]; c += o[2];
     }
+    const int other = (n + half) % N;
+    gpp[2 * other] = a; gpp[2 * other + 1] = b; gfl[other] = c;
 }
 
 // =====================================================================================================================
@@ -410,12 +390,12 @@ __global__ __launch_bounds__(256) void raster_inputs_backward_kernel(RiArgs A, c
 //   forward : corner c of face f of mesh n reads its vertex once and writes the projected, eye-shifted position
 //             ((pinhole + eye) * (1,-1,1)) - eye  -- the expression of raster_inputs_forward_kernel followed by look_at's
 //             subtraction (soft_renderer/functional/look_at.py:6-62 with LASR's constant eye on the -z axis: R = I), bit for bit --
-//             and the nine attributes; blocks also take min / max depth of a 256-vertex slice, and the launch's last block
-//             (device-scope ticket) folds them into near / far (mesh_net.py:304-311).
+//             and the nine attributes; blocks also take min / max depth of a 256-vertex slice; raster_inputs_nearfar_kernel folds
+//             them into near / far (mesh_net.py:304-311).
 //   backward: 16 lanes per vertex walk the vertex' incident corners (CSR built once per connectivity, corners ascending: the
 //             summation order of face_gather_backward_kernel) -- 3 position sums, 6 own-attribute sums, 3 sums of the position
 //             attribute this vertex lends to the other frame's mesh -- then one lane per vertex applies the projection's
-//             Jacobian; d pp / d fl: block partials in LDS order, folded by the last block in block order.
+//             Jacobian; d pp / d fl: block partials in LDS order, folded in block order by a second small launch.
 // faces: [Nf,F,3] int64 with Nf = N, or Nf = 1 when all meshes share the connectivity (LASR: always); same for the CSR.
 struct RfArgs {
     const float* verts_cam; const float* tex; const float* pp; const float* fl;
@@ -424,11 +404,9 @@ struct RfArgs {
 };
 
 __global__ __launch_bounds__(256) void raster_faces_forward_kernel(RfArgs A, float* __restrict__ fv, float* __restrict__ fa,
-                                                                   float* __restrict__ zpart, float* __restrict__ near_far,
-                                                                   unsigned int* __restrict__ ticket)
+                                                                   float* __restrict__ zpart)
 {
     __shared__ float red[8];
-    __shared__ int s_last;
     const int n = blockIdx.y, tid = threadIdx.x, V = A.V;
     const int other = (n + A.half) % A.N;
     const int c = blockIdx.x * 256 + tid;
@@ -459,35 +437,16 @@ __global__ __launch_bounds__(256) void raster_faces_forward_kernel(RfArgs A, flo
         zp[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
         zp[1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
     }
-    if (!pr_last_block(ticket, gridDim.x * gridDim.y, &s_last)) return;
-    zmin = 3.4e38f; zmax = -3.4e38f;
-    for (int k = tid; k < A.N * nblk; k += 256) {
-        zmin = fminf(zmin, ((const volatile float*)zpart)[2 * k]);
-        zmax = fmaxf(zmax, ((const volatile float*)zpart)[2 * k + 1]);
-    }
-    for (int d = 32; d >= 1; d >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, d)); zmax = fmaxf(zmax, __shfl_xor(zmax, d)); }
-    __syncthreads();
-    if ((tid & 63) == 0) { red[tid >> 6] = zmin; red[4 + (tid >> 6)] = zmax; }
-    __syncthreads();
-    if (tid == 0) {
-        zmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-        zmax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-        const float half_range = (zmax - zmin) / 2.f;              // mesh_net.py:306-311
-        near_far[0] = zmin - half_range;
-        near_far[1] = zmax + half_range;
-    }
 }
 
 constexpr int RF_VPB = 16;            // vertices per block of the backward (16 lanes each)
 __global__ __launch_bounds__(256) void raster_faces_backward_kernel(RfArgs A, const int* __restrict__ inc_ptr, const int* __restrict__ inc,
                                                                     const float* __restrict__ g_fv, const float* __restrict__ g_fa,
                                                                     float* __restrict__ g_cam, float* __restrict__ g_tex,
-                                                                    float* __restrict__ part, float* __restrict__ g_pp,
-                                                                    float* __restrict__ g_fl, unsigned int* __restrict__ ticket)
+                                                                    float* __restrict__ part)
 {
     __shared__ float sums[RF_VPB][16];
     __shared__ float bsum[RF_VPB][3];
-    __shared__ int s_last;
     const int n = blockIdx.y, tid = threadIdx.x, V = A.V, F3 = A.F3;
     const int other = (n + A.half) % A.N;              // the mesh whose attributes 6..8 are THIS mesh's positions
     const int vl = tid >> 4, lane = tid & 15, v = blockIdx.x * RF_VPB + vl;
@@ -543,13 +502,17 @@ __global__ __launch_bounds__(256) void raster_faces_backward_kernel(RfArgs A, co
         for (int k = 0; k < RF_VPB; k++) t += bsum[k][tid];                          // vertex order
         part[((size_t)n * nblk + blockIdx.x) * 4 + tid] = t;
     }
-    if (!pr_last_block(ticket, gridDim.x * gridDim.y, &s_last)) return;
-    for (int k = tid; k < A.N * 3; k += 256) {
-        const int m = k / 3, comp = k - 3 * m;
-        float t = 0.f;
-        for (int b = 0; b < nblk; b++) t += ((const volatile float*)part)[((size_t)m * nblk + b) * 4 + comp];   // block order
-        if (comp < 2) g_pp[2 * m + comp] = t; else g_fl[m] = t;
-    }
+}
+
+__global__ __launch_bounds__(256) void raster_faces_fold_kernel(const float* __restrict__ part, float* __restrict__ g_pp,
+                                                                float* __restrict__ g_fl, int N, int nblk)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N * 3) return;
+    const int m = k / 3, comp = k - 3 * m;
+    float t = 0.f;
+    for (int b = 0; b < nblk; b++) t += part[((size_t)m * nblk + b) * 4 + comp];        // block order
+    if (comp < 2) g_pp[2 * m + comp] = t; else g_fl[m] = t;
 }
 
 }  // namespace lasr
@@ -567,34 +530,41 @@ extern "C" size_t lasr_raster_faces_scratch_floats(int N, int V, int F)
 
 extern "C" int lasr_raster_faces_forward(const float* verts_cam, const float* tex, const float* pp, const float* fl, const float* eye,
                                          const long long* faces, int faces_shared, float* face_vertices, float* face_attrs,
-                                         float* near_far, float* scratch, unsigned int* ticket, int N, int V, int F, void* hip_stream)
+                                         float* near_far, float* scratch, int N, int V, int F, void* hip_stream)
 {
     if (N < 0 || V < 0 || F < 0 || (N % 2)) return LASR_E_BADARG;
     if (N == 0 || V == 0) return LASR_OK;
-    if (!verts_cam || !tex || !pp || !fl || !eye || !near_far || !scratch || !ticket) return LASR_E_BADARG;
+    if (!verts_cam || !tex || !pp || !fl || !eye || !near_far || !scratch) return LASR_E_BADARG;
     if (F > 0 && (!faces || !face_vertices || !face_attrs)) return LASR_E_BADARG;
     if ((long long)3 * F > 0x7fffffffLL) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
     RfArgs A{verts_cam, tex, pp, fl, faces, faces_shared, N, V, 3 * F, N / 2, eye[0], eye[1], eye[2]};
     const int cov = 3 * F > V ? 3 * F : V;
-    LASR_LAUNCH(K_RASTER_FACES, raster_faces_forward_kernel, dim3((cov + 255) / 256, N), dim3(256), 0, A, face_vertices, face_attrs,
-                scratch, near_far, ticket);
+    const int nblk = (cov + 255) / 256;
+    LASR_LAUNCH(K_RASTER_FACES, raster_faces_forward_kernel, dim3(nblk, N), dim3(256), 0, A, face_vertices, face_attrs, scratch);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_RASTER_FACES, raster_inputs_nearfar_kernel, dim3(1), dim3(64), 0, scratch, near_far, N * nblk);
     return launch_ok();
 }
 
 extern "C" int lasr_raster_faces_backward(const float* verts_cam, const float* fl, const int* inc_ptr, const int* inc,
                                           int faces_shared, const float* grad_face_vertices, const float* grad_face_attrs,
                                           float* grad_verts_cam, float* grad_tex, float* grad_pp, float* grad_fl, float* scratch,
-                                          unsigned int* ticket, int N, int V, int F, void* hip_stream)
+                                          int N, int V, int F, void* hip_stream)
 {
     if (N < 0 || V < 0 || F < 0 || (N % 2)) return LASR_E_BADARG;
     if (N == 0 || V == 0) return LASR_OK;
-    if (!verts_cam || !fl || !inc_ptr || !grad_verts_cam || !grad_tex || !grad_pp || !grad_fl || !scratch || !ticket) return LASR_E_BADARG;
+    if (!verts_cam || !fl || !inc_ptr || !grad_verts_cam || !grad_tex || !grad_pp || !grad_fl || !scratch) return LASR_E_BADARG;
     if (F > 0 && (!inc || !grad_face_vertices || !grad_face_attrs)) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
     RfArgs A{verts_cam, nullptr, nullptr, fl, nullptr, faces_shared, N, V, 3 * F, N / 2, 0.f, 0.f, 0.f};
-    LASR_LAUNCH(K_RASTER_FACES, raster_faces_backward_kernel, dim3((V + RF_VPB - 1) / RF_VPB, N), dim3(256), 0, A, inc_ptr, inc,
-                grad_face_vertices, grad_face_attrs, grad_verts_cam, grad_tex, scratch, grad_pp, grad_fl, ticket);
+    const int nblk = (V + RF_VPB - 1) / RF_VPB;
+    LASR_LAUNCH(K_RASTER_FACES, raster_faces_backward_kernel, dim3(nblk, N), dim3(256), 0, A, inc_ptr, inc, grad_face_vertices,
+                grad_face_attrs, grad_verts_cam, grad_tex, scratch);
+    int rc = launch_ok();
+    if (rc) return rc;
+    LASR_LAUNCH(K_RASTER_FACES, raster_faces_fold_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, scratch, grad_pp, grad_fl, N, nblk);
     return launch_ok();
 }
 
@@ -662,10 +632,13 @@ extern "C" int lasr_render_tables_forward(const float* px, const float* masks, c
     const PrScratch S = pr_scratch(scratch, I, H, P);
     const int N = I * H;
     LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_forward_kernel, dim3(N, A.nch), dim3(256), 0, A, (float2*)flow_rd, bgmask,
-                rndpair, S.part, S.cnt);
+                rndpair, S.part);
     if ((rc = launch_ok())) return rc;
     LASR_LAUNCH(K_RENDER_TABLES_FLOW, render_tables_flow_kernel, dim3(N, A.nch), dim3(256), 0, A, (const float2*)flow_rd, bgmask,
-                S.part, S.tot, S.img, mask_tab, tex_tab, 2.f * l1tex_wt, S.part2, flow_map, vis_mask, flow_tab, S.cnt);
+                S.part, S.tot, S.img, mask_tab, tex_tab, 2.f * l1tex_wt, S.part2, flow_map, vis_mask);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_RENDER_TABLES_FOLD, render_tables_flow_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part2, S.tot, flow_tab,
+                N, A.nch);
     return launch_ok();
 }
 
@@ -684,6 +657,9 @@ extern "C" int lasr_render_tables_backward(const float* px, const float* masks, 
     const PrScratch S = pr_scratch(const_cast<float*>(scratch), I, H, P);
     const int N = I * H;
     LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_backward_kernel, dim3(N, A.nch), dim3(256), 0, A, S.tot, S.img, grad_mask_tab,
-                grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3, grad_pp, grad_fl, S.cnt);
+                grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3);
+    if ((rc = launch_ok())) return rc;
+    LASR_LAUNCH(K_RENDER_TABLES_FOLD, render_tables_intrinsics_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part3, grad_pp,
+                grad_fl, N, A.nch, A.half);
     return launch_ok();
 }

@@ -261,8 +261,7 @@ class _RasterFaces(Function):
         with guard:
             rc = h.lasr_raster_faces_forward(verts_cam.data_ptr(), tex.data_ptr(), pp.data_ptr(), fl.data_ptr(),
                                              (ctypes.c_float * 3)(*[float(e) for e in eye]), faces.data_ptr(), shared,
-                                             fv.data_ptr(), fa.data_ptr(), nf.data_ptr(), scratch.data_ptr(),
-                                             _lib.ticket(dev, _lib.TICKET_RASTER_INPUTS), N, V, F_, st)
+                                             fv.data_ptr(), fa.data_ptr(), nf.data_ptr(), scratch.data_ptr(), N, V, F_, st)
         _lib.check(rc, 'lasr_raster_faces_forward')
         ctx.save_for_backward(verts_cam, fl, inc_ptr, inc)
         ctx.dims = (N, V, F_, shared)
@@ -284,8 +283,7 @@ class _RasterFaces(Function):
         with guard:
             rc = h.lasr_raster_faces_backward(verts_cam.data_ptr(), fl.data_ptr(), inc_ptr.data_ptr(), inc.data_ptr(), shared,
                                               g_fv.data_ptr(), g_fa.data_ptr(), g_cam.data_ptr(), g_tex.data_ptr(),
-                                              g_pp.data_ptr(), g_fl.data_ptr(), scratch.data_ptr(),
-                                              _lib.ticket(dev, _lib.TICKET_RASTER_INPUTS), N, V, F_, st)
+                                              g_pp.data_ptr(), g_fl.data_ptr(), scratch.data_ptr(), N, V, F_, st)
         _lib.check(rc, 'lasr_raster_faces_backward')
         return g_cam, g_tex, g_pp, g_fl, None, None, None, None
 
@@ -488,10 +486,12 @@ class _PointMesh(Function):
         dp, df = torch.empty(N, P, device=dev), torch.empty(N, F_, device=dev)
         ap = torch.empty(N, P, dtype=torch.int32, device=dev)
         af = torch.empty(N, F_, dtype=torch.int32, device=dev)
+        h = _lib.lib()
+        scratch = torch.empty(h.lasr_point_mesh_scratch_floats(N, F_, P), dtype=torch.float32, device=dev)
         guard, st = _lib.stream_of(verts)
         with guard:
-            rc = _lib.lib().lasr_point_mesh_forward(verts.data_ptr(), faces.data_ptr(), points.data_ptr(), dp.data_ptr(),
-                                                    ap.data_ptr(), df.data_ptr(), af.data_ptr(), N, V, F_, P, st)
+            rc = h.lasr_point_mesh_forward(verts.data_ptr(), faces.data_ptr(), points.data_ptr(), dp.data_ptr(),
+                                           ap.data_ptr(), df.data_ptr(), af.data_ptr(), scratch.data_ptr(), N, V, F_, P, st)
         _lib.check(rc, 'lasr_point_mesh_forward')
         ctx.save_for_backward(verts, faces, points, ap, af)
         return (dp.mean(1) + df.mean(1)).mean()
@@ -587,8 +587,7 @@ class _CosDistMulti(Function):
         pb = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fb])
         guard, st = _lib.stream_of(fb[0])
         with guard:
-            rc = h.lasr_cosdist_multi_forward(pa, pb, Cs, Ps, L, d.data_ptr(), scratch.data_ptr(),
-                                              _lib.ticket(dev, _lib.TICKET_COSDIST), N, rep, st)
+            rc = h.lasr_cosdist_multi_forward(pa, pb, Cs, Ps, L, d.data_ptr(), scratch.data_ptr(), N, rep, st)
         _lib.check(rc, 'lasr_cosdist_multi_forward')
         ctx.save_for_backward(*fa, *fb)
         ctx.rep, ctx.dims = rep, (Cs, Ps, L, N)
@@ -614,7 +613,7 @@ class _CosDistMulti(Function):
 def cosine_distance_layers(feats_obs, feats_rnd, repeat=1):
     """sum over the feature layers of cosine_distance(feats_obs[l], feats_rnd[l], repeat) -> [N]: the perceptual distance of
     /root/reference/third_party/PerceptualSimilarity/models/networks_basic.py:51-64 (unweighted layers) as ONE launch each way
-    instead of one reduce + one fold + one backward launch per layer.  Each layer's value, and the left-to-right sum of the
+    (+ one fold launch) instead of one reduce + one fold + one backward launch per layer.  Each layer's value, and the left-to-right sum of the
     layers, are bit-identical to the per-layer calls."""
     if len(feats_obs) != len(feats_rnd) or not 1 <= len(feats_rnd) <= 8:
         raise ValueError('1..8 feature layers, the same number on both sides')

@@ -31,20 +31,24 @@ class _LBS(Function):
         verts, Rmat, Tmat, skin = ctx.saved_tensors
         N, V, K, tocam = ctx.meta
         gout = gout.contiguous().float()
-        gv = torch.empty_like(verts)
-        gR = torch.empty_like(Rmat)
-        gT = torch.empty_like(Tmat)
-        gs = torch.empty(N, K - 1, V, dtype=torch.float32, device=verts.device) if K > 1 else None
+        # only what the caller differentiates: LASR's joint / control-point call passes detached transforms and a constant skin
+        # (mesh_net.py:285-288), so its backward is the g_verts part alone -- no transposed contraction, no fold launch
+        need_v, need_R, need_T, need_s = ctx.needs_input_grad[:4]
+        want_rt = need_R or need_T
+        gv = torch.empty_like(verts) if need_v else None
+        gR = torch.empty_like(Rmat) if want_rt else None
+        gT = torch.empty_like(Tmat) if want_rt else None
+        gs = torch.empty(N, K - 1, V, dtype=torch.float32, device=verts.device) if (K > 1 and need_s) else None
         h = _lib.lib()
-        scratch = torch.empty(h.lasr_lbs_backward_scratch_floats(N, V, K), dtype=torch.float32, device=verts.device)
+        scratch = torch.empty(h.lasr_lbs_backward_scratch_floats(N, V, K), dtype=torch.float32, device=verts.device) if want_rt else None
+        ptr = lambda t: t.data_ptr() if t is not None else None                  # noqa: E731
         guard, st = _lib.stream_of(verts)
         with guard:
             rc = h.lasr_lbs_backward(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(),
-                                     skin.data_ptr() if K > 1 else None, gout.data_ptr(), gv.data_ptr(),
-                                     gR.data_ptr(), gT.data_ptr(), gs.data_ptr() if K > 1 else None,
-                                     scratch.data_ptr(), _lib.ticket(verts.device, _lib.TICKET_LBS), N, V, K, 1 if tocam else 0, st)
+                                     skin.data_ptr() if K > 1 else None, gout.data_ptr(), ptr(gv), ptr(gR), ptr(gT), ptr(gs),
+                                     ptr(scratch), N, V, K, 1 if tocam else 0, st)
         _lib.check(rc, 'lasr_lbs_backward')
-        return gv, gR, gT, gs, None, None
+        return gv, gR if need_R else None, gT if need_T else None, gs, None, None
 
 
 class _LBSBoth(Function):
@@ -81,8 +85,7 @@ class _LBSBoth(Function):
         with guard:
             rc = h.lasr_lbs_backward_both(verts.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(), skin.data_ptr() if K > 1 else None,
                                           gcam.data_ptr(), gblend.data_ptr(), gv.data_ptr(), gR.data_ptr(), gT.data_ptr(),
-                                          gs.data_ptr() if K > 1 else None, scratch.data_ptr(),
-                                          _lib.ticket(verts.device, _lib.TICKET_LBS), N, V, K, st)
+                                          gs.data_ptr() if K > 1 else None, scratch.data_ptr(), N, V, K, st)
         _lib.check(rc, 'lasr_lbs_backward_both')
         return gv, gR, gT, gs, None
 

@@ -89,9 +89,23 @@ def run_both(tmp_path, independent=True, trainer=None, **over):
     for name, r in (('flow_fw', m.renderer_softflf), ('flow_bw', m.renderer_softflb), ('tex', m.renderer_softtex)):
         r.render_mesh = recording(name, r.render_mesh)
 
+    # LASR.forward forms the rasteriser's inputs per face corner in one launch (fused_ops.raster_faces) and never builds the
+    # per-vertex tensor the reference hands to render_mesh: record it from the same inputs with the per-vertex kernel
+    # (tests/test_step_fusions_gpu.py holds the two to bit-identical face vertices)
+    from lasr_amd.nnutils import fused_ops
+    per_corner = fused_ops.raster_faces
+
+    def recording_faces(verts_cam, tex, pp, fl, eye, faces, incidence):
+        with torch.no_grad():
+            captured['tex'] = fused_ops.raster_inputs(verts_cam.detach(), tex.detach(), pp.detach(), fl.detach(), eye)[0].cpu().clone()
+        return per_corner(verts_cam, tex, pp, fl, eye, faces, incidence)
+    fused_ops.raster_faces = recording_faces
     for p in m.parameters():
         p.grad = None
-    loss, aux = m({k: v.clone() for k, v in batch.items()})
+    try:
+        loss, aux = m({k: v.clone() for k, v in batch.items()})
+    finally:
+        fused_ops.raster_faces = per_corner
     loss.backward()
     captured['near_far'] = (float(m.renderer_softtex.rasterizer.near), float(m.renderer_softtex.rasterizer.far))
     if 'flow_fw' not in captured:

@@ -3,12 +3,10 @@
   cosine_distance_layers   == the per-layer cosine_distance calls added up (bit-identical, values and gradients)
   raster_faces             == raster_inputs -> `vertices - eye` -> two face gathers (values bit-identical; the intrinsics'
                               gradients are the same sums in another association)
-  LBS backward on MFMA     == the two-launch VALU backward (fp32 round-off: the contractions reassociate)
+  LBS backward on MFMA     == autograd of the reference formula in float64 (fp32 round-off: the contractions reassociate)
   mesh_regularisers        == LaplacianLoss / FlattenLoss / ARAPLoss called one by one
 References for the composed operators themselves (reference file:line) are in the tests of those operators
 (tests/test_ops_gpu.py, tests/test_render_tables_gpu.py)."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch
@@ -90,55 +88,55 @@ def test_raster_faces_equals_the_five_launches_it_replaces(cuda, n2, H, level):
     assert torch.equal(e[0].grad, c[0].grad) and torch.equal(e[1].grad, c[1].grad)
 
 
-@pytest.mark.parametrize('N,V,K,tocam', [(16, 642, 21, 1), (6, 1282, 36, 1), (2, 37, 2, 0), (4, 70, 1, 1), (3, 200, 66, 1)])
-def test_lbs_backward_on_the_matrix_cores_equals_the_valu_backward(cuda, N, V, K, tocam):
+def _lbs_reference(v, R, T, s, K, tocam):
+    """geom_utils.py:45-71 with torch ops (K-1 blended transforms, then the body transform); autograd gives the gradients the
+    reference's autograd gives."""
+    N = v.shape[0]
+    Rk, Tk = R.view(N, K, 3, 3), T.view(N, K, 1, 3)
+    vs = (s * (v[:, None] @ Rk[:, 1:] + Tk[:, 1:])).sum(1) if K > 1 else v
+    return (vs @ Rk[:, 0] + Tk[:, 0]) if tocam else vs
+
+
+@pytest.mark.parametrize('N,V,K,tocam', [(16, 642, 21, 1), (6, 1282, 36, 1), (2, 37, 2, 0), (4, 70, 1, 1), (3, 200, 66, 1),
+                                         (2, 129, 17, 1), (1, 64, 65, 0)])
+def test_lbs_backward_on_the_matrix_cores_matches_autograd_of_the_reference_formula(cuda, N, V, K, tocam):
+    # K <= 65: the three contractions run on v_mfma_f32_16x16x4_f32 (blocks of 64 vertices; V = 37 / 70 / 129 / 200 / 642 leave
+    # partial tiles); K = 66: the VALU kernel of rounds 1-4
     g = torch.Generator().manual_seed(N * K)
-    h = _lib.lib()
-    verts = torch.randn(N, V, 3, generator=g).to(cuda)
-    R = torch.randn(N * K, 9, generator=g).to(cuda)
-    T = torch.randn(N * K, 3, generator=g).to(cuda)
-    skin = torch.softmax(torch.randn(N, max(K - 1, 1), V, generator=g), 1).to(cuda)
-    gout, gblend = torch.randn(N, V, 3, generator=g).to(cuda), torch.randn(N, V, 3, generator=g).to(cuda)
-    st = torch.cuda.current_stream(cuda).cuda_stream
-    scratch = torch.empty(h.lasr_lbs_backward_scratch_floats(N, V, K), device=cuda)
-    outs = []
-    for ticket in (None, _lib.ticket(cuda, _lib.TICKET_LBS)):
-        gv, gR, gT = torch.full_like(verts, 7.), torch.full_like(R, 7.), torch.full_like(T, 7.)
-        gs = torch.full_like(skin, 7.)
-        sk, gsk = (skin.data_ptr(), gs.data_ptr()) if K > 1 else (None, None)
-        if tocam:
-            rc = h.lasr_lbs_backward_both(verts.data_ptr(), R.data_ptr(), T.data_ptr(), sk, gout.data_ptr(), gblend.data_ptr(),
-                                          gv.data_ptr(), gR.data_ptr(), gT.data_ptr(), gsk, scratch.data_ptr(), ticket, N, V, K, st)
-        else:
-            rc = h.lasr_lbs_backward(verts.data_ptr(), R.data_ptr(), T.data_ptr(), sk, gout.data_ptr(), gv.data_ptr(), gR.data_ptr(),
-                                     gT.data_ptr(), gsk, scratch.data_ptr(), ticket, N, V, K, 0, st)
-        _lib.check(rc, 'lasr_lbs_backward')
-        torch.cuda.synchronize()
-        outs.append((gv, gR, gT, gs if K > 1 else None))
-    for name, a, b in zip(('g_verts', 'g_R', 'g_T', 'g_skin'), outs[1], outs[0]):
-        if a is not None:
-            assert rel(a, b) <= 2e-5, name
-    assert int(_lib._tickets[(cuda.index, st)].abs().sum()) == 0            # every ticket word is left zero
+    leaves = [torch.randn(N, V, 3, generator=g), torch.randn(N * K, 3, 3, generator=g), torch.randn(N * K, 1, 3, generator=g),
+              torch.softmax(torch.randn(N, max(K - 1, 1), V, 1, generator=g), 1)]
+    up = torch.randn(N, V, 3, generator=g)
+    a = [t.clone().double().requires_grad_(True) for t in leaves]
+    (_lbs_reference(*a, K, tocam) * up.double()).sum().backward()
+    b = [t.clone().to(cuda).requires_grad_(True) for t in leaves]
+    (geom_utils.obj_to_cam(b[0], b[1], b[2], K, 1, b[3] if K > 1 else None, tocam=bool(tocam)) * up.to(cuda)).sum().backward()
+    for name, x, y in zip(('verts', 'Rmat', 'Tmat', 'skin')[:4 if K > 1 else 3], b, a):
+        if name in ('Rmat', 'Tmat') and not tocam and K == 1:
+            continue
+        assert rel(x.grad.cpu().double(), y.grad) <= 2e-5, name
 
 
-def test_lbs_operator_gradients_still_match_autograd_of_the_reference_formula(cuda):
-    # geom_utils.py:45-71 restated with torch ops (K-1 blended transforms, then the body transform), autograd as the reference
+def test_lbs_both_outputs_and_points_only_backward(cuda):
+    # the two outputs of one blend (mesh_net.py:291, :298) and LASR's joint call, where only the points receive gradient
     N, V, K = 4, 300, 9
     g = torch.Generator().manual_seed(3)
     leaves = [torch.randn(N, V, 3, generator=g), torch.randn(N * K, 3, 3, generator=g), torch.randn(N * K, 1, 3, generator=g),
               torch.softmax(torch.randn(N, K - 1, V, 1, generator=g), 1)]
-    up = torch.randn(N, V, 3, generator=g)
-
-    def ref(v, R, T, s):
-        Rk, Tk = R.view(N, K, 3, 3), T.view(N, K, 1, 3)
-        vs = (s * (v[:, None] @ Rk[:, 1:] + Tk[:, 1:])).sum(1)
-        return vs @ Rk[:, 0] + Tk[:, 0]
+    up0, up1 = torch.randn(N, V, 3, generator=g), torch.randn(N, V, 3, generator=g)
     a = [t.clone().double().requires_grad_(True) for t in leaves]
-    (ref(*a) * up.double()).sum().backward()
+    ((_lbs_reference(*a, K, 1) * up0.double()).sum() + (_lbs_reference(*a, K, 0) * up1.double()).sum()).backward()
     b = [t.clone().to(cuda).requires_grad_(True) for t in leaves]
-    (geom_utils.obj_to_cam(b[0], b[1], b[2], K, 1, b[3]) * up.to(cuda)).sum().backward()
+    cam, blend = geom_utils.obj_to_cam_both(b[0], b[1], b[2], K, 1, b[3])
+    ((cam * up0.to(cuda)).sum() + (blend * up1.to(cuda)).sum()).backward()
     for name, x, y in zip(('verts', 'Rmat', 'Tmat', 'skin'), b, a):
         assert rel(x.grad.cpu().double(), y.grad) <= 2e-5, name
+    c = leaves[0].clone().to(cuda).requires_grad_(True)
+    out = geom_utils.obj_to_cam(c, b[1].detach(), b[2].detach(), K, 1, b[3].detach())
+    (out * up0.to(cuda)).sum().backward()
+    a2 = [t.clone().double() for t in leaves]
+    a2[0].requires_grad_(True)
+    (_lbs_reference(*a2, K, 1) * up0.double()).sum().backward()
+    assert rel(c.grad.cpu().double(), a2[0].grad) <= 2e-5
 
 
 @pytest.mark.parametrize('level,N,NA', [(3, 16, 8), (2, 4, 2), (1, 2, 1)])
