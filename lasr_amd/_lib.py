@@ -124,7 +124,7 @@ class SrOptions(ctypes.Structure):
     """lasr_sr_options (include/lasr_sr.h): per-call kernel-choice thresholds of the forward pass and the size limit of the
     heaviest-first tile order; a negative field = default."""
     _fields_ = [('coop8_max_tiles', ctypes.c_longlong), ('coop_max_tiles', ctypes.c_longlong), ('choose_max_tiles', ctypes.c_longlong),
-                ('order_max_tiles', ctypes.c_longlong)]
+                ('order_max_tiles', ctypes.c_longlong), ('mixed_min_weight', ctypes.c_longlong)]
 
 
 _lib = None

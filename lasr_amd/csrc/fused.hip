@@ -244,15 +244,14 @@ __global__ __launch_bounds__(256) void skin_backward_kernel(const float* __restr
     constexpr int VPT = 4;                           // vertices per thread and pass: 2 x VPT x 5 independent loads in flight
     for (int vb = threadIdx.x; vb < V; vb += 256 * VPT) {
         float dot[VPT];
-#pragma unroll
-        for (int u = 0; u < VPT; u++) dot[u] = 0.f;
+        int vc[VPT];                                 // clamped vertex: every load is unconditional, so the compiler keeps all of
+#pragma unroll                                       // an unrolled round in flight (guarded loads compiled to a branch + wait each)
+        for (int u = 0; u < VPT; u++) { dot[u] = 0.f; vc[u] = min(vb + 256 * u, V - 1); }
 #pragma unroll 5
         for (int k = 0; k < J; k++) {                // bones in order: the value of the former dot kernel
+            const size_t row = ((size_t)h * J + k) * V;
 #pragma unroll
-            for (int u = 0; u < VPT; u++) {
-                const int v = vb + 256 * u;
-                if (v < V) { const size_t e = ((size_t)h * J + k) * V + v; dot[u] += skin[e] * gskin[e]; }
-            }
+            for (int u = 0; u < VPT; u++) dot[u] += skin[row + vc[u]] * gskin[row + vc[u]];
         }
 #pragma unroll
         for (int u = 0; u < VPT; u++) {

@@ -7,10 +7,10 @@
 // as three forward launches (one workgroup per mesh each) and five backward ones (ARAP, flatten edge + vertex stages, the
 // Laplacian recomputed, its transpose) plus autograd's add -- 9 launches of 5-10 us for a few hundred KB.  Here:
 //   forward : grid (meshes, 3 criteria); the Laplacian coordinates are kept for the backward;
-//   backward: a block owns 128 vertices of one mesh; one half of its threads forms the Laplacian part of d loss / d x, the other
-//             half the flatten part straight from the vertex' incident (edge, slot) pairs -- each pair's edge gradient is
-//             recomputed by the thread that needs it (4 x the arithmetic of the two-stage form, no edge table through memory) --
-//             and the sum is stored once; ARAP's two gradients come from the blocks of grid rows N .. N + NA - 1.
+//   backward: a block owns 16 vertices of one mesh, 16 lanes each: the flatten part straight from the vertex' incident
+//             (edge, slot) pairs -- each pair's edge gradient is recomputed by the lane that holds it (4 x the arithmetic of the
+//             two-stage form, no edge table through memory) -- then the Laplacian part, and the sum is stored once; ARAP's two
+//             gradients come from the blocks of grid rows N .. N + NA - 1.
 // The per-criterion arithmetic and every summation order are those of the separate kernels (ops.hip, fused.hip): the losses and
 // the gradients are bit-identical to calling them one by one.
 #include <hip/hip_runtime.h>
@@ -20,6 +20,19 @@
 #include "ops_common.h"
 
 namespace lasr {
+
+// max over the workgroup (every thread gets it): the number of 16-element rounds the block's longest list needs, so that all
+// threads reach the same barriers
+__device__ __forceinline__ int __reduce_max_block16(int x)
+{
+    __shared__ int s_max;
+    __syncthreads();
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    atomicMax(&s_max, x);
+    __syncthreads();
+    return s_max;
+}
 
 struct MeshRegArgs {
     const float* x;            // [N,V,3]   mean shape instances
@@ -51,34 +64,116 @@ __global__ __launch_bounds__(256) void mesh_reg_forward_kernel(MeshRegArgs A, fl
     }
 }
 
-constexpr int MR_VPB = 128;        // vertices per block of the backward
+// Backward: 16 lanes per vertex.  The per-vertex loops of the separate kernels (incident (edge, slot) pairs of the flatten term,
+// neighbours of the Laplacian / ARAP terms) are chains of dependent gathers -- index, then indices of the edge's vertices, then
+// coordinates -- walked one element after the other: 12 x 3 latency levels per vertex for the flatten part.  Here lane j of a
+// vertex' group evaluates element j (its products / its edge gradient) and parks the three numbers in LDS; lane 0 then adds them
+// up IN ELEMENT ORDER with the same expressions, so the sums are bit-identical to the sequential loops while the gathers of all
+// elements are in flight together.
+constexpr int MR_VPB = 16;         // vertices per block of the backward (x 16 lanes)
+
 __global__ __launch_bounds__(256) void mesh_reg_backward_kernel(MeshRegArgs A, const float* __restrict__ lx, const float* __restrict__ g_lap,
                                                                 const float* __restrict__ g_flat, const float* __restrict__ g_arap,
                                                                 float* __restrict__ gx, float* __restrict__ gdx, float* __restrict__ gax)
 {
-    __shared__ float part[MR_VPB][3];
-    const int V = A.V, tid = threadIdx.x, half = tid >> 7, t = tid & (MR_VPB - 1);
-    const int v = blockIdx.x * MR_VPB + t;
-    if ((int)blockIdx.y >= A.N) {                              // ARAP rows
+    __shared__ float term[MR_VPB][16][6];
+    const int V = A.V, tid = threadIdx.x, vl = tid >> 4, lane = tid & 15;
+    const int v = blockIdx.x * MR_VPB + vl;
+    const bool live = v < V;
+    if ((int)blockIdx.y >= A.N) {                              // ---- ARAP rows: each neighbour's (sg * p, sg * q)
         const int n = blockIdx.y - A.N;
-        if (half == 0 && v < V) {
+        const float* X = A.ax + (size_t)n * V * 3;
+        const float* D = A.dx + (size_t)n * V * 3;
+        const int e0 = live ? A.arap_ptr[v] : 0, e1 = live ? A.arap_ptr[v + 1] : 0;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        if (live) { a0 = X[3 * v]; a1 = X[3 * v + 1]; a2 = X[3 * v + 2]; b0 = D[3 * v]; b1 = D[3 * v + 1]; b2 = D[3 * v + 2]; }
+        float gx0 = 0, gx1 = 0, gx2 = 0, gd0 = 0, gd1 = 0, gd2 = 0;
+        int rounds = (e1 - e0 + 15) >> 4;
+        rounds = __reduce_max_block16(rounds);
+        for (int r = 0; r < rounds; r++) {
+            const int e = e0 + 16 * r + lane;
+            if (e < e1) {
+                const int u = A.arap_col[e];
+                const float p0 = a0 - X[3 * u], p1 = a1 - X[3 * u + 1], p2 = a2 - X[3 * u + 2];
+                const float q0 = b0 - D[3 * u], q1 = b1 - D[3 * u + 1], q2 = b2 - D[3 * u + 2];
+                const float sg = mesh_sgn((p0 * p0 + p1 * p1 + p2 * p2) - (q0 * q0 + q1 * q1 + q2 * q2));
+                float* t = term[vl][lane];
+                t[0] = sg * p0; t[1] = sg * p1; t[2] = sg * p2; t[3] = sg * q0; t[4] = sg * q1; t[5] = sg * q2;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                const int m = min(16, e1 - e0 - 16 * r);
+                for (int j = 0; j < m; j++) {
+                    const float* t = term[vl][j];
+                    gx0 += t[0]; gx1 += t[1]; gx2 += t[2]; gd0 -= t[3]; gd1 -= t[4]; gd2 -= t[5];
+                }
+            }
+            __syncthreads();
+        }
+        if (lane == 0 && live) {
+            const float k = 4.f * g_arap[n] / (float)A.arap_ptr[V];
             const size_t o = ((size_t)n * V + v) * 3;
-            arap_backward_vertex(A.ax + (size_t)n * V * 3, A.dx + (size_t)n * V * 3, A.arap_ptr, A.arap_col,
-                                 4.f * g_arap[n] / (float)A.arap_ptr[V], v, gax ? gax + o : nullptr, gdx ? gdx + o : nullptr);
+            if (gax) { gax[o] = k * gx0; gax[o + 1] = k * gx1; gax[o + 2] = k * gx2; }
+            if (gdx) { gdx[o] = k * gd0; gdx[o + 1] = k * gd1; gdx[o + 2] = k * gd2; }
         }
         return;
     }
     const int n = blockIdx.y;
-    float a[3] = {0.f, 0.f, 0.f};
-    if (v < V) {
-        if (half == 0) laplacian_backward_vertex(lx + (size_t)n * V * 3, A.lap_ptr, A.lap_col, 2.f * g_lap[n], v, a);
-        else flatten_backward_vertex(A.x + (size_t)n * V * 3, A.quads, A.inc_ptr, A.inc, g_flat[n], v, a);
+    const float* xn = A.x + (size_t)n * V * 3;
+    const float* L = lx + (size_t)n * V * 3;
+    // ---- flatten part: lane j = the vertex' j-th incident (edge, slot) pair
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+    {
+        const int i0 = live ? A.inc_ptr[v] : 0, i1 = live ? A.inc_ptr[v + 1] : 0;
+        const float gl = g_flat[n];
+        int rounds = (i1 - i0 + 15) >> 4;
+        rounds = __reduce_max_block16(rounds);
+        for (int r = 0; r < rounds; r++) {
+            const int i = i0 + 16 * r + lane;
+            if (i < i1) {
+                const int code = A.inc[i], e = code >> 2, slot = code & 3;
+                float o[12];
+                flatten_edge_gradient(xn, A.quads + 4 * (size_t)e, gl, o);
+                float* t = term[vl][lane];
+                t[0] = slot == 0 ? o[0] : (slot == 1 ? o[3] : (slot == 2 ? o[6] : o[9]));
+                t[1] = slot == 0 ? o[1] : (slot == 1 ? o[4] : (slot == 2 ? o[7] : o[10]));
+                t[2] = slot == 0 ? o[2] : (slot == 1 ? o[5] : (slot == 2 ? o[8] : o[11]));
+            }
+            __syncthreads();
+            if (lane == 0) {
+                const int m = min(16, i1 - i0 - 16 * r);
+                for (int j = 0; j < m; j++) { f0 += term[vl][j][0]; f1 += term[vl][j][1]; f2 += term[vl][j][2]; }
+            }
+            __syncthreads();
+        }
     }
-    if (half == 1) { part[t][0] = a[0]; part[t][1] = a[1]; part[t][2] = a[2]; }
-    __syncthreads();
-    if (half == 0 && v < V) {
+    // ---- Laplacian part: lane j = the j-th neighbour's lx[u] / deg(u)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    {
+        const int e0 = live ? A.lap_ptr[v] : 0, e1 = live ? A.lap_ptr[v + 1] : 0;
+        if (live && lane == 0) { a0 = L[3 * v]; a1 = L[3 * v + 1]; a2 = L[3 * v + 2]; }
+        int rounds = (e1 - e0 + 15) >> 4;
+        rounds = __reduce_max_block16(rounds);
+        for (int r = 0; r < rounds; r++) {
+            const int e = e0 + 16 * r + lane;
+            if (e < e1) {
+                const int u = A.lap_col[e];
+                const float inv = 1.f / (float)(A.lap_ptr[u + 1] - A.lap_ptr[u]);
+                float* t = term[vl][lane];
+                t[0] = L[3 * u] * inv; t[1] = L[3 * u + 1] * inv; t[2] = L[3 * u + 2] * inv;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                const int m = min(16, e1 - e0 - 16 * r);
+                for (int j = 0; j < m; j++) { a0 -= term[vl][j][0]; a1 -= term[vl][j][1]; a2 -= term[vl][j][2]; }
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0 && live) {
+        const float k = 2.f * g_lap[n];
         float* o = gx + ((size_t)n * V + v) * 3;
-        o[0] = a[0] + part[t][0]; o[1] = a[1] + part[t][1]; o[2] = a[2] + part[t][2];
+        o[0] = k * a0 + f0; o[1] = k * a1 + f1; o[2] = k * a2 + f2;
     }
 }
 

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void lbs_backward_fold_kernel(const float* __r
     const int n = blockIdx.x;
     for (int i = threadIdx.x; i < K * 12; i += 256) {
         float a = 0.f;
+#pragma unroll 8
         for (int ch = 0; ch < nchunks; ch++) a += partial[((size_t)n * nchunks + ch) * K * 12 + i];
         const int k = i / 12, c = i - k * 12;
         if (c < 9) { if (gR) gR[((size_t)n * K + k) * 9 + c] = a; }

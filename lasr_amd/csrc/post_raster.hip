@@ -504,15 +504,20 @@ __global__ __launch_bounds__(256) void raster_faces_backward_kernel(RfArgs A, co
     }
 }
 
+// one block per mesh: the block partials are staged into LDS by all threads (coalesced, all loads in flight), then three threads
+// add them up in block order
 __global__ __launch_bounds__(256) void raster_faces_fold_kernel(const float* __restrict__ part, float* __restrict__ g_pp,
                                                                 float* __restrict__ g_fl, int N, int nblk)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= N * 3) return;
-    const int m = k / 3, comp = k - 3 * m;
-    float t = 0.f;
-    for (int b = 0; b < nblk; b++) t += part[((size_t)m * nblk + b) * 4 + comp];        // block order
-    if (comp < 2) g_pp[2 * m + comp] = t; else g_fl[m] = t;
+    extern __shared__ float stage[];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < nblk * 4; i += 256) stage[i] = part[(size_t)m * nblk * 4 + i];
+    __syncthreads();
+    if (tid < 3) {
+        float t = 0.f;
+        for (int b = 0; b < nblk; b++) t += stage[b * 4 + tid];                           // block order
+        if (tid < 2) g_pp[2 * m + tid] = t; else g_fl[m] = t;
+    }
 }
 
 }  // namespace lasr
@@ -564,7 +569,8 @@ extern "C" int lasr_raster_faces_backward(const float* verts_cam, const float* f
                 grad_face_attrs, grad_verts_cam, grad_tex, scratch);
     int rc = launch_ok();
     if (rc) return rc;
-    LASR_LAUNCH(K_RASTER_FACES, raster_faces_fold_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, scratch, grad_pp, grad_fl, N, nblk);
+    if ((size_t)nblk * 16 > 60000) return LASR_E_BADARG;                    // V <= 60 000 vertices per mesh
+    LASR_LAUNCH(K_RASTER_FACES, raster_faces_fold_kernel, dim3(N), dim3(256), (size_t)nblk * 16, scratch, grad_pp, grad_fl, N, nblk);
     return launch_ok();
 }
 

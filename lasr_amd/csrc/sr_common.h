@@ -22,6 +22,9 @@ struct RasterArgs {
     int choice_max;                           // < 0: *choice is the id; else *choice is the launch's number of non-empty tiles
                                               // (sr_order_kernel) and the id is CHOICE_COOP iff it is at most this
     const int* __restrict__ order;            // forward, optional: block -> (image, 8x8 tile) table written by sr_order_kernel
+    const int* __restrict__ head;             // sr_forward_mixed_kernel: per XCD, how many leading entries of its ordered list go to
+                                              // the four-wave cooperative body (written by sr_order_kernel); order_per = entries per XCD
+    int order_per, head_max;
     float bg[9];
 };
 

@@ -50,23 +50,29 @@ __global__ __launch_bounds__(64) void sr_choose_kernel(const short4* __restrict_
     if (threadIdx.x == 0) *choice = tiles <= coop_max_tiles ? CHOICE_COOP : CHOICE_ONE_WAVE;
 }
 
-template <int NCH, int NW = 4, int EPW = 2, int E0 = 1>
-__global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, float* __restrict__ aggrs,
-                                                                  float* __restrict__ colors)
+// LDS of one cooperative tile: the ordered face list, the per-wave counts of the list building, the two hand-over buffers
+template <int NCH, int NW, int EPW, int E0>
+struct CoopLds {
+    static constexpr int STEP = (NW - 1) * EPW + E0;
+    static constexpr int FIELDS = 3 + NCH;              // flags, D, zn, NCH interpolated attributes
+    float buf[2][STEP][FIELDS][64];
+    int wcnt[2][NW];
+    unsigned short list[COOP_CAP];
+};
+
+// The tile body as a device function: sr_forward_coop_kernel is a thin wrapper, sr_forward_mixed_kernel (sr_raster.hip) calls it
+// for the crowded head of the launch's ordered tile table.
+template <int NCH, int NW, int EPW, int E0>
+__device__ __forceinline__ void coop_tile_body(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors, int bn, int tx, int ty,
+                                               CoopLds<NCH, NW, EPW, E0>& L)
 {
     constexpr int COOP_STEP = (NW - 1) * EPW + E0;
-    constexpr int FIELDS = 3 + NCH;                     // flags, D, zn, NCH interpolated attributes
-    __shared__ unsigned short s_list[COOP_CAP];
-    __shared__ int s_wcnt[2][NW];
-    __shared__ float s_buf[2][COOP_STEP][FIELDS][64];
-
-    if (A.choice && chosen_kernel(A) != CHOICE_COOP) return;   // the launch was left to the device, which took the other kernel
+    auto& s_list = L.list;
+    auto& s_wcnt = L.wcnt;
+    auto& s_buf = L.buf;
     const Modes m = Modes{2, 1, 2, 1, 1};               // LASR's configuration: euclidean, softmax, prod, vertex, double-sided
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
     const int IS = A.IS, P = IS * IS;
-    const int tiles_x = (IS + 7) / 8;
-    int bn, tx, ty;
-    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, A.order);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int qx0 = tx * 8, qy0 = ty * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -276,6 +282,17 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, 
     for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k] / s.ssum;
     aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
     aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
+}
+
+template <int NCH, int NW = 4, int EPW = 2, int E0 = 1>
+__global__ __launch_bounds__(NW * 64) void sr_forward_coop_kernel(RasterArgs A, float* __restrict__ aggrs,
+                                                                  float* __restrict__ colors)
+{
+    __shared__ CoopLds<NCH, NW, EPW, E0> L;
+    if (A.choice && chosen_kernel(A) != CHOICE_COOP) return;   // the launch was left to the device, which took the other kernel
+    int bn, tx, ty;
+    tile_of_block(blockIdx.x, gridDim.x, (A.IS + 7) / 8, bn, tx, ty, A.order);
+    coop_tile_body<NCH, NW, EPW, E0>(A, aggrs, colors, bn, tx, ty, L);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -172,8 +172,11 @@ __global__ __launch_bounds__(512) void sr_tile_weight_kernel(const short4* __res
     }
 }
 
+// head (optional, one workgroup per XCD only): head[x] = the number of this XCD's entries with weight >= head_weight -- the
+// crowded tiles sr_forward_mixed_kernel hands to its four-wave body.
 __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned char* __restrict__ keys, int N, int t8,
-                                                                 int* __restrict__ order, int* __restrict__ busy)
+                                                                 int* __restrict__ order, int* __restrict__ busy,
+                                                                 int* __restrict__ head, int head_weight)
 {
     extern __shared__ unsigned char s_key[];
     __shared__ unsigned s_hist[256], s_base[256], s_wave[4];
@@ -218,6 +221,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned 
         s_base[threadIdx.x] = above;
     }
     if (busy && threadIdx.x == 0) atomicAdd(busy, entries - (int)s_hist[0]);    // the launch's non-empty tiles: the forward kernels' choice
+    // entries with a key above head_weight - 1 = the first position of that key (before the scatter below advances the bases)
+    if (head && (int)threadIdx.x == head_weight - 1) head[x] = (int)s_base[threadIdx.x];
     __syncthreads();
     int* __restrict__ out = order + e_first;
     const float inv_tiles = 1.f / (float)tiles, inv_t8 = 1.f / (float)t8;
@@ -388,25 +393,20 @@ __device__ __forceinline__ void tile_of_block(int b, int total, int tiles_x, int
 // W1 = one wave per workgroup, the workgroup's tile IS the wave's 8x8 quadrant: no workgroup barrier anywhere and nothing held
 // until the slowest of four waves is done.  Affordable since the group rects (level 0) made the face scan cheap: a lone wave
 // tests the ~40 group rects, then scans only the groups that can touch its 64 pixels, compacting straight into its own list.
-template <bool LASR_FAST, int NCH, bool RX = false, bool W1 = false>
-__global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
-                                                         float* __restrict__ colors)
+// The tile body of sr_forward_kernel as a device function: the kernel below is a thin wrapper, and sr_forward_mixed_kernel runs the
+// W1 form once per WAVE of a four-wave workgroup (the W1 form has no workgroup barrier).  s_all / s_wcnt: the workgroup's LDS of
+// the four-wave form (unused by W1); mine_lds: this wave's list of LIST_CAP u16 entries.
+template <bool LASR_FAST, int NCH, bool RX, bool W1>
+__device__ __forceinline__ void forward_tile_body(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors, int bn, int tx, int ty,
+                                                  unsigned short* s_all, unsigned short* mine_lds, int (*s_wcnt)[4])
 {
     constexpr int CAP = LIST_CAP;
-    constexpr int NW = W1 ? 1 : 4, TW = W1 ? 8 : TILE;
-    __shared__ unsigned short s_all[W1 ? 1 : CAP];    // faces whose pixel rect touches the 16x16 tile, index order
-    __shared__ unsigned short s_mine[NW][CAP];        // per wave: the subset touching its 8x8 quadrant, index order
-    __shared__ int s_wcnt[2][4];
-
-    if (W1 && A.choice && chosen_kernel(A) != CHOICE_ONE_WAVE) return;      // the device took the cooperative kernel for this launch
+    constexpr int TW = W1 ? 8 : TILE;
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
 
     const int IS = A.IS, P = IS * IS;
-    const int tiles_x = (IS + TW - 1) / TW;
-    int bn, tx, ty;
-    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, W1 ? A.order : nullptr);
     const int tid = threadIdx.x, wave = W1 ? 0 : tid >> 6, lane = tid & 63;
 
     const int qx0 = tx * TW + (wave & 1) * 8, qy0 = ty * TW + (wave >> 1) * 8;       // this wave's quadrant
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     const int texstride = A.T * NCH;
     const UniRecip U = uni_recip(A);
     const int ok_bit = U.ok ? 32 : 0;
-    unsigned short* mine = s_mine[wave];
+    unsigned short* mine = mine_lds;
     const float thr_pad2 = A.thr * 1.10f;
     const float q_xlo = pix_center(qx0, IS), q_xhi = pix_center(min(qx0 + 7, IS - 1), IS);
     const float q_yhi = pix_center(IS - 1 - qy0, IS), q_ylo = pix_center(IS - 1 - min(qy0 + 7, IS - 1), IS);
@@ -627,9 +627,62 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     }
 }
 
+template <bool LASR_FAST, int NCH, bool RX = false, bool W1 = false>
+__global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __restrict__ aggrs,
+                                                         float* __restrict__ colors)
+{
+    constexpr int NW = W1 ? 1 : 4, TW = W1 ? 8 : TILE;
+    __shared__ unsigned short s_all[W1 ? 1 : LIST_CAP];    // faces whose pixel rect touches the 16x16 tile, index order
+    __shared__ unsigned short s_mine[NW][LIST_CAP];        // per wave: the subset touching its 8x8 quadrant, index order
+    __shared__ int s_wcnt[2][4];
+
+    if (W1 && A.choice && chosen_kernel(A) != CHOICE_ONE_WAVE) return;      // the device took the cooperative kernel for this launch
+    const int tiles_x = (A.IS + TW - 1) / TW;
+    int bn, tx, ty;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, W1 ? A.order : nullptr);
+    forward_tile_body<LASR_FAST, NCH, RX, W1>(A, aggrs, colors, bn, tx, ty, s_all, s_mine[W1 ? 0 : threadIdx.x >> 6], s_wcnt);
+}
+
 
 }  // namespace lasr
 #include "sr_forward_coop.h"
+namespace lasr {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One launch, two bodies, over the launch's ORDERED tile table (sr_order_kernel: every XCD's tiles in descending weight).
+// Between "a few frames" (every tile to the cooperative kernel) and "hundreds" (one wave per tile) lies the range LASR actually
+// launches -- 16 to 96 meshes per render (nnutils/mesh_net.py:318-363) -- where the chip is full of one-wave tiles and the
+// launch still lasts as long as its most crowded tile's serial walk (tools/tile_order_model.py).  With the
+// tiles sorted the choice need not be per launch: the first head[x] entries of XCD x's list (weight >= the threshold, at most
+// head_max) get a four-wave workgroup each and the cooperative body (sr_forward_coop.h: a third to a half of the one-wave
+// latency per entry); the rest are dealt four to a workgroup, one per WAVE, each wave running the barrier-free one-wave body on
+// its own tile -- neighbours in the sorted list have near-equal weights, so the four finish together.  Blocks are issued in
+// index order: the heads start first.  Block b: XCD b & 7, slot i = b >> 3; i < head: entry i; else entries
+// head + 4 (i - head) + wave.  Every tile runs exactly the arithmetic of the kernel it would have had: bit-identical output.
+template <int NCH, int EPW, int E0>
+__global__ __launch_bounds__(256) void sr_forward_mixed_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
+{
+    union Lds {
+        CoopLds<NCH, 4, EPW, E0> coop;
+        unsigned short mine[4][LIST_CAP];
+    };
+    __shared__ Lds L;
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3, per = A.order_per;
+    const int head = min(__builtin_amdgcn_readfirstlane(A.head[x]), A.head_max);
+    const int* __restrict__ mine_order = A.order + (size_t)x * per;
+    if (i < head) {
+        const int e = __builtin_amdgcn_readfirstlane(mine_order[i]);
+        coop_tile_body<NCH, 4, EPW, E0>(A, aggrs, colors, e >> 16, e & 255, (e >> 8) & 255, L.coop);
+        return;
+    }
+    const int wave = threadIdx.x >> 6;
+    const int slot = head + 4 * (i - head) + wave;
+    if (slot >= per) return;
+    const int e = __builtin_amdgcn_readfirstlane(mine_order[slot]);
+    forward_tile_body<true, NCH, false, true>(A, aggrs, colors, e >> 16, e & 255, (e >> 8) & 255, nullptr, L.mine[wave], nullptr);
+}
+
+}  // namespace lasr
 #include "sr_backward.h"
 namespace lasr {
 
@@ -716,6 +769,7 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     A.choice = nullptr;
     A.choice_max = -1;
     A.order = nullptr;
+    A.head = nullptr; A.order_per = 0; A.head_max = 0;
     return A;
 }
 
@@ -756,6 +810,9 @@ static const long long k_coop_max_tiles = env_blocks("LASR_SR_COOP_MAX_TILES", 1
 static const long long k_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES", 49152);
 // launches of up to this many 8x8 tiles (five frames and more, tile total a multiple of 8) issue their tiles heaviest first
 static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES", 1ll << 40);
+// ordered launches that would take the one-wave kernel (or leave the choice to the device): tiles of at least this weight (faces
+// whose pixel rect touches the tile) go to the four-wave body of sr_forward_mixed_kernel; 0 = one kernel per launch as in round 4
+static const long long k_mixed_min_weight = env_blocks("LASR_SR_MIXED_MIN_WEIGHT", 48);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -770,6 +827,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const long long g_coop_max_tiles = opt && opt->coop_max_tiles >= 0 ? opt->coop_max_tiles : k_coop_max_tiles;
     const long long g_choose_max_tiles = opt && opt->choose_max_tiles >= 0 ? opt->choose_max_tiles : k_choose_max_tiles;
     const long long g_order_max_tiles = opt && opt->order_max_tiles >= 0 ? opt->order_max_tiles : k_order_max_tiles;
+    const long long g_mixed_min_weight = opt && opt->mixed_min_weight >= 0 ? opt->mixed_min_weight : k_mixed_min_weight;
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
     if (rc) return rc;
     if (N == 0 || IS == 0) return LASR_OK;
@@ -828,17 +886,27 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const long long coop_max_plain = nch > 3 ? g_coop_max_tiles / 8 * 5 : g_coop_max_tiles;
     const long long coop_max = use_order && nch == 3 ? coop_max_plain / 7 * 4 : coop_max_plain;      // (nine channels, 6 | 8 | 12 frames: .146 | .164 | .238 four, .165 | .167 | .200 one)
     const long long choose_max = nch > 3 ? coop_max : use_order ? g_choose_max_tiles / 16 * 7 : g_choose_max_tiles;
-    const int plan = !tile_kernels || rx ? 0 : tiles8o <= coop8_max ? 2 : tiles8o <= coop_max ? 1 :
-                     (tiles8o <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;
+    int plan = !tile_kernels || rx ? 0 : tiles8o <= coop8_max ? 2 : tiles8o <= coop_max ? 1 :
+               (tiles8o <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;
+    // 4: the per-range choice over the ordered table (sr_forward_mixed_kernel) where one kernel per launch would be the one-wave
+    // kernel or the device's pick
+    const bool seg_flag = (flags & LASR_SR_SEGMENTED) != 0;
+    if (use_order && order_groups == 1 && tile_kernels && !rx && !seg_flag && (plan == 0 || plan == 3) && g_mixed_min_weight > 0 &&
+        g_mixed_min_weight < 256)
+        plan = 4;
     if (use_order) {
         int* order = (int*)(slot + 256);
         unsigned char* keys = (unsigned char*)order + align_up((size_t)tiles8o * sizeof(int), 256);
         int* busy = plan == 3 ? (int*)slot : nullptr;
+        int* head = plan == 4 ? (int*)(slot + 64) : nullptr;
         ProfScope po(K_SR_ORDER, st);
         hipLaunchKernelGGL(sr_tile_weight_kernel, dim3((unsigned)N), dim3(512), 0, st, rects, F, t8o, keys, busy);
         hipLaunchKernelGGL(sr_order_kernel, dim3(8 * order_groups), dim3(ORDER_THREADS), align_up((size_t)(tiles8o / 8 / order_groups), 16), st,
-                           keys, N, t8o, order, busy);
+                           keys, N, t8o, order, busy, head, (int)g_mixed_min_weight);
         A.order = order;
+        A.head = head;
+        A.order_per = (int)(tiles8o >> 3);
+        A.head_max = A.order_per / 4;
         if (plan == 3) {
             A.choice = busy;
             A.choice_max = (int)std::min<long long>(coop_max_plain / 8 * 3, 0x7fffffff);
@@ -875,6 +943,13 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                 if (nch == 9) hipLaunchKernelGGL((sr_forward_coop_kernel<9, 4, 1, 0>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 4, 1, 0>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            }
+            if (plan == 4) {
+                // 8 x (head_max + ceil(per / 4)) workgroups: enough for any head up to head_max (the surplus returns at once)
+                const dim3 gridm((unsigned)(8 * (A.head_max + (A.order_per + 3) / 4)));
+                if (nch == 9) hipLaunchKernelGGL((sr_forward_mixed_kernel<9, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6) hipLaunchKernelGGL((sr_forward_mixed_kernel<6, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_mixed_kernel<3, 2, 1>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
             }
             if (plan == 0 || plan == 3) {
                 if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);

@@ -37,15 +37,16 @@ def set_forward_flags(flags):
     return old
 
 
-def set_launch_thresholds(coop8_max_tiles=-1, coop_max_tiles=-1, choose_max_tiles=-1, order_max_tiles=-1):
+def set_launch_thresholds(coop8_max_tiles=-1, coop_max_tiles=-1, choose_max_tiles=-1, order_max_tiles=-1, mixed_min_weight=-1):
     """Launch options this operator passes with every forward call (lasr_sr_options; negative = library default, no argument =
     all defaults): the kernel-choice thresholds and the size limit of the heaviest-first tile order (0 = the fixed centre-out
     order).  The output is bit-identical whichever kernel runs in whichever order; tests force each one through here."""
     global _launch_options
-    if coop8_max_tiles < 0 and coop_max_tiles < 0 and choose_max_tiles < 0 and order_max_tiles < 0:
+    if coop8_max_tiles < 0 and coop_max_tiles < 0 and choose_max_tiles < 0 and order_max_tiles < 0 and mixed_min_weight < 0:
         _launch_options = None
     else:
-        _launch_options = _lib.SrOptions(int(coop8_max_tiles), int(coop_max_tiles), int(choose_max_tiles), int(order_max_tiles))
+        _launch_options = _lib.SrOptions(int(coop8_max_tiles), int(coop_max_tiles), int(choose_max_tiles), int(order_max_tiles),
+                                         int(mixed_min_weight))
 
 
 def _options_ref():

@@ -16,10 +16,15 @@ from lasr_amd.soft_renderer import functional as srf
 pytestmark = pytest.mark.gpu
 
 BIG = 10 ** 12
-#            coop8_max  coop_max  choose_max   (8x8-pixel tiles)
-VARIANTS = {'eight waves per 8x8 tile': (BIG, BIG, BIG),
-            'four waves per 8x8 tile': (0, BIG, BIG),
-            'one wave per 8x8 tile': (0, 0, 0)}
+#            coop8_max  coop_max  choose_max   (8x8-pixel tiles)   order_max  mixed_min_weight
+VARIANTS = {'eight waves per 8x8 tile': (BIG, BIG, BIG, -1, 0),
+            'four waves per 8x8 tile': (0, BIG, BIG, -1, 0),
+            'one wave per 8x8 tile': (0, 0, 0, -1, 0),
+            # round 5: ONE launch over the ordered tile table, the crowded head four waves per tile, the rest one wave each
+            # (ordered launches only: five frames and more, tile total a multiple of 8 -- elsewhere this is the one-wave kernel)
+            'mixed, tiles of 20+ faces four waves': (0, 0, 0, BIG, 20),
+            'mixed, every non-empty tile four waves (up to a quarter of the list)': (0, 0, 0, BIG, 1),
+            'mixed, nothing heavy enough': (0, 0, 0, BIG, 255)}
 DEFAULTS = (2200, 14336, 49152)
 
 
@@ -169,7 +174,7 @@ def test_heaviest_first_tile_order_gives_the_same_bits_in_every_kernel(cuda, cou
         out = {}
         for name, th in VARIANTS.items():
             for order_max in (0, BIG):
-                srf.set_launch_thresholds(*th, order_max)
+                srf.set_launch_thresholds(*th[:3], order_max, th[4])
                 out[name, order_max] = render(cuda, fv, ft, IS, kw)
         first = out[next(iter(out))]
         for key, img in out.items():
@@ -243,7 +248,7 @@ def test_ordered_launches_choose_on_the_count_of_non_empty_tiles(cuda):
         want = render(cuda, fv, ft, IS, kw)
         seen = {}
         for coop_max in (880, 160):                                     # x 3/8 = 330 and 60 non-empty tiles
-            srf.set_launch_thresholds(0, coop_max, BIG, BIG)
+            srf.set_launch_thresholds(0, coop_max, BIG, BIG, 0)      # mixed off: the device-side choice of round 4
             got = render(cuda, fv, ft, IS, kw)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
             ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
@@ -261,3 +266,42 @@ def test_ordered_launches_choose_on_the_count_of_non_empty_tiles(cuda):
     busy = int((w > 0).sum())
     assert 60 < busy <= 330, busy                                       # so the two settings took different kernels
     assert seen == {880: busy, 160: busy}, (seen, busy)
+
+
+def test_the_mixed_launch_hands_exactly_the_heavy_tiles_to_the_four_wave_body(cuda):
+    # 16 frames of 104x104 (13 x 13 tiles, ragged edge) and LASR's own launch (16 meshes, nine channels, 256x256): same bits as the
+    # one-wave kernel for every threshold, and the per-XCD head counts sr_order_kernel leaves next to the table are the numbers
+    # of that XCD's tiles whose weight reaches the threshold
+    import importlib
+    sr_mod = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
+    for N, IS, nu, channels in ((16, 104, 4, 3), (16, 256, 8, 9), (40, 64, 4, 6)):
+        fv, ft, near, far = synth.raster_batch(nu, 7, count=N)
+        rng = np.random.default_rng(N)
+        if channels > 3:
+            ft = np.concatenate([ft] + [rng.uniform(-2, 2, ft.shape).astype(np.float32) for _ in range(channels // 3 - 1)], -1)
+        kw = dict(synth.LASR_MODES, near=near, far=far, background_color=[0.125 * k for k in range(channels)])
+        F = fv.shape[1]
+        try:
+            srf.set_launch_thresholds(0, 0, 0, BIG, 0)
+            want = render(cuda, fv, ft, IS, kw)
+            for T in (1, 12, 30, 48, 200):
+                srf.set_launch_thresholds(0, 0, 0, BIG, T)
+                got = render(cuda, fv, ft, IS, kw)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, IS, T)
+                table, rects, t8 = _order_table(cuda, N, F, IS)
+                ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
+                up = lambda v: (v + 255) // 256 * 256
+                o_slot = (-ws.data_ptr()) % 256 + up(N * F * 48 * 4) + up(N * F * 8) + up(N * ((F + 63) // 64) * 8)
+                head = ws[o_slot + 64:o_slot + 96].view(torch.int32).cpu().numpy()
+                w = np.zeros((N, t8, t8), np.int64)
+                for n in range(N):
+                    for x0, x1, y0, y1 in rects[n]:
+                        if x1 >= x0 and y1 >= y0:
+                            w[n, y0 >> 3:(y1 >> 3) + 1, x0 >> 3:(x1 >> 3) + 1] += 1
+                per = N * t8 * t8 // 8
+                bn, ty, tx = table >> 16, (table >> 8) & 255, table & 255
+                for x in range(8):
+                    mine = slice(x * per, (x + 1) * per)
+                    assert head[x] == int((np.minimum(w[bn[mine], ty[mine], tx[mine]], 255) >= T).sum()), (N, IS, T, x)
+        finally:
+            srf.set_launch_thresholds()
