@@ -234,7 +234,8 @@ typedef struct lasr_sr_options {
     long long order_max_tiles;
     long long mixed_min_weight;   /* ordered launches beyond the cooperative range: tiles touched by at least this many faces' pixel
                                      rects get a four-wave workgroup, the rest one wave each, in ONE launch (sr_forward_mixed_kernel);
-                                     1..255, 0 = one kernel per launch; default 48 (LASR_SR_MIXED_MIN_WEIGHT at load time) */
+                                     1..255, 0 = one kernel per launch = the default (opt-in: measured slower than the better plain kernel,
+                                     profiles/experiments/r05_mixed_sweep.txt; LASR_SR_MIXED_MIN_WEIGHT at load time) */
 } lasr_sr_options;
 /* lasr_sr_forward_bg with options: `background` may be NULL (then soft_colors holds the pre-filled background, as for
  * lasr_sr_forward_ex), `options` may be NULL (all defaults). */

@@ -396,11 +396,10 @@ __device__ __forceinline__ void tile_of_block(int b, int total, int tiles_x, int
 // The tile body of sr_forward_kernel as a device function: the kernel below is a thin wrapper, and sr_forward_mixed_kernel runs the
 // W1 form once per WAVE of a four-wave workgroup (the W1 form has no workgroup barrier).  s_all / s_wcnt: the workgroup's LDS of
 // the four-wave form (unused by W1); mine_lds: this wave's list of LIST_CAP u16 entries.
-template <bool LASR_FAST, int NCH, bool RX, bool W1>
+template <bool LASR_FAST, int NCH, bool RX, bool W1, int CAP = LIST_CAP>
 __device__ __forceinline__ void forward_tile_body(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors, int bn, int tx, int ty,
                                                   unsigned short* s_all, unsigned short* mine_lds, int (*s_wcnt)[4])
 {
-    constexpr int CAP = LIST_CAP;
     constexpr int TW = W1 ? 8 : TILE;
     // fast path: LASR's training configuration (euclidean, softmax, prod, vertex, double-sided)
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
@@ -662,9 +661,10 @@ namespace lasr {
 template <int NCH, int EPW, int E0>
 __global__ __launch_bounds__(256) void sr_forward_mixed_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
 {
+    constexpr int MCAP = 1024;                         // list entries per round of a one-wave tile here (a longer list takes rounds)
     union Lds {
         CoopLds<NCH, 4, EPW, E0> coop;
-        unsigned short mine[4][LIST_CAP];
+        unsigned short mine[4][MCAP];
     };
     __shared__ Lds L;
     const int x = blockIdx.x & 7, i = blockIdx.x >> 3, per = A.order_per;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void sr_forward_mixed_kernel(RasterArgs A, flo
     const int slot = head + 4 * (i - head) + wave;
     if (slot >= per) return;
     const int e = __builtin_amdgcn_readfirstlane(mine_order[slot]);
-    forward_tile_body<true, NCH, false, true>(A, aggrs, colors, e >> 16, e & 255, (e >> 8) & 255, nullptr, L.mine[wave], nullptr);
+    forward_tile_body<true, NCH, false, true, MCAP>(A, aggrs, colors, e >> 16, e & 255, (e >> 8) & 255, nullptr, L.mine[wave], nullptr);
 }
 
 }  // namespace lasr
@@ -811,8 +811,11 @@ static const long long k_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES
 // launches of up to this many 8x8 tiles (five frames and more, tile total a multiple of 8) issue their tiles heaviest first
 static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES", 1ll << 40);
 // ordered launches that would take the one-wave kernel (or leave the choice to the device): tiles of at least this weight (faces
-// whose pixel rect touches the tile) go to the four-wave body of sr_forward_mixed_kernel; 0 = one kernel per launch as in round 4
-static const long long k_mixed_min_weight = env_blocks("LASR_SR_MIXED_MIN_WEIGHT", 48);
+// whose pixel rect touches the tile) go to the four-wave body of sr_forward_mixed_kernel; 0 = one kernel per launch (the default:
+// measured on an MI355X the one-launch form loses to the better of the two plain kernels at every size -- the tail's tiles are
+// dealt four to a workgroup, which then waits for four free wave slots on one CU and holds them until its slowest wave is done:
+// 64 frames, one wave per tile 0.49 ms, mixed with an empty head 0.61 ms; profiles/experiments/r05_mixed_sweep.txt)
+static const long long k_mixed_min_weight = env_blocks("LASR_SR_MIXED_MIN_WEIGHT", 0);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -949,7 +952,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                 const dim3 gridm((unsigned)(8 * (A.head_max + (A.order_per + 3) / 4)));
                 if (nch == 9) hipLaunchKernelGGL((sr_forward_mixed_kernel<9, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else if (nch == 6) hipLaunchKernelGGL((sr_forward_mixed_kernel<6, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
-                else hipLaunchKernelGGL((sr_forward_mixed_kernel<3, 2, 1>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_mixed_kernel<3, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
             }
             if (plan == 0 || plan == 3) {
                 if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);

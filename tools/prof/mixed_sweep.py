@@ -25,6 +25,8 @@ CASES = [('M2 3ch focal 9', 11, 3, 9.0, 256, (8, 16, 24, 32, 64, 128)),
          ('M1 9ch focal 16 (LASR crop)', 8, 9, 16.0, 256, (8, 16, 32, 96)),
          ('M1 9ch focal 9', 8, 9, 9.0, 256, (16, 96)),
          ('M2 3ch focal 9 512', 11, 3, 9.0, 512, (16, 64))]
+if len(sys.argv) > 1 and sys.argv[1] == 'short':
+    CASES = [('M2 3ch focal 9', 11, 3, 9.0, 256, (16, 24, 64)), ('M1 9ch focal 16 (LASR crop)', 8, 9, 16.0, 256, (16, 96))]
 FORMS = [('one wave', (0, 0, 0, BIG, 0)), ('four waves', (0, BIG, BIG, BIG, 0))] + \
         [('mixed %d' % t, (0, 0, 0, BIG, t)) for t in (8, 16, 24, 32, 48, 64, 96)]
 out = {}
