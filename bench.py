@@ -210,34 +210,116 @@ def cpu_baseline(F):
                       '3 passes of 1 frame' % (n, IS, IS, threads, n * bands)}
 
 
-def lbs_leg(dev):
-    """The one MFMA user on the path (north_star): linear-blend skinning, `skin^T[V,K-1] x RT[K-1,12]` on
-    v_mfma_f32_16x16x4_f32.  us per call from HIP events at the S0 / dog15 sizes of SURVEY section 8 and a large batch;
-    flop count = 2*N*V*(K-1)*12 (blend contraction) + 2*N*V*12 (body transform)."""
+LBS_SIZES = {'S0': (16, 642, 21), 'dog15': (6, 1282, 36), 'batch256': (256, 1212, 36)}
+
+
+def _lbs_case(dev, N, V, K):
+    gen = torch.Generator(device='cpu').manual_seed(0)
+    v = torch.randn(N, V, 3, generator=gen).to(dev).requires_grad_(True)
+    R = torch.randn(N * K, 3, 3, generator=gen).to(dev).requires_grad_(True)
+    T = torch.randn(N * K, 1, 3, generator=gen).to(dev).requires_grad_(True)
+    sk = torch.softmax(torch.randn(N, K - 1, V, 1, generator=gen), 1).to(dev).requires_grad_(True)
+    g = torch.randn(N, V, 3, generator=gen).to(dev)
+    return v, R, T, sk, g
+
+
+def lbs_worker():
+    """Child process of lbs_leg (run under rocprofv3 --kernel-trace): REPS forward + backward calls per size, in LBS_SIZES order."""
     from lasr_amd.nnutils import geom_utils
-    out = {'mfma_instruction': 'v_mfma_f32_16x16x4_f32', 'peak_tflops': MFMA_F32_PEAK_TF, 'sizes': {}}
-    for name, (N, V, K) in {'S0': (16, 642, 21), 'dog15': (6, 1282, 36), 'batch256': (256, 1212, 36)}.items():
-        gen = torch.Generator(device='cpu').manual_seed(0)
-        v = torch.randn(N, V, 3, generator=gen).to(dev)
-        R = torch.randn(N * K, 3, 3, generator=gen).to(dev)
-        T = torch.randn(N * K, 1, 3, generator=gen).to(dev)
-        sk = torch.softmax(torch.randn(N, K - 1, V, 1, generator=gen), 1).to(dev)
-        with torch.no_grad():
-            for _ in range(5):
-                geom_utils.obj_to_cam(v, R, T, K, 1, sk)
-            reps = 100
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                geom_utils.obj_to_cam(v, R, T, K, 1, sk)
-            e1.record()
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    for name, (N, V, K) in LBS_SIZES.items():
+        v, R, T, sk, g = _lbs_case(dev, N, V, K)
+        for _ in range(LBS_TRACE_REPS):
+            geom_utils.obj_to_cam(v, R, T, K, 1, sk).backward(g)
+    torch.cuda.synchronize()
+    print('lbs-worker done', flush=True)
+
+
+LBS_TRACE_REPS = 40
+
+
+def lbs_trace():
+    """Kernel durations of the LBS launches from a rocprofv3 kernel trace of lbs_worker (dispatch end - start; the last 30 of the
+    40 calls per size).  None when the profiler is not available."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix='lasr_lbs_', dir='/tmp')
+    try:
+        cmd = ['rocprofv3', '--kernel-trace', '-d', tmp, '-o', 't', '--', sys.executable, os.path.abspath(__file__), '--step-worker', 'lbs']
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        dbs = glob.glob(os.path.join(tmp, '**', '*.db'), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return {'error': 'rc %d: %s' % (r.returncode, r.stdout.decode(errors='replace')[-300:])}
+        c = sqlite3.connect(dbs[0])
+        rows = list(c.execute('select s.kernel_name, d.end - d.start from rocpd_kernel_dispatch d '
+                              'join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start'))
+        out = {}
+        for kern in ('lbs_forward_kernel', 'lbs_backward_mfma_kernel', 'lbs_backward_fold_kernel'):
+            d = [ns / 1e3 for nm, ns in rows if kern in nm]
+            if len(d) != LBS_TRACE_REPS * len(LBS_SIZES):
+                out[kern] = {'error': '%d dispatches, expected %d' % (len(d), LBS_TRACE_REPS * len(LBS_SIZES))}
+                continue
+            for i, name in enumerate(LBS_SIZES):
+                chunk = d[i * LBS_TRACE_REPS + 10:(i + 1) * LBS_TRACE_REPS]
+                out.setdefault(name, {})[kern] = round(sum(chunk) / len(chunk), 2)
+        return out
+    except Exception as e:
+        return {'error': repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def lbs_leg(dev):
+    """The one MFMA user on the path (north_star): linear-blend skinning, forward `skin^T[V,K-1] x RT[K-1,12]` and, since round 5, the
+    backward's three contractions (blended transform, g_skin = G x RT^T, g_RT = skin x G) on v_mfma_f32_16x16x4_f32.  us per
+    launch at the S0 / dog15 sizes of SURVEY section 8 and a large batch, two clocks: the library's own HIP events around each
+    launch of eager calls (a few us of event overhead on kernels this short), and the dispatch timestamps of a rocprofv3 kernel
+    trace of the same calls in a child process (`trace_us`, the figure that compares with the step profile).
+    Forward flops = 2 N V (K-1) 12 + 2 N V 12; backward = 3 contractions of 2 N V (K-1) 12 (+ the per-vertex products)."""
+    from lasr_amd.nnutils import geom_utils
+    h = _lib.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = {'mfma_instruction': 'v_mfma_f32_16x16x4_f32', 'peak_tflops': MFMA_F32_PEAK_TF, 'sizes': {},
+           'clock': 'library HIP events around each launch (lasr_prof_*), mean of 100 eager calls; trace_us: rocprofv3 kernel trace'}
+    trace = lbs_trace()
+    for name, (N, V, K) in LBS_SIZES.items():
+        v, R, T, sk, g = _lbs_case(dev, N, V, K)
+        for _ in range(5):
+            geom_utils.obj_to_cam(v, R, T, K, 1, sk).backward(g)
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / reps * 1e3
-        flops = 2 * N * V * (K - 1) * 12 + 2 * N * V * 12
-        mfma = N * -(-V // 16) * -(-(K - 1) // 4)        # one 16x16x4 instruction per 16 vertices x 4 bones (12 of 16 columns used)
-        out['sizes'][name] = {'N': N, 'V': V, 'K': K, 'us_per_call': round(us, 2), 'mfma_instructions': mfma,
-                              'achieved_tflops': flops / us / 1e6, 'frac_of_mfma_peak': flops / us / 1e6 / MFMA_F32_PEAK_TF,
-                              'achieved_GBs': N * (24 * V + 4 * V * (K - 1) + 48 * K) / us / 1e3}
+        reps = 100
+        h.lasr_prof_enable(st, 1)
+        for _ in range(reps):
+            geom_utils.obj_to_cam(v, R, T, K, 1, sk).backward(g)
+        torch.cuda.synchronize()
+        h.lasr_prof_enable(st, 0)
+        kt = collect_kernel_times(h, st)
+        us_f = kt['lbs_forward_kernel'][0] * 1e3
+        us_b = kt['lbs_backward_kernel'][0] * 1e3
+        us_fold = kt.get('lbs_backward_fold_kernel', (0.0, 0))[0] * 1e3
+        flops_f = 2 * N * V * (K - 1) * 12 + 2 * N * V * 12
+        flops_b = 3 * 2 * N * V * (K - 1) * 12 + 2 * N * V * 30
+        mfma_f = N * -(-V // 16) * -(-(K - 1) // 4)        # one 16x16x4 instruction per 16 vertices x 4 bones (12 of 16 columns used)
+        mfma_b = N * -(-V // 16) * (-(-(K - 1) // 4) + -(-(K - 1) // 16) * (3 + 4))
+        tr = (trace or {}).get(name, {}) if isinstance(trace, dict) else {}
+        out['sizes'][name] = {'N': N, 'V': V, 'K': K, 'us_per_call': round(us_f, 2), 'backward_us_per_call': round(us_b, 2),
+                              'backward_fold_us_per_call': round(us_fold, 2), 'mfma_instructions': mfma_f,
+                              'backward_mfma_instructions': mfma_b,
+                              'trace_us': {'forward': tr.get('lbs_forward_kernel'), 'backward': tr.get('lbs_backward_mfma_kernel'),
+                                           'backward_fold': tr.get('lbs_backward_fold_kernel')},
+                              'achieved_tflops': flops_f / us_f / 1e6, 'frac_of_mfma_peak': flops_f / us_f / 1e6 / MFMA_F32_PEAK_TF,
+                              'backward_achieved_tflops': flops_b / us_b / 1e6,
+                              'backward_frac_of_mfma_peak': flops_b / us_b / 1e6 / MFMA_F32_PEAK_TF,
+                              'achieved_GBs': N * (24 * V + 4 * V * (K - 1) + 48 * K) / us_f / 1e3,
+                              'backward_achieved_GBs': N * (36 * V + 8 * V * (K - 1) + 96 * K) / us_b / 1e3}
+    if isinstance(trace, dict) and 'error' in trace:
+        out['trace_error'] = trace['error']
     return out
 
 
@@ -502,6 +584,57 @@ def in_scope_step_leg():
     return out
 
 
+def allreduce_variants_leg(dev, nbytes, world, dist, reps=5):
+    """how the optimisation step's gradient message (nbytes, fp32) crosses the xGMI mesh, three ways, so that
+    the first 8-GPU run of this line can compare them (SURVEY section 5 predicts ring ~0.65 ms vs direct reduce-scatter /
+    all-gather ~0.09 ms for 57 MB on the 7-link full mesh):
+      one_all_reduce            one flat message (what the trainer sends without overlap)
+      reduce_scatter_all_gather the same reduction as its two halves: every link busy in both
+      buckets_25MB              DDP-sized buckets back to back (the reference's transport, nnutils/train_utils.py:104-109)
+    Each: HIP events on the calling stream around `reps` repetitions after 2 warm-ups, MAX over ranks; algbw = bytes / time,
+    busbw = algbw x 2 (world - 1) / world.  RCCL's own choice can be steered from outside with NCCL_ALGO / NCCL_PROTO (recorded)."""
+    n = max(world, nbytes // 4 // world * world)                 # floats, a multiple of the world size
+    buf = torch.ones(n, dtype=torch.float32, device=dev)
+    shard = torch.empty(n // world, dtype=torch.float32, device=dev)
+    bucket = max(world, (25 << 20) // 4 // world * world)
+
+    def one():
+        dist.all_reduce(buf)
+
+    def rs_ag():
+        dist.reduce_scatter_tensor(shard, buf)
+        dist.all_gather_into_tensor(buf, shard)
+
+    def buckets():
+        for o in range(0, n, bucket):
+            dist.all_reduce(buf[o:o + bucket])
+    out = {'message_bytes': n * 4, 'world_size': world, 'reps': reps,
+           'env': {k: os.environ.get(k) for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS',
+                                                  'RCCL_MSCCL_ENABLE', 'HSA_ENABLE_IPC_MODE_LEGACY')}}
+    for name, fn in (('one_all_reduce', one), ('reduce_scatter_all_gather', rs_ag), ('buckets_25MB', buckets)):
+        try:
+            for _ in range(2):
+                fn()
+                buf.fill_(1.)
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / reps], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+            out[name] = {'ms': ms, 'algbw_GBs': n * 4 / ms / 1e6, 'busbw_GBs': n * 4 / ms / 1e6 * 2 * (world - 1) / world,
+                         'collectives_per_message': {'one_all_reduce': 1, 'reduce_scatter_all_gather': 2}.get(name, -(-n // bucket))}
+        except Exception as e:                           # e.g. gloo has no reduce_scatter: the block keeps its shape
+            out[name] = {'error': repr(e)[:200]}
+        buf.fill_(1.)
+    return out
+
+
 RASTER_SOURCES = ('sr_raster.hip', 'sr_forward_coop.h', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
 VALU_PEAK_LANE_OPS = 1024 * 32 * 2.4e9      # 256 CUs x 4 SIMDs, 32 fp32 lanes per SIMD per clock (a wave64 op issues in 2), 2.4 GHz
 
@@ -668,7 +801,7 @@ def main():
     global IS, REBUILD_RECORDS
     a = parse()
     if a.step_worker:
-        return step_worker(a.step_worker)
+        return lbs_worker() if a.step_worker == 'lbs' else step_worker(a.step_worker)
     IS = a.image_size
     REBUILD_RECORDS = a.rebuild_records
     rank = int(os.environ.get('RANK', 0))
@@ -818,6 +951,8 @@ def main():
             torch.cuda.synchronize()
             out['in_scope_step'] = in_scope_step_leg()
     dp = optimize_dp_leg(dev, a.lasr_iters, rank, world, dist) if world > 1 and a.lasr_iters > 0 else None     # every rank takes part
+    if dp is not None:
+        dp['allreduce_variants'] = allreduce_variants_leg(dev, dp['no_overlap']['grad_message_bytes'], world, dist)
     if rank == 0:
         if dp is not None:
             out['optimize_py_dp'] = dp

@@ -43,6 +43,19 @@ int lasr_lbs_backward_both(const float* verts, const float* Rmat, const float* T
                            float* grad_Tmat, float* grad_skin, float* scratch, int N, int V, int K, void* hip_stream);
 
 /*
+ * Joint centres and control points into the image: the two obj_to_cam calls with an identity skin and the pinhole_cam of
+ * nnutils/mesh_net.py:285-288, :302 in one launch each way.  rest_ts / ctl_ts [H, K-1, 3]; Rmat [M*K,3,3], Tmat [M*K,3] with
+ * M = images x H (hypothesis fastest); pp [M/H, 2] per image, fl [M].  Point j of hypothesis h rides on part bone (j mod (K-1)) + 1
+ * and then the body transform (bone 0) of every m = img * H + h:  proj [M, 2(K-1), 4] = (pp + xy * fl / z, z, 1), joints first.
+ * The transforms and intrinsics are constants (the reference detaches them); backward: grad_rest / grad_ctl [H, K-1, 3], summed
+ * over the images in image order (overwritten).  Same association of the sums as lasr_lbs_forward + lasr_pinhole_forward.
+ */
+int lasr_project_points_forward(const float* rest_ts, const float* ctl_ts, const float* Rmat, const float* Tmat, const float* pp,
+                                const float* fl, float* proj, int M, int H, int K, void* hip_stream);
+int lasr_project_points_backward(const float* rest_ts, const float* ctl_ts, const float* Rmat, const float* Tmat, const float* fl,
+                                 const float* grad_proj, float* grad_rest, float* grad_ctl, int M, int H, int K, void* hip_stream);
+
+/*
  * Pinhole projection, nnutils/geom_utils.py:27-34 (pinhole_cam), with pp / fl already expanded per mesh:
  *   out.x = pp[n,0] + x * fl[n] / z ;  out.y = pp[n,1] + y * fl[n] / z ;  out.z = z ; out.w = w
  * verts/out [N,V,4], pp [N,2], fl [N].  Backward overwrites grad_verts [N,V,4], grad_pp [N,2], grad_fl [N].

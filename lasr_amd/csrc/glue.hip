@@ -227,6 +227,74 @@ __global__ __launch_bounds__(256) void bone_fixup_backward_kernel(const float* _
     }
 }
 
+// ---- joints and control points into the image (nnutils/mesh_net.py:285-288 + :302: two obj_to_cam calls with an identity "skin" and a
+// pinhole_cam) ----------------------------------------------------------------------------------------------------------------
+// Point j of hypothesis h (j < K-1: joint centre rest_ts[h, j]; else control point ctl_ts[h, j - (K-1)]) rides on part bone
+// b = j mod (K-1): p' = p R[m, b+1] + T[m, b+1], then the body transform R[m, 0], T[m, 0], then the pinhole projection with image
+// m's intrinsics -- for every (image, hypothesis) m = img * H + h.  The reference builds the repeated point tensor, the one-hot
+// skin, two LBS calls and a projection (~10 launches each way); the sums below associate exactly like lbs_forward_kernel's
+// row folds followed by pinhole_forward_kernel, so the values are the ones those kernels gave.  Transforms and intrinsics are
+// constants here (detached in the reference); only the points receive gradient, summed over the images in image order.
+__global__ __launch_bounds__(256) void project_points_forward_kernel(const float* __restrict__ rest, const float* __restrict__ ctl,
+                                                                     const float* __restrict__ Rmat, const float* __restrict__ Tmat,
+                                                                     const float* __restrict__ pp, const float* __restrict__ fl,
+                                                                     float4* __restrict__ proj, int M, int H, int K)
+{
+    const int nb = K - 1, Pn = 2 * nb;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * Pn) return;
+    const int m = i / Pn, j = i - m * Pn, h = m % H, b = j % nb;
+    const float* p = (j < nb ? rest : ctl) + ((size_t)h * nb + b) * 3;
+    const float* R = Rmat + ((size_t)m * K + b + 1) * 9;
+    const float* T = Tmat + ((size_t)m * K + b + 1) * 3;
+    const float* R0 = Rmat + (size_t)m * K * 9;
+    const float* T0 = Tmat + (size_t)m * K * 3;
+    float vs[3], c[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) vs[d] = (T[d] + p[2] * R[6 + d]) + (p[1] * R[3 + d] + p[0] * R[d]);     // lbs_forward_kernel's fold order
+#pragma unroll
+    for (int d = 0; d < 3; d++) c[d] = vs[0] * R0[d] + vs[1] * R0[3 + d] + vs[2] * R0[6 + d] + T0[d];
+    const int img = m / H;
+    const float f = fl[m];
+    proj[i] = make_float4(pp[2 * img] + c[0] * f / c[2], pp[2 * img + 1] + c[1] * f / c[2], c[2], 1.f);          // geom_utils.py:32-33
+}
+
+__global__ __launch_bounds__(256) void project_points_backward_kernel(const float* __restrict__ rest, const float* __restrict__ ctl,
+                                                                      const float* __restrict__ Rmat, const float* __restrict__ Tmat,
+                                                                      const float* __restrict__ fl, const float4* __restrict__ gproj,
+                                                                      float* __restrict__ grest, float* __restrict__ gctl, int M, int H,
+                                                                      int K)
+{
+    const int nb = K - 1, Pn = 2 * nb;
+    const int i = blockIdx.x * 256 + threadIdx.x;           // (h, point)
+    if (i >= H * Pn) return;
+    const int h = i / Pn, j = i - h * Pn, b = j % nb;
+    const float* p = (j < nb ? rest : ctl) + ((size_t)h * nb + b) * 3;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int img = 0; img < M / H; img++) {                  // image order: deterministic
+        const int m = img * H + h;
+        const float* R = Rmat + ((size_t)m * K + b + 1) * 9;
+        const float* T = Tmat + ((size_t)m * K + b + 1) * 3;
+        const float* R0 = Rmat + (size_t)m * K * 9;
+        const float* T0 = Tmat + (size_t)m * K * 3;
+        float vs[3], c[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) vs[d] = (T[d] + p[2] * R[6 + d]) + (p[1] * R[3 + d] + p[0] * R[d]);
+#pragma unroll
+        for (int d = 0; d < 3; d++) c[d] = vs[0] * R0[d] + vs[1] * R0[3 + d] + vs[2] * R0[6 + d] + T0[d];
+        const float4 g = gproj[(size_t)m * Pn + j];
+        const float f = fl[m], iz = 1.f / c[2], xz = c[0] * iz, yz = c[1] * iz;              // == pinhole_backward_kernel
+        const float gc[3] = {g.x * f * iz, g.y * f * iz, g.z - (g.x * xz + g.y * yz) * f * iz};
+        float gv[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) gv[d] = gc[0] * R0[3 * d] + gc[1] * R0[3 * d + 1] + gc[2] * R0[3 * d + 2];      // g_vs = g_c R0^T
+#pragma unroll
+        for (int d = 0; d < 3; d++) acc[d] += gv[0] * R[3 * d] + gv[1] * R[3 * d + 1] + gv[2] * R[3 * d + 2];       // g_p = g_vs R^T
+    }
+    float* o = (j < nb ? grest : gctl) + ((size_t)h * nb + b) * 3;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+}
+
 // ---- symmetric Chamfer distance of two small point sets (pytorch3d.loss.chamfer_distance as used at nnutils/mesh_net.py:503) --
 // a [N,P,3], b [N,Q,3] -> out[n] = mean_i min_j |a_i - b_j|^2 + mean_j min_i |b_j - a_i|^2, nearest indices kept for the
 // backward.  One workgroup per batch item (the control-point sets hold <= 35 points; larger sets loop).
@@ -498,6 +566,32 @@ extern "C" int lasr_bone_fixup_backward(const float* quat, const float* rest_ts,
     const int work = M * K > H * (K - 1) * 3 ? M * K : H * (K - 1) * 3;
     LASR_LAUNCH(K_BONE_FIXUP, bone_fixup_backward_kernel, dim3((work + 255) / 256), dim3(256), 0, quat, rest_ts, grad_rmat,
                 grad_tmat, grad_quat, grad_trans, grad_depth, grad_rest, M, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_project_points_forward(const float* rest_ts, const float* ctl_ts, const float* Rmat, const float* Tmat,
+                                           const float* pp, const float* fl, float* proj, int M, int H, int K, void* hip_stream)
+{
+    if (M < 0 || H < 1 || K < 2 || M % H != 0) return LASR_E_BADARG;
+    if (M == 0) return LASR_OK;
+    if (!rest_ts || !ctl_ts || !Rmat || !Tmat || !pp || !fl || !proj) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int total = M * 2 * (K - 1);
+    LASR_LAUNCH(K_PROJECT_POINTS, project_points_forward_kernel, dim3((total + 255) / 256), dim3(256), 0, rest_ts, ctl_ts, Rmat, Tmat, pp,
+                fl, (float4*)proj, M, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_project_points_backward(const float* rest_ts, const float* ctl_ts, const float* Rmat, const float* Tmat,
+                                            const float* fl, const float* grad_proj, float* grad_rest, float* grad_ctl, int M, int H,
+                                            int K, void* hip_stream)
+{
+    if (M < 0 || H < 1 || K < 2 || M % H != 0) return LASR_E_BADARG;
+    if (!rest_ts || !ctl_ts || !grad_rest || !grad_ctl || (M > 0 && (!Rmat || !Tmat || !fl || !grad_proj))) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int total = H * 2 * (K - 1);
+    LASR_LAUNCH(K_PROJECT_POINTS, project_points_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, rest_ts, ctl_ts, Rmat, Tmat, fl,
+                (const float4*)grad_proj, grad_rest, grad_ctl, M, H, K);
     return launch_ok();
 }
 

@@ -19,6 +19,7 @@
 // (device-scope ticket + __threadfence) was built and measured in round 5: with 512 blocks the L2 write-back of every block's
 // fence costs 20-26 us per launch on this part (8 XCD-private L2s) -- a 5 us fold launch is cheaper (profiles/experiments/).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include "../../include/lasr_ops.h"
 #include "ops_common.h"
@@ -198,6 +199,62 @@ __global__ __launch_bounds__(256) void render_tables_flow_fold_kernel(const floa
 // ---- backward: every plane of grad_px in one pass --------------------------------------------------------------------------------
 // g_rndpair may be null (perceptual term off).  Planes 3-5 (the rendering frame's own position) get zeros: its projection is
 // detached (mesh_net.py:101-102).  part3[n][chunk] = (d pp.x, d pp.y, d fl, -) of the OTHER frame's intrinsics.
+// per-image / per-(image, hypothesis) constants of the backward pass
+struct PrBwdK { float c0x, c0y, c1x, c1y, f0, f1, k_mask, k_tex, k_flow, wmean; };
+
+// one pixel: inputs in registers, the ten gradient values out, the three intrinsics sums accumulated
+struct PrBwdIn { float q[10], m, oc, io[3], iw[3], ox, oy, g1[3], g2[3]; };
+__device__ __forceinline__ void pr_backward_pixel(const PrBwdK& K, const PrBwdIn& I, bool pair, float* o, float& sx, float& sy, float& sf)
+{
+    const float a = I.q[9];
+    const float r[3] = {I.q[0], I.q[1], I.q[2]};
+    const bool on = I.oc != 0.f;
+    float ga = on ? K.k_mask * (a - I.m) : 0.f;
+    float gr[3] = {0.f, 0.f, 0.f};
+    if (on) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float s1 = pr_sgn(I.io[c] - r[c] * a);
+            const float s2 = pr_sgn(I.iw[c] - r[c]);
+            gr[c] = -K.k_tex * (s1 * a + s2);
+            ga += -K.k_tex * s1 * r[c];
+        }
+    }
+    if (pair) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            gr[c] += I.g1[c] * a + I.g2[c];
+            ga += I.g1[c] * r[c];
+        }
+    }
+    // flow: loss -> rendered flow -> the other frame's position (planes 6-8) and intrinsics
+    float x0 = I.q[3], y0 = I.q[4], z0 = I.q[5], x1 = I.q[6], y1 = I.q[7], z1 = I.q[8];
+    const bool b = (z0 < 1e-9f) | (z1 < 1e-9f);
+    float gx1 = 0.f, gy1 = 0.f, gz1 = 0.f;
+    if (b) x0 = y0 = z0 = x1 = y1 = z1 = 10.f;
+    const float u0 = K.c0x + (x0 * K.f0) / z0, v0 = K.c0y + (y0 * K.f0) / z0;
+    const float u1 = K.c1x + (x1 * K.f1) / z1, v1 = K.c1y + (y1 * K.f1) / z1;
+    const float dx = (u1 - u0) - I.ox, dy = (v1 - v0) - I.oy;
+    const bool sel = !b && on && I.m > 0.f;
+    // when image i has no selected pixel at all wmean is NaN and 0 * NaN = NaN reaches every pixel, exactly what
+    // autograd does with the reference code (flow_loss_backward_kernel keeps the same behaviour)
+    const float gn = (sel ? K.k_flow : 0.f) * (pr_sigmoid(-I.oc) / K.wmean);
+    const float nrm = sqrtf(dx * dx + dy * dy);
+    float2 gf = make_float2(0.f, 0.f);
+    if (nrm > 0.f) gf = make_float2(gn / nrm * dx, gn / nrm * dy);
+    if (!b) {
+        const float ax = gf.x / z1, ay = gf.y / z1;
+        gx1 = ax * K.f1; gy1 = ay * K.f1;
+        gz1 = -(ax * ((x1 * K.f1) / z1) + ay * ((y1 * K.f1) / z1));
+        sx += gf.x; sy += gf.y; sf += ax * x1 + ay * y1;
+    }
+    o[0] = gr[0]; o[1] = gr[1]; o[2] = gr[2]; o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = gx1; o[7] = gy1; o[8] = gz1; o[9] = ga;
+}
+
+// V4: four consecutive pixels per thread and round through 16-byte loads / stores (every plane, chunk start and chunk length a
+// multiple of four pixels: any power-of-two image); the launch streams ~7 MB per image at LASR's sizes and the 4-byte form left
+// it at 2.7 TB/s.  Same per-pixel arithmetic; the intrinsics' sums associate differently (gradient bar 2e-4 relative).
+template <bool V4>
 __global__ __launch_bounds__(256) void render_tables_backward_kernel(PrArgs A, const float* __restrict__ tot, const float* __restrict__ img,
                                                                      const float* __restrict__ g_mask, const float* __restrict__ g_flow,
                                                                      const float* __restrict__ g_tex, const float* __restrict__ g_rndpair,
@@ -213,69 +270,71 @@ __global__ __launch_bounds__(256) void render_tables_backward_kernel(PrArgs A, c
     const float* iw = A.img_white + (size_t)i * 3 * P;
     const float* ox = A.obs + (size_t)i * A.obs_stride;
     const float* oy = ox + P;
+    const float* gp1 = g_rndpair ? g_rndpair + (size_t)ij * 3 * P : nullptr;
+    const float* gp2 = g_rndpair ? g_rndpair + ((size_t)N + ij) * 3 * P : nullptr;
     const int other = (ij + A.half) % N;
-    const float c0x = A.pp[2 * ij], c0y = A.pp[2 * ij + 1], c1x = A.pp[2 * other], c1y = A.pp[2 * other + 1];
-    const float f0 = A.fl[ij], f1 = A.fl[other];
     const float* t = tot + (size_t)ij * 8;
-    const float k_mask = g_mask[ij] / t[1];                               // 0.5 * 2 * g / count (== mask_loss_backward_kernel)
-    const float k_tex = g_tex[ij] * (2.f * wt) / (3.f * t[1]);            // (== tex_loss_backward_kernel)
-    const float k_flow = t[5] > 0.f ? 0.5f * g_flow[ij] / t[5] : 0.f;     // (== flow_loss_backward_kernel)
-    const float wmean = img[4 * i] / img[4 * i + 1];
+    PrBwdK K;
+    K.c0x = A.pp[2 * ij]; K.c0y = A.pp[2 * ij + 1]; K.c1x = A.pp[2 * other]; K.c1y = A.pp[2 * other + 1];
+    K.f0 = A.fl[ij]; K.f1 = A.fl[other];
+    K.k_mask = g_mask[ij] / t[1];                               // 0.5 * 2 * g / count (== mask_loss_backward_kernel)
+    K.k_tex = g_tex[ij] * (2.f * wt) / (3.f * t[1]);            // (== tex_loss_backward_kernel)
+    K.k_flow = t[5] > 0.f ? 0.5f * g_flow[ij] / t[5] : 0.f;     // (== flow_loss_backward_kernel)
+    K.wmean = img[4 * i] / img[4 * i + 1];
     int p0, p1;
     pr_range(P, A.nch, ch, p0, p1);
     float sx = 0.f, sy = 0.f, sf = 0.f;
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-        const float a = q[9 * (size_t)P + p];
-        const float r[3] = {q[p], q[P + p], q[2 * (size_t)P + p]};
-        const float o = oc[p];
-        const bool on = o != 0.f;
-        float ga = on ? k_mask * (a - m[p]) : 0.f;
-        float gr[3] = {0.f, 0.f, 0.f};
-        if (on) {
+    const bool pair = g_rndpair != nullptr;
+    if (V4) {
+        for (int p = p0 + 4 * threadIdx.x; p < p1; p += 1024) {
+            float4 Q[10], M, OC, IO[3], IW[3], OX, OY, G1[3], G2[3];
+#pragma unroll
+            for (int c = 0; c < 10; c++) Q[c] = *reinterpret_cast<const float4*>(q + (size_t)c * P + p);
+            M = *reinterpret_cast<const float4*>(m + p); OC = *reinterpret_cast<const float4*>(oc + p);
+            OX = *reinterpret_cast<const float4*>(ox + p); OY = *reinterpret_cast<const float4*>(oy + p);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float s1 = pr_sgn(io[(size_t)c * P + p] - r[c] * a);
-                const float s2 = pr_sgn(iw[(size_t)c * P + p] - r[c]);
-                gr[c] = -k_tex * (s1 * a + s2);
-                ga += -k_tex * s1 * r[c];
+                IO[c] = *reinterpret_cast<const float4*>(io + (size_t)c * P + p);
+                IW[c] = *reinterpret_cast<const float4*>(iw + (size_t)c * P + p);
+                G1[c] = pair ? *reinterpret_cast<const float4*>(gp1 + (size_t)c * P + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                G2[c] = pair ? *reinterpret_cast<const float4*>(gp2 + (size_t)c * P + p) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            float out[10][4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                PrBwdIn In;
+#define LASR_EL(v) (e == 0 ? (v).x : e == 1 ? (v).y : e == 2 ? (v).z : (v).w)
+#pragma unroll
+                for (int c = 0; c < 10; c++) In.q[c] = LASR_EL(Q[c]);
+                In.m = LASR_EL(M); In.oc = LASR_EL(OC); In.ox = LASR_EL(OX); In.oy = LASR_EL(OY);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { In.io[c] = LASR_EL(IO[c]); In.iw[c] = LASR_EL(IW[c]); In.g1[c] = LASR_EL(G1[c]); In.g2[c] = LASR_EL(G2[c]); }
+#undef LASR_EL
+                float o[10];
+                pr_backward_pixel(K, In, pair, o, sx, sy, sf);
+#pragma unroll
+                for (int c = 0; c < 10; c++) out[c][e] = o[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 10; c++)
+                *reinterpret_cast<float4*>(g + (size_t)c * P + p) = make_float4(out[c][0], out[c][1], out[c][2], out[c][3]);
         }
-        if (g_rndpair) {
+    } else {
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            PrBwdIn In;
+#pragma unroll
+            for (int c = 0; c < 10; c++) In.q[c] = q[(size_t)c * P + p];
+            In.m = m[p]; In.oc = oc[p]; In.ox = ox[p]; In.oy = oy[p];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float g1 = g_rndpair[((size_t)ij * 3 + c) * P + p], g2 = g_rndpair[(((size_t)N + ij) * 3 + c) * P + p];
-                gr[c] += g1 * a + g2;
-                ga += g1 * r[c];
+                In.io[c] = io[(size_t)c * P + p]; In.iw[c] = iw[(size_t)c * P + p];
+                In.g1[c] = pair ? gp1[(size_t)c * P + p] : 0.f; In.g2[c] = pair ? gp2[(size_t)c * P + p] : 0.f;
             }
+            float o[10];
+            pr_backward_pixel(K, In, pair, o, sx, sy, sf);
+#pragma unroll
+            for (int c = 0; c < 10; c++) g[(size_t)c * P + p] = o[c];
         }
-        // flow: loss -> rendered flow -> the other frame's position (planes 6-8) and intrinsics
-        float x0 = q[3 * (size_t)P + p], y0 = q[4 * (size_t)P + p], z0 = q[5 * (size_t)P + p];
-        float x1 = q[6 * (size_t)P + p], y1 = q[7 * (size_t)P + p], z1 = q[8 * (size_t)P + p];
-        const bool b = (z0 < 1e-9f) | (z1 < 1e-9f);
-        float gx1 = 0.f, gy1 = 0.f, gz1 = 0.f;
-        {
-            if (b) x0 = y0 = z0 = x1 = y1 = z1 = 10.f;
-            const float u0 = c0x + (x0 * f0) / z0, v0 = c0y + (y0 * f0) / z0;
-            const float u1 = c1x + (x1 * f1) / z1, v1 = c1y + (y1 * f1) / z1;
-            const float dx = (u1 - u0) - ox[p], dy = (v1 - v0) - oy[p];
-            const bool sel = !b && on && m[p] > 0.f;
-            // when image i has no selected pixel at all wmean is NaN and 0 * NaN = NaN reaches every pixel, exactly what
-            // autograd does with the reference code (flow_loss_backward_kernel keeps the same behaviour)
-            const float gn = (sel ? k_flow : 0.f) * (pr_sigmoid(-o) / wmean);
-            const float nrm = sqrtf(dx * dx + dy * dy);
-            float2 gf = make_float2(0.f, 0.f);
-            if (nrm > 0.f) gf = make_float2(gn / nrm * dx, gn / nrm * dy);
-            if (!b) {
-                const float ax = gf.x / z1, ay = gf.y / z1;
-                gx1 = ax * f1; gy1 = ay * f1;
-                gz1 = -(ax * ((x1 * f1) / z1) + ay * ((y1 * f1) / z1));
-                sx += gf.x; sy += gf.y; sf += ax * x1 + ay * y1;
-            }
-        }
-        g[p] = gr[0]; g[P + p] = gr[1]; g[2 * (size_t)P + p] = gr[2];
-        g[3 * (size_t)P + p] = 0.f; g[4 * (size_t)P + p] = 0.f; g[5 * (size_t)P + p] = 0.f;
-        g[6 * (size_t)P + p] = gx1; g[7 * (size_t)P + p] = gy1; g[8 * (size_t)P + p] = gz1;
-        g[9 * (size_t)P + p] = ga;
     }
     sx = block_sum(sx, red); sy = block_sum(sy, red); sf = block_sum(sf, red);
     if (threadIdx.x == 0) {
@@ -662,8 +721,17 @@ extern "C" int lasr_render_tables_backward(const float* px, const float* masks, 
     hipStream_t st = (hipStream_t)hip_stream;
     const PrScratch S = pr_scratch(const_cast<float*>(scratch), I, H, P);
     const int N = I * H;
-    LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_backward_kernel, dim3(N, A.nch), dim3(256), 0, A, S.tot, S.img, grad_mask_tab,
-                grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3);
+    // 16-byte form: every plane 16-byte aligned and the chunks whole quads of pixels
+    const int per = (P + A.nch - 1) / A.nch;
+    const uintptr_t bits = (uintptr_t)px | (uintptr_t)masks | (uintptr_t)occ | (uintptr_t)flow_obs | (uintptr_t)img_obs | (uintptr_t)img_white |
+                           (uintptr_t)grad_px | (uintptr_t)grad_rndpair;
+    const bool v4 = (P % 4) == 0 && (per % 4) == 0 && (flow_obs_image_stride % 4) == 0 && (bits & 15) == 0;
+    if (v4)
+        LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_backward_kernel<true>, dim3(N, A.nch), dim3(256), 0, A, S.tot, S.img,
+                    grad_mask_tab, grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3);
+    else
+        LASR_LAUNCH(K_RENDER_TABLES_BACKWARD, render_tables_backward_kernel<false>, dim3(N, A.nch), dim3(256), 0, A, S.tot, S.img,
+                    grad_mask_tab, grad_flow_tab, grad_tex_tab, grad_rndpair, l1tex_wt, grad_px, S.part3);
     if ((rc = launch_ok())) return rc;
     LASR_LAUNCH(K_RENDER_TABLES_FOLD, render_tables_intrinsics_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part3, grad_pp,
                 grad_fl, N, A.nch, A.half);

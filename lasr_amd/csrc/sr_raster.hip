@@ -636,6 +636,10 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
     __shared__ int s_wcnt[2][4];
 
     if (W1 && A.choice && chosen_kernel(A) != CHOICE_ONE_WAVE) return;      // the device took the cooperative kernel for this launch
+#ifdef LASR_OCC_LDS        // measurement build (profiles/r05_occupancy_sweep.txt): extra LDS per workgroup caps the waves per SIMD
+    __shared__ unsigned char s_occ_pad[W1 ? LASR_OCC_LDS : 1];
+    if (A.N < 0) s_occ_pad[threadIdx.x] = (unsigned char)A.F;               // never true: keeps the allocation
+#endif
     const int tiles_x = (A.IS + TW - 1) / TW;
     int bn, tx, ty;
     tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, W1 ? A.order : nullptr);

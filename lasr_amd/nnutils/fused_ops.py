@@ -783,6 +783,49 @@ def bone_fixup(quat, trans, depth, rest_ts, H, K):
     return _BoneFixup.apply(quat, trans, depth, rest_ts if K > 1 else None, H, K)
 
 
+class _ProjectPoints(Function):
+    @staticmethod
+    def forward(ctx, rest, ctl, Rmat, Tmat, pp, fl, H, K):
+        _lib.need_cuda(rest, ctl, Rmat, Tmat, pp, fl)
+        rest, ctl = rest.contiguous().float(), ctl.contiguous().float()
+        Rmat, Tmat = Rmat.detach().contiguous().float(), Tmat.detach().contiguous().float()
+        pp, fl = pp.detach().contiguous().float(), fl.detach().contiguous().float()
+        M = Rmat.numel() // (9 * K)
+        if Tmat.numel() != 3 * M * K or fl.numel() != M or pp.numel() != 2 * (M // H) or rest.numel() != 3 * H * (K - 1) \
+                or ctl.numel() != rest.numel():
+            raise ValueError('project_points: rest_ts / ctl_ts [H,K-1,3], Rmat [M*K,3,3], Tmat [M*K,3], pp [M/H,2], fl [M]')
+        proj = torch.empty(M, 2 * (K - 1), 4, dtype=torch.float32, device=rest.device)
+        guard, st = _lib.stream_of(rest)
+        with guard:
+            rc = _lib.lib().lasr_project_points_forward(rest.data_ptr(), ctl.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(), pp.data_ptr(),
+                                                        fl.data_ptr(), proj.data_ptr(), M, H, K, st)
+        _lib.check(rc, 'lasr_project_points_forward')
+        ctx.save_for_backward(rest, ctl, Rmat, Tmat, fl)
+        ctx.dims = (M, H, K)
+        return proj
+
+    @staticmethod
+    def backward(ctx, g):
+        rest, ctl, Rmat, Tmat, fl = ctx.saved_tensors
+        M, H, K = ctx.dims
+        g = g.contiguous().float()
+        grest, gctl = torch.empty_like(rest), torch.empty_like(ctl)
+        guard, st = _lib.stream_of(rest)
+        with guard:
+            rc = _lib.lib().lasr_project_points_backward(rest.data_ptr(), ctl.data_ptr(), Rmat.data_ptr(), Tmat.data_ptr(), fl.data_ptr(),
+                                                         g.data_ptr(), grest.data_ptr(), gctl.data_ptr(), M, H, K, st)
+        _lib.check(rc, 'lasr_project_points_backward')
+        return grest, gctl, None, None, None, None, None, None
+
+
+def project_points(rest_ts, ctl_ts, Rmat, Tmat, ppoint, scale, n_hypo, n_bones):
+    """Joint centres and control points of every (image, hypothesis) projected into the image -- the two identity-skin obj_to_cam
+    calls and the pinhole_cam of /root/reference/nnutils/mesh_net.py:285-288, :302 -- in one launch each way: rest_ts / ctl_ts
+    [H(K-1),3], Rmat [M*K,3,3], Tmat [M*K,3] (constants: no gradient), ppoint [2B,2], scale [2B,H] -> proj [M, 2(K-1), 4]
+    (joints first, then control points; (u, v, z, 1)).  Gradient flows to rest_ts / ctl_ts only."""
+    return _ProjectPoints.apply(rest_ts, ctl_ts, Rmat, Tmat, ppoint, scale.reshape(-1), int(n_hypo), int(n_bones))
+
+
 class _Chamfer(Function):
     @staticmethod
     def forward(ctx, a, b):

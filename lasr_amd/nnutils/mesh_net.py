@@ -642,15 +642,16 @@ class LASR(MeshNet):
         if K > 1:
             skin_h = self._skinning(pred_v, n2)
             skin = skin_h.repeat(n2, 1, 1, 1)
-            eye = getattr(self, '_eye_bones', None)                              # identity "skin" of joints + control points
-            if eye is None or eye.device != Rmat.device or eye.shape[1] != K - 1:
+            # joints and control points through the same transforms and the projection, one launch each way (the reference: two
+            # obj_to_cam calls with an identity skin, :285-288, and pinhole_cam); only rest_ts / ctl_ts receive gradient
+            if Rmat.is_cuda:
+                proj = fused_ops.project_points(self.rest_ts, self.ctl_ts, Rmat, Tmat, ppoint, scale, H, K)
+            else:
                 eye = torch.eye(K - 1, device=Rmat.device)[None, :, :, None]
-                eye = self._eye_bones = torch.cat([eye, eye], 2)                 # [1, K-1, 2(K-1), 1]
-            # joints and control points through the same transforms, in one call (the reference makes two, :285-288); only
-            # rest_ts / ctl_ts receive gradient
-            pts = torch.cat([self.rest_ts.view(H, K - 1, 3), self.ctl_ts.view(H, K - 1, 3)], 1).repeat(n2, 1, 1)
-            jc = obj_to_cam(pts, Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
-            proj = pinhole_cam(torch.cat([jc, torch.ones_like(jc[:, :, :1])], -1), ppoint.detach(), scale.detach())
+                eye = torch.cat([eye, eye], 2)                                   # [1, K-1, 2(K-1), 1]
+                pts = torch.cat([self.rest_ts.view(H, K - 1, 3), self.ctl_ts.view(H, K - 1, 3)], 1).repeat(n2, 1, 1)
+                jc = obj_to_cam(pts, Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
+                proj = pinhole_cam(torch.cat([jc, torch.ones_like(jc[:, :, :1])], -1), ppoint.detach(), scale.detach())
             self.joints_proj, self.ctl_proj = proj.split([K - 1, K - 1], 1)
         # ---- 1) flow rendering (:298-335); deform_v (:291) is the same blend before the body transform: one launch for both
         verts_cam, self.deform_v = obj_to_cam_both(pred_v, Rmat, Tmat[:, None, :], K, H, skin)

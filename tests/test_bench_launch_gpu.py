@@ -45,6 +45,12 @@ def test_bench_two_ranks_self_launch(cuda):
         assert 0 <= v['allreduce_exposed_ms'] <= v['allreduce_span_ms'] * 1.001 and np.isfinite(v['final_loss'])
         assert abs(v['pairs_per_s'] - 2 * v['iters_per_s']) <= 1e-9 * v['pairs_per_s']
     assert dp['no_overlap']['allreduce_exposed_ms'] == dp['no_overlap']['allreduce_span_ms']
+    # the three transports of the gradient message, timed for the first multi-GPU run to compare (values only mean something on xGMI)
+    av = dp['allreduce_variants']
+    assert av['message_bytes'] > 40e6 and av['world_size'] == 2 and 'NCCL_ALGO' in av['env']
+    for name in ('one_all_reduce', 'reduce_scatter_all_gather', 'buckets_25MB'):
+        assert ('ms' in av[name] and av[name]['ms'] > 0 and av[name]['busbw_GBs'] > 0) or 'error' in av[name], av[name]
+    assert 'ms' in av['one_all_reduce'] and av['buckets_25MB'].get('collectives_per_message', 3) >= 2
 
 
 def test_bench_eight_ranks_self_launch_on_one_gpu(cuda):
@@ -58,6 +64,9 @@ def test_bench_eight_ranks_self_launch_on_one_gpu(cuda):
     assert out['config']['parallelism'].startswith('dp8')
     dp = out['optimize_py_dp']
     assert dp['world_size'] == 8 and dp['overlap']['pairs_per_s'] > 0 and dp['no_overlap']['pairs_per_s'] > 0
+    av = dp['allreduce_variants']
+    assert av['world_size'] == 8 and set(av) >= {'one_all_reduce', 'reduce_scatter_all_gather', 'buckets_25MB', 'env', 'message_bytes'}
+    assert 'ms' in av['one_all_reduce']
 
 
 def test_bench_single_gpu_line_has_every_block(cuda):

@@ -162,3 +162,33 @@ def test_mesh_regularisers_in_one_launch_equal_the_three_criteria(cuda, level, N
     assert torch.equal(l1.detach(), l0.detach()) and torch.equal(f1.detach(), f0.detach()) and torch.equal(a1.detach(), a0.detach())
     assert torch.equal(b[1].grad, a[1].grad) and torch.equal(b[2].grad, a[2].grad)
     assert rel(b[0].grad, a[0].grad) <= 1e-6            # Laplacian + flatten parts added inside the kernel
+
+
+@pytest.mark.parametrize('n2,H,K', [(2, 8, 21), (4, 1, 36), (2, 2, 2)])
+def test_project_points_equals_the_identity_skin_lbs_and_pinhole_calls(cuda, n2, H, K):
+    # nnutils/mesh_net.py:285-288 + :302 as the round-1..4 product ran them: cat / repeat of the points, obj_to_cam with a one-hot skin,
+    # homogeneous cat, pinhole_cam
+    g = torch.Generator().manual_seed(n2 * 100 + K)
+    M, nb = n2 * H, K - 1
+    rest = (0.3 * torch.randn(H * nb, 3, generator=g)).to(cuda)
+    ctl = (0.3 * torch.randn(H * nb, 3, generator=g)).to(cuda)
+    R = torch.randn(M * K, 3, 3, generator=g).to(cuda)
+    T = torch.randn(M * K, 3, generator=g).to(cuda)
+    T.view(M, K, 3)[:, 0, 2] += 8                                   # in front of the camera
+    ppoint = (0.1 * torch.randn(n2, 2, generator=g)).to(cuda)
+    scale = (torch.rand(n2, H, generator=g) + 8).to(cuda)
+    up = torch.randn(M, 2 * nb, 4, generator=g).to(cuda)
+
+    a = [t.clone().requires_grad_(True) for t in (rest, ctl)]
+    eye = torch.eye(nb, device=cuda)[None, :, :, None]
+    eye = torch.cat([eye, eye], 2)
+    pts = torch.cat([a[0].view(H, nb, 3), a[1].view(H, nb, 3)], 1).repeat(n2, 1, 1)
+    jc = geom_utils.obj_to_cam(pts, R, T[:, None], K, H, eye)
+    want = geom_utils.pinhole_cam(torch.cat([jc, torch.ones_like(jc[:, :, :1])], -1), ppoint, scale)
+    (want * up).sum().backward()
+    b = [t.clone().requires_grad_(True) for t in (rest, ctl)]
+    got = fused_ops.project_points(b[0], b[1], R, T, ppoint, scale, H, K)
+    (got * up).sum().backward()
+    assert got.shape == want.shape and rel(got.detach(), want.detach()) <= 1e-6
+    for x, y, name in zip(b, a, ('rest_ts', 'ctl_ts')):
+        assert rel(x.grad, y.grad) <= 2e-5, name
