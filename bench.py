@@ -658,7 +658,7 @@ def _latest_profile(suffix):
     d = json.load(open(files[-1]))
     name = os.path.basename(files[-1])
     if d.get('source_sha') != raster_source_hash():
-        msg = ('%s was measured on other raster sources (its source_sha %s, now %s): re-run tools/prof/r04_final.sh'
+        msg = ('%s was measured on other raster sources (its source_sha %s, now %s): re-run tools/prof/r05_final.sh'
                % (name, d.get('source_sha'), raster_source_hash()))
         print('bench.py: STALE COUNTER FILE -- ' + msg, file=sys.stderr, flush=True)
         return None, name, msg
