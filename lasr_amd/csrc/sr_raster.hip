@@ -33,6 +33,9 @@
 namespace lasr {
 
 constexpr int TILE = 16;        // pixels per tile side (4 waves of 8x8)
+#ifndef LASR_PREFETCH
+#define LASR_PREFETCH 1         // scalar-cache prefetch of the next list entry in the forward walk (A/B: profiles/r05_prefetch_ab.txt)
+#endif
 #ifndef LASR_LIST_CAP
 #define LASR_LIST_CAP 2048
 #endif
@@ -576,8 +579,25 @@ __device__ __forceinline__ void forward_tile_body(RasterArgs A, float* __restric
             for (int j = 0; j < n; j++) {
                 const int fn = base + __builtin_amdgcn_readlane(chunk, j);     // wave-uniform -> scalar loads
                 const cptr_t rec = as_const(recs + (size_t)fn * REC);
+#if LASR_PREFETCH
+                // The walk is a chain of dependent scalar loads per entry: rect, wait, test; first record line, wait; the other two
+                // lines and the attributes on demand, wait again -- three round trips to L2 one after the other, and the occupancy
+                // sweep (profiles/r05_occupancy_sweep.txt) puts a third of the launch in exposed latency even at eight waves per
+                // SIMD.  Touch the entry's other two record lines and its attribute line together with the rect load: one
+                // round trip, the later loads hit the scalar cache.  The touched words are never used (no arithmetic changes).
+                int pf1, pf2, pf3;
+                {
+                    const float* rn = recs + (size_t)fn * REC;
+                    const float* tn = texs + (size_t)fn * texstride;
+                    asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %4, 0x0"
+                                 : "=&s"(pf1), "=&s"(pf2), "=&s"(pf3) : "s"(rn), "s"(tn) : "memory");
+                }
+#endif
                 // exact integer form of the bbox test K.cu:375 (see first_pixel_ge / last_pixel_le)
                 const bool cand = rect_has(__float_as_int(rec[R_BB + 0]), __float_as_int(rec[R_BB + 1]), pxy);
+#if LASR_PREFETCH
+                asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(pf1), "s"(pf2), "s"(pf3));      // (the rect test has waited already)
+#endif
                 float w0, w1, w2;
                 barycentric(rec, xp, yp, w0, w1, w2);
                 const int lim = (A.N * A.F - (bn * A.F + fn)) * A.T;   // texels to the end of the tensor
