@@ -55,7 +55,9 @@ const char* lasr_strerror(int code);
 int         lasr_last_hip_error(void);      /* hipError_t of the most recent LASR_E_LAUNCH on this thread */
 
 /* Scratch the caller must provide to forward/backward (per-face records + tile
- * bounding boxes; replaces the reference's faces_info tensor, which becomes optional). */
+ * bounding boxes; replaces the reference's faces_info tensor, which becomes optional).
+ * The backward entry points touch the records and rects only: they accept lasr_sr_workspace_bytes(N, F, T, 0) (the size
+ * without the forward's tile-order table; a forward workspace is always large enough). */
 size_t lasr_sr_workspace_bytes(int N, int F, int T, int IS);
 
 /*

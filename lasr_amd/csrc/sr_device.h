@@ -126,7 +126,10 @@ __device__ __forceinline__ float max_finite(float a, float b)
 }
 
 // "pixel (px | py << 16) lies in the record's rect" (record fields R_BB, R_BB + 1): per 16-bit half d = p - first must not
-// exceed the extent; a pixel left of / above the rect wraps to d >= 32769 > any extent, the empty rect (first = 0xffff) holds none.
+// exceed the extent; a pixel left of / above the rect wraps to d >= 32769 > any extent, and the empty rect (first = 0xffff,
+// extent 0) holds no pixel of an image (coordinates <= 32766).  Lanes outside the image pass 0xfffe in both halves: against a
+// real rect d >= 0x7fff > any extent, against the empty one d = 0xffff > 0 -- no rect holds them (0xffff would match the
+// empty rect: d = 0).
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool rect_has(int lo, int ext, int pxy)
 {

@@ -78,7 +78,7 @@ __device__ __forceinline__ void coop_tile_body(RasterArgs A, float* __restrict__
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
     const int pn = py * IS + px;
-    const int pxy = valid ? px | (py << 16) : -1;                  // (-1 lies in no rect: rect_has)
+    const int pxy = valid ? px | (py << 16) : (int)0xfffefffeu;    // (lies in no rect, the empty one included: rect_has)
 
     PixState<NCH> s;                                    // lives in wave 0 only
     s.a = 1.f;
@@ -142,7 +142,19 @@ __device__ __forceinline__ void coop_tile_body(RasterArgs A, float* __restrict__
         const int fn = __builtin_amdgcn_readfirstlane(base + (int)s_list[e]);
         const cptr_t rec = as_const(recs + (size_t)fn * REC);
         const cptr_t tex = as_const(texs + (size_t)fn * texstride);
+#if LASR_PREFETCH       // the entry's other two record lines and its attribute line in the same round trip as the rect (sr_raster.hip)
+        int pf1, pf2, pf3;
+        {
+            const float* rn = recs + (size_t)fn * REC;
+            const float* tn = texs + (size_t)fn * texstride;
+            asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %4, 0x0"
+                         : "=&s"(pf1), "=&s"(pf2), "=&s"(pf3) : "s"(rn), "s"(tn) : "memory");
+        }
+#endif
         const bool cand = rect_has(__float_as_int(rec[R_BB + 0]), __float_as_int(rec[R_BB + 1]), pxy);
+#if LASR_PREFETCH
+        asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(pf1), "s"(pf2), "s"(pf3));
+#endif
         float w0, w1, w2;
         barycentric(rec, xp, yp, w0, w1, w2);
         const bool mk = (__float_as_int(rec[R_FLAGS]) & ok_bit) != 0;     // wave-uniform; ok_bit = U.ok ? 32 : 0 (no branch on U.ok per entry)
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(NW * 64) void sr_forward_seg_kernel(RasterArgs A, f
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
     const int pn = py * IS + px;
-    const int pxy = valid ? px | (py << 16) : -1;
+    const int pxy = valid ? px | (py << 16) : (int)0xfffefffeu;
 
     PixState<NCH> s;
     s.a = 1.f;

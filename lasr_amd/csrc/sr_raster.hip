@@ -129,7 +129,7 @@ __device__ __forceinline__ int div_small(int e, int d, float inv)
 __global__ __launch_bounds__(512) void sr_tile_weight_kernel(const short4* __restrict__ rects, int F, int t8,
                                                              unsigned char* __restrict__ keys, int* __restrict__ busy)
 {
-    __shared__ int s_d[(ORDER_MAX_SIDE + 1) * (ORDER_MAX_SIDE + 1)];
+    extern __shared__ int s_d[];                      // (t8 + 1)^2 ints: 4.3 KB for a 256x256 image, 64 KB at the 1016-pixel limit
     const int bn = blockIdx.x, S = t8 + 1, tiles = t8 * t8;
     if (busy && bn == 0 && threadIdx.x == 0) *busy = 0;                          // sr_order_kernel adds up the non-empty tiles
     for (int i = threadIdx.x; i < S * S; i += 512) s_d[i] = 0;
@@ -416,7 +416,7 @@ __device__ __forceinline__ void forward_tile_body(RasterArgs A, float* __restric
     const int py = qy0 + (lane >> 3);
     const bool valid = px < IS && py < IS;
     const int pn = py * IS + px;
-    const int pxy = valid ? px | (py << 16) : -1;                  // (-1 lies in no rect: rect_has)
+    const int pxy = valid ? px | (py << 16) : (int)0xfffefffeu;    // (lies in no rect, the empty one included: rect_has)
 
     PixState<NCH> s;
     s.a = (m.alpha == 2) ? 1.f : 0.f;
@@ -927,7 +927,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
         int* busy = plan == 3 ? (int*)slot : nullptr;
         int* head = plan == 4 ? (int*)(slot + 64) : nullptr;
         ProfScope po(K_SR_ORDER, st);
-        hipLaunchKernelGGL(sr_tile_weight_kernel, dim3((unsigned)N), dim3(512), 0, st, rects, F, t8o, keys, busy);
+        hipLaunchKernelGGL(sr_tile_weight_kernel, dim3((unsigned)N), dim3(512), (size_t)(t8o + 1) * (t8o + 1) * sizeof(int), st, rects, F, t8o, keys, busy);
         hipLaunchKernelGGL(sr_order_kernel, dim3(8 * order_groups), dim3(ORDER_THREADS), align_up((size_t)(tiles8o / 8 / order_groups), 16), st,
                            keys, N, t8o, order, busy, head, (int)g_mixed_min_weight);
         A.order = order;
@@ -1005,7 +1005,9 @@ static int backward_impl(const float* faces, const float* textures, const float*
     if (N == 0 || IS == 0 || F == 0) return LASR_OK;
     if (!faces || !textures || !soft_colors || !aggrs_info || !grad_faces || !grad_textures || !grad_soft_colors)
         return LASR_E_BADARG;
-    if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, IS)) return LASR_E_WORKSPACE;
+    // the backward touches the records, the rects and the group rects only: a workspace without the forward's tile-order table
+    // (lasr_sr_workspace_bytes(N, F, T, 0), the size of ABI versions 1-2) is enough
+    if (!workspace || workspace_bytes < lasr_sr_workspace_bytes(N, F, T, 0)) return LASR_E_WORKSPACE;
     hipStream_t st = (hipStream_t)hip_stream;
     float* recs; short4* rects; short4* grects;
     RasterArgs A = make_args(workspace, textures, N, F, T, IS, near, far, eps, sigma_val, func_id_dist, dist_eps,

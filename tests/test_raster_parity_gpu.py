@@ -451,6 +451,36 @@ def test_backward_on_the_forwards_records_equals_a_rebuild(cuda):
         out.append((gf.cpu().numpy(), gt.cpu().numpy()))
     assert np.abs(out[0][0]).max() > 0
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # the backward reads the records and rects only -- a workspace of the size WITHOUT the forward's tile-order table
+    # (lasr_sr_workspace_bytes(N, F, T, 0), what backward-only callers of ABI versions 1-2 allocated) is accepted; smaller is not
+    small = h.lasr_sr_workspace_bytes(N, F, 3, 0)
+    assert small < ws.numel()
+    ws2 = torch.empty(small, dtype=torch.uint8, device=cuda)
+    gf, gt = torch.zeros(N, F, 9, device=cuda), torch.zeros(N, F, 9, device=cuda)
+    _lib.check(h.lasr_sr_backward_ex(tfv.data_ptr(), tft.data_ptr(), colors.data_ptr(), aggrs.data_ptr(), gf.data_ptr(),
+                                     gt.data_ptr(), g.data_ptr(), ws2.data_ptr(), ws2.numel(), N, F, 3, 3, IS, float(near),
+                                     float(far), None, *tail, 0, st), 'backward_ex on a records-only workspace')
+    assert np.array_equal(gf.cpu().numpy(), out[1][0]) and np.array_equal(gt.cpu().numpy(), out[1][1])
+    assert h.lasr_sr_backward_ex(tfv.data_ptr(), tft.data_ptr(), colors.data_ptr(), aggrs.data_ptr(), gf.data_ptr(), gt.data_ptr(),
+                                 g.data_ptr(), ws2.data_ptr(), small - 1, N, F, 3, 3, IS, float(near), float(far), None, *tail, 0,
+                                 st) == -3
+
+
+def test_invalidate_records_accepts_a_device_without_an_index(cuda):
+    # torch.device('cuda').index is None; the helper used to match nothing and leave a pending eager backward on
+    # records a graph replay had overwritten
+    import importlib
+    sr_mod = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    img = srf.soft_rasterize(torch.from_numpy(fv).to(cuda), torch.from_numpy(ft).to(cuda), 32, **dict(synth.LASR_MODES, near=near, far=far))
+    key = (cuda.index, torch.cuda.current_stream(cuda).cuda_stream)
+    for dev in ('cuda', torch.device('cuda'), cuda, 'cuda:0'):
+        before = sr_mod._records_of[key]
+        srf.invalidate_records(dev)
+        assert sr_mod._records_of[key] == before + 1, dev
+    with pytest.raises(ValueError):
+        srf.invalidate_records('cpu')
+    del img
 
 
 @pytest.mark.parametrize('channels', [3, 6, 9])
