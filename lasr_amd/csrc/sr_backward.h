@@ -23,6 +23,9 @@ constexpr bool BWD_FM = true;
 constexpr int QCAP = 128;   // ring entries per wave (power of two, >= 2 * 64)
 constexpr int BWD_THREADS = 64;   // one wave per workgroup (see backward_impl)
 
+// (Register budget of the six- / nine-channel instantiations: 90 / 106 VGPRs = 5 / 4 waves per SIMD.  Asking for one wave more,
+// amdgpu_waves_per_eu(6 / 5), gives 78 / 88 VGPRs without a spill and a 28-50 % SLOWER kernel -- the schedule that fits re-derives
+// instead of keeping -- profiles/r05_backward_ab.txt.  Not requested.)
 template <bool LASR_FAST, int NCH>
 __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
                                                           const float* __restrict__ aggrs,
@@ -87,24 +90,26 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     // cheap reject only for the soft distance modes and well-conditioned faces; 2 % slack on thr
     const bool use_far = (m.dist == 2) && (flags & 16);
     const float thr_pad = A.thr * 1.05f;
-    const float inv_is = 1.f / (float)IS;
+    const float inv_is = A.inv_is;               // 1.f / (float)IS, from the host (sr_common.h)
     const bool pow2 = (IS & (IS - 1)) == 0;      // then n * (1/IS) == n / IS exactly: skip the division per pixel
     // pixel centres as ONE fma of the converted index: (2 i + 1 - IS) / IS = i * (2 / IS) + (1 - IS) / IS (K.cu:343-346; rows count
     // from the top: yi = IS - 1 - row).  For a power-of-two image every term and the result are exact in fp32; other sizes keep
     // the division in stage 2 (the distance code is ill-conditioned in the pixel position on edge-on faces, and the surface
     // texel choice must see the forward's barycentrics) and use the fma -- within an ulp -- for stage 1's conservative reject only
-    const float cx_a = 2.f * inv_is, cx_b = (float)(1 - IS) * inv_is, cy_b = (float)(IS - 1) * inv_is;
+    const float cx_a = A.cx_a, cx_b = A.cx_b, cy_b = A.cy_b;      // 2 / IS, (1 - IS) / IS, (IS - 1) / IS
     auto centre_x = [&](int xi) { return OPT_BWD_S1 && pow2 ? __builtin_fmaf((float)xi, cx_a, cx_b) : pix_center_p2(xi, IS, inv_is, pow2); };
     auto centre_y = [&](int row) { return OPT_BWD_S1 && pow2 ? __builtin_fmaf((float)row, -cx_a, cy_b) : pix_center_p2(IS - 1 - row, IS, inv_is, pow2); };
     // stage 1's reject as signed line distances: d_k = w_k * h_k (h_k = height of vertex k over its opposite edge) is linear in
     // the pixel, so the coefficients are scaled once per face and a pixel costs six fmas, one v_min3 and one compare:
     // "some d_k < -sqrt(thr_pad)" == certainly_far (conservative either way: 5 % slack on thr, fused vs unfused ~1e-7)
     float ld[9];
-    const float far_t = -sqrtf(thr_pad);
+    const float far_t = A.far_t;                 // -sqrtf(thr_pad)
     if (OPT_BWD_S1 && use_far) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float h = sqrtf(rec[R_HK2 + k]);
+            // (v_sqrt_f32, 1 ulp, instead of the 14-instruction IEEE expansion per height: the reject carries 5 % slack on thr,
+            // and flag 16 guarantees a well-scaled argument)
+            const float h = __builtin_amdgcn_sqrtf(rec[R_HK2 + k]);
             ld[3 * k] = rec[R_INV + 3 * k] * h; ld[3 * k + 1] = rec[R_INV + 3 * k + 1] * h; ld[3 * k + 2] = rec[R_INV + 3 * k + 2] * h;
         }
     }
@@ -121,6 +126,9 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     // scalar -- one 32-bit byte offset per pixel instead of an address computation per load -- were measured 1.5 % SLOWER,
     // profiles/r04_opt_ab.txt)
     auto ld_plane = [&](const float* base, int nplanes, int plane, int pn_) -> float {
+#if defined(LASR_BWD_ABL) && LASR_BWD_ABL == 3       // measurement build: everything but the pixel-plane loads
+        return 0.25f + 1e-3f * (float)(pn_ & 255) + 0.01f * (float)plane;
+#endif
         return base[((size_t)bn * nplanes + plane) * P + pn_];
     };
 
@@ -166,6 +174,10 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
         const bool active = lane < avail;
         const unsigned int packed = ring[(head + lane) & (QCAP - 1)];
         head += min(avail, 64);
+#if defined(LASR_BWD_ABL) && LASR_BWD_ABL == 1       // measurement build: prologue + stage 1 + ring + epilogue only
+        gv[0] += (float)packed;
+        continue;
+#endif
         if (!active) continue;
         const int xi = packed & 0xffff, row = packed >> 16;
         const int pn = row * IS + xi;
@@ -175,6 +187,10 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
         Frag fr;
         if (!fragment<FM, cptr_t, (OPT_BWD_MATH && LASR_FAST)>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
         const float D = fr.D;
+#if defined(LASR_BWD_ABL) && LASR_BWD_ABL == 2       // measurement build: + the distance code, nothing after it (no plane loads)
+        gv[0] += D + fr.dx + fr.dy + fr.t0 + fr.t1 + fr.t2 + fr.sign;
+        continue;
+#endif
 
         // alpha path (K.cu:583-593); hard alpha: the reference still adds g_alpha into C
         float Ca = ld_plane(gcolors, NCH + 1, NCH, pn);

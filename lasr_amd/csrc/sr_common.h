@@ -26,6 +26,10 @@ struct RasterArgs {
                                               // the four-wave cooperative body (written by sr_order_kernel); order_per = entries per XCD
     int order_per, head_max;
     float bg[9];
+    // launch constants of the backward pass, computed once on the host (IEEE division / square root: the bits the device
+    // expansions gave, without ~30 VALU instructions per face): 1 / IS, the pixel-centre fma coefficients 2 / IS, (1 - IS) / IS,
+    // (IS - 1) / IS, and stage 1's reject distance -sqrt(1.05 thr)
+    float inv_is, cx_a, cx_b, cy_b, far_t;
 };
 
 constexpr int CHOICE_ONE_WAVE = 0, CHOICE_COOP = 1;

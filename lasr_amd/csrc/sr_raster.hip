@@ -787,6 +787,9 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     A.N = N; A.F = F; A.T = T; A.res = (int)sqrt((double)T); A.IS = IS;   // K.cu:696
     A.near = near; A.far = far; A.near_far_dev = nullptr; A.eps = eps; A.sigma = sigma; A.gamma = gamma;
     A.thr = dist_eps * sigma;                                              // K.cu:352 (float product)
+    A.inv_is = 1.f / (float)IS;
+    A.cx_a = 2.f * A.inv_is; A.cx_b = (float)(1 - IS) * A.inv_is; A.cy_b = (float)(IS - 1) * A.inv_is;
+    { const float thr_pad = A.thr * 1.05f; A.far_t = -sqrtf(thr_pad); }
     A.m = Modes{dist, rgb, alpha, tex, double_side ? 1 : 0};
     A.overwrite_grads = 0;
     A.use_bg = 0;
