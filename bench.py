@@ -224,28 +224,40 @@ def _lbs_case(dev, N, V, K):
 
 
 def lbs_worker():
-    """Child process of lbs_leg (run under rocprofv3 --kernel-trace): REPS forward + backward calls per size, in LBS_SIZES order."""
+    """Child process of lbs_leg (run under rocprofv3 --kernel-trace).  Per size, in LBS_SIZES order: LBS_EAGER_CALLS eager forward +
+    backward calls, then one forward + backward captured as a HIP graph and replayed LBS_TRACE_REPS times -- the regime the
+    optimisation step runs these kernels in (eager launches of kernels this short are timed with whatever the previous launch
+    left in flight: 5.4 and 9.0 us for the same S0 forward on two boxes)."""
     from lasr_amd.nnutils import geom_utils
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    warm = _lbs_case(dev, 64, 1212, 37)                 # clocks and caches up before the counted sizes; lbs_trace skips these
-    for _ in range(LBS_WARM_CALLS):                     # launches by position
-        geom_utils.obj_to_cam(warm[0], warm[1], warm[2], 37, 1, warm[3]).backward(warm[4])
     for name, (N, V, K) in LBS_SIZES.items():
         v, R, T, sk, g = _lbs_case(dev, N, V, K)
-        for _ in range(LBS_TRACE_REPS):                 # (the first 10 calls of a size are dropped by lbs_trace: clocks, caches)
-            geom_utils.obj_to_cam(v, R, T, K, 1, sk).backward(g)
-    torch.cuda.synchronize()
+        ins = (v, R, T, sk)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(LBS_EAGER_CALLS):
+                torch.autograd.grad(geom_utils.obj_to_cam(v, R, T, K, 1, sk), ins, g)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            grads = torch.autograd.grad(geom_utils.obj_to_cam(v, R, T, K, 1, sk), ins, g)
+        for _ in range(LBS_TRACE_REPS):
+            graph.replay()
+        torch.cuda.synchronize()
+        del graph, grads
     print('lbs-worker done', flush=True)
 
 
-LBS_TRACE_REPS = 40
-LBS_WARM_CALLS = 60            # throw-away calls of lbs_worker before the counted sizes
+LBS_TRACE_REPS = 40            # graph replays per size (the trace keeps the last 30)
+LBS_EAGER_CALLS = 10           # eager calls per size before the capture (dropped by lbs_trace)
 
 
 def lbs_trace():
     """Kernel durations of the LBS launches from a rocprofv3 kernel trace of lbs_worker (dispatch end - start; the last 30 of the
-    40 calls per size).  None when the profiler is not available."""
+    40 graph replays per size).  None when the profiler is not available."""
     import glob
     import shutil
     import sqlite3
@@ -265,12 +277,13 @@ def lbs_trace():
                               'join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start'))
         out = {}
         for kern in ('lbs_forward_kernel', 'lbs_backward_mfma_kernel', 'lbs_backward_fold_kernel'):
-            d = [ns / 1e3 for nm, ns in rows if kern in nm][LBS_WARM_CALLS:]
-            if len(d) != LBS_TRACE_REPS * len(LBS_SIZES):
-                out[kern] = {'error': '%d dispatches, expected %d' % (len(d), LBS_TRACE_REPS * len(LBS_SIZES))}
+            d = [ns / 1e3 for nm, ns in rows if kern in nm]
+            per = LBS_EAGER_CALLS + LBS_TRACE_REPS
+            if len(d) != per * len(LBS_SIZES):
+                out[kern] = {'error': '%d dispatches, expected %d' % (len(d), per * len(LBS_SIZES))}
                 continue
             for i, name in enumerate(LBS_SIZES):
-                chunk = d[i * LBS_TRACE_REPS + 10:(i + 1) * LBS_TRACE_REPS]
+                chunk = d[i * per + LBS_EAGER_CALLS + 10:(i + 1) * per]
                 out.setdefault(name, {})[kern] = round(sum(chunk) / len(chunk), 2)
         return out
     except Exception as e:
@@ -284,13 +297,14 @@ def lbs_leg(dev):
     backward's three contractions (blended transform, g_skin = G x RT^T, g_RT = skin x G) on v_mfma_f32_16x16x4_f32.  us per
     launch at the S0 / dog15 sizes of SURVEY section 8 and a large batch, two clocks: the library's own HIP events around each
     launch of eager calls (a few us of event overhead on kernels this short), and the dispatch timestamps of a rocprofv3 kernel
-    trace of the same calls in a child process (`trace_us`, the figure that compares with the step profile).
+    trace of the same forward + backward replayed as a HIP graph in a child process (`trace_us`, the figure that compares with
+    the step profile).
     Forward flops = 2 N V (K-1) 12 + 2 N V 12; backward = 3 contractions of 2 N V (K-1) 12 (+ the per-vertex products)."""
     from lasr_amd.nnutils import geom_utils
     h = _lib.lib()
     st = torch.cuda.current_stream(dev).cuda_stream
     out = {'mfma_instruction': 'v_mfma_f32_16x16x4_f32', 'peak_tflops': MFMA_F32_PEAK_TF, 'sizes': {},
-           'clock': 'library HIP events around each launch (lasr_prof_*), mean of 100 eager calls; trace_us: rocprofv3 kernel trace'}
+           'clock': 'library HIP events around each launch (lasr_prof_*), mean of 100 eager calls; trace_us: rocprofv3 kernel trace of 30 HIP-graph replays of one forward + backward'}
     trace = lbs_trace()
     for name, (N, V, K) in LBS_SIZES.items():
         v, R, T, sk, g = _lbs_case(dev, N, V, K)

@@ -35,5 +35,6 @@ python $R/tools/valu_json.py $O/${T}_pmc_sq.txt 256 > $O/${T}_valu.json
 cd $R
 python tools/traffic_json.py $O/${T}_pmc.txt 256 "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py --no-cpu-baseline --no-lbs --no-sweep --lasr-iters 0 --steps 3 --warmup 1 (256 frames per launch, mesh M2, 256x256); KiB per dispatch summed over all TCC instances; bytes = FETCH_SIZE x 1024 x read_factor + WRITE_SIZE x 1024 x write_factor with the factors of profiles/r04_traffic_calibration.json (tools/ubench/traffic.hip: vector reads are tallied at half their bytes, scalar-cache reads and stores in full)" $R/profiles/r04_traffic_calibration.json > $O/${T}_traffic.json
 # ---- issue- or latency-bound?  the one-wave forward kernel at 8 / 6 / 4 / 2 waves per SIMD
-bash tools/prof/occupancy_sweep.sh > $O/${T}_occupancy_sweep.txt 2>&1
-cat $O/${T}_pmc.txt | cut -c1-120; grep -i lbs $O/${T}_pmc_lbs.txt | cut -c1-130; cat $O/${T}_occupancy_sweep.txt | grep -v Traceback | head -20
+# (needs the occ6 / occ4 / occ2 builds of tools/prof/occupancy_sweep.sh under lasr_amd/csrc/variants/; skipped when they are absent)
+[ -f lasr_amd/csrc/variants/liblasr_hip_occ4.so ] && bash tools/prof/occupancy_sweep.sh > $O/${T}_occupancy_sweep.txt 2>&1
+cat $O/${T}_pmc.txt | cut -c1-120; grep -i lbs $O/${T}_pmc_lbs.txt | cut -c1-130; [ -f $O/${T}_occupancy_sweep.txt ] && grep -v Traceback $O/${T}_occupancy_sweep.txt | head -20
