@@ -231,6 +231,13 @@ int lasr_face_gather_forward(const float* attr, const long long* faces, float* o
                              void* hip_stream);
 int lasr_face_gather_backward(const float* grad_out, const long long* faces, float* grad_attr, int N, int V, int F, int C,
                               void* hip_stream);
+/* The same backward over a CSR incidence structure the caller built once for the connectivity (the layout of
+ * lasr_raster_faces_backward: inc_ptr int32 [N or 1, V+1], inc int32 [N or 1, 3F] = corner ids 3 f + c grouped by vertex, ascending
+ * inside a vertex; inc_shared = 1 when all meshes share one).  Same summation order, hence the same bits, without the scan of the
+ * face tensor: for callers whose connectivity outlives a call (LASR's does; the Python operator caches the structure per face
+ * tensor). */
+int lasr_face_gather_backward_csr(const float* grad_out, const int* inc_ptr, const int* inc, int inc_shared, float* grad_attr,
+                                  int N, int V, int F, int C, void* hip_stream);
 
 /*
  * Brute-force nearest neighbour between two small point sets (the idx1/dist1 outputs of third_party/chamfer3D/chamfer3D.cu

@@ -58,6 +58,7 @@ SIGNATURES = {
     'lasr_flatten_backward': (_i, [_p] * 7 + [_i, _i, _i, _p]),
     'lasr_face_gather_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'lasr_face_gather_backward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    'lasr_face_gather_backward_csr': (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     'lasr_nearest_point': (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_point_mesh_scratch_floats': (_sz, [_i, _i, _i]),
     'lasr_point_mesh_forward': (_i, [_p] * 8 + [_i, _i, _i, _i, _p]),

@@ -355,9 +355,9 @@ __global__ __launch_bounds__(256) void face_gather_forward_kernel(const float* _
     for (int k = 0; k < C; k++) dst[k] = src[k];
 }
 
-template <int GATHER_VERTS>
-__global__ __launch_bounds__(256) void face_gather_backward_kernel(const float* __restrict__ gout, const long long* __restrict__ faces,
-                                                                   float* __restrict__ gattr, int V, int F3, int C)
+template <int GATHER_VERTS, int BT = 256>
+__global__ __launch_bounds__(BT) void face_gather_backward_kernel(const float* __restrict__ gout, const long long* __restrict__ faces,
+                                                                  float* __restrict__ gattr, int V, int F3, int C)
 {
     __shared__ int cnt[GATHER_VERTS];
     __shared__ int lists[GATHER_VERTS][GATHER_CAP];
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void face_gather_backward_kernel(const float* 
     const long long* fn = faces + (size_t)n * F3;
     if (tid < GATHER_VERTS) cnt[tid] = 0;
     __syncthreads();
-    for (int c = tid; c < F3; c += 256) {
+    for (int c = tid; c < F3; c += BT) {
         const long long d = fn[c] - v0;
         if (d >= 0 && d < GATHER_VERTS) {
             const int slot = atomicAdd(&cnt[(int)d], 1);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void face_gather_backward_kernel(const float* 
     }
     __syncthreads();
     const float* g = gout + (size_t)n * F3 * C;
-    for (int item = tid; item < GATHER_VERTS * C; item += 256) {
+    for (int item = tid; item < GATHER_VERTS * C; item += BT) {
         const int vi = item / C, ch = item - vi * C;
         if (v0 + vi >= V) continue;
         float acc = 0.f;
@@ -398,6 +398,34 @@ __global__ __launch_bounds__(256) void face_gather_backward_kernel(const float* 
         }
         gattr[((size_t)n * V + v0 + vi) * C + ch] = acc;
     }
+}
+
+// The same sums over a CSR vertex -> corner incidence the caller built once for the connectivity (fused_ops.face_incidence: corner
+// ids 3 f + c grouped by vertex, ascending inside a vertex = the order of the sorted lists above, so the result has the same
+// bits): no scan of the face tensor, no LDS filing.  One thread per (vertex, channel); a round keeps four gathers in flight
+// (clamped indices: a guarded load would cost a branch and a full wait each).
+__global__ __launch_bounds__(256) void face_gather_backward_csr_kernel(const float* __restrict__ gout, const int* __restrict__ inc_ptr,
+                                                                       const int* __restrict__ inc, float* __restrict__ gattr,
+                                                                       int V, int F3, int C, int shared)
+{
+    const int n = blockIdx.y, item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= V * C) return;
+    const int v = item / C, ch = item - v * C;
+    const int* ptr = inc_ptr + (shared ? 0 : (size_t)n * (V + 1));
+    const int* lst = inc + (shared ? 0 : (size_t)n * F3);
+    const float* g = gout + (size_t)n * F3 * C + ch;
+    const int b = ptr[v], e = ptr[v + 1];
+    float acc = 0.f;
+    for (int i = b; i < e; i += 4) {
+        const int last = e - 1;
+        const int c0 = lst[i], c1 = lst[min(i + 1, last)], c2 = lst[min(i + 2, last)], c3 = lst[min(i + 3, last)];
+        const float x0 = g[(size_t)c0 * C], x1 = g[(size_t)c1 * C], x2 = g[(size_t)c2 * C], x3 = g[(size_t)c3 * C];
+        acc += x0;
+        if (i + 1 < e) acc += x1;
+        if (i + 2 < e) acc += x2;
+        if (i + 3 < e) acc += x3;
+    }
+    gattr[(size_t)n * V * C + item] = acc;
 }
 
 // ===========================================================================
@@ -1093,9 +1121,24 @@ extern "C" int lasr_face_gather_backward(const float* grad_out, const long long*
         LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_kernel<256>, dim3((V + 255) / 256, N), dim3(256), 0,
                     grad_out, faces, grad_attr, V, 3 * F, C);
     } else {
-        LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_kernel<64>, dim3((V + 63) / 64, N), dim3(256), 0,
+        // few blocks on a mostly empty chip: the scan of the mesh's 3 F corner ids is the critical path, 1024 threads walk it in a
+        // quarter of the rounds (one frame of the bench mesh: 11 -> see profiles/r05_bench.json sweep)
+        LASR_LAUNCH(K_FACE_GATHER_BACKWARD, (face_gather_backward_kernel<64, 1024>), dim3((V + 63) / 64, N), dim3(1024), 0,
                     grad_out, faces, grad_attr, V, 3 * F, C);
     }
+    return launch_ok();
+}
+
+extern "C" int lasr_face_gather_backward_csr(const float* grad_out, const int* inc_ptr, const int* inc, int inc_shared,
+                                             float* grad_attr, int N, int V, int F, int C, void* hip_stream)
+{
+    if (N < 0 || V < 0 || F < 0 || C < 1) return LASR_E_BADARG;
+    if (N == 0 || V == 0) return LASR_OK;
+    if (!grad_attr || !inc_ptr || (F > 0 && (!grad_out || !inc))) return LASR_E_BADARG;
+    if ((long long)V * C > 0x7fffffffLL || N > 65535) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_FACE_GATHER_BACKWARD, face_gather_backward_csr_kernel, dim3((V * C + 255) / 256, N), dim3(256), 0, grad_out, inc_ptr,
+                inc, grad_attr, V, 3 * F, C, inc_shared ? 1 : 0);
     return launch_ok();
 }
 

@@ -8,6 +8,35 @@ import torch
 import torch.nn.functional as F
 
 
+# Connectivity that outlives a call (LASR's repeated face tensor, a Mesh rendered every iteration): the backward's vertex-centric
+# sums then run over a CSR incidence structure built once (nnutils/fused_ops.face_incidence) instead of scanning the face tensor in
+# every call.  The cache is keyed by the tensor OBJECT (a weak reference: an entry dies with its tensor, so a recycled address can
+# never be mistaken for it) and its version counter (in-place edits); the structure is built the second time a tensor is seen --
+# a face tensor made for one call costs nothing.
+_INC_CACHE = {}
+_INC_CACHE_MAX = 16
+
+
+def _incidence_of(faces, num_vertices):
+    import weakref
+    key = id(faces)
+    ent = _INC_CACHE.get(key)
+    if ent is not None and (ent[0]() is not faces or ent[1] != faces._version or ent[2] != num_vertices):
+        ent = None
+    if ent is None:
+        if len(_INC_CACHE) >= _INC_CACHE_MAX:
+            for k in [k for k, e in _INC_CACHE.items() if e[0]() is None] or list(_INC_CACHE)[:1]:
+                _INC_CACHE.pop(k, None)
+        _INC_CACHE[key] = [weakref.ref(faces), faces._version, num_vertices, None]
+        return None
+    if ent[3] is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                  # (built eagerly, outside a capture: argsort allocates)
+        from ...nnutils import fused_ops
+        ent[3] = fused_ops.face_incidence(faces, num_vertices)
+    return ent[3]
+
+
 class _FaceGather(torch.autograd.Function):
     """lasr_face_gather_* (include/lasr_ops.h)."""
 
@@ -25,6 +54,7 @@ class _FaceGather(torch.autograd.Function):
         _lib.check(rc, 'lasr_face_gather_forward')
         ctx.save_for_backward(faces)
         ctx.dims = (N, V, F_, C)
+        ctx.inc = _incidence_of(faces, V)
         return out
 
     @staticmethod
@@ -36,7 +66,12 @@ class _FaceGather(torch.autograd.Function):
         ga = torch.empty(N, V, C, dtype=torch.float32, device=g.device)
         guard, st = _lib.stream_of(g)
         with guard:
-            rc = _lib.lib().lasr_face_gather_backward(g.data_ptr(), faces.data_ptr(), ga.data_ptr(), N, V, F_, C, st)
+            if ctx.inc is not None:                     # connectivity seen before: the vertex-centric sums without the scan (same bits)
+                inc_ptr, inc = ctx.inc
+                rc = _lib.lib().lasr_face_gather_backward_csr(g.data_ptr(), inc_ptr.data_ptr(), inc.data_ptr(), 0, ga.data_ptr(),
+                                                              N, V, F_, C, st)
+            else:
+                rc = _lib.lib().lasr_face_gather_backward(g.data_ptr(), faces.data_ptr(), ga.data_ptr(), N, V, F_, C, st)
         _lib.check(rc, 'lasr_face_gather_backward')
         return ga, None
 

@@ -192,3 +192,64 @@ def test_project_points_equals_the_identity_skin_lbs_and_pinhole_calls(cuda, n2,
     assert got.shape == want.shape and rel(got.detach(), want.detach()) <= 1e-6
     for x, y, name in zip(b, a, ('rest_ts', 'ctl_ts')):
         assert rel(x.grad, y.grad) <= 2e-5, name
+
+
+@pytest.mark.parametrize('N,level,C,shared', [(1, 2, 3, True), (5, 3, 3, True), (4, 2, 9, False), (3, 1, 1, False), (16, 3, 3, True)])
+def test_face_gather_backward_over_the_incidence_lists_has_the_scan_kernel_s_bits(cuda, N, level, C, shared):
+    # lasr_face_gather_backward_csr: same ascending corner order per vertex as the scanning kernel -> torch.equal
+    v, f = synth.geodesic_sphere(2 ** level)
+    f = torch.from_numpy(np.ascontiguousarray(f)).long()
+    V, F = v.shape[0], f.shape[0]
+    gen = torch.Generator(device='cpu').manual_seed(7 + N)
+    if shared:
+        faces = f[None].expand(N, F, 3).contiguous().to(cuda)
+        inc_ptr, inc = fused_ops.face_incidence(f[None].to(cuda), V)
+    else:
+        faces = torch.stack([f[torch.randperm(F, generator=gen)] for _ in range(N)]).to(cuda)     # another corner order per mesh
+        inc_ptr, inc = fused_ops.face_incidence(faces, V)
+    g = torch.randn(N, F, 3, C, generator=gen).to(cuda)
+    h = _lib.lib()
+    want, got = torch.empty(N, V, C, device=cuda), torch.full((N, V, C), float('nan'), device=cuda)
+    st = torch.cuda.current_stream(cuda).cuda_stream
+    _lib.check(h.lasr_face_gather_backward(g.data_ptr(), faces.data_ptr(), want.data_ptr(), N, V, F, C, st), 'scan')
+    _lib.check(h.lasr_face_gather_backward_csr(g.data_ptr(), inc_ptr.data_ptr(), inc.data_ptr(), 1 if shared else 0, got.data_ptr(),
+                                               N, V, F, C, st), 'csr')
+    assert torch.equal(got, want)
+    # and it is the gradient of the gather
+    ref = torch.zeros(N, V, C, dtype=torch.float64, device=cuda)
+    ref.scatter_add_(1, faces.reshape(N, -1, 1).expand(N, 3 * F, C), g.reshape(N, 3 * F, C).double())
+    assert (got.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_face_vertices_caches_the_incidence_of_a_face_tensor_it_sees_again(cuda):
+    from lasr_amd.soft_renderer.functional import geometry
+    v, f = synth.geodesic_sphere(4)
+    f = torch.from_numpy(np.ascontiguousarray(f)).long()
+    V = v.shape[0]
+    faces = f[None].repeat(3, 1, 1).to(cuda)
+    verts = torch.randn(3, V, 3, device=cuda)
+    w = torch.randn(3, f.shape[0], 3, 3, device=cuda)
+
+    def grad(fc):
+        x = verts.clone().requires_grad_(True)
+        (geometry.face_vertices(x, fc) * w).sum().backward()
+        return x.grad
+
+    geometry._INC_CACHE.clear()
+    g1 = grad(faces)                                   # first sighting: scanning kernel, entry without a structure
+    ent = geometry._INC_CACHE[id(faces)]
+    assert ent[3] is None
+    g2 = grad(faces)                                   # second sighting: the structure is built and used
+    assert geometry._INC_CACHE[id(faces)][3] is not None and torch.equal(g1, g2)
+    faces[0, 0] = faces[0, 0].flip(0)                  # an in-place edit bumps the version: the entry is dropped, not reused
+    g3 = grad(faces)
+    assert geometry._INC_CACHE[id(faces)][3] is None
+    assert torch.equal(g3, grad(faces)) and torch.equal(g3, grad(faces.clone()))
+    tmp = faces.clone()
+    key = id(tmp)
+    grad(tmp)
+    del tmp                                            # the entry of a dead tensor never matches a new one at the same id
+    other = f[None].repeat(3, 1, 1).flip(1).to(cuda)
+    if id(other) == key:
+        assert geometry._INC_CACHE[key][0]() is None
+    assert torch.equal(grad(other), grad(other.clone()))
