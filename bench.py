@@ -259,6 +259,14 @@ LBS_TRACE_REPS = 40            # graph replays per size (the trace keeps the las
 LBS_EAGER_CALLS = 10           # eager calls per size before the capture (dropped by lbs_trace)
 
 
+def under_profiler():
+    """True when this process is itself running under rocprofv3 (its tool library is preloaded): the legs that start a rocprofv3 child
+    of their own are skipped then -- a profiler inside a profiled process, possibly one collecting PMC counters, is not worth a hung
+    or crashed box for two extra blocks of the line."""
+    return bool(os.environ.get('ROCP_TOOL_LIBRARIES')) or 'rocprofiler' in os.environ.get('LD_PRELOAD', '') or \
+        os.environ.get('LASR_BENCH_UNDER_PROFILER') == '1'                # (the last: the test of this switch)
+
+
 def lbs_trace():
     """Kernel durations of the LBS launches from a rocprofv3 kernel trace of lbs_worker (dispatch end - start; the last 30 of the
     40 graph replays per size).  None when the profiler is not available."""
@@ -269,6 +277,8 @@ def lbs_trace():
     import tempfile
     if shutil.which('rocprofv3') is None:
         return None
+    if under_profiler():
+        return {'error': 'skipped: bench.py is itself running under rocprofv3'}
     tmp = tempfile.mkdtemp(prefix='lasr_lbs_', dir='/tmp')
     try:
         cmd = ['rocprofv3', '--kernel-trace', '-d', tmp, '-o', 't', '--', sys.executable, os.path.abspath(__file__), '--step-worker', 'lbs']
@@ -577,6 +587,9 @@ def in_scope_step_leg():
                      'every other kernel of liblasr_hip.so; out_of_scope = MIOpen / rocBLAS / ATen kernels of the encoder and AlexNet'}
     if shutil.which('rocprofv3') is None:
         out['error'] = 'rocprofv3 not on PATH'
+        return out
+    if under_profiler():
+        out['error'] = 'skipped: bench.py is itself running under rocprofv3'
         return out
     shapes = {'spot3_s0': (2, 8, 256 * 256), 'camel_s4': (4, 1, 512 * 512)}
     for name in STEP_CONFIGS:

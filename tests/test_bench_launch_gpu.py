@@ -115,3 +115,28 @@ print('rccl ok', torch.cuda.nccl.version())
     p = subprocess.run([sys.executable, '-c', code % (ROOT, port)], cwd=ROOT, timeout=300, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and 'rccl ok' in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
+
+
+def test_bench_line_reports_the_in_scope_kernel_time_of_the_optimisation_step(cuda):
+    # the driver line carries the step's in-scope kernel time from a kernel trace taken in a child process
+    import shutil
+    if shutil.which('rocprofv3') is None:
+        pytest.skip('no rocprofv3 on this box')
+    args = ['--steps', '2', '--warmup', '1', '--frames', '16', '--lasr-iters', '2', '--no-cpu-baseline', '--no-sweep']
+    out = run_bench(args, timeout=900)
+    s = out['in_scope_step']
+    for cfg in ('spot3_s0', 'camel_s4'):
+        x = s[cfg]
+        assert 'error' not in x, x
+        assert 20 <= x['other_in_scope_launches'] <= 80 and 50 < x['other_in_scope_us'] < 2000
+        assert x['raster_us'] > 50 and x['tail_us'] > 10 and x['out_of_scope_us'] > x['other_in_scope_us']
+        assert abs(sum(v['us'] for v in x['other_in_scope'].values()) - x['other_in_scope_us']) < 1.0
+        lr = x['loss_reductions']
+        assert set(lr) == {'render_tables_forward', 'render_tables_backward', 'cosdist_forward', 'cosdist_backward'}
+        assert all(0.02 < g['frac_of_hbm_peak'] < 1.0 for g in lr.values())
+    tr = out['lbs']['sizes']['S0']['trace_us']
+    assert 2 < tr['forward'] < 20 and 2 < tr['backward'] < 30
+    # inside a profiled process the legs that would start a profiler of their own are skipped, the line still comes out
+    out = run_bench(args, {'LASR_BENCH_UNDER_PROFILER': '1'}, timeout=600)
+    assert 'skipped' in out['in_scope_step']['error'] and 'skipped' in out['lbs']['trace_error']
+    assert out['value'] > 0 and out['optimize_py']['iters_per_s'] > 0
