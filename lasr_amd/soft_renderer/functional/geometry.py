@@ -25,12 +25,16 @@ def _incidence_of(faces, num_vertices):
         ent = None
     if ent is None:
         if len(_INC_CACHE) >= _INC_CACHE_MAX:
-            for k in [k for k, e in _INC_CACHE.items() if e[0]() is None] or list(_INC_CACHE)[:1]:
+            # only entries of dead tensors are dropped: a structure that was handed out may sit in a captured HIP graph, which needs
+            # it for as long as it needs the face tensor itself -- and that tensor's entry keeps the structure alive
+            for k in [k for k, e in _INC_CACHE.items() if e[0]() is None]:
                 _INC_CACHE.pop(k, None)
+            if len(_INC_CACHE) >= _INC_CACHE_MAX:
+                return None                              # every slot belongs to a live face tensor: this one keeps the scanning kernel
         _INC_CACHE[key] = [weakref.ref(faces), faces._version, num_vertices, None]
         return None
     if ent[3] is None:
-        if torch.cuda.is_current_stream_capturing():
+        if faces.is_cuda and torch.cuda.is_current_stream_capturing():
             return None                                  # (built eagerly, outside a capture: argsort allocates)
         from ...nnutils import fused_ops
         ent[3] = fused_ops.face_incidence(faces, num_vertices)
