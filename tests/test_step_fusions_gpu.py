@@ -253,3 +253,62 @@ def test_face_vertices_caches_the_incidence_of_a_face_tensor_it_sees_again(cuda)
     if id(other) == key:
         assert geometry._INC_CACHE[key][0]() is None
     assert torch.equal(grad(other), grad(other.clone()))
+
+
+def _odd_meshes():
+    """Connectivities the sphere tests never produce: a tetrahedron with two vertices no face uses (valence 0) and a fan whose hub has
+    valence 37 (more than the 16 lanes / 4-corner batches the vertex-centric backward kernels work in)."""
+    tet = (np.array([[0, 0, 1], [1, 0, -0.5], [-0.5, 0.8, -0.5], [-0.5, -0.8, -0.5], [3, 3, 3], [-3, 3, 2]], np.float32) * 0.4,
+           np.array([[0, 1, 2], [0, 2, 3], [0, 3, 1], [1, 3, 2]], np.int64))
+    n = 37
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    rim = np.stack([np.cos(ang), np.sin(ang), 0.1 * np.sin(3 * ang)], 1)
+    fan_v = np.concatenate([[[0, 0, 0.3]], rim]).astype(np.float32) * 0.6
+    fan_f = np.array([[0, 1 + i, 1 + (i + 1) % n] for i in range(n)], np.int64)
+    return {'tetrahedron+isolated': tet, 'fan37': (fan_v, fan_f)}
+
+
+@pytest.mark.parametrize('name', ['tetrahedron+isolated', 'fan37'])
+def test_vertex_centric_backwards_on_odd_connectivities(cuda, name):
+    v, f = _odd_meshes()[name]
+    V, F, N = v.shape[0], f.shape[0], 4                               # (N even: image n pairs with (n + N/2) % N)
+    g = torch.Generator().manual_seed(V)
+    faces = torch.from_numpy(f)[None].repeat(N, 1, 1).to(cuda)
+    inc = fused_ops.face_incidence(faces[:1], V)
+    # ---- face gather over the incidence lists vs the scanning kernel; guard words either side of the output stay untouched
+    h = _lib.lib()
+    st = torch.cuda.current_stream(cuda).cuda_stream
+    gr = torch.randn(N, F, 3, 5, generator=g).to(cuda)
+    want = torch.empty(N, V, 5, device=cuda)
+    buf = torch.full((N * V * 5 + 64,), 12345.0, device=cuda)
+    _lib.check(h.lasr_face_gather_backward(gr.data_ptr(), faces.data_ptr(), want.data_ptr(), N, V, F, 5, st), 'scan')
+    _lib.check(h.lasr_face_gather_backward_csr(gr.data_ptr(), inc[0].data_ptr(), inc[1].data_ptr(), 1, buf[32:].data_ptr(), N, V, F, 5, st), 'csr')
+    assert torch.equal(buf[32:32 + N * V * 5].view(N, V, 5), want) and bool((buf[:32] == 12345.0).all()) and bool((buf[-32:] == 12345.0).all())
+    # ---- raster_faces vs raster_inputs + gathers
+    cam = torch.from_numpy(v)[None] + 0.05 * torch.randn(N, V, 3, generator=g)
+    cam[:, :, 2] += 8
+    tex, pp, fl = torch.rand(N, V, 3, generator=g), 0.1 * torch.randn(N, 2, generator=g), torch.rand(N, generator=g) + 8
+    eye = [0.0, 0.0, -2.732]
+    up_v, up_a = torch.randn(N, F, 3, 3, generator=g).to(cuda), torch.randn(N, F, 3, 9, generator=g).to(cuda)
+    a = [t.clone().to(cuda).requires_grad_(True) for t in (cam, tex, pp, fl)]
+    pre, attrs, nf = fused_ops.raster_inputs(*a, eye)
+    ((srf.face_vertices(srf.look_at(pre, eye), faces) * up_v).sum() + (srf.face_vertices(attrs, faces) * up_a).sum()).backward()
+    b = [t.clone().to(cuda).requires_grad_(True) for t in (cam, tex, pp, fl)]
+    fv1, fa1, nf1 = fused_ops.raster_faces(*b, eye, faces[:1].contiguous(), inc)
+    ((fv1 * up_v).sum() + (fa1 * up_a).sum()).backward()
+    assert torch.equal(b[0].grad, a[0].grad) and torch.equal(b[1].grad, a[1].grad)
+    assert rel(b[2].grad, a[2].grad) <= 2e-5 and rel(b[3].grad, a[3].grad) <= 2e-5
+    if name.startswith('tet'):
+        assert float(b[0].grad[:, 4:].abs().max()) == 0.0                       # vertices no face uses get a zero gradient
+    # ---- mesh regularisers (closed mesh only: the flatten term needs two faces per edge)
+    if name.startswith('tet'):
+        vt, ft = torch.from_numpy(v[:4]), torch.from_numpy(f)
+        lap, arap, flat = (loss_utils.LaplacianLoss(vt, ft).to(cuda), loss_utils.ARAPLoss(vt, ft).to(cuda), loss_utils.FlattenLoss(ft).to(cuda))
+        x = (vt[None] + 0.05 * torch.randn(2, 4, 3, generator=g)).to(cuda)
+        d0, d1 = (vt[None] + 0.05 * torch.randn(1, 4, 3, generator=g)).to(cuda), (vt[None] + 0.05 * torch.randn(1, 4, 3, generator=g)).to(cuda)
+        p = [t.clone().requires_grad_(True) for t in (x, d0, d1)]
+        (lap(p[0]).sum() + 2 * flat(p[0]).sum() + 3 * arap(p[1], p[2]).sum()).backward()
+        q = [t.clone().requires_grad_(True) for t in (x, d0, d1)]
+        l1, f1, a1 = fused_ops.mesh_regularisers(q[0], q[1], q[2], lap, flat, arap)
+        (l1.sum() + 2 * f1.sum() + 3 * a1.sum()).backward()
+        assert torch.equal(q[1].grad, p[1].grad) and torch.equal(q[2].grad, p[2].grad) and rel(q[0].grad, p[0].grad) <= 1e-6
