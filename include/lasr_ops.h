@@ -359,6 +359,15 @@ int lasr_bone_fixup_forward(const float* quat, const float* trans, const float* 
 int lasr_bone_fixup_backward(const float* quat, const float* rest_ts, const float* grad_rmat, const float* grad_tmat,
                              float* grad_quat, float* grad_trans, float* grad_depth, float* grad_rest, int M, int H, int K,
                              void* hip_stream);
+/* The same with the rotation distance between the two frames of every pair riding along (nnutils/mesh_net.py:514-516,
+ * third_party/ext_utils/util_rot.py:27-37): pair_angle[i] = angle(Q[i], Q[i + M*K/2]) for i < M*K/2 (M even: first half of the batch =
+ * frame t, second half = frame t') -- the values and gradients of lasr_geodesic_forward / _backward on (Q[:half], Q[half:]),
+ * bit for bit, without their two launches; grad_quat = the fix-up's part + the distance's part. */
+int lasr_bone_fixup_pair_forward(const float* quat, const float* trans, const float* depth, const float* rest_ts, float* rmat,
+                                 float* tmat, float* pair_angle, int M, int H, int K, void* hip_stream);
+int lasr_bone_fixup_pair_backward(const float* quat, const float* rest_ts, const float* grad_rmat, const float* grad_tmat,
+                                  const float* grad_pair_angle, float* grad_quat, float* grad_trans, float* grad_depth,
+                                  float* grad_rest, int M, int H, int K, void* hip_stream);
 
 /*
  * Symmetric squared Chamfer distance of small point sets -- pytorch3d.loss.chamfer_distance()[0] as used on the bones' control

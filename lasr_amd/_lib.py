@@ -79,6 +79,8 @@ SIGNATURES = {
     'lasr_intrinsics_backward': (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_bone_fixup_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_bone_fixup_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_bone_fixup_pair_forward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'lasr_bone_fixup_pair_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_forward': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_chamfer_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'lasr_fill_planes': (_i, [_p, _p, _i, _i, ctypes.c_longlong, _p]),

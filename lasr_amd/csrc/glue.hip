@@ -152,13 +152,20 @@ __global__ __launch_bounds__(256) void intrinsics_backward_kernel(const float* _
 //   root (k = 0):   R' = Q^T,  T' = t
 //   bones (k >= 1): R' = Q,    T' = t + c - Q^T c     with c = rest_ts[h, k-1] (rotate about the joint)
 // (the reference transposes every Q, applies -R c + T + c with R = Q^T, then transposes the bones back.)
+// pair_angle (optional, [M*K/2]): the rotation distance between matrix i of the first half of the batch (frame t) and matrix i of the
+// second half (frame t'), nnutils/mesh_net.py:514-516 -- the values lasr_geodesic_forward gives for (quat[:half], quat[half:]),
+// without a launch of its own (the fix-up reads every matrix anyway).
 __global__ __launch_bounds__(256) void bone_fixup_forward_kernel(const float* __restrict__ quat, const float* __restrict__ trans,
                                                                  const float* __restrict__ depth, const float* __restrict__ rest,
-                                                                 float* __restrict__ Rout, float* __restrict__ Tout, int M, int H,
-                                                                 int K)
+                                                                 float* __restrict__ Rout, float* __restrict__ Tout,
+                                                                 float* __restrict__ pair_angle, int M, int H, int K)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;                    // i = (m * K + k),  m = image * H + h
     if (i >= M * K) return;
+    if (pair_angle && i < (M * K) / 2) {
+        const float c = geodesic_cos(quat + 9 * (size_t)i, quat + 9 * ((size_t)i + (M * K) / 2));
+        pair_angle[i] = fabsf(c) < 1.f ? acosf(c) : (c > 0.f ? 0.f : 3.14159265358979323846f);
+    }
     const int k = i % K, h = (i / K) % H;
     const float* q = quat + 9 * (size_t)i;
     float* R = Rout + 9 * (size_t)i;
@@ -182,8 +189,11 @@ __global__ __launch_bounds__(256) void bone_fixup_forward_kernel(const float* __
 }
 
 // grad_quat / grad_trans / grad_depth per (m, k); grad_rest[h, k-1] = sum over the images of (g - Q g) in image order.
+// gangle (optional, [M*K/2]): the upstream gradient of the forward's pair_angle; its part of grad_quat (lasr_geodesic_backward's
+// expressions) is added to the fix-up's part -- the one addition autograd performs on the two gradients of `quat`.
 __global__ __launch_bounds__(256) void bone_fixup_backward_kernel(const float* __restrict__ quat, const float* __restrict__ rest,
                                                                   const float* __restrict__ gR, const float* __restrict__ gT,
+                                                                  const float* __restrict__ gangle,
                                                                   float* __restrict__ gquat, float* __restrict__ gtrans,
                                                                   float* __restrict__ gdepth, float* __restrict__ grest, int M,
                                                                   int H, int K)
@@ -196,19 +206,32 @@ __global__ __launch_bounds__(256) void bone_fixup_backward_kernel(const float* _
         const float* t = gT + 3 * (size_t)i;
         float* gq = gquat + 9 * (size_t)i;
         gtrans[2 * (size_t)i] = t[0]; gtrans[2 * (size_t)i + 1] = t[1]; gdepth[i] = t[2];
+        float v[9];
         if (k == 0) {
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) gq[3 * c + r] = g[3 * r + c];
+                for (int c = 0; c < 3; c++) v[3 * c + r] = g[3 * r + c];
         } else {
             const float* c = rest + 3 * ((size_t)h * (K - 1) + (k - 1));
             // T'_r = t_r + c_r - sum_j Q[j][r] c_j   =>   dT'_r / dQ[j][r] = -c_j
 #pragma unroll
             for (int j = 0; j < 3; j++)
 #pragma unroll
-                for (int r = 0; r < 3; r++) gq[3 * j + r] = g[3 * j + r] - c[j] * t[r];
+                for (int r = 0; r < 3; r++) v[3 * j + r] = g[3 * j + r] - c[j] * t[r];
         }
+        if (gangle) {
+            const int half = total / 2, first = i < half ? i : i - half;
+            const float* a = quat + 9 * (size_t)first;
+            const float* b = quat + 9 * ((size_t)first + half);
+            const float cs = geodesic_cos(a, b);
+            const float gc = fabsf(cs) < 1.f ? -gangle[first] / sqrtf(1.f - cs * cs) * 0.5f : 0.f;
+            const float* other = i < half ? b : a;
+#pragma unroll
+            for (int j = 0; j < 9; j++) v[j] = v[j] + gc * other[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) gq[j] = v[j];
     }
     // rest_ts: one thread per (h, k-1, component) sums its images in order
     const int nrest = H * (K - 1) * 3;
@@ -550,7 +573,19 @@ extern "C" int lasr_bone_fixup_forward(const float* quat, const float* trans, co
     if (!quat || !trans || !depth || !rmat || !tmat || (K > 1 && !rest_ts)) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
     LASR_LAUNCH(K_BONE_FIXUP, bone_fixup_forward_kernel, dim3((M * K + 255) / 256), dim3(256), 0, quat, trans, depth, rest_ts,
-                rmat, tmat, M, H, K);
+                rmat, tmat, (float*)nullptr, M, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_bone_fixup_pair_forward(const float* quat, const float* trans, const float* depth, const float* rest_ts,
+                                            float* rmat, float* tmat, float* pair_angle, int M, int H, int K, void* hip_stream)
+{
+    if (M < 0 || H < 1 || K < 1 || M % H != 0 || M % 2 != 0) return LASR_E_BADARG;
+    if (M == 0) return LASR_OK;
+    if (!quat || !trans || !depth || !rmat || !tmat || !pair_angle || (K > 1 && !rest_ts)) return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LASR_LAUNCH(K_BONE_FIXUP, bone_fixup_forward_kernel, dim3((M * K + 255) / 256), dim3(256), 0, quat, trans, depth, rest_ts,
+                rmat, tmat, pair_angle, M, H, K);
     return launch_ok();
 }
 
@@ -565,7 +600,23 @@ extern "C" int lasr_bone_fixup_backward(const float* quat, const float* rest_ts,
     hipStream_t st = (hipStream_t)hip_stream;
     const int work = M * K > H * (K - 1) * 3 ? M * K : H * (K - 1) * 3;
     LASR_LAUNCH(K_BONE_FIXUP, bone_fixup_backward_kernel, dim3((work + 255) / 256), dim3(256), 0, quat, rest_ts, grad_rmat,
-                grad_tmat, grad_quat, grad_trans, grad_depth, grad_rest, M, H, K);
+                grad_tmat, (const float*)nullptr, grad_quat, grad_trans, grad_depth, grad_rest, M, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_bone_fixup_pair_backward(const float* quat, const float* rest_ts, const float* grad_rmat, const float* grad_tmat,
+                                             const float* grad_pair_angle, float* grad_quat, float* grad_trans, float* grad_depth,
+                                             float* grad_rest, int M, int H, int K, void* hip_stream)
+{
+    if (M < 0 || H < 1 || K < 1 || M % H != 0 || M % 2 != 0) return LASR_E_BADARG;
+    if (M == 0) return LASR_OK;
+    if (!quat || !grad_rmat || !grad_tmat || !grad_pair_angle || !grad_quat || !grad_trans || !grad_depth ||
+        (K > 1 && (!rest_ts || !grad_rest)))
+        return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int work = M * K > H * (K - 1) * 3 ? M * K : H * (K - 1) * 3;
+    LASR_LAUNCH(K_BONE_FIXUP, bone_fixup_backward_kernel, dim3((work + 255) / 256), dim3(256), 0, quat, rest_ts, grad_rmat,
+                grad_tmat, grad_pair_angle, grad_quat, grad_trans, grad_depth, grad_rest, M, H, K);
     return launch_ok();
 }
 

@@ -737,7 +737,7 @@ def intrinsics(cams, pp, scale, depth, ppoint, img_size):
 
 class _BoneFixup(Function):
     @staticmethod
-    def forward(ctx, quat, trans, depth, rest_ts, H, K):
+    def forward(ctx, quat, trans, depth, rest_ts, H, K, pair):
         _lib.need_cuda(quat, trans, depth, rest_ts)
         quat, trans, depth = quat.contiguous().float(), trans.contiguous().float(), depth.contiguous().float()
         rest = rest_ts.contiguous().float() if rest_ts is not None else None
@@ -745,42 +745,53 @@ class _BoneFixup(Function):
         M = MK // K
         rmat = torch.empty(MK, 3, 3, dtype=torch.float32, device=quat.device)
         tmat = torch.empty(MK, 3, dtype=torch.float32, device=quat.device)
+        angle = torch.empty(MK // 2, dtype=torch.float32, device=quat.device) if pair else None
+        h = _lib.lib()
         guard, st = _lib.stream_of(quat)
         with guard:
-            rc = _lib.lib().lasr_bone_fixup_forward(quat.data_ptr(), trans.data_ptr(), depth.data_ptr(),
-                                                    rest.data_ptr() if rest is not None else None, rmat.data_ptr(), tmat.data_ptr(),
-                                                    M, H, K, st)
+            args = (quat.data_ptr(), trans.data_ptr(), depth.data_ptr(), rest.data_ptr() if rest is not None else None,
+                    rmat.data_ptr(), tmat.data_ptr())
+            rc = h.lasr_bone_fixup_pair_forward(*args, angle.data_ptr(), M, H, K, st) if pair else \
+                h.lasr_bone_fixup_forward(*args, M, H, K, st)
         _lib.check(rc, 'lasr_bone_fixup_forward')
         ctx.save_for_backward(quat, rest)
-        ctx.dims = (M, H, K)
+        ctx.dims = (M, H, K, bool(pair))
         ctx.in_shapes = (quat.shape, trans.shape, depth.shape, None if rest is None else rest_ts.shape)
-        return rmat, tmat
+        return (rmat, tmat, angle) if pair else (rmat, tmat)
 
     @staticmethod
-    def backward(ctx, gR, gT):
+    def backward(ctx, gR, gT, g_angle=None):
         quat, rest = ctx.saved_tensors
-        M, H, K = ctx.dims
-        gR, gT = gR.contiguous().float(), gT.contiguous().float()
+        M, H, K, pair = ctx.dims
         dev = quat.device
+        gR = gR.contiguous().float() if gR is not None else torch.zeros(M * K, 3, 3, device=dev)
+        gT = gT.contiguous().float() if gT is not None else torch.zeros(M * K, 3, device=dev)
         gq = torch.empty(M * K, 9, dtype=torch.float32, device=dev)
         gt = torch.empty(M * K, 2, dtype=torch.float32, device=dev)
         gd = torch.empty(M * K, dtype=torch.float32, device=dev)
         gr = torch.empty(H, K - 1, 3, dtype=torch.float32, device=dev) if rest is not None else None
+        h = _lib.lib()
         guard, st = _lib.stream_of(quat)
         with guard:
-            rc = _lib.lib().lasr_bone_fixup_backward(quat.data_ptr(), rest.data_ptr() if rest is not None else None, gR.data_ptr(),
-                                                     gT.data_ptr(), gq.data_ptr(), gt.data_ptr(), gd.data_ptr(),
-                                                     gr.data_ptr() if gr is not None else None, M, H, K, st)
+            head = (quat.data_ptr(), rest.data_ptr() if rest is not None else None, gR.data_ptr(), gT.data_ptr())
+            tail = (gq.data_ptr(), gt.data_ptr(), gd.data_ptr(), gr.data_ptr() if gr is not None else None, M, H, K, st)
+            if pair:
+                g_angle = g_angle.contiguous().float() if g_angle is not None else torch.zeros(M * K // 2, device=dev)
+                rc = h.lasr_bone_fixup_pair_backward(*head, g_angle.data_ptr(), *tail)
+            else:
+                rc = h.lasr_bone_fixup_backward(*head, *tail)
         _lib.check(rc, 'lasr_bone_fixup_backward')
         qs, ts, ds, rs = ctx.in_shapes
-        return gq.view(qs), gt.view(ts), gd.view(ds), (gr.view(rs) if gr is not None else None), None, None
+        return gq.view(qs), gt.view(ts), gd.view(ds), (gr.view(rs) if gr is not None else None), None, None, None
 
 
-def bone_fixup(quat, trans, depth, rest_ts, H, K):
+def bone_fixup(quat, trans, depth, rest_ts, H, K, pair_angle=False):
     """Bone-transform fix-up (/root/reference/nnutils/mesh_net.py:259-283): quat [M*K,9] (or [M*K,3,3]) predicted matrices,
     trans [M*K,2], depth [M*K,1], rest_ts [H,(K-1)*3] joint centres (None for K == 1) -> (Rmat [M*K,3,3], Tmat [M*K,3]):
-    root = transposed prediction; bones rotate about their joint: T' = -Q^T c + T + c, R' = Q."""
-    return _BoneFixup.apply(quat, trans, depth, rest_ts if K > 1 else None, H, K)
+    root = transposed prediction; bones rotate about their joint: T' = -Q^T c + T + c, R' = Q.
+    pair_angle: also return the rotation distance [M*K/2] between every matrix of the first half of the batch and its counterpart
+    in the second half (:514-516: geodesic_distance(quat[:half], quat[half:])) -- same values and gradients, no launches of its own."""
+    return _BoneFixup.apply(quat, trans, depth, rest_ts if K > 1 else None, H, K, bool(pair_angle))
 
 
 class _ProjectPoints(Function):

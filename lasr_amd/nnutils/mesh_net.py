@@ -637,7 +637,13 @@ class LASR(MeshNet):
 
         # ---- rigid + articulated transforms (:259-289): Rmat = predicted matrix transposed, Tmat = (trans, depth); bones
         # k >= 1 rotate about their joint (T' = -R c + T + c with c = rest_ts) and are transposed back -- one kernel (row a3)
-        Rmat, Tmat = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K)
+        # (without ground-truth poses the camera term is the rotation distance between the two frames' matrices, :514-516: it rides on
+        # the fix-up's launches)
+        pair_angle = None
+        if opts.use_gtpose:
+            Rmat, Tmat = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K)
+        else:
+            Rmat, Tmat, pair_angle = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K, pair_angle=True)
         skin = None
         if K > 1:
             skin_h = self._skinning(pred_v, n2)
@@ -792,8 +798,10 @@ class LASR(MeshNet):
             for pred, gt in ((scale_pred, scale), (trans_pred, trans), (depth_pred, depth), (ppoint_pred, ppoint)):
                 terms.append(((pred - gt).abs(), 0.2, G_CAM))
         else:
-            q0, q1 = quat.view(2, -1, 3, 3).unbind(0)
-            terms.append((geodesic_distance(q0, q1), 0.001, G_CAM))
+            if pair_angle is None:
+                q0, q1 = quat.view(2, -1, 3, 3).unbind(0)
+                pair_angle = geodesic_distance(q0, q1)
+            terms.append((pair_angle, 0.001, G_CAM))
             if K > 1:
                 t0, t1 = trans.view(2, B * H, K, 2).unbind(0)
                 d0, d1 = depth.view(2, B * H, K, 1).unbind(0)

@@ -312,3 +312,35 @@ def test_vertex_centric_backwards_on_odd_connectivities(cuda, name):
         l1, f1, a1 = fused_ops.mesh_regularisers(q[0], q[1], q[2], lap, flat, arap)
         (l1.sum() + 2 * f1.sum() + 3 * a1.sum()).backward()
         assert torch.equal(q[1].grad, p[1].grad) and torch.equal(q[2].grad, p[2].grad) and rel(q[0].grad, p[0].grad) <= 1e-6
+
+
+@pytest.mark.parametrize('M,H,K', [(16, 8, 21), (4, 1, 36), (2, 1, 1), (6, 3, 2)])
+def test_bone_fixup_with_the_pair_angle_equals_fixup_plus_rotation_distance(cuda, M, H, K):
+    # lasr_bone_fixup_pair_*: Rmat / Tmat of the plain fix-up and the angles of geodesic_distance(quat[:half], quat[half:]), with the
+    # gradient of quat = the sum autograd forms of the two parts -- torch.equal
+    g = torch.Generator().manual_seed(M * 10 + K)
+    q, _ = torch.linalg.qr(torch.randn(M * K, 3, 3, generator=g))
+    q[M * K // 2] = q[0]                                            # one identical pair: cos = 1, zero gradient branch
+    leaves = [q.reshape(M * K, 9), torch.randn(M * K, 2, generator=g), torch.randn(M * K, 1, generator=g) + 8,
+              0.3 * torch.randn(H, max(K - 1, 1) * 3, generator=g)]
+    upR, upT, upA = torch.randn(M * K, 3, 3, generator=g).to(cuda), torch.randn(M * K, 3, generator=g).to(cuda), torch.randn(M * K // 2, generator=g).to(cuda)
+    a = [t.clone().to(cuda).requires_grad_(True) for t in leaves]
+    R0, T0 = fused_ops.bone_fixup(a[0], a[1], a[2], a[3], H, K)
+    q0, q1 = a[0].view(2, -1, 3, 3).unbind(0)
+    A0 = fused_ops.geodesic_distance(q0, q1)
+    ((R0 * upR).sum() + (T0 * upT).sum() + (A0 * upA).sum()).backward()
+    b = [t.clone().to(cuda).requires_grad_(True) for t in leaves]
+    R1, T1, A1 = fused_ops.bone_fixup(b[0], b[1], b[2], b[3], H, K, pair_angle=True)
+    ((R1 * upR).sum() + (T1 * upT).sum() + (A1 * upA).sum()).backward()
+    assert torch.equal(R1, R0) and torch.equal(T1, T0) and torch.equal(A1, A0)
+    for x, y, name in zip(b, a, ('quat', 'trans', 'depth', 'rest_ts')):
+        if name == 'rest_ts' and K == 1:
+            continue
+        assert torch.equal(x.grad, y.grad), name
+    # only the angle used: the other outputs' gradients arrive as None
+    c = [t.clone().to(cuda).requires_grad_(True) for t in leaves]
+    (fused_ops.bone_fixup(c[0], c[1], c[2], c[3], H, K, pair_angle=True)[2] * upA).sum().backward()
+    d = leaves[0].clone().to(cuda).requires_grad_(True)
+    d0, d1 = d.view(2, -1, 3, 3).unbind(0)
+    (fused_ops.geodesic_distance(d0, d1) * upA).sum().backward()
+    assert torch.equal(c[0].grad, d.grad)
