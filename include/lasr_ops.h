@@ -155,6 +155,22 @@ int lasr_mesh_regularisers_backward(const float* x, const float* arap_dx, const 
                                     const int* inc_ptr, const int* inc, const float* lap_coords, const float* grad_lap,
                                     const float* grad_flat, const float* grad_arap, float* grad_x, float* grad_arap_dx,
                                     float* grad_arap_x, int N, int NA, int V, int E, void* hip_stream);
+/* The same two launches with a fourth criterion riding along: the symmetric squared Chamfer distance of NC pairs of small point sets
+ * (the bones' control points against their mirror images, nnutils/mesh_net.py:500-503) -- cham_a [NC,P,3], cham_b [NC,Q,3] ->
+ * cham_loss [NC], nn_ab [NC,P] / nn_ba [NC,Q] (int32, kept by the caller for the backward); the values and gradients of
+ * lasr_chamfer_forward / _backward, bit for bit, without their two launches.  NC = 0: exactly lasr_mesh_regularisers_*. */
+int lasr_step_regularisers_forward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
+                                   const int* lap_col, const int* arap_row_ptr, const int* arap_col, const int* quads,
+                                   float* lap_loss, float* lap_coords, float* flat_loss, float* arap_loss, int N, int NA, int V,
+                                   int E, const float* cham_a, const float* cham_b, float* cham_loss, int* nn_ab, int* nn_ba, int NC,
+                                   int P, int Q, void* hip_stream);
+int lasr_step_regularisers_backward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
+                                    const int* lap_col, const int* arap_row_ptr, const int* arap_col, const int* quads,
+                                    const int* inc_ptr, const int* inc, const float* lap_coords, const float* grad_lap,
+                                    const float* grad_flat, const float* grad_arap, float* grad_x, float* grad_arap_dx,
+                                    float* grad_arap_x, int N, int NA, int V, int E, const float* cham_a, const float* cham_b,
+                                    const int* nn_ab, const int* nn_ba, const float* grad_cham, float* grad_cham_a,
+                                    float* grad_cham_b, int NC, int P, int Q, void* hip_stream);
 
 /*
  * Flow reprojection, nnutils/mesh_net.py:93-104 (the tail of render_flow_soft_2 after the render).

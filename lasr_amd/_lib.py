@@ -45,6 +45,8 @@ SIGNATURES = {
     'lasr_laplacian_backward': (_i, [_p] * 6 + [_i, _i, _p]),
     'lasr_mesh_regularisers_forward': (_i, [_p] * 12 + [_i, _i, _i, _i, _p]),
     'lasr_mesh_regularisers_backward': (_i, [_p] * 17 + [_i, _i, _i, _i, _p]),
+    'lasr_step_regularisers_forward': (_i, [_p] * 12 + [_i, _i, _i, _i] + [_p] * 5 + [_i, _i, _i, _p]),
+    'lasr_step_regularisers_backward': (_i, [_p] * 17 + [_i, _i, _i, _i] + [_p] * 7 + [_i, _i, _i, _p]),
     'lasr_flow_reproject_scratch_floats': (_sz, [_i, _i]),
     'lasr_flow_reproject_forward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_flow_reproject_backward': (_i, [_p] * 7 + [_i, _i, _p]),

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/lasr_ops.h"
+#include "mesh_losses.h"
 #include "ops_common.h"
 
 namespace lasr {
@@ -327,34 +328,8 @@ __global__ __launch_bounds__(256) void chamfer_forward_kernel(const float* __res
 {
     __shared__ float red[4];
     const int n = blockIdx.x;
-    const float* A = a + (size_t)n * P * 3;
-    const float* Bp = b + (size_t)n * Q * 3;
-    float sa = 0.f, sb = 0.f;
-    for (int i = threadIdx.x; i < P; i += 256) {
-        const float x = A[3 * i], y = A[3 * i + 1], z = A[3 * i + 2];
-        float best = 3.4e38f; int arg = 0;
-        for (int j = 0; j < Q; j++) {
-            const float dx = x - Bp[3 * j], dy = y - Bp[3 * j + 1], dz = z - Bp[3 * j + 2];
-            const float d = dx * dx + dy * dy + dz * dz;
-            if (d < best) { best = d; arg = j; }                    // first minimum, like min(dim)
-        }
-        nn_ab[(size_t)n * P + i] = arg;
-        sa += best;
-    }
-    for (int j = threadIdx.x; j < Q; j += 256) {
-        const float x = Bp[3 * j], y = Bp[3 * j + 1], z = Bp[3 * j + 2];
-        float best = 3.4e38f; int arg = 0;
-        for (int i = 0; i < P; i++) {
-            const float dx = x - A[3 * i], dy = y - A[3 * i + 1], dz = z - A[3 * i + 2];
-            const float d = dx * dx + dy * dy + dz * dz;
-            if (d < best) { best = d; arg = i; }
-        }
-        nn_ba[(size_t)n * Q + j] = arg;
-        sb += best;
-    }
-    sa = block_sum(sa, red);
-    sb = block_sum(sb, red);
-    if (threadIdx.x == 0) out[n] = sa / (float)P + sb / (float)Q;
+    const float v = chamfer_forward_item(a + (size_t)n * P * 3, b + (size_t)n * Q * 3, nn_ab + (size_t)n * P, nn_ba + (size_t)n * Q, P, Q, red);
+    if (threadIdx.x == 0) out[n] = v;
 }
 
 // grad_a[n,i] = g[n] * (2/P (a_i - b_nn(i)) + 2/Q sum_{j: nn'(j) = i} (a_i - b_j)), grad_b likewise (gather form: deterministic)
@@ -364,29 +339,8 @@ __global__ __launch_bounds__(256) void chamfer_backward_kernel(const float* __re
                                                                float* __restrict__ gb, int P, int Q)
 {
     const int n = blockIdx.x;
-    const float* A = a + (size_t)n * P * 3;
-    const float* Bp = b + (size_t)n * Q * 3;
-    const int* ab = nn_ab + (size_t)n * P;
-    const int* ba = nn_ba + (size_t)n * Q;
-    const float wp = g[n] * 2.f / (float)P, wq = g[n] * 2.f / (float)Q;
-    for (int i = threadIdx.x; i < P; i += 256) {
-        const float x = A[3 * i], y = A[3 * i + 1], z = A[3 * i + 2];
-        const int j0 = ab[i];
-        float gx = wp * (x - Bp[3 * j0]), gy = wp * (y - Bp[3 * j0 + 1]), gz = wp * (z - Bp[3 * j0 + 2]);
-        for (int j = 0; j < Q; j++)
-            if (ba[j] == i) { gx += wq * (x - Bp[3 * j]); gy += wq * (y - Bp[3 * j + 1]); gz += wq * (z - Bp[3 * j + 2]); }
-        float* o = ga + ((size_t)n * P + i) * 3;
-        o[0] = gx; o[1] = gy; o[2] = gz;
-    }
-    for (int j = threadIdx.x; j < Q; j += 256) {
-        const float x = Bp[3 * j], y = Bp[3 * j + 1], z = Bp[3 * j + 2];
-        const int i0 = ba[j];
-        float gx = wq * (x - A[3 * i0]), gy = wq * (y - A[3 * i0 + 1]), gz = wq * (z - A[3 * i0 + 2]);
-        for (int i = 0; i < P; i++)
-            if (ab[i] == j) { gx += wp * (x - A[3 * i]); gy += wp * (y - A[3 * i + 1]); gz += wp * (z - A[3 * i + 2]); }
-        float* o = gb + ((size_t)n * Q + j) * 3;
-        o[0] = gx; o[1] = gy; o[2] = gz;
-    }
+    chamfer_backward_item(a + (size_t)n * P * 3, b + (size_t)n * Q * 3, nn_ab + (size_t)n * P, nn_ba + (size_t)n * Q, g[n],
+                          ga + (size_t)n * P * 3, gb + (size_t)n * Q * 3, P, Q);
 }
 
 // ---- mean shape of the batch (third_party/ext_nnutils/mesh_net.py:128-149, 171-185) ------------------------------------------

@@ -185,4 +185,61 @@ __device__ __forceinline__ void flatten_backward_vertex(const float* __restrict_
     a[0] = a0; a[1] = a1; a[2] = a2;
 }
 
+// ---- symmetric squared Chamfer distance of one pair of small point sets (pytorch3d.loss.chamfer_distance()[0] as used on the bones'
+// control points, nnutils/mesh_net.py:500-503): bodies shared by glue.hip's chamfer_* kernels and mesh_reg.hip's step launch.
+// A [P,3], Bp [Q,3]; ab [P] / ba [Q] receive the nearest-neighbour indices (first minimum, like min(dim)).  256 threads.
+__device__ __forceinline__ float chamfer_forward_item(const float* __restrict__ A, const float* __restrict__ Bp, int* __restrict__ ab,
+                                                      int* __restrict__ ba, int P, int Q, float* red)
+{
+    float sa = 0.f, sb = 0.f;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const float x = A[3 * i], y = A[3 * i + 1], z = A[3 * i + 2];
+        float best = 3.4e38f; int arg = 0;
+        for (int j = 0; j < Q; j++) {
+            const float dx = x - Bp[3 * j], dy = y - Bp[3 * j + 1], dz = z - Bp[3 * j + 2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; arg = j; }                    // first minimum, like min(dim)
+        }
+        ab[i] = arg;
+        sa += best;
+    }
+    for (int j = threadIdx.x; j < Q; j += 256) {
+        const float x = Bp[3 * j], y = Bp[3 * j + 1], z = Bp[3 * j + 2];
+        float best = 3.4e38f; int arg = 0;
+        for (int i = 0; i < P; i++) {
+            const float dx = x - A[3 * i], dy = y - A[3 * i + 1], dz = z - A[3 * i + 2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; arg = i; }
+        }
+        ba[j] = arg;
+        sb += best;
+    }
+    sa = block_sum(sa, red);
+    sb = block_sum(sb, red);
+    return sa / (float)P + sb / (float)Q;
+}
+
+__device__ __forceinline__ void chamfer_backward_item(const float* __restrict__ A, const float* __restrict__ Bp, const int* __restrict__ ab,
+                                                      const int* __restrict__ ba, float g, float* __restrict__ ga,
+                                                      float* __restrict__ gb, int P, int Q)
+{
+    const float wp = g * 2.f / (float)P, wq = g * 2.f / (float)Q;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const float x = A[3 * i], y = A[3 * i + 1], z = A[3 * i + 2];
+        const int j0 = ab[i];
+        float gx = wp * (x - Bp[3 * j0]), gy = wp * (y - Bp[3 * j0 + 1]), gz = wp * (z - Bp[3 * j0 + 2]);
+        for (int j = 0; j < Q; j++)
+            if (ba[j] == i) { gx += wq * (x - Bp[3 * j]); gy += wq * (y - Bp[3 * j + 1]); gz += wq * (z - Bp[3 * j + 2]); }
+        ga[3 * i] = gx; ga[3 * i + 1] = gy; ga[3 * i + 2] = gz;
+    }
+    for (int j = threadIdx.x; j < Q; j += 256) {
+        const float x = Bp[3 * j], y = Bp[3 * j + 1], z = Bp[3 * j + 2];
+        const int i0 = ba[j];
+        float gx = wq * (x - A[3 * i0]), gy = wq * (y - A[3 * i0 + 1]), gz = wq * (z - A[3 * i0 + 2]);
+        for (int i = 0; i < P; i++)
+            if (ab[i] == j) { gx += wp * (x - A[3 * i]); gy += wp * (y - A[3 * i + 1]); gz += wp * (z - A[3 * i + 2]); }
+        gb[3 * j] = gx; gb[3 * j + 1] = gy; gb[3 * j + 2] = gz;
+    }
+}
+
 }  // namespace lasr

@@ -42,13 +42,26 @@ struct MeshRegArgs {
     const int* arap_ptr; const int* arap_col;
     const int* quads; const int* inc_ptr; const int* inc;
     int N, NA, V, E;
+    // optional fourth criterion of the step's launch (lasr_step_regularisers_*): the symmetric Chamfer distance of NC pairs of small
+    // point sets (the bones' control points against their mirror images, nnutils/mesh_net.py:500-503)
+    const float* ca; const float* cb;    // [NC,P,3], [NC,Q,3]
+    int* nn_ab; int* nn_ba;              // [NC,P], [NC,Q] nearest-neighbour indices: written by the forward, read by the backward
+    int NC, CP, CQ;
 };
 
 __global__ __launch_bounds__(256) void mesh_reg_forward_kernel(MeshRegArgs A, float* __restrict__ lap_loss, float* __restrict__ lx,
-                                                               float* __restrict__ flat_loss, float* __restrict__ arap_loss)
+                                                               float* __restrict__ flat_loss, float* __restrict__ arap_loss,
+                                                               float* __restrict__ cham_loss)
 {
     __shared__ float red[4];
     const int n = blockIdx.x, V = A.V;
+    if (blockIdx.y == 3) {
+        if (n >= A.NC) return;
+        const float s = chamfer_forward_item(A.ca + (size_t)n * A.CP * 3, A.cb + (size_t)n * A.CQ * 3, A.nn_ab + (size_t)n * A.CP,
+                                             A.nn_ba + (size_t)n * A.CQ, A.CP, A.CQ, red);
+        if (threadIdx.x == 0) cham_loss[n] = s;
+        return;
+    }
     if (blockIdx.y == 0) {
         if (n >= A.N) return;
         const float s = laplacian_forward_block(A.x + (size_t)n * V * 3, A.lap_ptr, A.lap_col, lx + (size_t)n * V * 3, V, red);
@@ -74,9 +87,18 @@ constexpr int MR_VPB = 16;         // vertices per block of the backward (x 16 l
 
 __global__ __launch_bounds__(256) void mesh_reg_backward_kernel(MeshRegArgs A, const float* __restrict__ lx, const float* __restrict__ g_lap,
                                                                 const float* __restrict__ g_flat, const float* __restrict__ g_arap,
-                                                                float* __restrict__ gx, float* __restrict__ gdx, float* __restrict__ gax)
+                                                                float* __restrict__ gx, float* __restrict__ gdx, float* __restrict__ gax,
+                                                                const float* __restrict__ g_cham, float* __restrict__ gca,
+                                                                float* __restrict__ gcb)
 {
     __shared__ float term[MR_VPB][16][6];
+    if ((int)blockIdx.y >= A.N + A.NA) {                       // ---- Chamfer pairs: grid rows N + NA .. N + NA + NC - 1, one block each
+        if (blockIdx.x != 0) return;
+        const int n = blockIdx.y - A.N - A.NA;
+        chamfer_backward_item(A.ca + (size_t)n * A.CP * 3, A.cb + (size_t)n * A.CQ * 3, A.nn_ab + (size_t)n * A.CP,
+                              A.nn_ba + (size_t)n * A.CQ, g_cham[n], gca + (size_t)n * A.CP * 3, gcb + (size_t)n * A.CQ * 3, A.CP, A.CQ);
+        return;
+    }
     const int V = A.V, tid = threadIdx.x, vl = tid >> 4, lane = tid & 15;
     const int v = blockIdx.x * MR_VPB + vl;
     const bool live = v < V;
@@ -181,19 +203,39 @@ __global__ __launch_bounds__(256) void mesh_reg_backward_kernel(MeshRegArgs A, c
 
 using namespace lasr;
 
+static int step_reg_forward(MeshRegArgs A, float* lap_loss, float* lap_coords, float* flat_loss, float* arap_loss, float* cham_loss,
+                            hipStream_t st)
+{
+    const int gx = (A.N > A.NA ? A.N : A.NA) > A.NC ? (A.N > A.NA ? A.N : A.NA) : A.NC;
+    LASR_LAUNCH(K_MESH_REG, mesh_reg_forward_kernel, dim3(gx, A.NC > 0 ? 4 : 3), dim3(256), 0, A, lap_loss, lap_coords, flat_loss,
+                arap_loss, cham_loss);
+    return launch_ok();
+}
+
 extern "C" int lasr_mesh_regularisers_forward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
                                               const int* lap_col, const int* arap_row_ptr, const int* arap_col, const int* quads,
                                               float* lap_loss, float* lap_coords, float* flat_loss, float* arap_loss, int N, int NA,
                                               int V, int E, void* hip_stream)
 {
-    if (N < 0 || NA < 0 || V < 0 || E < 0) return LASR_E_BADARG;
-    if ((N == 0 && NA == 0) || V == 0) return LASR_OK;
+    return lasr_step_regularisers_forward(x, arap_dx, arap_x, lap_row_ptr, lap_col, arap_row_ptr, arap_col, quads, lap_loss, lap_coords,
+                                          flat_loss, arap_loss, N, NA, V, E, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, hip_stream);
+}
+
+extern "C" int lasr_step_regularisers_forward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
+                                              const int* lap_col, const int* arap_row_ptr, const int* arap_col, const int* quads,
+                                              float* lap_loss, float* lap_coords, float* flat_loss, float* arap_loss, int N, int NA,
+                                              int V, int E, const float* cham_a, const float* cham_b, float* cham_loss, int* nn_ab,
+                                              int* nn_ba, int NC, int P, int Q, void* hip_stream)
+{
+    if (N < 0 || NA < 0 || V < 0 || E < 0 || NC < 0 || (NC > 0 && (P < 1 || Q < 1))) return LASR_E_BADARG;
+    if (V == 0) { N = 0; NA = 0; }
+    if (N == 0 && NA == 0 && NC == 0) return LASR_OK;
     if (N > 0 && (!x || !lap_row_ptr || !lap_col || !lap_loss || !lap_coords || !flat_loss || (E > 0 && !quads))) return LASR_E_BADARG;
     if (NA > 0 && (!arap_dx || !arap_x || !arap_row_ptr || !arap_col || !arap_loss)) return LASR_E_BADARG;
-    hipStream_t st = (hipStream_t)hip_stream;
-    MeshRegArgs A{x, arap_dx, arap_x, lap_row_ptr, lap_col, arap_row_ptr, arap_col, quads, nullptr, nullptr, N, NA, V, E};
-    LASR_LAUNCH(K_MESH_REG, mesh_reg_forward_kernel, dim3(N > NA ? N : NA, 3), dim3(256), 0, A, lap_loss, lap_coords, flat_loss, arap_loss);
-    return launch_ok();
+    if (NC > 0 && (!cham_a || !cham_b || !cham_loss || !nn_ab || !nn_ba)) return LASR_E_BADARG;
+    MeshRegArgs A{x, arap_dx, arap_x, lap_row_ptr, lap_col, arap_row_ptr, arap_col, quads, nullptr, nullptr, N, NA, V, E,
+                  cham_a, cham_b, nn_ab, nn_ba, NC, P, Q};
+    return step_reg_forward(A, lap_loss, lap_coords, flat_loss, arap_loss, cham_loss, (hipStream_t)hip_stream);
 }
 
 extern "C" int lasr_mesh_regularisers_backward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
@@ -202,14 +244,32 @@ extern "C" int lasr_mesh_regularisers_backward(const float* x, const float* arap
                                                const float* grad_flat, const float* grad_arap, float* grad_x, float* grad_arap_dx,
                                                float* grad_arap_x, int N, int NA, int V, int E, void* hip_stream)
 {
-    if (N < 0 || NA < 0 || V < 0 || E < 0) return LASR_E_BADARG;
-    if ((N == 0 && NA == 0) || V == 0) return LASR_OK;
+    return lasr_step_regularisers_backward(x, arap_dx, arap_x, lap_row_ptr, lap_col, arap_row_ptr, arap_col, quads, inc_ptr, inc, lap_coords,
+                                           grad_lap, grad_flat, grad_arap, grad_x, grad_arap_dx, grad_arap_x, N, NA, V, E, nullptr, nullptr,
+                                           nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, hip_stream);
+}
+
+extern "C" int lasr_step_regularisers_backward(const float* x, const float* arap_dx, const float* arap_x, const int* lap_row_ptr,
+                                               const int* lap_col, const int* arap_row_ptr, const int* arap_col, const int* quads,
+                                               const int* inc_ptr, const int* inc, const float* lap_coords, const float* grad_lap,
+                                               const float* grad_flat, const float* grad_arap, float* grad_x, float* grad_arap_dx,
+                                               float* grad_arap_x, int N, int NA, int V, int E, const float* cham_a, const float* cham_b,
+                                               const int* nn_ab, const int* nn_ba, const float* grad_cham, float* grad_cham_a,
+                                               float* grad_cham_b, int NC, int P, int Q, void* hip_stream)
+{
+    if (N < 0 || NA < 0 || V < 0 || E < 0 || NC < 0 || (NC > 0 && (P < 1 || Q < 1))) return LASR_E_BADARG;
+    if (V == 0) { N = 0; NA = 0; }
+    if (N == 0 && NA == 0 && NC == 0) return LASR_OK;
     if (N > 0 && (!x || !lap_row_ptr || !lap_col || !lap_coords || !grad_lap || !grad_flat || !grad_x || !inc_ptr ||
                   (E > 0 && (!quads || !inc)))) return LASR_E_BADARG;
     if (NA > 0 && (!arap_dx || !arap_x || !arap_row_ptr || !arap_col || !grad_arap)) return LASR_E_BADARG;
+    if (NC > 0 && (!cham_a || !cham_b || !nn_ab || !nn_ba || !grad_cham || !grad_cham_a || !grad_cham_b)) return LASR_E_BADARG;
+    if (N + NA + NC > 65535) return LASR_E_BADARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    MeshRegArgs A{x, arap_dx, arap_x, lap_row_ptr, lap_col, arap_row_ptr, arap_col, quads, inc_ptr, inc, N, NA, V, E};
-    LASR_LAUNCH(K_MESH_REG, mesh_reg_backward_kernel, dim3((V + MR_VPB - 1) / MR_VPB, N + NA), dim3(256), 0, A, lap_coords, grad_lap,
-                grad_flat, grad_arap, grad_x, grad_arap_dx, grad_arap_x);
+    MeshRegArgs A{x, arap_dx, arap_x, lap_row_ptr, lap_col, arap_row_ptr, arap_col, quads, inc_ptr, inc, N, NA, V, E,
+                  cham_a, cham_b, const_cast<int*>(nn_ab), const_cast<int*>(nn_ba), NC, P, Q};
+    const int gx = V > 0 && N + NA > 0 ? (V + MR_VPB - 1) / MR_VPB : 1;
+    LASR_LAUNCH(K_MESH_REG, mesh_reg_backward_kernel, dim3(gx, N + NA + NC), dim3(256), 0, A, lap_coords, grad_lap,
+                grad_flat, grad_arap, grad_x, grad_arap_dx, grad_arap_x, grad_cham, grad_cham_a, grad_cham_b);
     return launch_ok();
 }

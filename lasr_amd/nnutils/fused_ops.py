@@ -410,7 +410,7 @@ def flatten_loss(x, quads, inc_ptr, inc):
 
 class _MeshReg(Function):
     @staticmethod
-    def forward(ctx, x, dx, ax, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc):
+    def forward(ctx, x, dx, ax, ca, cb, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc):
         _lib.need_cuda(x, dx, ax, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc)
         x, dx, ax = x.contiguous().float(), dx.contiguous().float(), ax.contiguous().float()
         N, V = x.shape[:2]
@@ -418,45 +418,71 @@ class _MeshReg(Function):
         if dx.shape != ax.shape or (NA and dx.shape[1] != V):
             raise ValueError('the ARAP pair must be two [NA,V,3] tensors on the same vertex set')
         dev = x.device
-        out = torch.empty(2 * N + NA, dtype=torch.float32, device=dev)
+        NC = P = Q = 0
+        nn = None
+        if ca is not None:
+            _lib.need_cuda(ca, cb)
+            ca, cb = ca.contiguous().float(), cb.contiguous().float()
+            NC, P, Q = ca.shape[0], ca.shape[1], cb.shape[1]
+            nn = torch.empty(NC * (P + Q), dtype=torch.int32, device=dev)
+        out = torch.empty(2 * N + NA + NC, dtype=torch.float32, device=dev)
         lx = torch.empty_like(x)
+        ptr = lambda t_: t_.data_ptr() if t_ is not None else None            # noqa: E731
         guard, st = _lib.stream_of(x)
         with guard:
-            rc = _lib.lib().lasr_mesh_regularisers_forward(x.data_ptr(), dx.data_ptr(), ax.data_ptr(), lap_ptr.data_ptr(), lap_col.data_ptr(),
-                                                           arap_ptr.data_ptr(), arap_col.data_ptr(), quads.data_ptr(), out.data_ptr(),
-                                                           lx.data_ptr(), out[N:].data_ptr(), out[2 * N:].data_ptr(), N, NA, V, E, st)
-        _lib.check(rc, 'lasr_mesh_regularisers_forward')
-        ctx.save_for_backward(x, dx, ax, lx, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc)
+            rc = _lib.lib().lasr_step_regularisers_forward(
+                x.data_ptr(), dx.data_ptr(), ax.data_ptr(), lap_ptr.data_ptr(), lap_col.data_ptr(), arap_ptr.data_ptr(), arap_col.data_ptr(),
+                quads.data_ptr(), out.data_ptr(), lx.data_ptr(), out[N:].data_ptr(), out[2 * N:].data_ptr(), N, NA, V, E,
+                ptr(ca), ptr(cb), out[2 * N + NA:].data_ptr() if NC else None, ptr(nn), (nn.data_ptr() + 4 * NC * P) if NC else None,
+                NC, P, Q, st)
+        _lib.check(rc, 'lasr_step_regularisers_forward')
+        ctx.save_for_backward(x, dx, ax, lx, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc, ca, cb, nn)
+        if NC:
+            return out[:N], out[N:2 * N], out[2 * N:2 * N + NA], out[2 * N + NA:]
         return out[:N], out[N:2 * N], out[2 * N:]
 
     @staticmethod
-    def backward(ctx, g_lap, g_flat, g_arap):
-        x, dx, ax, lx, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc = ctx.saved_tensors
+    def backward(ctx, g_lap, g_flat, g_arap, g_cham=None):
+        x, dx, ax, lx, lap_ptr, lap_col, arap_ptr, arap_col, quads, inc_ptr, inc, ca, cb, nn = ctx.saved_tensors
         N, V = x.shape[:2]
         NA, E = dx.shape[0], quads.shape[0]
-        g_lap, g_flat, g_arap = g_lap.contiguous().float(), g_flat.contiguous().float(), g_arap.contiguous().float()
+        dev = x.device
+        zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)     # noqa: E731
+        g_lap = g_lap.contiguous().float() if g_lap is not None else zeros(N)
+        g_flat = g_flat.contiguous().float() if g_flat is not None else zeros(N)
+        g_arap = g_arap.contiguous().float() if g_arap is not None else zeros(NA)
         gx, gdx, gax = torch.empty_like(x), torch.empty_like(dx), torch.empty_like(ax)
+        NC = P = Q = 0
+        gca = gcb = None
+        if ca is not None:
+            NC, P, Q = ca.shape[0], ca.shape[1], cb.shape[1]
+            g_cham = g_cham.contiguous().float() if g_cham is not None else zeros(NC)
+            gca, gcb = torch.empty_like(ca), torch.empty_like(cb)
+        ptr = lambda t_: t_.data_ptr() if t_ is not None else None            # noqa: E731
         guard, st = _lib.stream_of(x)
         with guard:
-            rc = _lib.lib().lasr_mesh_regularisers_backward(x.data_ptr(), dx.data_ptr(), ax.data_ptr(), lap_ptr.data_ptr(), lap_col.data_ptr(),
-                                                            arap_ptr.data_ptr(), arap_col.data_ptr(), quads.data_ptr(), inc_ptr.data_ptr(),
-                                                            inc.data_ptr(), lx.data_ptr(), g_lap.data_ptr(), g_flat.data_ptr(),
-                                                            g_arap.data_ptr(), gx.data_ptr(), gdx.data_ptr(), gax.data_ptr(), N, NA, V, E, st)
-        _lib.check(rc, 'lasr_mesh_regularisers_backward')
-        return (gx, gdx, gax) + (None,) * 7
+            rc = _lib.lib().lasr_step_regularisers_backward(
+                x.data_ptr(), dx.data_ptr(), ax.data_ptr(), lap_ptr.data_ptr(), lap_col.data_ptr(), arap_ptr.data_ptr(), arap_col.data_ptr(),
+                quads.data_ptr(), inc_ptr.data_ptr(), inc.data_ptr(), lx.data_ptr(), g_lap.data_ptr(), g_flat.data_ptr(), g_arap.data_ptr(),
+                gx.data_ptr(), gdx.data_ptr(), gax.data_ptr(), N, NA, V, E, ptr(ca), ptr(cb), ptr(nn),
+                (nn.data_ptr() + 4 * NC * P) if NC else None, ptr(g_cham) if NC else None, ptr(gca), ptr(gcb), NC, P, Q, st)
+        _lib.check(rc, 'lasr_step_regularisers_backward')
+        return (gx, gdx, gax, gca, gcb) + (None,) * 7
 
 
-def mesh_regularisers(x, arap_dx, arap_x, laplacian, flatten, arap):
+def mesh_regularisers(x, arap_dx, arap_x, laplacian, flatten, arap, chamfer_pair=None):
     """(laplacian(x), flatten(x), arap(arap_dx, arap_x)) for the criteria LaplacianLoss / FlattenLoss / ARAPLoss of
     nnutils/loss_utils.py (average = False), in one launch each way instead of three forward and five backward launches; values and
-    gradients bit-identical to the three calls (/root/reference/nnutils/mesh_net.py:449-459, :494-497)."""
+    gradients bit-identical to the three calls (/root/reference/nnutils/mesh_net.py:449-459, :494-497).
+    chamfer_pair = (a [NC,P,3], b [NC,Q,3]): a fourth result, chamfer(a, b) [NC] (:500-503), rides on the same two launches."""
     V = x.shape[1]
     dev = x.device
     ptr = flatten.inc_ptr
     if ptr.numel() < V + 1:                                           # trailing vertices no face refers to
         ptr = torch.cat([ptr, ptr[-1:].repeat(V + 1 - ptr.numel())])
-    return _MeshReg.apply(x, arap_dx, arap_x, laplacian.row_ptr.to(dev), laplacian.col.to(dev), arap.row_ptr.to(dev), arap.col.to(dev),
-                          flatten.quads.to(dev), ptr.to(dev), flatten.inc.to(dev))
+    ca, cb = chamfer_pair if chamfer_pair is not None else (None, None)
+    return _MeshReg.apply(x, arap_dx, arap_x, ca, cb, laplacian.row_ptr.to(dev), laplacian.col.to(dev), arap.row_ptr.to(dev),
+                          arap.col.to(dev), flatten.quads.to(dev), ptr.to(dev), flatten.inc.to(dev))
 
 
 def nearest_point(a, b):

@@ -754,7 +754,7 @@ class LASR(MeshNet):
         stock = (pred_v.is_cuda and type(self.triangle_loss_fn_sr) is loss_utils.LaplacianLoss and not self.triangle_loss_fn_sr.average
                  and type(self.flatten_loss) is loss_utils.FlattenLoss and not self.flatten_loss.average
                  and (K == 1 or type(self.arap_loss_fn) is loss_utils.ARAPLoss))
-        arap_l = None
+        arap_l = cham_l = None
         if stock:
             # Laplacian + flatten on the mean shape and ARAP between the two frames' shapes: one launch each way
             # (fused_ops.mesh_regularisers), values and gradients bit-identical to the three criteria called one by one
@@ -762,8 +762,15 @@ class LASR(MeshNet):
                 dv0, dv1 = self.deform_v.reshape(2, B * H, -1, 3).unbind(0)
             else:
                 dv0 = dv1 = pred_v.new_empty(0, pred_v.shape[1], 3)
-            lap_l, flat_l, arap_l = fused_ops.mesh_regularisers(pred_v, dv0, dv1, self.triangle_loss_fn_sr, self.flatten_loss,
-                                                               self.arap_loss_fn if K > 1 else self.triangle_loss_fn_sr)
+            # (the bones' symmetric Chamfer term, :500-503, rides on the same launches)
+            cham_pair = None
+            if K > 1 and opts.symmetric_loss:
+                ca = self.ctl_ts.view(H, -1, 3)
+                cham_pair = (ca, ca * sr.functional.const_tensor([-1, 1, 1], ca.device))
+            res = fused_ops.mesh_regularisers(pred_v, dv0, dv1, self.triangle_loss_fn_sr, self.flatten_loss,
+                                              self.arap_loss_fn if K > 1 else self.triangle_loss_fn_sr, cham_pair)
+            lap_l, flat_l, arap_l = res[:3]
+            cham_l = res[3] if cham_pair is not None else None
         else:
             lap_l, flat_l = self.triangle_loss_fn_sr(pred_v), self.flatten_loss(pred_v)
         tri = lap_l * (factor * (0.005 * (4 ** opts.subdivide) / 64.))
@@ -790,8 +797,10 @@ class LASR(MeshNet):
                 arap_l = self.arap_loss_fn(dv0, dv1)
             terms.append((arap_l, (4 ** opts.subdivide) / 64., G_ARAP))
             if opts.symmetric_loss:                                              # bone symmetry (:500-503)
-                ca = self.ctl_ts.view(H, -1, 3)
-                terms.append((fused_ops.chamfer(ca, ca * sr.functional.const_tensor([-1, 1, 1], ca.device)), 0.1, G_BONESYM))
+                if cham_l is None:
+                    ca = self.ctl_ts.view(H, -1, 3)
+                    cham_l = fused_ops.chamfer(ca, ca * sr.functional.const_tensor([-1, 1, 1], ca.device))
+                terms.append((cham_l, 0.1, G_BONESYM))
         # 7) camera (:506-522)
         if opts.use_gtpose:
             terms.append((geodesic_distance(quat.view(-1, 3, 3), quat_pred.view(-1, 3, 3)), 0.2, G_CAM))

@@ -344,3 +344,39 @@ def test_bone_fixup_with_the_pair_angle_equals_fixup_plus_rotation_distance(cuda
     d0, d1 = d.view(2, -1, 3, 3).unbind(0)
     (fused_ops.geodesic_distance(d0, d1) * upA).sum().backward()
     assert torch.equal(c[0].grad, d.grad)
+
+
+@pytest.mark.parametrize('level,N,NA,NC,P', [(3, 16, 8, 8, 20), (2, 4, 2, 1, 35), (1, 2, 0, 3, 1)])
+def test_step_regularisers_with_the_chamfer_pair_equal_the_four_criteria(cuda, level, N, NA, NC, P):
+    v, f = synth.geodesic_sphere(2 ** level)
+    V = v.shape[0]
+    g = torch.Generator().manual_seed(level + NC)
+    faces = torch.from_numpy(np.asarray(f, np.int64))
+    lap = loss_utils.LaplacianLoss(torch.from_numpy(v), faces).to(cuda)
+    arap = loss_utils.ARAPLoss(torch.from_numpy(v), faces).to(cuda)
+    flat = loss_utils.FlattenLoss(faces).to(cuda)
+    x = (torch.from_numpy(v)[None] + 0.05 * torch.randn(N, V, 3, generator=g)).to(cuda)
+    d0 = (torch.from_numpy(v)[None] + 0.05 * torch.randn(NA, V, 3, generator=g)).to(cuda) if NA else x.new_empty(0, V, 3)
+    d1 = (torch.from_numpy(v)[None] + 0.05 * torch.randn(NA, V, 3, generator=g)).to(cuda) if NA else x.new_empty(0, V, 3)
+    ctl = (0.3 * torch.randn(NC, P, 3, generator=g)).to(cuda)
+    flip = torch.tensor([-1., 1., 1.], device=cuda)
+    ups = [torch.randn(n, generator=g).to(cuda) for n in (N, N, NA, NC)]
+
+    a = [t.clone().requires_grad_(True) for t in (x, d0, d1, ctl)]
+    l0, f0 = lap(a[0]), flat(a[0])
+    a0 = arap(a[1], a[2]) if NA else x.new_zeros(0)
+    c0 = fused_ops.chamfer(a[3], a[3] * flip)
+    ((l0 * ups[0]).sum() + (f0 * ups[1]).sum() + (a0 * ups[2]).sum() + (c0 * ups[3]).sum()).backward()
+    b = [t.clone().requires_grad_(True) for t in (x, d0, d1, ctl)]
+    l1, f1, a1, c1 = fused_ops.mesh_regularisers(b[0], b[1], b[2], lap, flat, arap, (b[3], b[3] * flip))
+    ((l1 * ups[0]).sum() + (f1 * ups[1]).sum() + (a1 * ups[2]).sum() + (c1 * ups[3]).sum()).backward()
+    assert torch.equal(l1.detach(), l0.detach()) and torch.equal(f1.detach(), f0.detach()) and torch.equal(c1.detach(), c0.detach())
+    assert torch.equal(b[3].grad, a[3].grad)
+    if NA:
+        assert torch.equal(a1.detach(), a0.detach()) and torch.equal(b[1].grad, a[1].grad) and torch.equal(b[2].grad, a[2].grad)
+    assert rel(b[0].grad, a[0].grad) <= 1e-6
+    # the Chamfer result unused: its gradient arrives as None, the control points get zeros
+    e = [t.clone().requires_grad_(True) for t in (x, d0, d1, ctl)]
+    res = fused_ops.mesh_regularisers(e[0], e[1], e[2], lap, flat, arap, (e[3], e[3] * flip))
+    (res[0] * ups[0]).sum().backward()
+    assert e[3].grad is None or float(e[3].grad.abs().max()) == 0.0
