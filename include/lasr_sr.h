@@ -49,7 +49,7 @@ extern "C" {
  *      scratch; lasr_render_tables_* run 3 + 2 launches (same signatures and scratch size);
  *      lasr_sr_options gains mixed_min_weight (fifth field); lasr_sr_backward* accept a records-only workspace;
  *      new: lasr_cosdist_multi_*, lasr_raster_faces_*, lasr_mesh_regularisers_*, lasr_project_points_*,
- *      lasr_face_gather_backward_csr, lasr_point_mesh_scratch_floats (+ a scratch argument of lasr_point_mesh_forward). */
+ *      lasr_face_gather_backward_csr, lasr_bone_fixup_pair_*, lasr_step_regularisers_*, lasr_point_mesh_scratch_floats (+ a scratch argument of lasr_point_mesh_forward). */
 #define LASR_ABI_VERSION 3
 int         lasr_abi_version(void);
 const char* lasr_strerror(int code);
