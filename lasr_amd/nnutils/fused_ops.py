@@ -520,6 +520,8 @@ class _PointMesh(Function):
                                            ap.data_ptr(), df.data_ptr(), af.data_ptr(), scratch.data_ptr(), N, V, F_, P, st)
         _lib.check(rc, 'lasr_point_mesh_forward')
         ctx.save_for_backward(verts, faces, points, ap, af)
+        from ..soft_renderer.functional.geometry import _incidence_of
+        ctx.inc = _incidence_of(faces, V)                # the model's face tensor is seen every step: vertex -> corner lists, built once
         return (dp.mean(1) + df.mean(1)).mean()
 
     @staticmethod
@@ -531,7 +533,7 @@ class _PointMesh(Function):
         gtri = torch.empty(N, F_, 3, 3, dtype=torch.float32, device=verts.device)
         gpts = torch.empty_like(points)
         gverts = torch.empty_like(verts)
-        faces_n = faces[None].expand(N, F_, 3).contiguous()
+        faces_n = faces[None].expand(N, F_, 3).contiguous() if ctx.inc is None else None
         guard, st = _lib.stream_of(verts)
         with guard:
             # unit weights here; the incoming scalar gradient multiplies the results (it may live on the device)
@@ -539,7 +541,11 @@ class _PointMesh(Function):
                                             af.data_ptr(), 1.0 / (N * P), 1.0 / (N * F_), gtri.data_ptr(), gpts.data_ptr(),
                                             N, V, F_, P, st)
             _lib.check(rc, 'lasr_point_mesh_backward')
-            rc = h.lasr_face_gather_backward(gtri.data_ptr(), faces_n.data_ptr(), gverts.data_ptr(), N, V, F_, 3, st)
+            if ctx.inc is not None:                      # same sums, same order, no scan of the face tensor (and no expanded copy of it)
+                rc = h.lasr_face_gather_backward_csr(gtri.data_ptr(), ctx.inc[0].data_ptr(), ctx.inc[1].data_ptr(), 1, gverts.data_ptr(),
+                                                     N, V, F_, 3, st)
+            else:
+                rc = h.lasr_face_gather_backward(gtri.data_ptr(), faces_n.data_ptr(), gverts.data_ptr(), N, V, F_, 3, st)
         _lib.check(rc, 'lasr_face_gather_backward')
         return gverts * g, None, gpts * g
 

@@ -37,7 +37,7 @@ def _incidence_of(faces, num_vertices):
         if faces.is_cuda and torch.cuda.is_current_stream_capturing():
             return None                                  # (built eagerly, outside a capture: argsort allocates)
         from ...nnutils import fused_ops
-        ent[3] = fused_ops.face_incidence(faces, num_vertices)
+        ent[3] = fused_ops.face_incidence(faces if faces.dim() == 3 else faces[None], num_vertices)      # [F,3]: one shared mesh
     return ent[3]
 
 

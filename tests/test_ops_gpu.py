@@ -369,6 +369,17 @@ def test_point_mesh_distance_matches_restatement(cuda, seed):
     assert abs(float(rb) - float(ra)) <= 1e-5 * abs(float(ra))
     for name, x, y in zip(('verts', 'points'), b, a):
         assert float((x.grad.cpu() - y.grad).abs().max()) <= 2e-4 * float(y.grad.abs().max()), name
+    # a face tensor that is seen again (the model's is, every step): from the second call on the backward's face -> vertex
+    # reduction runs over the cached incidence lists -- same sums, same order, same bits
+    from lasr_amd.soft_renderer.functional import geometry
+    fc = faces.to(cuda)
+    grads = []
+    for _ in range(3):
+        c = [verts.clone().to(cuda).requires_grad_(True), pts.clone().to(cuda).requires_grad_(True)]
+        (fused_ops.point_mesh_face_distance(c[0], fc, c[1]) * 1.7).backward()
+        grads.append((c[0].grad, c[1].grad))
+    assert geometry._INC_CACHE[id(fc)][3] is not None
+    assert all(torch.equal(gv, b[0].grad) and torch.equal(gp, b[1].grad) for gv, gp in grads)
 
 
 def test_nearest_point_and_chamfer(cuda):
