@@ -508,9 +508,27 @@ __device__ __forceinline__ void load_tri(const float* verts, const long long* f,
 
 // Forward, two launches.  Rounds 1-4 ran one thread per point over ALL faces and one thread per face over ALL points: 6 and 10
 // workgroups for the 1282-point / 2560-face mesh of the camel schedule's last stage, 3.4 ms per step.  Now the other set is cut
-// into chunks of PMF tile size and a block owns (256 points, one face chunk) or (256 faces, one point chunk): hundreds of blocks,
-// the same candidate order inside a chunk; per-chunk minima go to scratch and pmf_fold_kernel takes the minimum over the chunks
-// in chunk order with a strict `<` -- the lowest index wins ties exactly as the single scan did.
+// into chunks of PMF tile size and a block owns (256 points, one face chunk): hundreds of blocks, the same candidate order inside a
+// chunk; per-chunk minima (of every point over the chunk's faces, of every face over the block's points) go to scratch and
+// pmf_fold_kernel takes the minimum over the chunks in chunk order with a strict `<` -- the lowest index wins ties exactly as the
+// single scan did.
+// minimum over the wave in lane 63: six DPP steps in registers (a shuffle tree through the LDS crossbar puts ~600 cycles of
+// dependent latency into every face of the pair loop below)
+__device__ __forceinline__ float wave_min_to_lane63(float v)
+{
+    const int inf = 0x7f800000;
+#define LASR_DPP_MIN(ctrl, rmask, bmask) \
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), ctrl, rmask, bmask, false)))
+    LASR_DPP_MIN(0x111, 0xf, 0xf);   // row_shr:1
+    LASR_DPP_MIN(0x112, 0xf, 0xf);   // row_shr:2
+    LASR_DPP_MIN(0x114, 0xf, 0xe);   // row_shr:4
+    LASR_DPP_MIN(0x118, 0xf, 0xc);   // row_shr:8
+    LASR_DPP_MIN(0x142, 0xa, 0xf);   // row_bcast:15
+    LASR_DPP_MIN(0x143, 0xc, 0xf);   // row_bcast:31
+#undef LASR_DPP_MIN
+    return v;
+}
+
 __host__ __device__ inline int pmf_tile(int n) { int t = 32; while ((n + t - 1) / t > 64) t *= 2; return t; }
 
 struct PmfArgs {
@@ -520,56 +538,53 @@ struct PmfArgs {
     int V, F, P, FT, PT, FC, PC;
 };
 
+// (Round 5, late: every (point, face) pair is evaluated ONCE.  A block owns 256 points and one chunk of faces; a thread keeps the
+// nearest face of its point as before, and for every face of the chunk the block also reduces the 256 distances it has just computed
+// to the nearest point among its 256 -- a wave minimum, the lowest lane among equals (= the lowest point index), then the four waves
+// in order -- which is that face's partial for this block of points.  The separate faces-against-points blocks, which evaluated
+// every pair a second time, are gone: point_triangle() is ~150 instructions, the wave minimum ~20.)
 __global__ __launch_bounds__(256) void pmf_partial_kernel(PmfArgs A)
 {
     __shared__ float tile[128 * 9];
-    const int n = blockIdx.z, tid = threadIdx.x;
+    __shared__ float wmin_d[4][128];
+    __shared__ int wmin_p[4][128];
+    const int n = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* vn = A.verts + (size_t)n * A.V * 3;
-    if ((int)blockIdx.y < A.FC) {                                   // ---- points against one chunk of faces
-        const int p = blockIdx.x * 256 + tid;
-        if (blockIdx.x * 256 >= A.P) return;
-        const int fbeg = blockIdx.y * A.FT, fend = min(A.F, fbeg + A.FT);
-        float q[3] = {0.f, 0.f, 0.f};
-        if (p < A.P) { const float* s = A.pts + ((size_t)n * A.P + p) * 3; q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; }
-        float best = INFINITY; int barg = fbeg;
-        for (int f0 = fbeg; f0 < fend; f0 += 128) {
-            const int m = min(128, fend - f0);
-            __syncthreads();
-            for (int i = tid; i < m * 9; i += 256) {
-                const int f = i / 9, r = i - 9 * f;
-                tile[i] = vn[3 * A.faces[(size_t)(f0 + f) * 3 + r / 3] + r % 3];
-            }
-            __syncthreads();
-            for (int j = 0; j < m; j++) {
-                const Closest c = point_triangle(q, tile + 9 * j, tile + 9 * j + 3, tile + 9 * j + 6);
-                if (c.d2 < best) { best = c.d2; barg = f0 + j; }
-            }
-        }
-        if (p < A.P) {
-            const size_t o = ((size_t)n * A.FC + blockIdx.y) * A.P + p;
-            A.part_pd[o] = best; A.part_pa[o] = barg;
-        }
-        return;
-    }
-    const int f = blockIdx.x * 256 + tid;                           // ---- faces against one chunk of points
-    if (blockIdx.x * 256 >= A.F) return;
-    const int pc = blockIdx.y - A.FC, pbeg = pc * A.PT, pend = min(A.P, pbeg + A.PT);
-    float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f};
-    if (f < A.F) load_tri(vn, A.faces + (size_t)f * 3, a, b, c);
-    float best = INFINITY; int barg = pbeg;
-    for (int p0 = pbeg; p0 < pend; p0 += 256) {
-        const int m = min(256, pend - p0);
+    const int p = blockIdx.x * 256 + tid;
+    const int fbeg = blockIdx.y * A.FT, fend = min(A.F, fbeg + A.FT);
+    float q[3] = {0.f, 0.f, 0.f};
+    if (p < A.P) { const float* s = A.pts + ((size_t)n * A.P + p) * 3; q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; }
+    float best = INFINITY; int barg = fbeg;
+    for (int f0 = fbeg; f0 < fend; f0 += 128) {
+        const int m = min(128, fend - f0);
         __syncthreads();
-        for (int i = tid; i < m * 3; i += 256) tile[i] = A.pts[((size_t)n * A.P + p0) * 3 + i];
+        for (int i = tid; i < m * 9; i += 256) {
+            const int f = i / 9, r = i - 9 * f;
+            tile[i] = vn[3 * A.faces[(size_t)(f0 + f) * 3 + r / 3] + r % 3];
+        }
         __syncthreads();
         for (int j = 0; j < m; j++) {
-            const Closest cl = point_triangle(tile + 3 * j, a, b, c);
-            if (cl.d2 < best) { best = cl.d2; barg = p0 + j; }
+            const Closest c = point_triangle(q, tile + 9 * j, tile + 9 * j + 3, tile + 9 * j + 6);
+            if (c.d2 < best) { best = c.d2; barg = f0 + j; }
+            // the face's nearest point among this wave's 64: minimum, then the lowest lane that has it
+            const float mine = p < A.P ? c.d2 : INFINITY;
+            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_min_to_lane63(mine)), 63));
+            const unsigned long long eq = __ballot(mine == w);
+            if (lane == 0) { wmin_d[wave][j] = w; wmin_p[wave][j] = blockIdx.x * 256 + wave * 64 + (eq ? __ffsll((long long)eq) - 1 : 0); }
+        }
+        __syncthreads();
+        if (tid < m) {                                              // the four waves in order, strict `<`: the lowest point index wins ties
+            float d = wmin_d[0][tid]; int a = wmin_p[0][tid];
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if (wmin_d[k][tid] < d) { d = wmin_d[k][tid]; a = wmin_p[k][tid]; }
+            const size_t o = ((size_t)n * A.PC + blockIdx.x) * A.F + f0 + tid;
+            A.part_fd[o] = d; A.part_fa[o] = a;
         }
     }
-    if (f < A.F) {
-        const size_t o = ((size_t)n * A.PC + pc) * A.F + f;
-        A.part_fd[o] = best; A.part_fa[o] = barg;
+    if (p < A.P) {
+        const size_t o = ((size_t)n * A.FC + blockIdx.y) * A.P + p;
+        A.part_pd[o] = best; A.part_pa[o] = barg;
     }
 }
 
@@ -1154,7 +1169,7 @@ extern "C" int lasr_nearest_point(const float* a, const float* b, float* d2, int
 
 static void pmf_layout(int F, int P, int& FT, int& PT, int& FC, int& PC)
 {
-    FT = pmf_tile(F); PT = pmf_tile(P);
+    FT = pmf_tile(F); PT = 256;                                      // face chunks of the tile size; point "chunks" = blocks of 256 points
     FC = (F + FT - 1) / FT; PC = (P + PT - 1) / PT;
 }
 
@@ -1181,8 +1196,8 @@ extern "C" int lasr_point_mesh_forward(const float* verts, const long long* face
     A.part_pd = scratch; A.part_fd = scratch + np;
     A.part_pa = reinterpret_cast<int*>(scratch + np + nf); A.part_fa = A.part_pa + np;
     const int gx = ((P > F ? P : F) + 255) / 256;
-    if (A.FC + A.PC > 65535 || N > 65535) return LASR_E_BADARG;
-    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_partial_kernel, dim3(gx, A.FC + A.PC, N), dim3(256), 0, A);
+    if (A.FC > 65535 || N > 65535) return LASR_E_BADARG;
+    LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_partial_kernel, dim3(A.PC, A.FC, N), dim3(256), 0, A);
     int rc = launch_ok();
     if (rc) return rc;
     LASR_LAUNCH(K_POINT_MESH_FORWARD, pmf_fold_kernel, dim3(gx, 2, N), dim3(256), 0, A, dmin_point, arg_point, dmin_face, arg_face);

@@ -99,7 +99,7 @@ def test_fused_operator_argument_validation():
     assert h.lasr_face_gather_forward(None, None, None, 1, 5, 5, 0, None) == -1                           # zero channels
     assert h.lasr_nearest_point(None, None, None, None, 1, 5, 0, None) == -1                              # empty target set
     assert h.lasr_point_mesh_forward(None, None, None, None, None, None, None, None, 1, 5, 0, 5, None) == -1
-    assert h.lasr_point_mesh_scratch_floats(1, 2560, 1282) >= 2 * (40 * 1282 + 41 * 2560)
+    assert h.lasr_point_mesh_scratch_floats(1, 2560, 1282) >= 2 * (40 * 1282 + 6 * 2560)        # 40 face chunks, 6 blocks of 256 points
     assert h.lasr_cosdist_forward(None, None, None, None, 2, 8, 16, 0, None) == -1                        # rep must be >= 1
     assert h.lasr_cosdist_scratch_floats(4, 1000) >= 16
     # unknown forward flag bits are refused before anything is launched
