@@ -445,10 +445,24 @@ __global__ __launch_bounds__(256) void nearest_point_kernel(const float* __restr
     const int per = (Q + 15) >> 4, q0 = sub * per, q1 = min(Q, q0 + per);
     const float* __restrict__ bn = b + (size_t)n * Q * 3;
     float best = INFINITY; int arg = 0x7fffffff;
-    for (int q = q0; q < q1; q++) {
-        const float dx = x - bn[3 * q], dy = y - bn[3 * q + 1], dz = z - bn[3 * q + 2];
-        const float d = dx * dx + dy * dy + dz * dz;
-        if (d < best) { best = d; arg = q; }
+    // four candidates per round with all twelve loads in flight (clamped indices: a repeated last candidate can never win the strict
+    // `<` against itself); one at a time, each round waited for its own loads: 24 us for 1282 x 1282 points
+    for (int q = q0; q < q1; q += 4) {
+        const int last = q1 - 1;
+        const int i0 = q, i1 = min(q + 1, last), i2 = min(q + 2, last), i3 = min(q + 3, last);
+        const float ax = bn[3 * i0], ay = bn[3 * i0 + 1], az = bn[3 * i0 + 2];
+        const float bx = bn[3 * i1], by = bn[3 * i1 + 1], bz = bn[3 * i1 + 2];
+        const float cx = bn[3 * i2], cy = bn[3 * i2 + 1], cz = bn[3 * i2 + 2];
+        const float ex = bn[3 * i3], ey = bn[3 * i3 + 1], ez = bn[3 * i3 + 2];
+        float dx = x - ax, dy = y - ay, dz = z - az;
+        float d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; arg = i0; }
+        dx = x - bx; dy = y - by; dz = z - bz; d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; arg = i1; }
+        dx = x - cx; dy = y - cy; dz = z - cz; d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; arg = i2; }
+        dx = x - ex; dy = y - ey; dz = z - ez; d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; arg = i3; }
     }
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {                       // merge the 16 sub-ranges of a point (16 consecutive lanes)
