@@ -655,13 +655,19 @@ __global__ __launch_bounds__(256) void pmf_backward_face_kernel(const float* __r
         }
     };
     if (P > 0) add(arg_f[(size_t)n * F + f], gf);
-    for (int p0 = 0; p0 < P; p0 += 64) {
-        const int p = p0 + lane;
-        unsigned long long hits = __ballot(p < P && arg_p[(size_t)n * P + p] == f);
-        while (hits) {
-            const int j = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            add(p0 + j, gp);
+    for (int p0 = 0; p0 < P; p0 += 256) {              // (four rounds of the table per step, loads in flight together)
+        int av[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) av[u] = arg_p[(size_t)n * P + min(p0 + 64 * u + lane, P - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = p0 + 64 * u + lane;
+            unsigned long long hits = __ballot(p < P && av[u] == f);
+            while (hits) {
+                const int j = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                add(p0 + 64 * u + j, gp);
+            }
         }
     }
     if (lane == 0) {
@@ -690,13 +696,20 @@ __global__ __launch_bounds__(256) void pmf_backward_point_kernel(const float* __
         for (int d = 0; d < 3; d++) acc[d] += 2.f * wgt * (q[d] - (cl.w[0] * a[d] + cl.w[1] * b[d] + cl.w[2] * c[d]));
     };
     if (F > 0) add(arg_p[(size_t)n * P + p], gp);
-    for (int f0 = 0; f0 < F; f0 += 64) {
-        const int f = f0 + lane;
-        unsigned long long hits = __ballot(f < F && arg_f[(size_t)n * F + f] == p);
-        while (hits) {
-            const int j = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            add(f0 + j, gf);
+    // (four rounds of the table per step, their loads in flight together: one round at a time is a chain of F / 64 L2 round trips)
+    for (int f0 = 0; f0 < F; f0 += 256) {
+        int av[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) av[u] = arg_f[(size_t)n * F + min(f0 + 64 * u + lane, F - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int f = f0 + 64 * u + lane;
+            unsigned long long hits = __ballot(f < F && av[u] == p);
+            while (hits) {
+                const int j = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                add(f0 + 64 * u + j, gf);
+            }
         }
     }
     if (lane == 0) {
