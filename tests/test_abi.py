@@ -167,3 +167,27 @@ def test_operator_launch_options_are_per_call_arguments_not_library_state():
     old = srf.set_forward_flags(srf.SR_SEGMENTED) if hasattr(srf, 'SR_SEGMENTED') else None
     if old is not None:
         srf.set_forward_flags(old)
+
+
+def test_round5_entry_points_validate_on_the_host():
+    # argument checks of the entry points added in round 5 run before any launch: callable without a device
+    from lasr_amd import _lib
+    h = _lib.lib()
+    n = None
+    assert h.lasr_face_gather_backward_csr(n, n, n, 1, n, 1, 5, 4, 0, n) == -1                   # zero channels
+    assert h.lasr_face_gather_backward_csr(n, n, n, 1, n, 0, 5, 4, 3, n) == 0                    # empty batch
+    assert h.lasr_face_gather_backward_csr(n, n, n, 1, n, 2, 5, 4, 3, n) == -1                   # null buffers
+    assert h.lasr_bone_fixup_pair_forward(n, n, n, n, n, n, n, 3, 1, 2, n) == -1                 # odd number of meshes: no frame pairs
+    assert h.lasr_bone_fixup_pair_forward(n, n, n, n, n, n, n, 0, 1, 2, n) == 0
+    assert h.lasr_bone_fixup_pair_backward(n, n, n, n, n, n, n, n, n, 4, 3, 2, n) == -1          # M not a multiple of H
+    reg_f = lambda N, NA, V, NC, P, Q: h.lasr_step_regularisers_forward(n, n, n, n, n, n, n, n, n, n, n, n, N, NA, V, 0,      # noqa: E731
+                                                                        n, n, n, n, n, NC, P, Q, n)
+    assert reg_f(0, 0, 5, 0, 0, 0) == 0 and reg_f(0, 0, 5, 2, 0, 3) == -1 and reg_f(0, 0, 5, 2, 3, 3) == -1 and reg_f(-1, 0, 5, 0, 0, 0) == -1
+    reg_b = lambda N, NA, V, NC, P, Q: h.lasr_step_regularisers_backward(n, n, n, n, n, n, n, n, n, n, n, n, n, n, n, n, n, N, NA, V, 0,   # noqa: E731
+                                                                         n, n, n, n, n, n, n, NC, P, Q, n)
+    assert reg_b(0, 0, 5, 0, 0, 0) == 0 and reg_b(0, 0, 5, 1, 2, 2) == -1 and reg_b(0, 0, 0, 0, 0, 0) == 0
+    assert h.lasr_mesh_regularisers_forward(n, n, n, n, n, n, n, n, n, n, n, n, 0, 0, 5, 0, n) == 0
+    assert h.lasr_cosdist_multi_forward(n, n, n, n, 0, n, n, 2, 1, n) == -1                      # no layers
+    assert h.lasr_cosdist_multi_scratch_floats(n, 3, 2) == 0
+    assert h.lasr_raster_faces_scratch_floats(2, 10, 16) > 0
+    assert h.lasr_project_points_forward(n, n, n, n, n, n, n, 0, 1, 2, n) in (0, -1)
