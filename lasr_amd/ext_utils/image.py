@@ -21,22 +21,33 @@ def compute_dt_barrier(mask, k=50):
     return 1. / (1 + np.exp(k * -diff))
 
 
-def sample_contour(mask, sample_size=1000, seed=None):
-    """1000 points (x, y) in [-1, 1] sampled from a 2-pixel band around the silhouette boundary (image.py:140-190).
-    The reference traces the boundary with skimage.measure.find_contours; here it is the set of mask pixels with a
-    background 4-neighbour (the field is carried in the batch but not read by the loss path)."""
-    from scipy.ndimage import binary_erosion
+def contour_vertices(mask):
+    """The vertex set of skimage.measure.find_contours(mask, 0) for a 0 / 1 mask, as (row, col) pixel coordinates (image.py:146).
+    Marching squares places a vertex on every cell edge that joins a pixel above the level to one that is not, at
+    from + (level - v_from) / (v_to - v_from) * (to - from); with level 0 and values in {0, 1} that fraction is 0 when the edge starts
+    at the background pixel and 1 when it ends there: every vertex sits exactly ON the background pixel.  The set is therefore the
+    background pixels that have a foreground 4-neighbour inside the image (skimage, absent from this image, is restated from its
+    published algorithm: parity unpinned; tests/test_dataloader.py enumerates the cell edges independently)."""
     m = np.asarray(mask) > 0
-    edge = m & ~binary_erosion(m)
-    contour = np.argwhere(edge).astype(np.float64)                   # (row, col)
+    near = np.zeros_like(m)
+    near[1:] |= m[:-1]; near[:-1] |= m[1:]; near[:, 1:] |= m[:, :-1]; near[:, :-1] |= m[:, 1:]
+    return np.argwhere(near & ~m).astype(np.float64)
+
+
+def sample_contour(mask, sample_size=1000, seed=None):
+    """1000 points (x, y) in [-1, 1] sampled from a 2-pixel band around the silhouette boundary (image.py:140-190): the contour
+    vertices (contour_vertices: find_contours at level 0), each shifted by the reference's 17 offsets and clipped to the image, then
+    sample_size of them drawn without replacement (with replacement only when the band is smaller than that, where the reference's
+    np.random.choice raises), x and y swapped, normalised.  The field is carried in the batch but not read by the loss path."""
+    contour = contour_vertices(mask)                                 # (row, col)
     if len(contour) == 0:
         return np.zeros((sample_size, 2))
-    size = m.shape[0]
+    size = np.asarray(mask).shape[0]
     offs = np.array([[0, 0], [0, 1], [0, 2], [0, -1], [0, -2], [1, 0], [2, 0], [-1, 0], [-2, 0], [-1, -1], [-2, -2],
                      [1, 1], [2, 2], [-1, 1], [-2, 2], [1, -1], [2, -2]])
     band = np.concatenate([np.clip(contour + o, 0, size - 1) for o in offs])
     rng = np.random.default_rng(seed)
-    pick = band[rng.integers(0, len(band), sample_size)]
+    pick = band[rng.choice(len(band), sample_size, replace=len(band) < sample_size)]
     pick = (pick / size) * 2 - 1
     return pick[:, ::-1].copy()                                       # (x, y)
 

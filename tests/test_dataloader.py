@@ -44,6 +44,40 @@ def test_distance_transforms_and_contour():
     assert iu.compute_dt(m, iters=10)[15, 2] == 0                                  # inside the 10-pixel dilation
     c = iu.sample_contour(m, seed=0)
     assert c.shape == (1000, 2) and np.abs(c).max() <= 1
+    # every sample lies within the reference's 2-pixel band of a contour vertex; (x, y) order, [-1, 1] normalisation
+    rc = (c[:, ::-1] + 1) / 2 * 32
+    cv = iu.contour_vertices(m)
+    assert np.abs(rc[:, None] - cv[None]).max(-1).min(1).max() <= 2 + 1e-9
+    assert len(np.unique(np.round(rc).astype(int), axis=0)) > 100                 # drawn without replacement from a band of > 1000 points
+
+
+def _marching_squares_vertices(mask, level=0.0):
+    """The vertices find_contours would emit, enumerated edge by edge from the published algorithm (Lorensen & Cline marching squares
+    as in skimage/measure/_find_contours_cy.pyx): an edge of a 2x2 cell carries a vertex when exactly one of its end pixels is > level."""
+    m = np.asarray(mask, np.float64)
+    out = set()
+    H, W = m.shape
+
+    def vertex(a, b):
+        va, vb = m[a], m[b]
+        frac = 0.0 if vb == va else (level - va) / (vb - va)
+        return (a[0] + frac * (b[0] - a[0]), a[1] + frac * (b[1] - a[1]))
+    for r in range(H - 1):
+        for c in range(W - 1):
+            ul, ur, ll, lr = (r, c), (r, c + 1), (r + 1, c), (r + 1, c + 1)
+            for a, b in ((ul, ur), (ur, lr), (ll, lr), (ul, ll)):
+                if (m[a] > level) != (m[b] > level):
+                    out.add(vertex(a, b))
+    return out
+
+
+def test_contour_vertices_are_the_marching_squares_vertices_at_level_zero():
+    yy, xx = np.mgrid[:40, :40]
+    shapes = [((xx - 19.3) ** 2 + (yy - 17.8) ** 2 <= 11 ** 2), np.zeros((40, 40), bool), (xx + yy) % 7 == 0]
+    shapes[1][5:30, 8:9] = True; shapes[1][0:6, 20:30] = True                      # a one-pixel line and a block touching the border
+    for s in shapes:
+        got = {tuple(v) for v in iu.contour_vertices(s.astype(np.float64)).tolist()}
+        assert got == _marching_squares_vertices(s.astype(np.float64))
 
 
 def write_sequence(root, name='toy', n=4, W=96, H=80, step=(5, -3)):
