@@ -619,6 +619,48 @@ def in_scope_step_leg():
     return out
 
 
+class LineOnce:
+    """Rank 0's single JSON line, printable from the main thread or from the watchdog below, whichever comes first."""
+
+    def __init__(self):
+        import threading
+        self._gate, self._done = threading.Lock(), False
+
+    def __call__(self, obj):
+        with self._gate:
+            if self._done:
+                return False
+            self._done = True
+        print(json.dumps(obj), flush=True)
+        return True
+
+
+def run_optional_collective_legs(fn, rank, out, key, limit_s, emit):
+    """Run the legs that only exist for N > 1 (collectives between the ranks: nothing this builder could execute on more than one GPU)
+    so that the contract line cannot be lost to them.  If `fn` raises on this rank, or has not returned after limit_s seconds (a rank
+    that failed leaves the others waiting in a collective), rank 0 prints the line measured so far with {key: {'error': ...}} and
+    every rank leaves with os._exit(0) -- no communicator tear-down, which could block on the same dead collective.
+    Returns fn()'s value otherwise."""
+    import threading
+
+    def give_up(reason):
+        if rank == 0 and out is not None:
+            out[key] = {'error': reason}
+            emit(out)
+        sys.stdout.flush()
+        os._exit(0)
+    timer = threading.Timer(limit_s, give_up, ('did not finish within %.0f s on rank %d (LASR_BENCH_DP_TIMEOUT)' % (limit_s, rank),))
+    timer.daemon = True
+    timer.start()
+    try:
+        value = fn()
+    except Exception as e:                                   # noqa: BLE001 -- whatever it is, the headline line goes out
+        timer.cancel()
+        give_up('failed on rank %d: %s' % (rank, repr(e)[:300]))
+    timer.cancel()
+    return value
+
+
 def allreduce_variants_leg(dev, nbytes, world, dist, reps=5):
     """how the optimisation step's gradient message (nbytes, fp32) crosses the xGMI mesh, three ways, so that
     the first 8-GPU run of this line can compare them (SURVEY section 5 predicts ring ~0.65 ms vs direct reduce-scatter /
@@ -986,13 +1028,20 @@ def main():
             # after every timed leg: the child process shares this GPU while it runs
             torch.cuda.synchronize()
             out['in_scope_step'] = in_scope_step_leg()
-    dp = optimize_dp_leg(dev, a.lasr_iters, rank, world, dist) if world > 1 and a.lasr_iters > 0 else None     # every rank takes part
-    if dp is not None:
-        dp['allreduce_variants'] = allreduce_variants_leg(dev, dp['no_overlap']['grad_message_bytes'], world, dist)
+    emit = LineOnce()
+    dp = None
+    if world > 1 and a.lasr_iters > 0:                       # every rank takes part
+
+        def dp_legs():
+            d = optimize_dp_leg(dev, a.lasr_iters, rank, world, dist)
+            d['allreduce_variants'] = allreduce_variants_leg(dev, d['no_overlap']['grad_message_bytes'], world, dist)
+            return d
+        dp = run_optional_collective_legs(dp_legs, rank, out if rank == 0 else None, 'optimize_py_dp',
+                                          float(os.environ.get('LASR_BENCH_DP_TIMEOUT', '600')), emit)
     if rank == 0:
         if dp is not None:
             out['optimize_py_dp'] = dp
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
