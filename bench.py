@@ -1014,16 +1014,22 @@ def main():
                                                'note': 'opt-in; distance + threshold decision bit-faithful, the rest fp32 rcp/exp'}
             finally:
                 job.forward_flags = 0
+        def optional(key, fn):
+            # the informational legs after the timed region: one that fails leaves {'error': ...} in its block, the line still goes out
+            try:
+                out[key] = fn()
+            except Exception as e:                           # noqa: BLE001
+                out[key] = {'error': repr(e)[:400]}
         if world == 1 and not a.no_sweep:
-            out['sweep'] = sweep_leg(dev, [(1, 256), (4, 256), (16, 256), (64, 256), (64, 512)])
+            optional('sweep', lambda: sweep_leg(dev, [(1, 256), (4, 256), (16, 256), (64, 256), (64, 512)]))
             IS = a.image_size
-            out['other_points'] = variants_leg(dev, B)
+            optional('other_points', lambda: variants_leg(dev, B))
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(F)
+            optional('cpu_baseline', lambda: cpu_baseline(F))
         if world == 1 and not a.no_lbs:
-            out['lbs'] = lbs_leg(dev)
+            optional('lbs', lambda: lbs_leg(dev))
         if world == 1 and a.lasr_iters > 0:
-            out['optimize_py'] = optimize_leg(dev, a.lasr_iters)
+            optional('optimize_py', lambda: optimize_leg(dev, a.lasr_iters))
         if world == 1 and a.lasr_iters > 0 and not a.no_step_profile:
             # after every timed leg: the child process shares this GPU while it runs
             torch.cuda.synchronize()
