@@ -49,8 +49,11 @@ extern "C" {
  *      scratch; lasr_render_tables_* run 3 + 2 launches (same signatures and scratch size);
  *      lasr_sr_options gains mixed_min_weight (fifth field); lasr_sr_backward* accept a records-only workspace;
  *      new: lasr_cosdist_multi_*, lasr_raster_faces_*, lasr_mesh_regularisers_*, lasr_project_points_*,
- *      lasr_face_gather_backward_csr, lasr_bone_fixup_pair_*, lasr_step_regularisers_*, lasr_point_mesh_scratch_floats (+ a scratch argument of lasr_point_mesh_forward). */
-#define LASR_ABI_VERSION 3
+ *      lasr_face_gather_backward_csr, lasr_bone_fixup_pair_*, lasr_step_regularisers_*, lasr_point_mesh_scratch_floats (+ a scratch argument of lasr_point_mesh_forward).
+ *      (lasr_lbs_backward_scratch_floats grew about 4x with the 64-vertex chunks of the MFMA backward: re-query it, never cache it per (N, V, K).)
+ *   4  round 6: lasr_sr_options.mixed_min_weight (fifth field) became pair_min_tiles -- the one-launch mix of two tile bodies is gone,
+ *      launches from that many 8x8 tiles up take the pair-walk forward kernel. */
+#define LASR_ABI_VERSION 4
 int         lasr_abi_version(void);
 const char* lasr_strerror(int code);
 int         lasr_last_hip_error(void);      /* hipError_t of the most recent LASR_E_LAUNCH on this thread */
@@ -235,10 +238,11 @@ typedef struct lasr_sr_options {
     long long coop_max_tiles;
     long long choose_max_tiles;
     long long order_max_tiles;
-    long long mixed_min_weight;   /* ordered launches beyond the cooperative range: tiles touched by at least this many faces' pixel
-                                     rects get a four-wave workgroup, the rest one wave each, in ONE launch (sr_forward_mixed_kernel);
-                                     1..255, 0 = one kernel per launch = the default (opt-in: measured slower than the better plain kernel,
-                                     profiles/experiments/r05_mixed_sweep.txt; LASR_SR_MIXED_MIN_WEIGHT at load time) */
+    long long pair_min_tiles;     /* LASR's mode combination: launches of at least this many 8x8-pixel tiles (frames x tiles per
+                                     frame) take the pair-walk kernel (sr_forward_pairs.h: every lane walks the (pixel, face) pairs
+                                     of its own pixel, records staged in LDS); 0 = every launch, a huge value = never.  Its image
+                                     agrees with the other kernels' to ~1e-6 (another accumulation order per pixel), not bit for
+                                     bit.  Negative: the built-in default (LASR_SR_PAIR_MIN_TILES at load time) */
 } lasr_sr_options;
 /* lasr_sr_forward_bg with options: `background` may be NULL (then soft_colors holds the pre-filled background, as for
  * lasr_sr_forward_ex), `options` may be NULL (all defaults). */

@@ -120,7 +120,7 @@ SIGNATURES = {
     'lasr_prof_collect': (_i, [_p, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
 }
 
-ABI_VERSION = 3                                     # LASR_ABI_VERSION of include/lasr_sr.h (tests/test_abi.py compares them)
+ABI_VERSION = 4                                     # LASR_ABI_VERSION of include/lasr_sr.h (tests/test_abi.py compares them)
 # flags of the *_ex entry points (include/lasr_sr.h)
 SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_SEGMENTED, SR_RECORDS_VALID, SR_GRADS_OVERWRITE = -1, 1, 2, 4, 8
 MEANS_MAX_TERMS, TAIL_MAX_GROUPS = 24, 16          # LASR_MEANS_MAX_TERMS / LASR_TAIL_MAX_GROUPS of include/lasr_ops.h
@@ -131,7 +131,7 @@ class SrOptions(ctypes.Structure):
     """lasr_sr_options (include/lasr_sr.h): per-call kernel-choice thresholds of the forward pass and the size limit of the
     heaviest-first tile order; a negative field = default."""
     _fields_ = [('coop8_max_tiles', ctypes.c_longlong), ('coop_max_tiles', ctypes.c_longlong), ('choose_max_tiles', ctypes.c_longlong),
-                ('order_max_tiles', ctypes.c_longlong), ('mixed_min_weight', ctypes.c_longlong)]
+                ('order_max_tiles', ctypes.c_longlong), ('pair_min_tiles', ctypes.c_longlong)]
 
 
 _lib = None

@@ -22,9 +22,6 @@ struct RasterArgs {
     int choice_max;                           // < 0: *choice is the id; else *choice is the launch's number of non-empty tiles
                                               // (sr_order_kernel) and the id is CHOICE_COOP iff it is at most this
     const int* __restrict__ order;            // forward, optional: block -> (image, 8x8 tile) table written by sr_order_kernel
-    const int* __restrict__ head;             // sr_forward_mixed_kernel: per XCD, how many leading entries of its ordered list go to
-                                              // the four-wave cooperative body (written by sr_order_kernel); order_per = entries per XCD
-    int order_per, head_max;
     float bg[9];
     // launch constants of the backward pass, computed once on the host (IEEE division / square root: the bits the device
     // expansions gave, without ~30 VALU instructions per face): 1 / IS, the pixel-centre fma coefficients 2 / IS, (1 - IS) / IS,

@@ -1,0 +1,592 @@
+// sr_forward_pairs.h -- the forward raster kernel of LASR's mode combination for launches that fill the chip: every LANE walks
+// the (pixel, face) pairs of its own pixel.
+//
+// The one-wave-per-tile kernel (sr_raster.hip: forward_tile_body) keeps the face index wave-uniform: every one of the ~290
+// instructions of a list entry is issued for the 64 pixels of the tile while ~27 of them lie within the face's reach (41.5 % live
+// lanes, profiles/r05_valu.json), and the record arrives as SGPR operands, which halve the issue rate of an fp32 instruction
+// (profiles/r02_valu_issue.txt).  Here the face index is PER LANE:
+//
+//   list     four waves share a 16x16-pixel tile and build its ordered face list as before (group rects, pixel rects, corner cull);
+//   stage    64 list entries at a time: their records (+ vertex attributes) are copied into LDS in a layout made for per-lane
+//            gathers -- 16-byte quads grouped by use, each edge's constants in a block of its own (so the edge an outside pixel
+//            projects to is ONE run-time offset, not three exec-masked code variants), the obtuse-corner test's operands
+//            precomputed -- at an odd quad stride, so that 16 lanes reading the same quad of 16 different entries hit 16
+//            different bank groups;
+//   classify (wave-uniform entry, lanes = the wave's 8x8 pixels, record by LDS broadcast): exact integer rect test, barycentrics,
+//            then one bit per (pixel, entry) in one of three per-lane 64-bit masks: INSIDE the face, OUTSIDE but not certainly
+//            beyond the distance threshold (the backward's conservative line-distance reject, sr_device.h: certainly_far), or
+//            SLOW (a record that is not tame: handled by the generic arithmetic, wave-uniform, at the end of the chunk);
+//   balance  the lanes are ranked by their pair count (six ballots) and lane of rank r is partnered with rank 63 - r: the lighter
+//            partner takes the upper half of the difference from the heavier one's outside mask and folds it into a private
+//            partial state;
+//   walk     every lane pops its own masks, inside pairs first (the three-projection branch of the distance code then runs in
+//            the first few iterations of a chunk only), gathers the entry's record from LDS with 16-byte reads and applies the
+//            pair with exactly the arithmetic of forward_face;
+//   merge    partial states (alpha product, running maximum, rescaled sums) are folded into their pixel's state.
+//
+// What changes against the one-wave kernel is the ORDER in which a pixel's fragments meet its state (inside fragments first,
+// then outside fragments in index order, a stolen run merged at the end of each chunk): alpha product and depth softmax are
+// symmetric in the fragments, only the rounding sequence moves (image within ~1e-6 of the reference-order kernels; the running
+// maximum is exact).  Every (pixel, face) pair itself goes through the same instruction sequence as in forward_face
+// (K.cu:370-453).
+#pragma once
+
+namespace lasr {
+
+constexpr int PW_CAP = 64;            // list entries per staged chunk = bits per lane mask
+constexpr int PW_LIST = 1024;         // tile list entries per round (u16 ids relative to the round's first face)
+constexpr int PW_TILE = 16;
+
+typedef unsigned long long u64_t;
+
+// ---- the staged record (floats; 14 quads + the attributes)
+//   q0  inv0..3      q1  inv4..7      q2  inv8, flags, rect lo, rect ext
+//   q3  far[0..2], -: far[k] = -sqrt(1.05 thr / hk2[k]), the barycentric w_k below which a pixel is certainly beyond the threshold
+//   q4  x0 y0 x1 y1  q5  x2 y2 z0 z1  q6  z2, 1/z0, 1/z1, 1/z2
+//   q7  obtuse corner c (flags bit0..2): x_c, y_c, x_o - x_c, y_o - y_c with o = (c + 2) % 3   (K.cu:113-125's override test)
+//   q8 + 2k, q9 + 2k   edge k: e[k][0..2], e[k][(k+1)%3]  |  den[k], 1/den[k], -, -
+//   56 ..  attributes [vertex][channel]
+constexpr int PR_INV = 0, PR_FLAGS = 9, PR_BB = 10, PR_HK2 = 12, PR_XY = 16, PR_Z = 22, PR_IZ = 25, PR_OBT = 28, PR_EDGE = 32, PR_TEX = 56;
+
+// record field (sr_device.h index) -> staged slot; compile-time for the generic arithmetic, which indexes with constants
+__host__ __device__ constexpr int pr_of(int i)
+{
+    return i == R_BB ? PR_BB : i == R_BB + 1 ? PR_BB + 1 : i == R_FLAGS ? PR_FLAGS
+         : (i >= R_INV && i < R_INV + 9) ? PR_INV + (i - R_INV)
+         : (i >= R_HK2 && i < R_HK2 + 3) ? PR_HK2 + (i - R_HK2)
+         : (i >= R_FACE && i < R_FACE + 9) ? ((i - R_FACE) % 3 == 2 ? PR_Z + (i - R_FACE) / 3 : PR_XY + 2 * ((i - R_FACE) / 3) + (i - R_FACE) % 3)
+         : (i >= R_DEN && i < R_DEN + 3) ? PR_EDGE + 8 * (i - R_DEN) + 4
+         : (i >= R_IDEN && i < R_IDEN + 3) ? PR_EDGE + 8 * (i - R_IDEN) + 5
+         : (i >= R_E && i < R_E + 9) ? PR_EDGE + 8 * ((i - R_E) / 3) + (i - R_E) % 3
+         : (i >= R_IZ && i < R_IZ + 3) ? PR_IZ + (i - R_IZ) : 15;
+}
+// staged slot -> record field it is copied from (-1: padding, -2: computed by the staging code)
+__host__ __device__ constexpr int pr_src(int d)
+{
+    return d < 9 ? R_INV + d : d == 9 ? R_FLAGS : d == 10 ? R_BB : d == 11 ? R_BB + 1 : d < 15 ? R_HK2 + (d - 12) : d == 15 ? -1
+         : d < 22 ? R_FACE + 3 * ((d - 16) / 2) + (d - 16) % 2 : d < 25 ? R_FACE + 3 * (d - 22) + 2 : d < 28 ? R_IZ + (d - 25)
+         : d < 32 ? -2
+         : (d - 32) % 8 < 3 ? R_E + 3 * ((d - 32) / 8) + (d - 32) % 8
+         : (d - 32) % 8 == 3 ? R_E + 3 * ((d - 32) / 8) + ((d - 32) / 8 + 1) % 3
+         : (d - 32) % 8 == 4 ? R_DEN + (d - 32) / 8 : (d - 32) % 8 == 5 ? R_IDEN + (d - 32) / 8 : -1;
+}
+struct PairRecView {                                   // the staged record behind the record indices of sr_device.h
+    const float* p;
+    __device__ __forceinline__ float operator[](int i) const { return p[pr_of(i)]; }
+};
+
+// LDS: the chunk's staged records at an ODD number of quads per slot, the tile's list, the list builder's counts
+template <int NCH>
+struct PairLds {
+    static constexpr int Q0 = (PR_TEX + 3 * NCH + 3) / 4;
+    static constexpr int RS = 4 * (Q0 | 1);
+    float rec[PW_CAP * RS];
+    unsigned short list[PW_LIST];
+    int wcnt[2][4];
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+// "these values are needed HERE": keeps the compiler from sinking an LDS read to its first use, where the wave would sit out the
+// whole round trip alone -- reads requested together come back together (nothing is emitted)
+#ifndef LASR_PW_FENCE
+#define LASR_PW_FENCE 0
+#endif
+#ifndef LASR_PW_WAVES
+#define LASR_PW_WAVES 8      // registers for eight waves per SIMD (three channels; the spills this costs sit in the list builder, not in the walk)
+#endif
+#define PW_LANDED(q) asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w))
+
+// the conservative corner cull of the tile kernels on a block of pixels [xlo, xhi] x [ylo, yhi]: false when all four corners lie
+// beyond one edge's line by more than sqrt(thr_cull)
+template <typename RP>
+__device__ __forceinline__ bool reaches_block(RP R, float xlo, float xhi, float ylo, float yhi, float thr_cull)
+{
+    bool hit = true;
+    if (__float_as_int(R[R_FLAGS]) & 16) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float a = R[R_INV + 3 * k], b = R[R_INV + 3 * k + 1], c = R[R_INV + 3 * k + 2];
+            const float w00 = a * xlo + b * ylo + c, w01 = a * xhi + b * ylo + c;
+            const float w10 = a * xlo + b * yhi + c, w11 = a * xhi + b * yhi + c;
+            const float wmax = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
+            if (wmax < 0.f && wmax * wmax * R[R_HK2 + k] > thr_cull) hit = false;
+        }
+    }
+    return hit;
+}
+
+// staging: source quads [Q0, Q1) of a record (global layout, sr_device.h) into their staged slots
+__host__ __device__ constexpr bool rec_used(int i) { return i < 15 || (i >= 16 && i < 31) || (i >= 32 && i < 44); }
+template <int Q0, int Q1>
+__device__ __forceinline__ void stage_quads(const float4* __restrict__ src, float* __restrict__ dst, float thr_far)
+{
+    float4 v[Q1 - Q0];
+#pragma unroll
+    for (int q = Q0; q < Q1; q++) v[q - Q0] = src[q];
+#pragma unroll
+    for (int q = Q0; q < Q1; q++) {
+        const float w[4] = {v[q - Q0].x, v[q - Q0].y, v[q - Q0].z, v[q - Q0].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = 4 * q + j;
+            if (!rec_used(i)) continue;
+            if (i >= R_HK2 && i < R_HK2 + 3) { dst[pr_of(i)] = -sqrtf(thr_far / w[j]); continue; }
+            dst[pr_of(i)] = w[j];
+            if (i == R_E + 1) dst[PR_EDGE + 3] = w[j];            // e[k][(k+1)%3] once more, as the fourth word of edge k's block
+            if (i == R_E + 5) dst[PR_EDGE + 8 + 3] = w[j];
+            if (i == R_E + 6) dst[PR_EDGE + 16 + 3] = w[j];
+        }
+    }
+}
+
+// merge of a partial state P (fragments folded on their own, starting from "no fragment": a = 1, sum 0, reference level
+// smax = eps) into S:  a = a_S a_P;  m = max(m_S, m_P);  sum = sum_S e^((m_S - m) / gamma) + sum_P e^((m_P - m) / gamma)
+template <int NCH>
+__device__ __forceinline__ void merge_partial(PixState<NCH>& S, float pa, float pm, float ps, const float (&pc)[NCH],
+                                              float gamma, float inv_gamma)
+{
+    S.a = (float)((double)S.a * (double)pa);
+    const float mx = fmaxf(S.smax, pm);
+    const float ds = S.smax - mx, dp = pm - mx;            // one of them is exactly 0
+    const float es = exp_1ulp(div_by_recip(ds, gamma, inv_gamma));
+    const float ep = exp_1ulp(div_by_recip(dp, gamma, inv_gamma));
+    S.ssum = S.ssum * es + ps * ep;
+#pragma unroll
+    for (int k = 0; k < NCH; k++) S.c[k] = S.c[k] * es + pc[k] * ep;
+    S.smax = mx;
+}
+
+// One (pixel, face) pair of a TAME record against the pixel state: forward_face<LASR, MK = true> (sr_raster.hip) with the record
+// gathered per lane from its staged slot R.  is_in: the classification's inside test (the same predicate on the same
+// barycentrics as euclid<.., TAME>).  Same operations in the same order per pair: the fragment's D, depth and weights are the
+// bits the one-wave kernel computes.
+template <int NCH>
+__device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& U, const float* __restrict__ R, bool is_in,
+                                           float xp, float yp, PixState<NCH>& s)
+{
+#pragma clang fp contract(off)
+    float4 q0 = ld4(R), q1 = ld4(R + 4), q2 = ld4(R + 8);
+    float4 q4 = ld4(R + PR_XY), q5 = ld4(R + PR_XY + 4), ob = ld4(R + PR_OBT);      // one LDS round trip for the six quads
+#if LASR_PW_FENCE & 1
+    PW_LANDED(q0); PW_LANDED(q1); PW_LANDED(q2); PW_LANDED(q4); PW_LANDED(q5); PW_LANDED(ob);
+#endif
+    const float w0 = q0.x * xp + q0.y * yp + q0.z;                    // K.cu:24-29 (barycentric())
+    const float w1 = q0.w * xp + q1.x * yp + q1.y;
+    const float w2 = q1.z * xp + q1.w * yp + q2.x;
+    const float x0 = q4.x, y0 = q4.y, x1 = q4.z, y1 = q4.w, x2 = q5.x, y2 = q5.y, z0 = q5.z, z1 = q5.w;
+    float narg;
+    if (is_in) {
+        // K.cu:61-110: project on all three edges, keep the nearest (euclid<.., FWD>'s inside branch)
+        float best = 100000000.f, bx = 0, by = 0;
+#pragma unroll
+        for (int K = 0; K < 3; K++) {
+            const float4 ea = ld4(R + PR_EDGE + 8 * K);
+            const float2 eb = *(const float2*)(R + PR_EDGE + 8 * K + 4);
+            const float num = w0 * ea.x + w1 * ea.y + w2 * ea.z - ea.w;
+            const float ta = div_by_recip(num, eb.x, eb.y);
+            const float tb = 1 - ta;
+            float t[3];
+            t[K] = ta; t[(K + 1) % 3] = tb; t[(K + 2) % 3] = 0;
+            const float u0 = t[0] - w0, u1 = t[1] - w1, u2 = t[2] - w2;
+            const float px = u0 * x0 + u1 * x1 + u2 * x2;
+            const float py = u0 * y0 + u1 * y1 + u2 * y2;
+            const float d2 = px * px + py * py;
+            if (d2 < best) { best = d2; bx = px; by = py; }
+        }
+        narg = (-bx) * bx - by * by;
+    } else {
+        // K.cu:113-150: which edge (sign pattern of the barycentrics, obtuse-corner override), ONE clamped projection
+        const int flags = __float_as_int(q2.y);
+        const bool over = (flags & 7) != 0 && (xp - ob.x) * ob.z + (yp - ob.y) * ob.w > 0;
+        const bool o0 = over && (flags & 1), o1 = over && (flags & 2), o2 = over && (flags & 4);
+        const bool n0 = w0 <= 0, n1 = w1 <= 0, n2 = w2 <= 0;
+        const bool c12 = n1 & n2, c20 = n2 & n0 & !n1, c01 = n0 & n1 & !n2;
+        const bool e1 = (c20 & !o1) | (c01 & o2) | (n0 & !n1 & !n2);
+        const bool e2 = (c01 & !o2) | (c12 & o0) | (n1 & !n0 & !n2);
+        const int k = e1 ? 1 : e2 ? 2 : 0;
+        const float* E = R + PR_EDGE + 8 * k;
+        const float4 ea = ld4(E);
+        const float2 eb = *(const float2*)(E + 4);
+        const float num = w0 * ea.x + w1 * ea.y + w2 * ea.z - ea.w;
+        float ta = div_by_recip(num, eb.x, eb.y);
+        float tb = 1 - ta;
+        ta = fminf(fmaxf(ta, 0.f), 1.f);
+        tb = fminf(fmaxf(tb, 0.f), 1.f);
+        const bool k0 = k == 0, k1 = k == 1, k2 = k == 2;
+        const float t0 = k0 ? ta : k2 ? tb : 0.f, t1 = k1 ? ta : k0 ? tb : 0.f, t2 = k2 ? ta : k1 ? tb : 0.f;
+        const float u0 = t0 - w0, u1 = t1 - w1, u2 = t2 - w2;
+        const float dx = u0 * x0 + u1 * x1 + u2 * x2;
+        const float dy = u0 * y0 + u1 * y1 + u2 * y2;
+        narg = dx * dx + dy * dy;
+        if (narg >= A.thr) return;                                                   // K.cu:402
+    }
+    float4 q6 = ld4(R + PR_XY + 8);                                                  // z2, 1/z0, 1/z1, 1/z2
+    float4 tq[(3 * NCH + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (3 * NCH + 3) / 4; q++) tq[q] = ld4(R + PR_TEX + 4 * q);
+    const float D = sigmoid_neg_<false, true>(div_by_recip(narg, A.sigma, U.inv_sigma));
+    s.a = (float)((double)s.a * (1. - (double)D));                                   // K.cu:409-417
+#if LASR_PW_FENCE & 2
+    PW_LANDED(q6);
+#pragma unroll
+    for (int q = 0; q < (3 * NCH + 3) / 4; q++) PW_LANDED(tq[q]);
+#endif
+    float c0 = w0, c1 = w1, c2 = w2;
+    clip_normalise<false, true>(c0, c1, c2);
+    const float zs = div_by_recip(c0, z0, q6.y) + div_by_recip(c1, z1, q6.z) + div_by_recip(c2, q6.x, q6.w);
+    const float zp = recip_noscale(zs);
+    if (!(zp >= A.near && zp <= A.far)) return;
+    const float zn = div_by_recip(A.far - zp, A.far - A.near, U.inv_fmn);
+    const bool up = zn > s.smax;
+    const float d = -fabsf(zn - s.smax);
+    const float Ex = exp_1ulp(div_by_recip(d, A.gamma, U.inv_gamma));
+    const float hist = up ? Ex : 1.f, wgt = up ? D : Ex * D;
+    s.smax = max_finite(zn, s.smax);
+    s.ssum = hist * s.ssum + wgt;
+    float tex[3 * NCH];
+#pragma unroll
+    for (int q = 0; q < (3 * NCH + 3) / 4; q++) {
+        const float4 t = tq[q];
+        tex[4 * q] = t.x;
+        if (4 * q + 1 < 3 * NCH) tex[4 * q + 1] = t.y;
+        if (4 * q + 2 < 3 * NCH) tex[4 * q + 2] = t.z;
+        if (4 * q + 3 < 3 * NCH) tex[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; k++) s.c[k] = hist * s.c[k] + wgt * (c0 * tex[k] + c1 * tex[NCH + k] + c2 * tex[2 * NCH + k]);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256)
+#if LASR_PW_WAVES
+__attribute__((amdgpu_waves_per_eu(LASR_PW_WAVES, LASR_PW_WAVES)))
+#endif
+void sr_forward_pairs_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
+{
+    typedef PairLds<NCH> Lds;
+    constexpr int RS = Lds::RS;
+    __shared__ __attribute__((aligned(16))) Lds L;
+
+    const Modes m = Modes{2, 1, 2, 1, 1};               // LASR's configuration: euclidean, softmax, prod, vertex, double-sided
+    if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
+    const int IS = A.IS, P = IS * IS;
+    const int tiles_x = (IS + PW_TILE - 1) / PW_TILE;
+    int bn, tx, ty;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, A.order);      // this launch's own order when the host built one (16x16 tiles)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifndef LASR_PW_ROWS
+#define LASR_PW_ROWS 1
+#endif
+#if LASR_PW_ROWS
+    // wave w takes the rows w, w + 4, w + 8, w + 12 of the tile (16 pixels = 64 bytes each): the four waves of a tile see the same
+    // load (they meet at two barriers per chunk), and a store instruction covers whole 64-byte segments
+    const int px = tx * PW_TILE + (lane & 15), py = ty * PW_TILE + wave + 4 * (lane >> 4);
+#else
+    const int qx0 = tx * PW_TILE + (wave & 1) * 8, qy0 = ty * PW_TILE + (wave >> 1) * 8;       // this wave's 8x8 quadrant
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+#endif
+    const bool valid = px < IS && py < IS;
+    const int pn = py * IS + px;
+
+    PixState<NCH> s;
+    s.a = 1.f;
+    s.fbest = -1;
+    s.ssum = expf(A.eps / A.gamma); s.smax = A.eps;
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        const float bg = A.use_bg ? A.bg[k] : (valid ? colors[((size_t)bn * (NCH + 1) + k) * P + pn] : 1.f);
+        s.c[k] = bg * s.ssum;
+    }
+
+    // level 0: the groups of 64 consecutive faces whose union rect meets the 16x16 tile (every wave evaluates the same test)
+    const int G = groups_of(A.F);
+    const short4* __restrict__ grects = A.grects + (size_t)bn * G;
+    const int tX0 = tx * PW_TILE, tX1 = tX0 + PW_TILE - 1, tY0 = ty * PW_TILE, tY1 = tY0 + PW_TILE - 1;
+    u64_t gmask;
+    {
+        bool t = false;
+        if (lane < G) {
+            const short4 q = grects[lane];
+            t = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
+        }
+        gmask = wave_mask(t);
+    }
+    if (gmask != 0 || G > 64) {
+    const float xp = pix_center(px, IS);
+    const float yp = pix_center(IS - 1 - py, IS);
+    const short4* __restrict__ rects = A.rects + (size_t)bn * A.F;
+    const float* __restrict__ recs = A.recs + (size_t)bn * A.F * REC;
+    const int texstride = A.T * NCH;
+    const float* __restrict__ texs = A.textures + (size_t)bn * A.F * texstride;
+    const UniRecip U = uni_recip(A);
+    const int ok_bit = U.ok ? 32 : 0;
+    const float thr_cull = A.thr * 1.10f, thr_far = A.thr * 1.05f;
+    // corners of the tile (list building) and of this wave's quadrant (which entries of a chunk the wave looks at); wave-uniform
+    // values the VALU computed (divisions) go back to scalar registers
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float t_xlo = uni(pix_center(tX0, IS)), t_xhi = uni(pix_center(min(tX1, IS - 1), IS));
+    const float t_yhi = uni(pix_center(IS - 1 - tY0, IS)), t_ylo = uni(pix_center(IS - 1 - min(tY1, IS - 1), IS));
+#if !LASR_PW_ROWS
+    const float q_xlo = uni(pix_center(qx0, IS)), q_xhi = uni(pix_center(min(qx0 + 7, IS - 1), IS));
+    const float q_yhi = uni(pix_center(IS - 1 - qy0, IS)), q_ylo = uni(pix_center(IS - 1 - min(qy0 + 7, IS - 1), IS));
+#endif
+    int g_next = 64, g_mask0 = 0;
+    bool more = true;
+    while (more) {                                    // one round unless the tile meets more than PW_LIST - 256 faces
+        // ---- ordered list of the faces that reach the tile: four touched groups per step, one per wave
+        int count = 0, flip = 0, base = -1;
+        for (;;) {
+            if (gmask == 0) {
+                if (g_next >= G) { more = false; break; }
+                g_mask0 = g_next;
+                bool t = false;
+                if (g_next + lane < G) {
+                    const short4 q = grects[g_next + lane];
+                    t = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
+                }
+                gmask = wave_mask(t);
+                g_next += 64;
+                continue;
+            }
+            u64_t mm = gmask;
+            int mine_g = -1, last_g = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (mm) {
+                    const int bit = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    if (k == wave) mine_g = g_mask0 + bit;
+                    last_g = g_mask0 + bit;
+                }
+            }
+            const int first_g = g_mask0 + __builtin_ctzll(gmask);
+            if (base < 0) base = first_g * GROUP;
+            if (count + 256 > PW_LIST || (last_g + 1) * GROUP - base > 65536) break;  // walk what we have, then continue
+            gmask = mm;
+            const int f = mine_g * GROUP + lane;
+            bool hit = false;
+            if (mine_g >= 0 && f < A.F) {
+                const short4 q = rects[f];
+                hit = !(q.x > tX1 || q.y < tX0 || q.z > tY1 || q.w < tY0);
+                if (hit) hit = reaches_block(recs + (size_t)f * REC, t_xlo, t_xhi, t_ylo, t_yhi, thr_cull);
+            }
+            const u64_t mask = wave_mask(hit);
+            if (lane == 0) L.wcnt[flip][wave] = __popcll(mask);
+            __syncthreads();
+            const int c0 = L.wcnt[flip][0], c1 = L.wcnt[flip][1], c2 = L.wcnt[flip][2], c3 = L.wcnt[flip][3];
+            const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+            if (hit) L.list[count + before + bits_below_lane(mask)] = (unsigned short)(f - base);
+            count += c0 + c1 + c2 + c3;
+            flip ^= 1;
+        }
+        if (base < 0) base = 0;
+        __syncthreads();
+
+        for (int c0 = 0; c0 < count; c0 += PW_CAP) {
+            const int n = min(PW_CAP, count - c0);
+            // ---- stage: lane = entry, every wave a quarter of the record's source quads (all loads of a chunk in flight at once)
+            if (lane < n) {
+                const int fn = base + (int)L.list[c0 + lane];
+                const float4* __restrict__ src = (const float4*)(recs + (size_t)fn * REC);
+                const float* __restrict__ ta = texs + (size_t)fn * texstride;
+                float* dst = L.rec + lane * RS;
+                float tv[(3 * NCH + 3) / 4];
+#pragma unroll
+                for (int i = 0; i < (3 * NCH + 3) / 4; i++) tv[i] = wave + 4 * i < 3 * NCH ? ta[wave + 4 * i] : 0.f;
+                if (wave == 0) stage_quads<0, 3>(src, dst, thr_far);
+                else if (wave == 1) stage_quads<3, 6>(src, dst, thr_far);
+                else if (wave == 2) stage_quads<6, 9>(src, dst, thr_far);
+                else {
+                    stage_quads<9, 11>(src, dst, thr_far);
+                    // the obtuse corner's operands (see the layout above)
+                    const float* f = (const float*)src;
+                    const int fl = __float_as_int(f[R_FLAGS]);
+                    const int c = (fl & 1) ? 0 : (fl & 2) ? 1 : 2, o = c == 0 ? 2 : c - 1;
+                    const float xc = f[R_FACE + 3 * c], yc = f[R_FACE + 3 * c + 1], xo = f[R_FACE + 3 * o], yo = f[R_FACE + 3 * o + 1];
+                    *(float4*)(dst + PR_OBT) = make_float4(xc, yc, xo - xc, yo - yc);
+                }
+#pragma unroll
+                for (int i = 0; i < (3 * NCH + 3) / 4; i++)
+                    if (wave + 4 * i < 3 * NCH) dst[PR_TEX + wave + 4 * i] = tv[i];
+            }
+            __syncthreads();
+
+            // ---- candidates: bit e of a lane's mask = "entry e's pixel rect holds my pixel" (the exact bbox test, K.cu:375).  Lanes =
+            // entries: each turns its rect into a 16-bit column mask and a mask of this wave's rows; one ballot per column / row
+            // hands every pixel lane the entries of its column and of its row
+            u64_t cand;
+            {
+                int cm = 0, rm = 0;
+                if (lane < n) {
+                    const float* Rl = L.rec + lane * RS;
+                    const int lo = __float_as_int(Rl[PR_BB]), ext = __float_as_int(Rl[PR_BB + 1]);
+                    if (lo != -1) {
+                        const int x0 = (lo & 0xffff) - tX0, r0 = (int)((unsigned)lo >> 16) - tY0;
+                        const int x1 = x0 + (ext & 0xffff), r1 = r0 + (int)((unsigned)ext >> 16);
+                        const int a0 = max(x0, 0), a1 = min(x1, PW_TILE - 1), b0 = max(r0, 0), b1 = min(r1, PW_TILE - 1);
+                        if (a0 <= a1) cm = (2 << a1) - (1 << a0);
+                        if (b0 <= b1) rm = (2 << b1) - (1 << b0);
+                    }
+                }
+                u64_t cxv = 0, ryv = 0;
+                const int mycol = px - tX0, myrow = py - tY0;
+#pragma unroll
+                for (int x = 0; x < PW_TILE; x++) {
+                    const u64_t B = wave_mask((cm >> x) & 1);
+                    if (mycol == x) cxv = B;
+                }
+#if LASR_PW_ROWS
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u64_t B = wave_mask((rm >> (wave + 4 * j)) & 1);
+                    if ((lane >> 4) == j) ryv = B;
+                }
+#else
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const u64_t B = wave_mask((rm >> ((wave >> 1) * 8 + j)) & 1);
+                    if ((lane >> 3) == j) ryv = B;
+                }
+#endif
+                (void)myrow;
+                cand = valid ? cxv & ryv : 0ull;
+            }
+#if defined(LASR_PW_ABL) && LASR_PW_ABL == 2        // measurement build: list + stage only
+            s.a += (float)__popcll(cand); cand = 0;
+#endif
+            // ---- classify: every lane pops its own candidates; one bit per (pixel, entry) in two planes (01 outside and within
+            // reach, 10 inside, 11 slow = a record that is not tame, 00 dropped)
+            u64_t pa_ = 0, pb_ = 0;
+            while (wave_mask(cand != 0) != 0) {
+                if (cand != 0) {
+                    const int e = __builtin_ctzll(cand);
+                    const u64_t rest = cand & (cand - 1), bit = cand ^ rest;
+                    cand = rest;
+                    const float* R = L.rec + e * RS;
+                    const float4 q0 = ld4(R), q1 = ld4(R + 4), q2 = ld4(R + 8), q3 = ld4(R + PR_HK2);
+                    const int flags = __float_as_int(q2.y);
+                    const float w0 = q0.x * xp + q0.y * yp + q0.z;                  // barycentric()
+                    const float w1 = q0.w * xp + q1.x * yp + q1.y;
+                    const float w2 = q1.z * xp + q1.w * yp + q2.x;
+                    const bool tame = (flags & ok_bit) != 0;                         // else (or an unsafe launch): generic arithmetic
+                    const bool inside = (bool)((int)(fminf(fminf(w0, w1), w2) > 0) & (int)(fmaxf(fmaxf(w0, w1), w2) < 1));   // == euclid<.., TAME>
+                    const bool far = (bool)((int)((flags & 16) != 0) & ((int)(w0 < q3.x) | (int)(w1 < q3.y) | (int)(w2 < q3.z)));
+                    const bool a_ = !tame || (!inside && !far), b_ = !tame || inside;
+                    if (a_) pa_ |= bit;
+                    if (b_) pb_ |= bit;
+                }
+            }
+            u64_t mi = pb_ & ~pa_, mo = pa_ & ~pb_, ms = pa_ & pb_;
+
+#if defined(LASR_PW_ABL) && LASR_PW_ABL == 1        // measurement build: no walk
+            s.a += (float)(__popcll(mi) + 2 * __popcll(mo)); mi = mo = 0;
+#endif
+#if defined(LASR_PW_ABL) && LASR_PW_ABL == 3        // measurement build: no balance (every lane its own pairs)
+            const bool no_steal = true;
+#else
+            const bool no_steal = false;
+#endif
+            // ---- balance: rank the lanes by their pair count (heaviest first), partner rank r with rank 63 - r
+            const int kmine = min(__popcll(mi) + __popcll(mo), 63);
+            int rank;
+            {
+                u64_t Gm = ~0ull;
+                int greater = 0;
+#pragma unroll
+                for (int b = 5; b >= 0; b--) {
+                    const bool mine = (kmine >> b) & 1;
+                    const u64_t B = wave_mask(mine);
+                    const u64_t GB = Gm & B;
+                    if (!mine) { greater += __popcll(GB); Gm ^= GB; }
+                    else Gm = GB;
+                }
+                rank = greater + bits_below_lane(Gm);
+            }
+            const int id_at_rank = __builtin_amdgcn_ds_permute(rank << 2, lane);                 // lane r: the lane of rank r
+            const int partner = __builtin_amdgcn_ds_bpermute((63 - rank) << 2, id_at_rank);
+            const int kpart = __builtin_amdgcn_ds_bpermute(partner << 2, kmine);
+            const unsigned pmo_lo = (unsigned)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(unsigned)mo);
+            const unsigned pmo_hi = (unsigned)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(unsigned)(mo >> 32));
+            const float xq = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(xp)));
+            const float yq = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(yp)));
+            const bool heavy = rank < 32;
+            // the heavier partner's outside mask and the number of its pairs that change hands (both partners compute the same)
+            const u64_t hm = heavy ? mo : ((u64_t)pmo_hi << 32 | pmo_lo);
+            const int moved = min((heavy ? kmine - kpart : kpart - kmine) >> 1, (int)__popcll(hm));
+            u64_t st = 0;                                                       // light lane: the pairs it takes over
+            bool gave = false;
+            if (moved > 0 && !no_steal) {
+                // smallest position whose upper part holds at most `moved` bits
+                int p = 0;
+                u64_t top = hm;
+                if (__popcll(hm) > moved) {
+#pragma unroll
+                    for (int sft = 32; sft >= 1; sft >>= 1)
+                        if (p + sft <= 63 && __popcll(hm >> (p + sft)) > moved) p += sft;
+                    top = p >= 63 ? 0ull : (hm >> (p + 1)) << (p + 1);
+                }
+                if (heavy) { mo ^= top; gave = top != 0; }
+                else st = top;
+            }
+
+            // ---- walk: every lane pops its own pairs, inside pairs first
+            float cx = xp, cy = yp;
+            bool in_stolen = false;
+            PixState<NCH> saved = s;
+            for (;;) {
+                if ((mi | mo) == 0 && st != 0) {                                // own pairs done: the partner's share, into a fresh partial state
+                    saved = s;
+                    s.a = 1.f; s.ssum = 0.f; s.smax = A.eps;
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) s.c[k] = 0.f;
+                    cx = xq; cy = yq; mo = st; st = 0; in_stolen = true;
+                }
+                const u64_t work = mi | mo;
+                if (wave_mask(work != 0) == 0) break;
+                if (work != 0) {
+                    const bool is_in = mi != 0;
+                    u64_t mm = is_in ? mi : mo;
+                    const int e = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    if (is_in) mi = mm; else mo = mm;
+                    pair_apply<NCH>(A, U, L.rec + e * RS, is_in, cx, cy, s);
+                }
+            }
+            // ---- merge the partial states into their pixels
+            float pa = s.a, pm = s.smax, ps = s.ssum, pc[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) pc[k] = s.c[k];
+            if (in_stolen) s = saved;
+            if (wave_mask(gave) != 0) {
+                pa = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(pa)));
+                pm = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(pm)));
+                ps = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(ps)));
+#pragma unroll
+                for (int k = 0; k < NCH; k++) pc[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(pc[k])));
+                if (gave) merge_partial<NCH>(s, pa, pm, ps, pc, A.gamma, U.inv_gamma);
+            }
+            // ---- the chunk's slow pairs (records that are not tame): wave-uniform entry, generic arithmetic
+            for (int e = 0; wave_mask(ms != 0) != 0 && e < n; e++) {
+                if (wave_mask((ms >> e) & 1) == 0) continue;
+                const PairRecView R{L.rec + e * RS};
+                if ((ms >> e) & 1) {
+                    float w0, w1, w2;
+                    barycentric(R, xp, yp, w0, w1, w2);
+                    forward_face<true, false, NCH>(A, m, R, L.rec + e * RS + PR_TEX, 0, 0, xp, yp, w0, w1, w2, s, U);
+                }
+            }
+            __syncthreads();                            // the slots are rewritten by the next chunk
+        }
+    }
+    }   // tile meets at least one group
+
+    if (!valid) return;
+    // ---- finalise (K.cu:458-482)
+    colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = (float)(1. - (double)s.a);
+#pragma unroll
+    for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k] / s.ssum;
+    aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
+    aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
+}
+
+}  // namespace lasr

@@ -127,7 +127,7 @@ __device__ __forceinline__ int div_small(int e, int d, float inv)
 }
 
 __global__ __launch_bounds__(512) void sr_tile_weight_kernel(const short4* __restrict__ rects, int F, int t8,
-                                                             unsigned char* __restrict__ keys, int* __restrict__ busy)
+                                                             unsigned char* __restrict__ keys, int* __restrict__ busy, int shift)
 {
     extern __shared__ int s_d[];                      // (t8 + 1)^2 ints: 4.3 KB for a 256x256 image, 64 KB at the 1016-pixel limit
     const int bn = blockIdx.x, S = t8 + 1, tiles = t8 * t8;
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(512) void sr_tile_weight_kernel(const short4* __res
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (r[k].y < r[k].x || r[k].w < r[k].z) continue;                   // empty rect (culled face)
-            const int tx0 = r[k].x >> 3, tx1 = min((int)r[k].y >> 3, t8 - 1) + 1;
-            const int ty0 = r[k].z >> 3, ty1 = min((int)r[k].w >> 3, t8 - 1) + 1;
+            const int tx0 = r[k].x >> shift, tx1 = min((int)r[k].y >> shift, t8 - 1) + 1;    // shift 3: 8x8-pixel tiles, 4: 16x16
+            const int ty0 = r[k].z >> shift, ty1 = min((int)r[k].w >> shift, t8 - 1) + 1;
             atomicAdd(&s_d[ty0 * S + tx0], 1);
             atomicAdd(&s_d[ty0 * S + tx1], -1);
             atomicAdd(&s_d[ty1 * S + tx0], -1);
@@ -175,11 +175,8 @@ __global__ __launch_bounds__(512) void sr_tile_weight_kernel(const short4* __res
     }
 }
 
-// head (optional, one workgroup per XCD only): head[x] = the number of this XCD's entries with weight >= head_weight -- the
-// crowded tiles sr_forward_mixed_kernel hands to its four-wave body.
 __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned char* __restrict__ keys, int N, int t8,
-                                                                 int* __restrict__ order, int* __restrict__ busy,
-                                                                 int* __restrict__ head, int head_weight)
+                                                                 int* __restrict__ order, int* __restrict__ busy)
 {
     extern __shared__ unsigned char s_key[];
     __shared__ unsigned s_hist[256], s_base[256], s_wave[4];
@@ -224,8 +221,6 @@ __global__ __launch_bounds__(ORDER_THREADS) void sr_order_kernel(const unsigned 
         s_base[threadIdx.x] = above;
     }
     if (busy && threadIdx.x == 0) atomicAdd(busy, entries - (int)s_hist[0]);    // the launch's non-empty tiles: the forward kernels' choice
-    // entries with a key above head_weight - 1 = the first position of that key (before the scatter below advances the bases)
-    if (head && (int)threadIdx.x == head_weight - 1) head[x] = (int)s_base[threadIdx.x];
     __syncthreads();
     int* __restrict__ out = order + e_first;
     const float inv_tiles = 1.f / (float)tiles, inv_t8 = 1.f / (float)t8;
@@ -396,9 +391,8 @@ __device__ __forceinline__ void tile_of_block(int b, int total, int tiles_x, int
 // W1 = one wave per workgroup, the workgroup's tile IS the wave's 8x8 quadrant: no workgroup barrier anywhere and nothing held
 // until the slowest of four waves is done.  Affordable since the group rects (level 0) made the face scan cheap: a lone wave
 // tests the ~40 group rects, then scans only the groups that can touch its 64 pixels, compacting straight into its own list.
-// The tile body of sr_forward_kernel as a device function: the kernel below is a thin wrapper, and sr_forward_mixed_kernel runs the
-// W1 form once per WAVE of a four-wave workgroup (the W1 form has no workgroup barrier).  s_all / s_wcnt: the workgroup's LDS of
-// the four-wave form (unused by W1); mine_lds: this wave's list of LIST_CAP u16 entries.
+// The tile body of sr_forward_kernel as a device function (the kernel below is a thin wrapper).  s_all / s_wcnt: the workgroup's
+// LDS of the four-wave form (unused by W1); mine_lds: this wave's list of LIST_CAP u16 entries.
 template <bool LASR_FAST, int NCH, bool RX, bool W1, int CAP = LIST_CAP>
 __device__ __forceinline__ void forward_tile_body(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors, int bn, int tx, int ty,
                                                   unsigned short* s_all, unsigned short* mine_lds, int (*s_wcnt)[4])
@@ -669,42 +663,8 @@ __global__ __launch_bounds__(256) void sr_forward_kernel(RasterArgs A, float* __
 
 }  // namespace lasr
 #include "sr_forward_coop.h"
+#include "sr_forward_pairs.h"
 namespace lasr {
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// One launch, two bodies, over the launch's ORDERED tile table (sr_order_kernel: every XCD's tiles in descending weight).
-// Between "a few frames" (every tile to the cooperative kernel) and "hundreds" (one wave per tile) lies the range LASR actually
-// launches -- 16 to 96 meshes per render (nnutils/mesh_net.py:318-363) -- where the chip is full of one-wave tiles and the
-// launch still lasts as long as its most crowded tile's serial walk (tools/tile_order_model.py).  With the
-// tiles sorted the choice need not be per launch: the first head[x] entries of XCD x's list (weight >= the threshold, at most
-// head_max) get a four-wave workgroup each and the cooperative body (sr_forward_coop.h: a third to a half of the one-wave
-// latency per entry); the rest are dealt four to a workgroup, one per WAVE, each wave running the barrier-free one-wave body on
-// its own tile -- neighbours in the sorted list have near-equal weights, so the four finish together.  Blocks are issued in
-// index order: the heads start first.  Block b: XCD b & 7, slot i = b >> 3; i < head: entry i; else entries
-// head + 4 (i - head) + wave.  Every tile runs exactly the arithmetic of the kernel it would have had: bit-identical output.
-template <int NCH, int EPW, int E0>
-__global__ __launch_bounds__(256) void sr_forward_mixed_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
-{
-    constexpr int MCAP = 1024;                         // list entries per round of a one-wave tile here (a longer list takes rounds)
-    union Lds {
-        CoopLds<NCH, 4, EPW, E0> coop;
-        unsigned short mine[4][MCAP];
-    };
-    __shared__ Lds L;
-    const int x = blockIdx.x & 7, i = blockIdx.x >> 3, per = A.order_per;
-    const int head = min(__builtin_amdgcn_readfirstlane(A.head[x]), A.head_max);
-    const int* __restrict__ mine_order = A.order + (size_t)x * per;
-    if (i < head) {
-        const int e = __builtin_amdgcn_readfirstlane(mine_order[i]);
-        coop_tile_body<NCH, 4, EPW, E0>(A, aggrs, colors, e >> 16, e & 255, (e >> 8) & 255, L.coop);
-        return;
-    }
-    const int wave = threadIdx.x >> 6;
-    const int slot = head + 4 * (i - head) + wave;
-    if (slot >= per) return;
-    const int e = __builtin_amdgcn_readfirstlane(mine_order[slot]);
-    forward_tile_body<true, NCH, false, true, MCAP>(A, aggrs, colors, e >> 16, e & 255, (e >> 8) & 255, nullptr, L.mine[wave], nullptr);
-}
 
 }  // namespace lasr
 #include "sr_backward.h"
@@ -796,7 +756,6 @@ static RasterArgs make_args(void* ws, const float* textures, int N, int F, int T
     A.choice = nullptr;
     A.choice_max = -1;
     A.order = nullptr;
-    A.head = nullptr; A.order_per = 0; A.head_max = 0;
     return A;
 }
 
@@ -837,12 +796,17 @@ static const long long k_coop_max_tiles = env_blocks("LASR_SR_COOP_MAX_TILES", 1
 static const long long k_choose_max_tiles = env_blocks("LASR_SR_CHOOSE_MAX_TILES", 49152);
 // launches of up to this many 8x8 tiles (five frames and more, tile total a multiple of 8) issue their tiles heaviest first
 static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES", 1ll << 40);
-// ordered launches that would take the one-wave kernel (or leave the choice to the device): tiles of at least this weight (faces
-// whose pixel rect touches the tile) go to the four-wave body of sr_forward_mixed_kernel; 0 = one kernel per launch (the default:
-// measured on an MI355X the one-launch form loses to the better of the two plain kernels at every size -- the tail's tiles are
-// dealt four to a workgroup, which then waits for four free wave slots on one CU and holds them until its slowest wave is done:
-// 64 frames, one wave per tile 0.49 ms, mixed with an empty head 0.61 ms; profiles/experiments/r05_mixed_sweep.txt)
-static const long long k_mixed_min_weight = env_blocks("LASR_SR_MIXED_MIN_WEIGHT", 0);
+// LASR's mode combination, launches of at least this many 8x8 tiles: the pair-walk kernel (sr_forward_pairs.h), whose lanes walk
+// their own pixel's (pixel, face) pairs; smaller launches keep the latency designs above.  Its output differs from theirs in the
+// rounding sequence only (image within ~1e-6).  LASR_SR_PAIR_MIN_TILES at load time, lasr_sr_options.pair_min_tiles per call.
+// Measured on an MI355X (profiles/r06_pairs_ab.txt), mesh M2 at 256x256, forward + order kernels, one wave per tile -> pair walk:
+//   16 frames .188 -> .166 ms, 32: .293 -> .254, 64: .499 -> .463, 128: .971 -> .904, 256: 1.927 -> 1.758; 8 frames: .097 -> .15
+//   (four waves per tile win).  By DEFAULT the kernel is taken for three channels and at most 48 pixels per face only: where the
+//   faces are large against an 8x8 tile the one-wave kernel's lanes are already full (64 frames of M2 at 512x512, 108 pixels per
+//   face: 1.21 -> 1.23 ms; the nine-channel render of spot3 stage 0, 16 meshes of 1280 faces filling the frame: 104 -> 106 us).
+//   An explicit pair_min_tiles applies to every channel count and size.
+static const long long k_pair_min_tiles = env_blocks("LASR_SR_PAIR_MIN_TILES", 16384);
+static const bool k_pair_forced = getenv("LASR_SR_PAIR_MIN_TILES") != nullptr;
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -857,7 +821,6 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const long long g_coop_max_tiles = opt && opt->coop_max_tiles >= 0 ? opt->coop_max_tiles : k_coop_max_tiles;
     const long long g_choose_max_tiles = opt && opt->choose_max_tiles >= 0 ? opt->choose_max_tiles : k_choose_max_tiles;
     const long long g_order_max_tiles = opt && opt->order_max_tiles >= 0 ? opt->order_max_tiles : k_order_max_tiles;
-    const long long g_mixed_min_weight = opt && opt->mixed_min_weight >= 0 ? opt->mixed_min_weight : k_mixed_min_weight;
     int rc = check_common(N, F, T, IS, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type);
     if (rc) return rc;
     if (N == 0 || IS == 0) return LASR_OK;
@@ -876,6 +839,14 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     // the 8x8-tile kernels, five frames and more: this launch's own tile order (sr_order_kernel)
     const int t8o = (IS + 7) / 8;
     const long long tiles8o = (long long)N * t8o * t8o;
+    const long long g_pair_min_tiles = opt && opt->pair_min_tiles >= 0 ? opt->pair_min_tiles : k_pair_min_tiles;
+    // the pair-walk kernel: LASR's modes, default arithmetic, launches from pair_min_tiles up; its tiles are 16x16 pixels
+    const bool pair_any = (opt && opt->pair_min_tiles >= 0) || k_pair_forced;             // explicit threshold: no density rule
+    const bool pairs = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && !(flags & (LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) &&
+                       tiles8o >= g_pair_min_tiles && (pair_any || (nch == 3 && (long long)IS * IS <= 48ll * F));
+    const int tile_shift = pairs ? 4 : 3;
+    const int tso = (IS + (1 << tile_shift) - 1) >> tile_shift;              // tiles per side of the order table
+    const long long tileso = (long long)N * tso * tso;
     // (an XCD walks the crowded tiles of ALL its N / 8 images at once while their records fit about twice its 4 MB L2 -- 128 frames of
     // 2420 faces, 7.4 MB per XCD: forward -8 % -- beyond that the record fetch multiplies for nothing: 256 frames, 14.9 MB: FETCH_SIZE
     // 172 MB -> 1.18 GB per launch.  Larger launches sort and issue the XCD's images four at a time, the interleave of the fixed
@@ -884,11 +855,11 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     static const int order_min_frames = (int)env_blocks("LASR_SR_ORDER_MIN_FRAMES", 5);
     static const int order_group_images = (int)env_blocks("LASR_SR_ORDER_GROUP_IMAGES", 4);
     int order_groups = 1;
-    if ((long long)((N + 7) >> 3) * F * REC * (long long)sizeof(float) > (8ll << 20) || tiles8o > 8ll * ORDER_MAX_ENTRIES)
+    if ((long long)((N + 7) >> 3) * F * REC * (long long)sizeof(float) > (8ll << 20) || tileso > 8ll * ORDER_MAX_ENTRIES)
         order_groups = (N & 7) == 0 && order_group_images > 0 && (N >> 3) % order_group_images == 0 ? (N >> 3) / order_group_images : 0;
-    const bool use_order = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && N >= order_min_frames && (tiles8o & 7) == 0 &&
-                           tiles8o <= g_order_max_tiles && t8o <= ORDER_MAX_SIDE && order_groups > 0 &&
-                           tiles8o <= 8ll * order_groups * ORDER_MAX_ENTRIES && N < 32768;
+    const bool use_order = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && N >= order_min_frames && (tileso & 7) == 0 &&
+                           tiles8o <= g_order_max_tiles && tso <= ORDER_MAX_SIDE && order_groups > 0 &&
+                           tileso <= 8ll * order_groups * ORDER_MAX_ENTRIES && N < 32768;
     char* const slot = (char*)grects + align_up((size_t)N * groups_of_host(F) * sizeof(short4), 256);   // [0] sr_choose_kernel's word
     if (total > 0) {
         {
@@ -918,25 +889,18 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const long long choose_max = nch > 3 ? coop_max : use_order ? g_choose_max_tiles / 16 * 7 : g_choose_max_tiles;
     int plan = !tile_kernels || rx ? 0 : tiles8o <= coop8_max ? 2 : tiles8o <= coop_max ? 1 :
                (tiles8o <= choose_max && total > 0 && coop_max > 0) ? 3 : 0;
-    // 4: the per-range choice over the ordered table (sr_forward_mixed_kernel) where one kernel per launch would be the one-wave
-    // kernel or the device's pick
     const bool seg_flag = (flags & LASR_SR_SEGMENTED) != 0;
-    if (use_order && order_groups == 1 && tile_kernels && !rx && !seg_flag && (plan == 0 || plan == 3) && g_mixed_min_weight > 0 &&
-        g_mixed_min_weight < 256)
-        plan = 4;
+    if (pairs) plan = 5;
+    (void)seg_flag;
     if (use_order) {
         int* order = (int*)(slot + 256);
-        unsigned char* keys = (unsigned char*)order + align_up((size_t)tiles8o * sizeof(int), 256);
+        unsigned char* keys = (unsigned char*)order + align_up((size_t)tileso * sizeof(int), 256);
         int* busy = plan == 3 ? (int*)slot : nullptr;
-        int* head = plan == 4 ? (int*)(slot + 64) : nullptr;
         ProfScope po(K_SR_ORDER, st);
-        hipLaunchKernelGGL(sr_tile_weight_kernel, dim3((unsigned)N), dim3(512), (size_t)(t8o + 1) * (t8o + 1) * sizeof(int), st, rects, F, t8o, keys, busy);
-        hipLaunchKernelGGL(sr_order_kernel, dim3(8 * order_groups), dim3(ORDER_THREADS), align_up((size_t)(tiles8o / 8 / order_groups), 16), st,
-                           keys, N, t8o, order, busy, head, (int)g_mixed_min_weight);
+        hipLaunchKernelGGL(sr_tile_weight_kernel, dim3((unsigned)N), dim3(512), (size_t)(tso + 1) * (tso + 1) * sizeof(int), st, rects, F, tso, keys, busy, tile_shift);
+        hipLaunchKernelGGL(sr_order_kernel, dim3(8 * order_groups), dim3(ORDER_THREADS), align_up((size_t)(tileso / 8 / order_groups), 16), st,
+                           keys, N, tso, order, busy);
         A.order = order;
-        A.head = head;
-        A.order_per = (int)(tiles8o >> 3);
-        A.head_max = A.order_per / 4;
         if (plan == 3) {
             A.choice = busy;
             A.choice_max = (int)std::min<long long>(coop_max_plain / 8 * 3, 0x7fffffff);
@@ -974,12 +938,12 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                 else if (nch == 6) hipLaunchKernelGGL((sr_forward_coop_kernel<6, 4, 1, 0>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else hipLaunchKernelGGL((sr_forward_coop_kernel<3, 4, 2, 1>), grid8, dim3(256), 0, st, A, aggrs_info, soft_colors);
             }
-            if (plan == 4) {
-                // 8 x (head_max + ceil(per / 4)) workgroups: enough for any head up to head_max (the surplus returns at once)
-                const dim3 gridm((unsigned)(8 * (A.head_max + (A.order_per + 3) / 4)));
-                if (nch == 9) hipLaunchKernelGGL((sr_forward_mixed_kernel<9, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
-                else if (nch == 6) hipLaunchKernelGGL((sr_forward_mixed_kernel<6, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
-                else hipLaunchKernelGGL((sr_forward_mixed_kernel<3, 1, 0>), gridm, dim3(256), 0, st, A, aggrs_info, soft_colors);
+            if (plan == 5) {
+                const int t16 = (IS + PW_TILE - 1) / PW_TILE;
+                const dim3 grid16((unsigned)(N * t16 * t16));
+                if (nch == 9) hipLaunchKernelGGL((sr_forward_pairs_kernel<9>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else if (nch == 6) hipLaunchKernelGGL((sr_forward_pairs_kernel<6>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL((sr_forward_pairs_kernel<3>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
             }
             if (plan == 0 || plan == 3) {
                 if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);

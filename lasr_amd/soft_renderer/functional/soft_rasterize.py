@@ -37,16 +37,18 @@ def set_forward_flags(flags):
     return old
 
 
-def set_launch_thresholds(coop8_max_tiles=-1, coop_max_tiles=-1, choose_max_tiles=-1, order_max_tiles=-1, mixed_min_weight=-1):
+def set_launch_thresholds(coop8_max_tiles=-1, coop_max_tiles=-1, choose_max_tiles=-1, order_max_tiles=-1, pair_min_tiles=-1):
     """Launch options this operator passes with every forward call (lasr_sr_options; negative = library default, no argument =
     all defaults): the kernel-choice thresholds and the size limit of the heaviest-first tile order (0 = the fixed centre-out
-    order).  The output is bit-identical whichever kernel runs in whichever order; tests force each one through here."""
+    order), and the launch size from which the pair-walk kernel takes over (pair_min_tiles; 0 = always, huge = never).  The output of
+    the other kernels is bit-identical whichever runs in whichever order; the pair-walk kernel's agrees with theirs to ~1e-6
+    (another accumulation order per pixel).  Tests force each one through here."""
     global _launch_options
-    if coop8_max_tiles < 0 and coop_max_tiles < 0 and choose_max_tiles < 0 and order_max_tiles < 0 and mixed_min_weight < 0:
+    if coop8_max_tiles < 0 and coop_max_tiles < 0 and choose_max_tiles < 0 and order_max_tiles < 0 and pair_min_tiles < 0:
         _launch_options = None
     else:
         _launch_options = _lib.SrOptions(int(coop8_max_tiles), int(coop_max_tiles), int(choose_max_tiles), int(order_max_tiles),
-                                         int(mixed_min_weight))
+                                         int(pair_min_tiles))
 
 
 def _options_ref():

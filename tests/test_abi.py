@@ -136,7 +136,7 @@ def test_options_struct_of_the_python_mirror_is_the_header_s():
     body = re.search(r'typedef struct lasr_sr_options \{(.*?)\} lasr_sr_options;', sr, re.S).group(1)
     fields = re.findall(r'long long\s+(\w+);', body)
     assert fields == [n for n, _ in _lib.SrOptions._fields_] == ['coop8_max_tiles', 'coop_max_tiles', 'choose_max_tiles', 'order_max_tiles',
-                                                                 'mixed_min_weight']
+                                                                 'pair_min_tiles']
     assert all(t is ctypes.c_longlong for _, t in _lib.SrOptions._fields_) and ctypes.sizeof(_lib.SrOptions) == 8 * len(fields)
     h = _lib.lib()
     small, large = h.lasr_sr_workspace_bytes(8, 100, 3, 64), h.lasr_sr_workspace_bytes(8, 100, 3, 256)
