@@ -96,6 +96,7 @@ class RasterStep:
         self.stream = torch.cuda.current_stream(dev).cuda_stream
         self.white = (ctypes.c_float * 3)(1., 1., 1.)
         self.forward_flags = 0                                    # per-call flag of the forward pass (_lib.SR_RELAXED_MATH: opt-in)
+        self.options = None                                       # per-call lasr_sr_options (None = the library's defaults)
         # face -> vertex reduction of the product (lasr_face_gather_backward_csr, geometry.py: _FaceGather): per-frame vertex gradients
         self.faces_n = self.faces_idx[None].expand(B, self.F, 3).contiguous()
         self.gv = torch.empty(2, B, self.V, 3, device=dev)
@@ -110,10 +111,11 @@ class RasterStep:
         # which writes every element of soft_colors (the reference pre-fills and re-reads it, soft_rasterize.py:50-53), and the
         # backward stores every gradient element (LASR_SR_GRADS_OVERWRITE).
         near, far, tail = self.scalars[0], self.scalars[1], self.scalars[2:]
-        rc = h.lasr_sr_forward_bg(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
-                                  self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                                  B, F, 3, 3, IS, near, far, None, *tail, self.white, self.forward_flags, self.stream)
-        _lib.check(rc, 'lasr_sr_forward_bg')
+        rc = h.lasr_sr_forward_opt(self.fv.data_ptr(), self.ft.data_ptr(), None, self.aggrs.data_ptr(),
+                                   self.colors.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                   B, F, 3, 3, IS, near, far, None, *tail, self.white, self.forward_flags,
+                                   ctypes.byref(self.options) if self.options is not None else None, self.stream)
+        _lib.check(rc, 'lasr_sr_forward_opt')
         # the per-face records in the backward, as the autograd operator handles them (soft_rasterize.py: _records_of): the
         # forward's are reused, one launch less (profiles/r04_flag_sweep.txt; --rebuild-records 1 times the other way)
         rebuild = REBUILD_RECORDS > 0
@@ -453,7 +455,7 @@ STEP_CONFIGS = {
                           '512x512, 4 meshes per render'),
 }
 RASTER_KERNELS = ('sr_forward_kernel', 'sr_backward_kernel', 'sr_setup_kernel', 'sr_tile_weight_kernel', 'sr_order_kernel',
-                  'sr_forward_coop_kernel', 'sr_forward_mixed_kernel', 'sr_forward_seg_kernel')
+                  'sr_forward_coop_kernel', 'sr_forward_pairs_kernel', 'sr_forward_pairs3_kernel', 'sr_forward_seg_kernel')
 
 
 def step_worker(name):
@@ -712,7 +714,7 @@ def allreduce_variants_leg(dev, nbytes, world, dist, reps=5):
     return out
 
 
-RASTER_SOURCES = ('sr_raster.hip', 'sr_forward_coop.h', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
+RASTER_SOURCES = ('sr_raster.hip', 'sr_forward_coop.h', 'sr_forward_pairs.h', 'sr_device.h', 'sr_common.h', 'sr_backward.h', 'sr_backward_fast.hip', 'Makefile')
 VALU_PEAK_LANE_OPS = 1024 * 32 * 2.4e9      # 256 CUs x 4 SIMDs, 32 fp32 lanes per SIMD per clock (a wave64 op issues in 2), 2.4 GHz
 
 

@@ -257,15 +257,9 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256)
-#if LASR_PW_WAVES
-__attribute__((amdgpu_waves_per_eu(LASR_PW_WAVES, LASR_PW_WAVES)))
-#endif
-void sr_forward_pairs_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
+__device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors, PairLds<NCH>& L)
 {
-    typedef PairLds<NCH> Lds;
-    constexpr int RS = Lds::RS;
-    __shared__ __attribute__((aligned(16))) Lds L;
+    constexpr int RS = PairLds<NCH>::RS;
 
     const Modes m = Modes{2, 1, 2, 1, 1};               // LASR's configuration: euclidean, softmax, prod, vertex, double-sided
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
@@ -587,6 +581,25 @@ void sr_forward_pairs_kernel(RasterArgs A, float* __restrict__ aggrs, float* __r
     for (int k = 0; k < NCH; k++) colors[((size_t)bn * (NCH + 1) + k) * P + pn] = s.c[k] / s.ssum;
     aggrs[((size_t)bn * 2 + 0) * P + pn] = s.ssum;
     aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
+}
+
+// six / nine channels: the compiler's own register budget (87 / 104 VGPRs; the LDS slots allow six workgroups per CU there anyway)
+template <int NCH>
+__global__ __launch_bounds__(256) void sr_forward_pairs_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
+{
+    __shared__ __attribute__((aligned(16))) PairLds<NCH> L;
+    pairs_tile_body<NCH>(A, aggrs, colors, L);
+}
+// three channels: registers for eight waves per SIMD (64 VGPRs; what that spills sits in the list builder, not in the walk --
+// measured 1.855 -> 1.80 ms at 256 frames, profiles/experiments/r06_pair_walk.md)
+__global__ __launch_bounds__(256)
+#if LASR_PW_WAVES
+__attribute__((amdgpu_waves_per_eu(LASR_PW_WAVES, LASR_PW_WAVES)))
+#endif
+void sr_forward_pairs3_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
+{
+    __shared__ __attribute__((aligned(16))) PairLds<3> L;
+    pairs_tile_body<3>(A, aggrs, colors, L);
 }
 
 }  // namespace lasr

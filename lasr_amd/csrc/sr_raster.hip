@@ -943,7 +943,7 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
                 const dim3 grid16((unsigned)(N * t16 * t16));
                 if (nch == 9) hipLaunchKernelGGL((sr_forward_pairs_kernel<9>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else if (nch == 6) hipLaunchKernelGGL((sr_forward_pairs_kernel<6>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
-                else hipLaunchKernelGGL((sr_forward_pairs_kernel<3>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                else hipLaunchKernelGGL(sr_forward_pairs3_kernel, grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
             }
             if (plan == 0 || plan == 3) {
                 if (nch == 9 && rx) hipLaunchKernelGGL((sr_forward_kernel<true, 9, true, true>), grid8, dim3(64), 0, st, A, aggrs_info, soft_colors);

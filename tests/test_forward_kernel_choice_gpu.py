@@ -1,11 +1,14 @@
-"""The forward pass of LASR's mode combination picks one of three kernels by launch size (lasr_amd/csrc/sr_raster.hip
+"""The forward pass of LASR's mode combination picks one of four kernels by launch size (lasr_amd/csrc/sr_raster.hip
 forward_impl): eight or four waves sharing an 8x8 tile for launches that cannot fill the chip (sr_forward_coop.h), one wave per
-8x8 tile for the rest; in between a one-wave kernel estimates the busy tiles ON THE DEVICE and both candidates are launched.
-The kernels evaluate every (pixel, face) pair with the same instruction sequence and visit the faces of a pixel in index
-order, so their outputs must be IDENTICAL bit for bit: this file forces each one in turn (lasr_sr_options through the operator's set_launch_thresholds,
-include/lasr_sr.h) on the same inputs -- ragged image sizes, 3 / 6 / 9 channels, a tile whose list needs more than one round,
-device-resident near/far, an empty mesh -- and compares the raw bits; one of them is also held against the oracle, which pins
-all of them.  The device-side choice is checked against both of its outcomes."""
+8x8 tile, and -- from 16 frames of 256x256 up -- the pair-walk kernel (sr_forward_pairs.h), whose lanes walk the (pixel, face)
+pairs of their own pixel.  The first three evaluate every pair with the same instruction sequence and visit the faces of a pixel
+in index order, so their outputs must be IDENTICAL bit for bit; the pair-walk kernel evaluates every pair with that same
+sequence but folds a pixel's fragments in another order (inside fragments first, a stolen run merged at the end of a chunk):
+alpha product and depth softmax are symmetric in the fragments, so its image agrees to rounding (<= 1e-6 asked, ~5e-7 measured),
+and the running depth maximum exactly.  This file forces each kernel in turn (lasr_sr_options through the operator's
+set_launch_thresholds, include/lasr_sr.h) on the same inputs -- ragged image sizes, 3 / 6 / 9 channels, a tile whose list needs
+more than one round, device-resident near/far, an empty mesh, degenerate faces -- and compares; the kernels are also held against
+the oracle.  The device-side choice is checked against both of its outcomes."""
 import numpy as np
 import pytest
 import torch
@@ -16,15 +19,12 @@ from lasr_amd.soft_renderer import functional as srf
 pytestmark = pytest.mark.gpu
 
 BIG = 10 ** 12
-#            coop8_max  coop_max  choose_max   (8x8-pixel tiles)   order_max  mixed_min_weight
-VARIANTS = {'eight waves per 8x8 tile': (BIG, BIG, BIG, -1, 0),
-            'four waves per 8x8 tile': (0, BIG, BIG, -1, 0),
-            'one wave per 8x8 tile': (0, 0, 0, -1, 0),
-            # round 5: ONE launch over the ordered tile table, the crowded head four waves per tile, the rest one wave each
-            # (ordered launches only: five frames and more, tile total a multiple of 8 -- elsewhere this is the one-wave kernel)
-            'mixed, tiles of 20+ faces four waves': (0, 0, 0, BIG, 20),
-            'mixed, every non-empty tile four waves (up to a quarter of the list)': (0, 0, 0, BIG, 1),
-            'mixed, nothing heavy enough': (0, 0, 0, BIG, 255)}
+#            coop8_max  coop_max  choose_max   (8x8-pixel tiles)   order_max  pair_min_tiles
+VARIANTS = {'eight waves per 8x8 tile': (BIG, BIG, BIG, -1, BIG),
+            'four waves per 8x8 tile': (0, BIG, BIG, -1, BIG),
+            'one wave per 8x8 tile': (0, 0, 0, -1, BIG)}
+PAIR_WALK = (0, 0, 0, -1, 0)              # round 6: every launch through the pair-walk kernel
+PAIR_TOL = 1e-6
 DEFAULTS = (2200, 14336, 49152)
 
 
@@ -51,6 +51,10 @@ def all_variants(thresholds, dev, fv, ft, IS, kw):
         assert img.shape == out[first].shape
         assert np.array_equal(img.view(np.uint32), out[first].view(np.uint32)), \
             '%s differs from %s: max %.3e' % (name, first, np.abs(img - out[first]).max())
+    srf.set_launch_thresholds(*PAIR_WALK)
+    pw = render(dev, fv, ft, IS, kw)
+    assert pw.shape == out[first].shape and np.isfinite(pw).all()
+    assert np.abs(pw - out[first]).max() <= PAIR_TOL, 'pair walk: max %.3e' % np.abs(pw - out[first]).max()
     return out[first]
 
 
@@ -61,6 +65,9 @@ def test_every_kernel_gives_the_same_bits_on_ragged_image_sizes(thresholds, orac
     img = all_variants(thresholds, cuda, fv, ft, IS, kw)
     ref = oracle.forward(fv, ft, IS, **kw)
     assert np.abs(img - ref['soft_colors']).max() <= 1e-6
+    thresholds('one wave per 8x8 tile')
+    srf.set_launch_thresholds(*PAIR_WALK)
+    assert np.abs(render(cuda, fv, ft, IS, kw) - ref['soft_colors']).max() <= 1e-6      # the pair walk against the oracle itself
 
 
 @pytest.mark.parametrize('channels', [6, 9])
@@ -125,7 +132,7 @@ def test_the_device_side_choice_takes_either_kernel_and_the_bits_do_not_change(t
     import ctypes
     seen = {}
     for coop_max in (300, 40):
-        srf.set_launch_thresholds(0, coop_max, BIG, 0)           # fixed tile order: sr_choose_kernel's bounding-box estimate decides
+        srf.set_launch_thresholds(0, coop_max, BIG, 0, BIG)      # fixed tile order: sr_choose_kernel's bounding-box estimate decides
         got = render(cuda, fv, ft, 64, kw)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
@@ -137,12 +144,34 @@ def test_the_device_side_choice_takes_either_kernel_and_the_bits_do_not_change(t
 
 def test_default_thresholds_pick_by_launch_size(cuda):
     # the defaults are in force outside this file's fixture: a 1-frame and a 16-frame launch go through without error and agree
-    # with each other frame by frame (a frame rendered alone or in a batch gives the same bits)
+    # with each other frame by frame (a frame rendered alone or in a batch gives the same bits -- 1280 faces at 256x256 are 51
+    # pixels per face: over the density the pair-walk kernel is taken for by default, so both launches keep the reference order);
+    # 16 frames of the 2420-face mesh (27 pixels per face) take the pair walk by default: same image to rounding
     fv, ft, near, far = synth.raster_batch(8, 3, count=16)
     kw = dict(synth.LASR_MODES, near=near, far=far)
     batch = render(cuda, fv, ft, 256, kw)
     one = render(cuda, fv[5:6], ft[5:6], 256, kw)
     assert np.array_equal(batch[5:6], one)
+    fv, ft, near, far = synth.raster_batch(11, 3, count=16)
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    batch = render(cuda, fv, ft, 256, kw)
+    one = render(cuda, fv[5:6], ft[5:6], 256, kw)
+    assert np.abs(batch[5:6] - one).max() <= PAIR_TOL and not np.array_equal(batch[5:6], one)
+
+
+def test_the_pair_walk_handles_faces_that_are_not_tame(thresholds, oracle, cuda):
+    # a sliver, a zero-area face, a face in front of the near plane, huge coordinates: records without the tame flag go through
+    # the generic arithmetic at the end of each chunk (sr_forward_pairs.h: the slow mask)
+    fv, ft, near, far = synth.raster_batch(4, 3, count=2)
+    fv = fv.copy()
+    fv[0, 0] = [[0, 0, 3], [0.5, 0.5, 3], [1e-7, 0, 3]]
+    fv[0, 1] = [[0.1, 0.1, 3], [0.1, 0.1, 3], [0.1, 0.1, 3]]
+    fv[1, 2, :, 2] = 1e-9
+    fv[1, 3] = [[-3e4, -2e4, 3], [4e4, -1e4, 3], [0, 5e4, 3]]
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    img = all_variants(thresholds, cuda, fv, ft, 64, kw)
+    ref = oracle.forward(fv, ft, 64, **kw)
+    assert np.abs(img - ref['soft_colors']).max() <= 1e-5
 
 
 # ---- this launch's own tile order (sr_order_kernel): five frames and more issue their 8x8 tiles heaviest first
@@ -244,11 +273,11 @@ def test_ordered_launches_choose_on_the_count_of_non_empty_tiles(cuda):
     kw = dict(synth.LASR_MODES, near=near, far=far)
     h = _lib.lib()
     try:
-        srf.set_launch_thresholds(0, 0, 0, 0)
+        srf.set_launch_thresholds(0, 0, 0, 0, BIG)
         want = render(cuda, fv, ft, IS, kw)
         seen = {}
         for coop_max in (880, 160):                                     # x 3/8 = 330 and 60 non-empty tiles
-            srf.set_launch_thresholds(0, coop_max, BIG, BIG, 0)      # mixed off: the device-side choice of round 4
+            srf.set_launch_thresholds(0, coop_max, BIG, BIG, BIG)    # pair walk off: the device-side choice of round 4
             got = render(cuda, fv, ft, IS, kw)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
             ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
@@ -268,40 +297,21 @@ def test_ordered_launches_choose_on_the_count_of_non_empty_tiles(cuda):
     assert seen == {880: busy, 160: busy}, (seen, busy)
 
 
-def test_the_mixed_launch_hands_exactly_the_heavy_tiles_to_the_four_wave_body(cuda):
-    # 16 frames of 104x104 (13 x 13 tiles, ragged edge) and LASR's own launch (16 meshes, nine channels, 256x256): same bits as the
-    # one-wave kernel for every threshold, and the per-XCD head counts sr_order_kernel leaves next to the table are the numbers
-    # of that XCD's tiles whose weight reaches the threshold
-    import importlib
-    sr_mod = importlib.import_module('lasr_amd.soft_renderer.functional.soft_rasterize')
-    for N, IS, nu, channels in ((16, 104, 4, 3), (16, 256, 8, 9), (40, 64, 4, 6)):
-        fv, ft, near, far = synth.raster_batch(nu, 7, count=N)
-        rng = np.random.default_rng(N)
-        if channels > 3:
-            ft = np.concatenate([ft] + [rng.uniform(-2, 2, ft.shape).astype(np.float32) for _ in range(channels // 3 - 1)], -1)
-        kw = dict(synth.LASR_MODES, near=near, far=far, background_color=[0.125 * k for k in range(channels)])
-        F = fv.shape[1]
-        try:
-            srf.set_launch_thresholds(0, 0, 0, BIG, 0)
-            want = render(cuda, fv, ft, IS, kw)
-            for T in (1, 12, 30, 48, 200):
-                srf.set_launch_thresholds(0, 0, 0, BIG, T)
-                got = render(cuda, fv, ft, IS, kw)
-                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, IS, T)
-                table, rects, t8 = _order_table(cuda, N, F, IS)
-                ws = sr_mod._workspaces[(cuda.index, torch.cuda.current_stream(cuda).cuda_stream)]
-                up = lambda v: (v + 255) // 256 * 256
-                o_slot = (-ws.data_ptr()) % 256 + up(N * F * 48 * 4) + up(N * F * 8) + up(N * ((F + 63) // 64) * 8)
-                head = ws[o_slot + 64:o_slot + 96].view(torch.int32).cpu().numpy()
-                w = np.zeros((N, t8, t8), np.int64)
-                for n in range(N):
-                    for x0, x1, y0, y1 in rects[n]:
-                        if x1 >= x0 and y1 >= y0:
-                            w[n, y0 >> 3:(y1 >> 3) + 1, x0 >> 3:(x1 >> 3) + 1] += 1
-                per = N * t8 * t8 // 8
-                bn, ty, tx = table >> 16, (table >> 8) & 255, table & 255
-                for x in range(8):
-                    mine = slice(x * per, (x + 1) * per)
-                    assert head[x] == int((np.minimum(w[bn[mine], ty[mine], tx[mine]], 255) >= T).sum()), (N, IS, T, x)
-        finally:
-            srf.set_launch_thresholds()
+@pytest.mark.parametrize('count,IS,channels', [(8, 64, 3), (16, 96, 3), (16, 256, 3), (8, 128, 9), (7, 64, 6)])
+def test_the_pair_walk_gives_the_same_bits_in_any_tile_order_and_run_after_run(cuda, count, IS, channels):
+    # which workgroup renders which 16x16 tile changes no tile's arithmetic, and nothing in the kernel depends on timing (the
+    # lanes' pairing is a function of the pair counts): fixed order, the launch's own order, and a second run are identical
+    fv, ft, near, far = synth.raster_batch(4 if IS < 256 else 11, 5, count=count)
+    rng = np.random.default_rng(count)
+    if channels > 3:
+        ft = np.concatenate([ft] + [rng.uniform(-2, 2, ft.shape).astype(np.float32) for _ in range(channels // 3 - 1)], -1)
+    kw = dict(synth.LASR_MODES, near=near, far=far, background_color=[0.125 * k for k in range(channels)])
+    try:
+        srf.set_launch_thresholds(0, 0, 0, 0, 0)
+        a = render(cuda, fv, ft, IS, kw)
+        srf.set_launch_thresholds(0, 0, 0, BIG, 0)
+        b = render(cuda, fv, ft, IS, kw)
+        c = render(cuda, fv, ft, IS, kw)
+    finally:
+        srf.set_launch_thresholds()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
