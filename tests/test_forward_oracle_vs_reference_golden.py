@@ -1,0 +1,95 @@
+"""The composition oracle against the EXECUTED reference (CPU only, no GPU, nothing read from /root/reference at run time).
+
+tests/golden/lasr_forward.npz was written by oracle/gen_forward_golden.py, which imports the reference's own
+`nnutils/mesh_net.py` in the build container and runs `LASR.forward` + backward on three small configurations (the fixture's
+manifest lists what was executed and the handful of replacements: encoder / perceptual network injected, the compiled rasteriser
+served by oracle/sr_oracle.c, three third-party functions by their restatements).  oracle/lasr_forward_oracle.py -- the
+statement-by-statement restatement every `-m gpu` whole-forward test compares the HIP path with -- must reproduce the reference's
+total loss, every loss table, the rendered tables and the gradients of all parameters and of the injected code: that is what
+pins the COMPOSITION (loss weights, reg_decay, term order, masks, detaches, which half of the intrinsics feeds which render)
+instead of leaving it a second reading of the source.
+
+Tolerances: both sides run torch fp32 on the CPU with the same rasteriser; where the two op sequences are the same the values
+agree to the last bits.  The soft rasteriser amplifies one-ulp differences of its geometry input, so the
+render-dependent quantities get 2e-4 of their scale and the gradients 2e-3 of their largest entry (measured: see the asserts'
+messages with -s)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'lasr_forward.npz')
+CASES = ('articulated_two_hypotheses', 'single_hypothesis_unsymmetric', 'rigid_ground_truth_cameras')
+BATCH_KEYS = ('input_imgs  ', 'imgs        ', 'masks       ', 'cams        ', 'depth_gt    ', 'flow        ', 'dts_barrier ',
+              'ddts_barrier', 'mask_contour', 'pp          ', 'occ         ', 'oriimg_shape', 'frameid', 'dataid', 'is_canonical')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(GOLD)
+
+
+def test_the_fixture_says_what_was_executed_and_what_was_replaced(gold):
+    man = json.loads(bytes(gold['manifest']).decode())
+    assert any('LASR.forward' in e for e in man['executed'])
+    assert len(man['arithmetic_stand_ins']) == 4 and all('->' in s for s in man['arithmetic_stand_ins'])
+    assert 'sr_oracle.c' in man['extension']
+    for c in CASES:
+        assert np.isfinite(gold[c + '/total_loss'])
+
+
+def run_oracle(gold, case):
+    from oracle import lasr_forward_oracle as lfo
+    g = lambda k: gold[case + '/' + k]
+    cfg = json.loads(str(g('cfg')))
+    cfg['faces'] = g('faces')
+    cfg['opt_tex'] = True
+    t = lambda a: torch.from_numpy(np.array(a))
+    P = {k[len(case) + 3:]: t(gold[k]).requires_grad_(True) for k in gold.files if k.startswith(case + '/P_')}
+    code = {n: t(g('code_' + n)).requires_grad_(True) for n in ('scale', 'trans', 'quat', 'depth', 'ppoint')}
+    batch = {k: t(g('batch_' + k.strip())) for k in BATCH_KEYS}
+    total, out = lfo.lasr_forward(P, tuple(code[n] for n in ('scale', 'trans', 'quat', 'depth', 'ppoint')), batch, cfg)
+    total.backward()
+    return cfg, P, code, total, out
+
+
+def close(name, a, b, rtol, scale=None):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    s = scale if scale is not None else max(np.abs(b).max(), 1e-12)
+    err = np.abs(a - b).max() / s
+    print('%-40s max err / scale %.2e (scale %.3e)' % (name, err, s))
+    assert err <= rtol, '%s: %.3e of %.3e' % (name, err, s)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_the_composition_oracle_reproduces_the_executed_reference(gold, case):
+    g = lambda k: gold[case + '/' + k]
+    cfg, P, code, total, out = run_oracle(gold, case)
+    K = cfg['n_bones']
+    # the clipping planes the reference derived from the projected vertices (mesh_net.py:304-311): same floats
+    close('near_far', out['near_far'], g('near_far'), 1e-6)
+    close('deform_v', out['deform_v'].detach(), g('aux_deform_v'), 1e-6)
+    # what the three render calls produced
+    close('mask_pred', out['mask_pred'].detach(), g('aux_mask_pred'), 2e-4, 1.0)
+    close('texture_render', out['texture_render'].detach(), g('aux_texture_render'), 2e-4, 1.0)
+    ref_bg = ~g('aux_vis_mask').astype(bool)
+    flow = out['flow_rd'].detach().numpy()
+    ok = ~(out['bgmask'].numpy() | np.isnan(g('aux_flow_rd')).any(-1))
+    close('flow_rd (foreground)', flow[ok], g('aux_flow_rd')[ok], 2e-4, max(np.abs(g('aux_flow_rd')[ok]).max(), 1.0))
+    close('flow_rd_map', np.nan_to_num(out['flow_rd_map'].detach().numpy()) * ~ref_bg, np.nan_to_num(g('aux_flow_rd_map')) * ~ref_bg, 2e-4,
+          max(np.abs(np.nan_to_num(g('aux_flow_rd_map')) * ~ref_bg).max(), 1.0))
+    # the loss tables and the scalar
+    for n in ('mask_loss_sub', 'flow_rd_loss_sub', 'texture_loss_sub', 'triangle_loss_sub', 'cam_loss') + (('lmotion_loss_sub', 'arap_loss') if K > 1 else ()):
+        close(n, out[n].detach(), g('ref_' + n), 2e-4)
+    close('total_loss', total.item(), g('total_loss'), 1e-5)
+    # gradients of every parameter and of the injected code
+    for k, v in P.items():
+        close('grad ' + k, v.grad, g('gP_' + k), 2e-3)
+    for k, v in code.items():
+        close('grad code ' + k, v.grad if v.grad is not None else torch.zeros_like(v), g('gcode_' + k), 2e-3)

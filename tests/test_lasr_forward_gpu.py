@@ -315,3 +315,39 @@ def test_render_syn_with_surface_textures(tmp_path, cuda):
     fg = imgs['s'][mask]
     assert fg.std(0).min() > 5                                  # the atlas pattern shows on the object
     assert np.abs(imgs['s'][mask] - imgs['v'][mask]).mean() > 5  # and differs from the vertex-coloured render
+
+
+def test_normal_consistency_of_the_mesh_evaluation_on_analytic_meshes(cuda):
+    # scripts/eval_mesh.py (reference :165-167,:197): the normal term of chamfer_distance on area-sampled points with face normals.
+    # Two meshes whose normals are known in closed form: an octahedron (every face normal is (+-1, +-1, +-1) / sqrt(3)) and a
+    # finely subdivided sphere (the normal of a face is the direction of its points up to the facet angle).
+    import importlib.util
+    from lasr_amd import synth
+    spec = importlib.util.spec_from_file_location('eval_mesh', os.path.join(ROOT, 'scripts', 'eval_mesh.py'))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    ov = torch.tensor([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=torch.float32, device=cuda)
+    of = torch.tensor([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], device=cuda)
+    p, nrm = ev.sample_points(ov, of, 4000, gen, True)
+    assert torch.allclose(nrm.abs(), torch.full_like(nrm, 3 ** -0.5), atol=1e-6)
+    assert torch.allclose((p * nrm).sum(1), torch.full((4000,), 3 ** -0.5, device=cuda), atol=1e-5)      # outward, on the plane x.n = 1/sqrt(3)
+    assert torch.allclose(p.abs().sum(1), torch.ones(4000, device=cuda), atol=1e-5)                     # |x| + |y| + |z| = 1
+    v, f, _ = synth.blobby_mesh(8)
+    f = torch.from_numpy(np.asarray(f, np.int64)).to(cuda)
+    sphere = torch.nn.functional.normalize(torch.from_numpy(v).float().to(cuda), dim=1)
+    q, nq = ev.sample_points(sphere, f, 4000, gen, True)
+    assert float((torch.nn.functional.normalize(q, dim=1) * nq).sum(1).abs().min()) > 0.97              # facet angle of 1280 faces
+    # the metric: a mesh against itself (other samples), against its copy with every face flipped (abs_cosine: still ~1),
+    # against another shape (lower); the octahedron against itself is 1 up to sampling at the edges
+    same_cd, same_nc = ev.evaluate_pair((sphere, f), (sphere, f), with_normals=True)
+    flip_cd, flip_nc = ev.evaluate_pair((sphere, f.flip(1)), (sphere, f), with_normals=True)
+    blob = torch.from_numpy(v).float().to(cuda)
+    other_cd, other_nc = ev.evaluate_pair((blob, f), (sphere, f), with_normals=True)
+    assert same_nc > 0.97 and abs(flip_nc - same_nc) < 0.01 and other_nc < same_nc - 0.02 and other_cd > 5 * same_cd
+    # closed form for the normal term: every sampled point of octant (+,+,+) matched to a point of the SAME face gives cos = 1
+    x, nx = ev.sample_points(ov, of, 6000, gen, True)
+    y, ny = ev.sample_points(ov, of, 6000, gen, True)
+    cd, norm = ev.chamfer_with_normals(x, nx, y, ny)
+    frac_cross = float(((nx * ny[torch.cdist(x, y).argmin(1)]).sum(1).abs() < 0.99).float().mean())     # neighbours across an edge: |cos| = 1/3
+    assert norm <= 2 * (2. / 3.) * frac_cross + 0.02 and norm < 0.1
