@@ -118,7 +118,7 @@ __device__ __forceinline__ bool reaches_block(RP R, float xlo, float xhi, float 
 // staging: source quads [Q0, Q1) of a record (global layout, sr_device.h) into their staged slots
 __host__ __device__ constexpr bool rec_used(int i) { return i < 15 || (i >= 16 && i < 31) || (i >= 32 && i < 44); }
 template <int Q0, int Q1>
-__device__ __forceinline__ void stage_quads(const float4* __restrict__ src, float* __restrict__ dst, float thr_far)
+__device__ __forceinline__ void stage_quads(const float4* __restrict__ src, float* __restrict__ dst, float thr_far, bool well)
 {
     float4 v[Q1 - Q0];
 #pragma unroll
@@ -130,7 +130,10 @@ __device__ __forceinline__ void stage_quads(const float4* __restrict__ src, floa
         for (int j = 0; j < 4; j++) {
             const int i = 4 * q + j;
             if (!rec_used(i)) continue;
-            if (i >= R_HK2 && i < R_HK2 + 3) { dst[pr_of(i)] = -sqrtf(thr_far / w[j]); continue; }
+            if (i >= R_HK2 && i < R_HK2 + 3) {                 // the far threshold; -inf (never far) unless the face is well conditioned
+                dst[pr_of(i)] = well ? -sqrtf(thr_far / w[j]) : -__builtin_huge_valf();
+                continue;
+            }
             dst[pr_of(i)] = w[j];
             if (i == R_E + 1) dst[PR_EDGE + 3] = w[j];            // e[k][(k+1)%3] once more, as the fourth word of edge k's block
             if (i == R_E + 5) dst[PR_EDGE + 8 + 3] = w[j];
@@ -203,7 +206,7 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
         const bool c12 = n1 & n2, c20 = n2 & n0 & !n1, c01 = n0 & n1 & !n2;
         const bool e1 = (c20 & !o1) | (c01 & o2) | (n0 & !n1 & !n2);
         const bool e2 = (c01 & !o2) | (c12 & o0) | (n1 & !n0 & !n2);
-        const int k = e1 ? 1 : e2 ? 2 : 0;
+        const int k = (int)e1 + 2 * (int)e2;                          // (a pixel projects to exactly one edge: e1 and e2 exclude each other)
         const float* E = R + PR_EDGE + 8 * k;
         const float4 ea = ld4(E);
         const float2 eb = *(const float2*)(E + 4);
@@ -387,11 +390,12 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
                 float tv[(3 * NCH + 3) / 4];
 #pragma unroll
                 for (int i = 0; i < (3 * NCH + 3) / 4; i++) tv[i] = wave + 4 * i < 3 * NCH ? ta[wave + 4 * i] : 0.f;
-                if (wave == 0) stage_quads<0, 3>(src, dst, thr_far);
-                else if (wave == 1) stage_quads<3, 6>(src, dst, thr_far);
-                else if (wave == 2) stage_quads<6, 9>(src, dst, thr_far);
+                const bool well = (__float_as_int(((const float*)src)[R_FLAGS]) & 16) != 0;
+                if (wave == 0) stage_quads<0, 3>(src, dst, thr_far, well);
+                else if (wave == 1) stage_quads<3, 6>(src, dst, thr_far, well);
+                else if (wave == 2) stage_quads<6, 9>(src, dst, thr_far, well);
                 else {
-                    stage_quads<9, 11>(src, dst, thr_far);
+                    stage_quads<9, 11>(src, dst, thr_far, well);
                     // the obtuse corner's operands (see the layout above)
                     const float* f = (const float*)src;
                     const int fl = __float_as_int(f[R_FLAGS]);
@@ -408,12 +412,14 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
             // ---- candidates: bit e of a lane's mask = "entry e's pixel rect holds my pixel" (the exact bbox test, K.cu:375).  Lanes =
             // entries: each turns its rect into a 16-bit column mask and a mask of this wave's rows; one ballot per column / row
             // hands every pixel lane the entries of its column and of its row
-            u64_t cand;
+            u64_t cand, tame_mask;
             {
                 int cm = 0, rm = 0;
+                bool tame_e = false;
                 if (lane < n) {
                     const float* Rl = L.rec + lane * RS;
                     const int lo = __float_as_int(Rl[PR_BB]), ext = __float_as_int(Rl[PR_BB + 1]);
+                    tame_e = (__float_as_int(Rl[PR_FLAGS]) & ok_bit) != 0;
                     if (lo != -1) {
                         const int x0 = (lo & 0xffff) - tX0, r0 = (int)((unsigned)lo >> 16) - tY0;
                         const int x1 = x0 + (ext & 0xffff), r1 = r0 + (int)((unsigned)ext >> 16);
@@ -444,33 +450,35 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
 #endif
                 (void)myrow;
                 cand = valid ? cxv & ryv : 0ull;
+                tame_mask = wave_mask(tame_e);
             }
 #if defined(LASR_PW_ABL) && LASR_PW_ABL == 2        // measurement build: list + stage only
             s.a += (float)__popcll(cand); cand = 0;
 #endif
-            // ---- classify: every lane pops its own candidates; one bit per (pixel, entry) in two planes (01 outside and within
-            // reach, 10 inside, 11 slow = a record that is not tame, 00 dropped)
-            u64_t pa_ = 0, pb_ = 0;
+            // ---- classify: every lane pops its own candidates of TAME records (the others -- or every record of a launch whose
+            // uniforms are not safe for the reciprocal arithmetic -- go to the slow mask as they are): inside the face, or outside
+            // and not certainly beyond the threshold (the staged far[k]: w_k < far[k] puts the pixel farther than sqrt(1.05 thr)
+            // beyond edge k's line; -inf for faces the conservative reject does not apply to)
+            u64_t ms = cand & ~tame_mask, mi = 0, mo = 0;
+            cand &= tame_mask;
             while (wave_mask(cand != 0) != 0) {
                 if (cand != 0) {
                     const int e = __builtin_ctzll(cand);
                     const u64_t rest = cand & (cand - 1), bit = cand ^ rest;
                     cand = rest;
                     const float* R = L.rec + e * RS;
-                    const float4 q0 = ld4(R), q1 = ld4(R + 4), q2 = ld4(R + 8), q3 = ld4(R + PR_HK2);
-                    const int flags = __float_as_int(q2.y);
+                    const float4 q0 = ld4(R), q1 = ld4(R + 4);
+                    const float inv8 = R[8];
+                    const float4 q3 = ld4(R + PR_HK2);
                     const float w0 = q0.x * xp + q0.y * yp + q0.z;                  // barycentric()
                     const float w1 = q0.w * xp + q1.x * yp + q1.y;
-                    const float w2 = q1.z * xp + q1.w * yp + q2.x;
-                    const bool tame = (flags & ok_bit) != 0;                         // else (or an unsafe launch): generic arithmetic
+                    const float w2 = q1.z * xp + q1.w * yp + inv8;
                     const bool inside = (bool)((int)(fminf(fminf(w0, w1), w2) > 0) & (int)(fmaxf(fmaxf(w0, w1), w2) < 1));   // == euclid<.., TAME>
-                    const bool far = (bool)((int)((flags & 16) != 0) & ((int)(w0 < q3.x) | (int)(w1 < q3.y) | (int)(w2 < q3.z)));
-                    const bool a_ = !tame || (!inside && !far), b_ = !tame || inside;
-                    if (a_) pa_ |= bit;
-                    if (b_) pb_ |= bit;
+                    const bool far = (bool)((int)(w0 < q3.x) | (int)(w1 < q3.y) | (int)(w2 < q3.z));
+                    if (inside) mi |= bit;
+                    else if (!far) mo |= bit;
                 }
             }
-            u64_t mi = pb_ & ~pa_, mo = pa_ & ~pb_, ms = pa_ & pb_;
 
 #if defined(LASR_PW_ABL) && LASR_PW_ABL == 1        // measurement build: no walk
             s.a += (float)(__popcll(mi) + 2 * __popcll(mo)); mi = mo = 0;
@@ -481,7 +489,7 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
             const bool no_steal = false;
 #endif
             // ---- balance: rank the lanes by their pair count (heaviest first), partner rank r with rank 63 - r
-            const int kmine = min(__popcll(mi) + __popcll(mo), 63);
+            const int kmine = min((int)__popcll(mi) + (int)__popcll(mo), 63);
             int rank;
             {
                 u64_t Gm = ~0ull;

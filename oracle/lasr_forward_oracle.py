@@ -13,9 +13,14 @@ What is injected instead of computed: the outputs of the encoder + code predicto
 section 2 rows marked OUT) enter as the leaf tensors `code = (scale, trans, quat, depth, ppoint)`; the perceptual
 network is off (`ptex_loss = None`); the pose-noise branch (:220-235, random) is not taken (epoch 0).
 
-PARITY STATUS: nnutils/mesh_net.py cannot be imported here (absl / kornia / pytorch3d missing) and has no tests
-upstream, so this composition is "parity unpinned" like the tables it uses; it is a second, independent, line-by-line
-reading of the reference against which the product's fused kernels + graph-friendly rewrites are compared.
+PARITY STATUS: PINNED.  oracle/gen_forward_golden.py imports the reference's nnutils/mesh_net.py in the build container (with
+placeholder modules for absl / torchvision / trimesh, the encoder and the perceptual network injected, the compiled rasteriser
+served by oracle/sr_oracle.c, and the same three third-party restatements this file uses: its manifest lists them), runs
+`LASR.forward` + backward on three small configurations and stores inputs and outputs in tests/golden/lasr_forward.npz;
+tests/test_forward_oracle_vs_reference_golden.py holds this file to it: total loss bit for bit, tables and gradients to ~1e-6.
+(That run also showed what mesh_net.py:281 does on a CPU -- `Rmat[:,1:] = Rmat[:,1:].permute(0,1,3,2)` copies a tensor onto
+itself through a transposed view; see the generator's note -- this file restates the statement out of place, as the transpose
+the code means and the device computes.)
 """
 import numpy as np
 import torch

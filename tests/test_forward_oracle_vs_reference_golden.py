@@ -9,10 +9,9 @@ total loss, every loss table, the rendered tables and the gradients of all param
 pins the COMPOSITION (loss weights, reg_decay, term order, masks, detaches, which half of the intrinsics feeds which render)
 instead of leaving it a second reading of the source.
 
-Tolerances: both sides run torch fp32 on the CPU with the same rasteriser; where the two op sequences are the same the values
-agree to the last bits.  The soft rasteriser amplifies one-ulp differences of its geometry input, so the
-render-dependent quantities get 2e-4 of their scale and the gradients 2e-3 of their largest entry (measured: see the asserts'
-messages with -s)."""
+Tolerances: both sides run torch fp32 on the CPU with the same rasteriser.  Measured (pytest -s prints every figure): the total
+loss agrees BIT FOR BIT in all three configurations, the loss tables to 1e-7, the rendered tables to 1.6e-6, the gradients to
+1.2e-6 of their largest entry.  Asked: 2e-5 everywhere (1e-6 for the scalar)."""
 import json
 import os
 import sys
@@ -76,20 +75,20 @@ def test_the_composition_oracle_reproduces_the_executed_reference(gold, case):
     close('near_far', out['near_far'], g('near_far'), 1e-6)
     close('deform_v', out['deform_v'].detach(), g('aux_deform_v'), 1e-6)
     # what the three render calls produced
-    close('mask_pred', out['mask_pred'].detach(), g('aux_mask_pred'), 2e-4, 1.0)
-    close('texture_render', out['texture_render'].detach(), g('aux_texture_render'), 2e-4, 1.0)
+    close('mask_pred', out['mask_pred'].detach(), g('aux_mask_pred'), 2e-5, 1.0)
+    close('texture_render', out['texture_render'].detach(), g('aux_texture_render'), 2e-5, 1.0)
     ref_bg = ~g('aux_vis_mask').astype(bool)
     flow = out['flow_rd'].detach().numpy()
     ok = ~(out['bgmask'].numpy() | np.isnan(g('aux_flow_rd')).any(-1))
-    close('flow_rd (foreground)', flow[ok], g('aux_flow_rd')[ok], 2e-4, max(np.abs(g('aux_flow_rd')[ok]).max(), 1.0))
-    close('flow_rd_map', np.nan_to_num(out['flow_rd_map'].detach().numpy()) * ~ref_bg, np.nan_to_num(g('aux_flow_rd_map')) * ~ref_bg, 2e-4,
+    close('flow_rd (foreground)', flow[ok], g('aux_flow_rd')[ok], 2e-5, max(np.abs(g('aux_flow_rd')[ok]).max(), 1.0))
+    close('flow_rd_map', np.nan_to_num(out['flow_rd_map'].detach().numpy()) * ~ref_bg, np.nan_to_num(g('aux_flow_rd_map')) * ~ref_bg, 2e-5,
           max(np.abs(np.nan_to_num(g('aux_flow_rd_map')) * ~ref_bg).max(), 1.0))
     # the loss tables and the scalar
     for n in ('mask_loss_sub', 'flow_rd_loss_sub', 'texture_loss_sub', 'triangle_loss_sub', 'cam_loss') + (('lmotion_loss_sub', 'arap_loss') if K > 1 else ()):
-        close(n, out[n].detach(), g('ref_' + n), 2e-4)
-    close('total_loss', total.item(), g('total_loss'), 1e-5)
+        close(n, out[n].detach(), g('ref_' + n), 2e-5)
+    close('total_loss', total.item(), g('total_loss'), 1e-6)
     # gradients of every parameter and of the injected code
     for k, v in P.items():
-        close('grad ' + k, v.grad, g('gP_' + k), 2e-3)
+        close('grad ' + k, v.grad, g('gP_' + k), 2e-5)
     for k, v in code.items():
-        close('grad code ' + k, v.grad if v.grad is not None else torch.zeros_like(v), g('gcode_' + k), 2e-3)
+        close('grad code ' + k, v.grad if v.grad is not None else torch.zeros_like(v), g('gcode_' + k), 2e-5)
