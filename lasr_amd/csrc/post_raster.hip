@@ -563,20 +563,25 @@ __global__ __launch_bounds__(256) void raster_faces_backward_kernel(RfArgs A, co
     }
 }
 
-// one block per mesh: the block partials are staged into LDS by all threads (coalesced, all loads in flight), then three threads
-// add them up in block order
+// one block per mesh: the block partials are staged into LDS by all threads (coalesced, all loads in flight), 1024 blocks at a
+// time -- any number of vertices -- then three threads add them up in block order
+constexpr int RF_FOLD_CHUNK = 1024;
 __global__ __launch_bounds__(256) void raster_faces_fold_kernel(const float* __restrict__ part, float* __restrict__ g_pp,
                                                                 float* __restrict__ g_fl, int N, int nblk)
 {
-    extern __shared__ float stage[];
+    __shared__ float stage[RF_FOLD_CHUNK * 4];
     const int m = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < nblk * 4; i += 256) stage[i] = part[(size_t)m * nblk * 4 + i];
-    __syncthreads();
-    if (tid < 3) {
-        float t = 0.f;
-        for (int b = 0; b < nblk; b++) t += stage[b * 4 + tid];                           // block order
-        if (tid < 2) g_pp[2 * m + tid] = t; else g_fl[m] = t;
+    float t = 0.f;
+    for (int b0 = 0; b0 < nblk; b0 += RF_FOLD_CHUNK) {
+        const int nb = min(RF_FOLD_CHUNK, nblk - b0);
+        if (b0) __syncthreads();
+        for (int i = tid; i < nb * 4; i += 256) stage[i] = part[((size_t)m * nblk + b0) * 4 + i];
+        __syncthreads();
+        if (tid < 3)
+            for (int b = 0; b < nb; b++) t += stage[b * 4 + tid];                         // block order
     }
+    if (tid < 2) g_pp[2 * m + tid] = t;
+    else if (tid == 2) g_fl[m] = t;
 }
 
 }  // namespace lasr
@@ -628,8 +633,7 @@ extern "C" int lasr_raster_faces_backward(const float* verts_cam, const float* f
                 grad_face_attrs, grad_verts_cam, grad_tex, scratch);
     int rc = launch_ok();
     if (rc) return rc;
-    if ((size_t)nblk * 16 > 60000) return LASR_E_BADARG;                    // V <= 60 000 vertices per mesh
-    LASR_LAUNCH(K_RASTER_FACES, raster_faces_fold_kernel, dim3(N), dim3(256), (size_t)nblk * 16, scratch, grad_pp, grad_fl, N, nblk);
+    LASR_LAUNCH(K_RASTER_FACES, raster_faces_fold_kernel, dim3(N), dim3(256), 0, scratch, grad_pp, grad_fl, N, nblk);
     return launch_ok();
 }
 

@@ -22,16 +22,23 @@ def compute_dt_barrier(mask, k=50):
 
 
 def contour_vertices(mask):
-    """The vertex set of skimage.measure.find_contours(mask, 0) for a 0 / 1 mask, as (row, col) pixel coordinates (image.py:146).
-    Marching squares places a vertex on every cell edge that joins a pixel above the level to one that is not, at
-    from + (level - v_from) / (v_to - v_from) * (to - from); with level 0 and values in {0, 1} that fraction is 0 when the edge starts
-    at the background pixel and 1 when it ends there: every vertex sits exactly ON the background pixel.  The set is therefore the
-    background pixels that have a foreground 4-neighbour inside the image (skimage, absent from this image, is restated from its
-    published algorithm: parity unpinned; tests/test_dataloader.py enumerates the cell edges independently)."""
+    """The vertices of skimage.measure.find_contours(mask, 0) for a 0 / 1 mask, as (row, col) pixel coordinates (image.py:146),
+    one per crossed cell edge.  Marching squares places a vertex on every cell edge that joins a pixel above the level to one that
+    is not, at from + (level - v_from) / (v_to - v_from) * (to - from); with level 0 and values in {0, 1} that fraction is 0 when
+    the edge starts at the background pixel and 1 when it ends there: every vertex sits exactly ON the background pixel.  So the
+    vertex LIST is: every background pixel once per foreground 4-neighbour inside the image (a background pixel in a concave
+    corner of the silhouette appears two or three times, which weights sample_contour's draw the way the reference's concatenated
+    contours do).  Not reproduced: find_contours closes a contour by repeating its first point -- one extra copy of one vertex
+    per connected contour, at a position that depends on skimage's traversal order.  (skimage is absent from this image and
+    restated from its published algorithm: parity unpinned; tests/test_dataloader.py enumerates the cell edges independently.)"""
     m = np.asarray(mask) > 0
-    near = np.zeros_like(m)
-    near[1:] |= m[:-1]; near[:-1] |= m[1:]; near[:, 1:] |= m[:, :-1]; near[:, :-1] |= m[:, 1:]
-    return np.argwhere(near & ~m).astype(np.float64)
+    bg = ~m
+    parts = []
+    for fg_shifted, sl in ((m[:-1], np.s_[1:, :]), (m[1:], np.s_[:-1, :]), (m[:, :-1], np.s_[:, 1:]), (m[:, 1:], np.s_[:, :-1])):
+        hit = np.zeros_like(m)
+        hit[sl] = fg_shifted                                         # the neighbour above / below / left / right is foreground
+        parts.append(np.argwhere(hit & bg))
+    return np.concatenate(parts).astype(np.float64)
 
 
 def sample_contour(mask, sample_size=1000, seed=None):

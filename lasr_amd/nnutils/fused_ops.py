@@ -230,6 +230,8 @@ def face_incidence(faces, num_vertices):
     torch ops; callers cache it per connectivity (LASR.forward: with its repeated face tensor)."""
     N = faces.shape[0]
     flat = faces.reshape(N, -1).long()
+    if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= num_vertices):      # (built once per connectivity: one sync)
+        raise ValueError('face indices must lie in [0, %d)' % num_vertices)
     order = torch.argsort(flat, dim=1, stable=True)                  # stable: ascending corner id inside a vertex
     counts = torch.zeros(N, num_vertices, dtype=torch.long, device=faces.device)
     counts.scatter_add_(1, flat, torch.ones_like(flat))
@@ -251,6 +253,13 @@ class _RasterFaces(Function):
         if faces.shape[0] not in (1, N) or inc_ptr.shape[0] != faces.shape[0] or inc.shape[0] != faces.shape[0]:
             raise ValueError('faces / incidence must be [N,...] or [1,...] (shared connectivity)')
         F_ = faces.shape[1]
+        # the backward walks inc_ptr / inc without bounds checks: a structure built for another mesh (or left as int64) must not
+        # reach the kernels
+        if (inc_ptr.dtype != torch.int32 or inc.dtype != torch.int32 or not inc_ptr.is_contiguous() or not inc.is_contiguous()
+                or tuple(inc_ptr.shape[1:]) != (V + 1,) or tuple(inc.shape[1:]) != (3 * F_,)):
+            raise ValueError('incidence must be face_incidence(faces, V): int32, contiguous, [Nf, V + 1] and [Nf, 3 F] '
+                             '(got %s %s and %s %s for V = %d, F = %d)' % (inc_ptr.dtype, tuple(inc_ptr.shape), inc.dtype,
+                                                                            tuple(inc.shape), V, F_))
         dev = verts_cam.device
         h = _lib.lib()
         fv = torch.empty(N, F_, 3, 3, dtype=torch.float32, device=dev)

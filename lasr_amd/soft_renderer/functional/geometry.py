@@ -10,35 +10,60 @@ import torch.nn.functional as F
 
 # Connectivity that outlives a call (LASR's repeated face tensor, a Mesh rendered every iteration): the backward's vertex-centric
 # sums then run over a CSR incidence structure built once (nnutils/fused_ops.face_incidence) instead of scanning the face tensor in
-# every call.  The cache is keyed by the tensor OBJECT (a weak reference: an entry dies with its tensor, so a recycled address can
-# never be mistaken for it) and its version counter (in-place edits); the structure is built the second time a tensor is seen --
-# a face tensor made for one call costs nothing.
+# every call.  The cache is keyed by the CALLER's tensor object (a weak reference: an entry dies with its tensor, so a recycled
+# address can never be mistaken for it -- and an int32 face tensor is recognised although its int64 copy is new in every call) and
+# checked against its storage address, shape, dtype and version counter.  The structure is built the second time a tensor is seen
+# -- a face tensor made for one call costs nothing.
+# Edits the version counter does not see (`faces.data[...] = ...`, `set_`) leave a stale structure behind: call
+# invalidate_incidence(faces) after such an edit (in-place operations on the tensor itself are tracked).
 _INC_CACHE = {}
 _INC_CACHE_MAX = 16
+_INC_CLOCK = [0]
 
 
-def _incidence_of(faces, num_vertices):
+def _inc_signature(faces, num_vertices):
+    return (faces.data_ptr(), tuple(faces.shape), faces.dtype, faces._version, num_vertices)
+
+
+def invalidate_incidence(faces=None):
+    """Forget the cached incidence structure of `faces` (or of every tensor): needed only after an edit that bypasses the
+    tensor's version counter."""
+    if faces is None:
+        _INC_CACHE.clear()
+    else:
+        _INC_CACHE.pop(id(faces), None)
+
+
+def _incidence_of(faces, num_vertices, faces_long=None):
+    """faces: the tensor the caller passed (the cache key); faces_long: its contiguous int64 form, if already made."""
     import weakref
     key = id(faces)
     ent = _INC_CACHE.get(key)
-    if ent is not None and (ent[0]() is not faces or ent[1] != faces._version or ent[2] != num_vertices):
+    _INC_CLOCK[0] += 1
+    if ent is not None and (ent[0]() is not faces or ent[1] != _inc_signature(faces, num_vertices)):
         ent = None
     if ent is None:
         if len(_INC_CACHE) >= _INC_CACHE_MAX:
-            # only entries of dead tensors are dropped: a structure that was handed out may sit in a captured HIP graph, which needs
-            # it for as long as it needs the face tensor itself -- and that tensor's entry keeps the structure alive
+            # entries of dead tensors go first; then the least recently seen tensor whose structure was never built (nothing holds
+            # it).  A structure that was handed out may sit in a captured HIP graph, which needs it for as long as it needs the face
+            # tensor itself -- and that tensor's entry keeps the structure alive: such entries stay
             for k in [k for k, e in _INC_CACHE.items() if e[0]() is None]:
                 _INC_CACHE.pop(k, None)
             if len(_INC_CACHE) >= _INC_CACHE_MAX:
-                return None                              # every slot belongs to a live face tensor: this one keeps the scanning kernel
-        _INC_CACHE[key] = [weakref.ref(faces), faces._version, num_vertices, None]
+                idle = [(e[3], k) for k, e in _INC_CACHE.items() if e[2] is None]
+                if not idle:
+                    return None                          # every slot holds a live structure: this tensor keeps the scanning kernel
+                _INC_CACHE.pop(min(idle)[1], None)
+        _INC_CACHE[key] = [weakref.ref(faces), _inc_signature(faces, num_vertices), None, _INC_CLOCK[0]]
         return None
-    if ent[3] is None:
+    ent[3] = _INC_CLOCK[0]
+    if ent[2] is None:
         if faces.is_cuda and torch.cuda.is_current_stream_capturing():
             return None                                  # (built eagerly, outside a capture: argsort allocates)
         from ...nnutils import fused_ops
-        ent[3] = fused_ops.face_incidence(faces if faces.dim() == 3 else faces[None], num_vertices)      # [F,3]: one shared mesh
-    return ent[3]
+        fl = faces_long if faces_long is not None else faces.contiguous().long()
+        ent[2] = fused_ops.face_incidence(fl if fl.dim() == 3 else fl[None], num_vertices)      # [F,3]: one shared mesh
+    return ent[2]
 
 
 class _FaceGather(torch.autograd.Function):
@@ -48,6 +73,7 @@ class _FaceGather(torch.autograd.Function):
     def forward(ctx, attr, faces):
         from ... import _lib
         attr = attr.contiguous()
+        faces_key = faces
         faces = faces.contiguous().long()
         N, V, C = attr.shape
         F_ = faces.shape[1]
@@ -58,7 +84,7 @@ class _FaceGather(torch.autograd.Function):
         _lib.check(rc, 'lasr_face_gather_forward')
         ctx.save_for_backward(faces)
         ctx.dims = (N, V, F_, C)
-        ctx.inc = _incidence_of(faces, V)
+        ctx.inc = _incidence_of(faces_key, V, faces)
         return out
 
     @staticmethod

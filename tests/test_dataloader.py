@@ -76,8 +76,24 @@ def test_contour_vertices_are_the_marching_squares_vertices_at_level_zero():
     shapes = [((xx - 19.3) ** 2 + (yy - 17.8) ** 2 <= 11 ** 2), np.zeros((40, 40), bool), (xx + yy) % 7 == 0]
     shapes[1][5:30, 8:9] = True; shapes[1][0:6, 20:30] = True                      # a one-pixel line and a block touching the border
     for s in shapes:
-        got = {tuple(v) for v in iu.contour_vertices(s.astype(np.float64)).tolist()}
+        verts = iu.contour_vertices(s.astype(np.float64))
+        got = {tuple(v) for v in verts.tolist()}
         assert got == _marching_squares_vertices(s.astype(np.float64))
+        # one vertex per crossed cell EDGE (the list find_contours' contours add up to, minus each closed contour's repeated first
+        # point): a background pixel appears once per foreground 4-neighbour -- counted here edge by edge
+        edges = {}
+        H, W = s.shape
+        for r in range(H):
+            for c in range(W):
+                for rr, cc in ((r, c + 1), (r + 1, c)):
+                    if rr < H and cc < W and s[r, c] != s[rr, cc]:
+                        bg = (r, c) if not s[r, c] else (rr, cc)
+                        edges[(float(bg[0]), float(bg[1]))] = edges.get((float(bg[0]), float(bg[1])), 0) + 1
+        mult = {}
+        for v in verts.tolist():
+            mult[tuple(v)] = mult.get(tuple(v), 0) + 1
+        assert mult == edges
+    assert max(np.unique(iu.contour_vertices(shapes[0].astype(np.float64)), axis=0, return_counts=True)[1]) >= 2    # the disc has concave pixel corners
 
 
 def write_sequence(root, name='toy', n=4, W=96, H=80, step=(5, -3)):
