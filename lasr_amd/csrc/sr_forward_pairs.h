@@ -175,6 +175,15 @@ __device__ __forceinline__ float sigmoid_from_exp(float e)
     return (float)__builtin_fma(__builtin_fma(-x, y, 1.), y, y);
 }
 
+// clamp to [0, 1] of a finite value as the output modifier of a multiplication by one (v_mul_f32 issues at the fma rate, v_med3 /
+// v_max at 0.6 of it, profiles/r04_ubench_mix.txt); same value as v_med3(x, 0, 1) up to the sign of a zero
+__device__ __forceinline__ float clamp01(float x)
+{
+    float r;
+    asm("v_mul_f32_e64 %0, 1.0, %1 clamp" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // merge of a partial state P (fragments folded on their own, starting from "no fragment": a = 1, sum 0, reference level
 // smax = eps) into S:  a = a_S a_P;  m = max(m_S, m_P);  sum = sum_S e^((m_S - m) / gamma) + sum_P e^((m_P - m) / gamma)
 template <int NCH>
@@ -234,15 +243,15 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
         // K.cu:113-150: which edge (sign pattern of the barycentrics, obtuse-corner override), ONE clamped projection
         const bool over = (xp - ob.x) * ob.z + (yp - ob.y) * ob.w > 0;
         const int sh = (w0 <= 0 ? 2 : 0) | (w1 <= 0 ? 4 : 0) | (w2 <= 0 ? 8 : 0) | (over ? 16 : 0);
-        const int k = (int)((__float_as_uint(q2.w) >> sh) & 3u);
+        const int k = (int)__builtin_amdgcn_ubfe(__float_as_uint(q2.w), (unsigned)sh, 2u);
         const float* E = R + PR_EDGE + 8 * k;
         const float4 ea = ld4(E);
         const float2 eb = *(const float2*)(E + 4);
         const float num = w0 * ea.x + w1 * ea.y + w2 * ea.z - ea.w;
         float ta = div_by_recip(num, eb.x, eb.y);
         float tb = 1 - ta;
-        ta = fminf(fmaxf(ta, 0.f), 1.f);
-        tb = fminf(fmaxf(tb, 0.f), 1.f);
+        ta = clamp01(ta);
+        tb = clamp01(tb);
         // t[k] = ta, t[(k + 1) % 3] = tb, the third 0, by exact 0 / 1 factors (ta, tb lie in [0, 1]: every product and sum is exact)
         const float4 fa = ld4(SEL + 8 * k);
         const float2 fb = *(const float2*)(SEL + 8 * k + 4);
@@ -258,14 +267,16 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
 #pragma unroll
     for (int q = 0; q < (3 * NCH + 3) / 4; q++) tq[q] = ld4(R + PR_TEX + 4 * q);
     const float D = sigmoid_from_exp(exp_1ulp(div_by_recip1(narg, A.sigma, U.inv_sigma)));
-    s.a = (float)((double)s.a * (1. - (double)D));                                   // K.cu:409-417
+    // K.cu:409-417, (float)((double)a * (1. - (double)D)): a - a D in ONE rounding is that product rounded once -- the same float
+    // except where the double rounding of the reference's form shows (about one product in 2^29)
+    s.a = __builtin_fmaf(-s.a, D, s.a);
 #if LASR_PW_FENCE & 2
     PW_LANDED(q6);
 #pragma unroll
     for (int q = 0; q < (3 * NCH + 3) / 4; q++) PW_LANDED(tq[q]);
 #endif
     // clip / normalise (K.cu:53-58) and depth (K.cu:423) with single-correction quotients (div_by_recip1)
-    float c0 = __builtin_amdgcn_fmed3f(w0, 0.f, 1.f), c1 = __builtin_amdgcn_fmed3f(w1, 0.f, 1.f), c2 = __builtin_amdgcn_fmed3f(w2, 0.f, 1.f);
+    float c0 = clamp01(w0), c1 = clamp01(w1), c2 = clamp01(w2);
     {
         const float sm = fmaxf(c0 + c1 + c2, 1e-5f);
         float y = __builtin_amdgcn_rcpf(sm);
@@ -286,7 +297,8 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
     const float Ex = exp_1ulp(div_by_recip1(d, A.gamma, U.inv_gamma));
     const float hist = up ? Ex : 1.f, wgt = up ? D : Ex * D;
     s.smax = max_finite(zn, s.smax);
-    s.ssum = hist * s.ssum + wgt;
+    // (the sums as fused multiply-adds: the pair walk folds a pixel's fragments in its own order anyway, see the header)
+    s.ssum = __builtin_fmaf(hist, s.ssum, wgt);
     float tex[3 * NCH];
 #pragma unroll
     for (int q = 0; q < (3 * NCH + 3) / 4; q++) {
@@ -297,7 +309,10 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
         if (4 * q + 3 < 3 * NCH) tex[4 * q + 3] = t.w;
     }
 #pragma unroll
-    for (int k = 0; k < NCH; k++) s.c[k] = hist * s.c[k] + wgt * (c0 * tex[k] + c1 * tex[NCH + k] + c2 * tex[2 * NCH + k]);
+    for (int k = 0; k < NCH; k++) {
+        const float col = __builtin_fmaf(c2, tex[2 * NCH + k], __builtin_fmaf(c1, tex[NCH + k], c0 * tex[k]));
+        s.c[k] = __builtin_fmaf(wgt, col, hist * s.c[k]);
+    }
 }
 
 template <int NCH>
