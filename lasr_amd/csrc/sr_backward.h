@@ -20,6 +20,9 @@ namespace lasr {
 // compaction they would idle through the heavy code.  The heavy code uses v_rcp/v_exp based math
 // (FM = true): the reference backward is itself only defined up to float-atomic ordering.
 constexpr bool BWD_FM = true;
+#ifndef LASR_BWD_ONE
+#define LASR_BWD_ONE 1      // one edge projection per pixel for well-conditioned faces (sr_device.h: euclid_one)
+#endif
 constexpr int QCAP = 128;   // ring entries per wave (power of two, >= 2 * 64)
 constexpr int BWD_THREADS = 64;   // one wave per workgroup (see backward_impl)
 
@@ -185,6 +188,12 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
 
         float w0, w1, w2;
         Frag fr;
+#if LASR_BWD_ONE
+        // (wave-uniform choice: the face's flags)
+        if (LASR_FAST && (flags & 16)) {
+            if (!fragment_one(rec, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+        } else
+#endif
         if (!fragment<FM, cptr_t, (OPT_BWD_MATH && LASR_FAST)>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
         const float D = fr.D;
 #if defined(LASR_BWD_ABL) && LASR_BWD_ABL == 2       // measurement build: + the distance code, nothing after it (no plane loads)

@@ -464,6 +464,67 @@ __device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
     return true;
 }
 
+// Well-conditioned faces (flags bit 4), euclidean distance: ONE edge projection per pixel, inside or outside, wherever the choice of
+// the edge is clear.  K.cu:61-110 projects an inside pixel on all three edge LINES (no clamp) and keeps the nearest: that is the
+// line with the smallest perpendicular distance d_k = w_k h_k (h_k = height of vertex k over its opposite edge, hk2 = h_k^2 in
+// the record).  The three products q = w_k^2 hk2_k cost six multiplications; when the smallest is below the second smallest by
+// more than NEAR_TIE (the reference's own projections are only accurate to a fraction of a percent on small faces, so its
+// choice near an angle bisector is decided by its rounding), only that projection is evaluated -- by the same instructions on the
+// same barycentrics as edge_project<k>, hence with the bits the three-projection form gives for that edge.  The clamp of the
+// outside branch is a no-op for an inside pixel (the foot of the perpendicular on the nearest line lies on the triangle's
+// boundary), so both kinds of pixel share the three exec-masked projections.  Inside pixels near a bisector take the reference's
+// three projections (a region most batches skip).  Why: in the bench launch 15 % of the surviving pixels of a face are inside and
+// nearly every batch holds some -- the three-projection branch ran for every batch at ~10 live lanes.
+constexpr float NEAR_TIE = 0.985f;
+template <typename RP>
+__device__ __forceinline__ void euclid_one(RP rec, float xp, float yp, float w0, float w1, float w2, Frag& fr)
+{
+#pragma clang fp contract(off)   // see edge_project
+    const float x0 = rec[R_FACE + 0], y0 = rec[R_FACE + 1], x1 = rec[R_FACE + 3], y1 = rec[R_FACE + 4], x2 = rec[R_FACE + 6], y2 = rec[R_FACE + 7];
+    const bool inside = (bool)((int)(fminf(fminf(w0, w1), w2) > 0) & (int)(fmaxf(fmaxf(w0, w1), w2) < 1));
+    const int flags = __float_as_int(rec[R_FLAGS]);
+    const bool n0 = w0 <= 0, n1 = w1 <= 0, n2 = w2 <= 0;
+    bool o0 = false, o1 = false, o2 = false;
+    if (flags & 7) {
+        if (flags & 1) o0 = (xp - x0) * (x2 - x0) + (yp - y0) * (y2 - y0) > 0;
+        if (flags & 2) o1 = (xp - x1) * (x0 - x1) + (yp - y1) * (y0 - y1) > 0;
+        if (flags & 4) o2 = (xp - x2) * (x1 - x2) + (yp - y2) * (y1 - y2) > 0;
+    }
+    const bool c12 = n1 & n2, c20 = n2 & n0 & !n1, c01 = n0 & n1 & !n2;
+    bool e1 = (c20 & !o1) | (c01 & o2) | (n0 & !n1 & !n2);
+    bool e2 = (c01 & !o2) | (c12 & o0) | (n1 & !n0 & !n2);
+    // inside: edge k (from vertex k to k + 1, edge_project<k>) is the one opposite vertex (k + 2) % 3, at distance w_{k+2} h_{k+2}
+    const float q0 = w2 * w2 * rec[R_HK2 + 2], q1 = w0 * w0 * rec[R_HK2 + 0], q2 = w1 * w1 * rec[R_HK2 + 1];   // edge 0, 1, 2
+    const float qlo = fminf(fminf(q0, q1), q2), qmid = __builtin_amdgcn_fmed3f(q0, q1, q2);
+    const bool tie = (bool)((int)inside & (int)!(qlo < NEAR_TIE * qmid));
+    float u0, u1, u2;
+    if (tie) {
+        float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
+#define LASR_TRY_EDGE(K)                                                          \
+        edge_project<K, false, true, false, RP, true>(rec, w0, w1, w2, u0, u1, u2);   \
+        {                                                                         \
+            const float px = u0 * x0 + u1 * x1 + u2 * x2;                         \
+            const float py = u0 * y0 + u1 * y1 + u2 * y2;                         \
+            const float d2 = px * px + py * py;                                   \
+            if (d2 < best) { best = d2; bx = px; by = py; b0 = u0; b1 = u1; b2 = u2; } \
+        }
+        LASR_TRY_EDGE(0) LASR_TRY_EDGE(1) LASR_TRY_EDGE(2)
+#undef LASR_TRY_EDGE
+        fr.dx = bx; fr.dy = by; u0 = b0; u1 = b1; u2 = b2;
+    } else {
+        const bool i1 = q1 == qlo, i2 = q2 == qlo;      // (clear of a tie: exactly one)
+        e1 = inside ? i1 : e1;
+        e2 = inside ? i2 : e2;
+        const bool e0 = !(e1 | e2);
+        if (e0) edge_project<0, true, true, false, RP, true>(rec, w0, w1, w2, u0, u1, u2);
+        if (e1) edge_project<1, true, true, false, RP, true>(rec, w0, w1, w2, u0, u1, u2);
+        if (e2) edge_project<2, true, true, false, RP, true>(rec, w0, w1, w2, u0, u1, u2);
+        fr.dx = u0 * x0 + u1 * x1 + u2 * x2;
+        fr.dy = u0 * y0 + u1 * y1 + u2 * y2;
+    }
+    fr.t0 = u0; fr.t1 = u1; fr.t2 = u2; fr.sign = inside ? 1.f : -1.f;
+}
+
 // Fragment probability of the face in `rec` at (xp,yp): K.cu:387-404.  false = face skipped.
 template <typename RP>
 __device__ __forceinline__ void barycentric(RP rec, float xp, float yp, float& w0, float& w1, float& w2)
@@ -512,6 +573,19 @@ __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float si
         if (fr.sign < 0 && fr.dis >= thr) return false;
         fr.D = sigmoid_neg_<FM, (!FM && MK && OPT_NOSCALE)>(MK ? div_by_recip(-fr.sign * fr.dis, sigma, inv_sigma) : div_<FM>(-fr.sign * fr.dis, sigma));
     }
+    return true;
+}
+
+// fragment<FM = true, .., BT = true> for a well-conditioned face in the euclidean mode, on euclid_one
+template <typename RP>
+__device__ __forceinline__ bool fragment_one(RP rec, float thr, float sigma, float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
+{
+#pragma clang fp contract(off)   // see edge_project
+    barycentric(rec, xp, yp, w0, w1, w2);
+    euclid_one(rec, xp, yp, w0, w1, w2, fr);
+    fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
+    if (fr.sign < 0 && fr.dis >= thr) return false;
+    fr.D = sigmoid_neg_<true>(div_<true>(-fr.sign * fr.dis, sigma));
     return true;
 }
 

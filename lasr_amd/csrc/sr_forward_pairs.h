@@ -47,8 +47,9 @@ typedef unsigned long long u64_t;
 //   q4  x0 y0 x1 y1  q5  x2 y2 z0 z1  q6  z2, 1/z0, 1/z1, 1/z2
 //   q7  obtuse corner c (flags bit0..2): x_c, y_c, x_o - x_c, y_o - y_c with o = (c + 2) % 3   (K.cu:113-125's override test)
 //   q8 + 2k, q9 + 2k   edge k: e[k][0..2], e[k][(k+1)%3]  |  den[k], 1/den[k], -, -
-//   56 ..  attributes [vertex][channel]
-constexpr int PR_INV = 0, PR_FLAGS = 9, PR_BB = 10, PR_ETBL = 11, PR_HK2 = 12, PR_BBE = 15, PR_XY = 16, PR_Z = 22, PR_IZ = 25, PR_OBT = 28, PR_EDGE = 32, PR_TEX = 56;
+//   q14 hq[0..2]: the squared height over edge k's line (hk2 of the vertex opposite edge k; 0 unless the face is well conditioned)
+//   60 ..  attributes [vertex][channel]
+constexpr int PR_INV = 0, PR_FLAGS = 9, PR_BB = 10, PR_ETBL = 11, PR_HK2 = 12, PR_BBE = 15, PR_XY = 16, PR_Z = 22, PR_IZ = 25, PR_OBT = 28, PR_EDGE = 32, PR_HQ = 56, PR_TEX = 60;
 
 // record field (sr_device.h index) -> staged slot; compile-time for the generic arithmetic, which indexes with constants
 __host__ __device__ constexpr int pr_of(int i)
@@ -126,6 +127,7 @@ __device__ __forceinline__ void stage_quads(const float4* __restrict__ src, floa
             if (!rec_used(i)) continue;
             if (i >= R_HK2 && i < R_HK2 + 3) {                 // the far threshold; -inf (never far) unless the face is well conditioned
                 dst[pr_of(i)] = well ? -sqrtf(thr_far / w[j]) : -__builtin_huge_valf();
+                dst[PR_HQ + (i - R_HK2 + 1) % 3] = well ? w[j] : 0.f;     // vertex k lies opposite edge (k + 1) % 3
                 continue;
             }
             dst[pr_of(i)] = w[j];
@@ -220,7 +222,19 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
     const float w2 = q1.z * xp + q1.w * yp + q2.x;
     const float x0 = q4.x, y0 = q4.y, x1 = q4.z, y1 = q4.w, x2 = q5.x, y2 = q5.y, z0 = q5.z, z1 = q5.w;
     float narg;
-    if (is_in) {
+    // which edge: an inside pixel's nearest edge LINE from the three products w^2 hk2 (sr_device.h: euclid_one), an outside pixel's
+    // from the sign pattern of its barycentrics (K.cu:113-125); inside pixels near an angle bisector -- or of a face that is not
+    // well conditioned (hq = 0) -- take the reference's three projections
+    bool tie = false;
+    int k_in = 0;
+    if (wave_mask(is_in) != 0) {
+        const float4 hq = ld4(R + PR_HQ);
+        const float g0 = w2 * w2 * hq.x, g1 = w0 * w0 * hq.y, g2 = w1 * w1 * hq.z;
+        const float glo = fminf(fminf(g0, g1), g2), gmid = __builtin_amdgcn_fmed3f(g0, g1, g2);
+        tie = (bool)((int)is_in & (int)!(glo < NEAR_TIE * gmid));
+        k_in = g1 == glo ? 1 : g2 == glo ? 2 : 0;
+    }
+    if (tie) {
         // K.cu:61-110: project on all three edges, keep the nearest (euclid<.., FWD>'s inside branch)
         float best = 100000000.f, bx = 0, by = 0;
 #pragma unroll
@@ -240,10 +254,12 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
         }
         narg = (-bx) * bx - by * by;
     } else {
-        // K.cu:113-150: which edge (sign pattern of the barycentrics, obtuse-corner override), ONE clamped projection
+        // K.cu:113-150: which edge (sign pattern of the barycentrics, obtuse-corner override), ONE clamped projection (the clamp
+        // leaves an inside pixel's projection on its nearest line as it is: the foot lies on the triangle's boundary)
         const bool over = (xp - ob.x) * ob.z + (yp - ob.y) * ob.w > 0;
         const int sh = (w0 <= 0 ? 2 : 0) | (w1 <= 0 ? 4 : 0) | (w2 <= 0 ? 8 : 0) | (over ? 16 : 0);
-        const int k = (int)__builtin_amdgcn_ubfe(__float_as_uint(q2.w), (unsigned)sh, 2u);
+        int k = (int)__builtin_amdgcn_ubfe(__float_as_uint(q2.w), (unsigned)sh, 2u);
+        k = is_in ? k_in : k;
         const float* E = R + PR_EDGE + 8 * k;
         const float4 ea = ld4(E);
         const float2 eb = *(const float2*)(E + 4);
@@ -259,8 +275,9 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
         const float u0 = t0 - w0, u1 = t1 - w1, u2 = t2 - w2;
         const float dx = u0 * x0 + u1 * x1 + u2 * x2;
         const float dy = u0 * y0 + u1 * y1 + u2 * y2;
-        narg = dx * dx + dy * dy;
-        if ((bool)((int)(narg >= A.thr) | (int)!has)) return;                        // K.cu:402 (has: false for a lane that rides along)
+        const float d2 = dx * dx + dy * dy;
+        narg = is_in ? -d2 : d2;                        // inside: (-dx) dx - dy dy, the same bits
+        if ((bool)((int)!is_in & ((int)(d2 >= A.thr) | (int)!has))) return;          // K.cu:402 (has: false for a lane that rides along)
     }
     float4 q6 = ld4(R + PR_XY + 8);                                                  // z2, 1/z0, 1/z1, 1/z2
     float4 tq[(3 * NCH + 3) / 4];

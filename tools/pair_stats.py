@@ -78,7 +78,7 @@ for fr in frames:
                     kk=(ci+co)[w::4].reshape(-1); cand=cc[w::4].reshape(-1)
                     srt=np.sort(kk)[::-1]
                     bal=np.maximum.reduce([np.ceil((srt[i]+srt[63-i])/2) for i in range(32)])
-                    row.append((kk.sum(),kk.max(),bal,cand.max(),cand.sum()))
+                    row.append((kk.sum(),kk.max(),bal,cand.max(),cand.sum(),ci[w::4].max(),ci[w::4].sum()))
                 stats.append((len(ch),row))
 print(tot)
 st=stats
@@ -94,6 +94,7 @@ densew=sum(math.ceil(r[0]/64) for _,rows in st for r in rows)
 print('frames',len(frames),'chunks',nchunks,'entries',sum(n for n,_ in st))
 print('pairs',pairs,'wave-iters: unbalanced',M,'balanced',Mb,'tile-synced',Mt,'dense per wave',densew,'dense per tile',dense)
 print('classify iters (max cand per wave)',Cm,'cand sum/64',Cs/64)
+print('inside-mode iterations (max inside pairs per lane of a chunk-wave)',sum(r[5] for _,rows in st for r in rows),'inside pairs / 64',sum(r[6] for _,rows in st for r in rows)/64)
 import collections
 Ts=np.array([r[0] for _,rows in st for r in rows])
 print('chunk-waves',len(Ts),'mean T',Ts.mean(),'pct',np.percentile(Ts,[50,75,90,95,99,100]))
