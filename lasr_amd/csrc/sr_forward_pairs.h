@@ -526,26 +526,25 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
             // beyond edge k's line; -inf for faces the conservative reject does not apply to)
             u64_t ms = cand & ~tame_mask, mi = 0, mo = 0;
             cand &= tame_mask;
-            while (wave_mask(cand != 0) != 0) {
-                if (cand != 0) {
-                    const int e = __builtin_ctzll(cand);
-                    const u64_t rest = cand & (cand - 1), bit = cand ^ rest;
-                    cand = rest;
-                    const float* R = L.rec + e * RS;
-                    const float4 q0 = ld4(R), q1 = ld4(R + 4);
-                    const float inv8 = R[8];
-                    const float4 q3 = ld4(R + PR_HK2);
-                    // (unfused like the walk's: on an edge-on face the fused form moves the barycentrics by whole pixels, and which
-                    // distance formula a pixel gets must be the reference's choice)
-                    const float w0 = q0.x * xp + q0.y * yp + q0.z;                  // barycentric()
-                    const float w1 = q0.w * xp + q1.x * yp + q1.y;
-                    const float w2 = q1.z * xp + q1.w * yp + inv8;
-                    const bool inside = (bool)((int)(fminf(fminf(w0, w1), w2) > 0) & (int)(fmaxf(fmaxf(w0, w1), w2) < 1));
-                    const bool far = (bool)((int)(w0 < q3.x) | (int)(w1 < q3.y) | (int)(w2 < q3.z));
-                    mi |= inside ? bit : 0ull;
-                    mo |= (bool)((int)!inside & (int)!far) ? bit : 0ull;
-                }
-            }
+            // (no divergent region: a lane without candidates rides along on slot 63 with an empty bit)
+            if (wave_mask(cand != 0) != 0) do {
+                const int e = __builtin_ctzll(cand | (1ull << 63));
+                const u64_t rest = cand & (cand - 1), bit = cand ^ rest;
+                cand = rest;
+                const float* R = L.rec + e * RS;
+                const float4 q0 = ld4(R), q1 = ld4(R + 4);
+                const float inv8 = R[8];
+                const float4 q3 = ld4(R + PR_HK2);
+                // (unfused like the walk's: on an edge-on face the fused form moves the barycentrics by whole pixels, and which
+                // distance formula a pixel gets must be the reference's choice)
+                const float w0 = q0.x * xp + q0.y * yp + q0.z;                  // barycentric()
+                const float w1 = q0.w * xp + q1.x * yp + q1.y;
+                const float w2 = q1.z * xp + q1.w * yp + inv8;
+                const bool inside = (bool)((int)(fminf(fminf(w0, w1), w2) > 0) & (int)(fmaxf(fmaxf(w0, w1), w2) < 1));
+                const bool far = (bool)((int)(w0 < q3.x) | (int)(w1 < q3.y) | (int)(w2 < q3.z));
+                mi |= inside ? bit : 0ull;
+                mo |= (bool)((int)!inside & (int)!far) ? bit : 0ull;
+            } while (wave_mask(cand != 0) != 0);
 
 #if defined(LASR_PW_ABL) && LASR_PW_ABL == 1        // measurement build: no walk
             s.a += (float)(__popcll(mi) + 2 * __popcll(mo)); mi = mo = 0;

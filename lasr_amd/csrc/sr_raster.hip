@@ -799,14 +799,11 @@ static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES",
 // LASR's mode combination, launches of at least this many 8x8 tiles: the pair-walk kernel (sr_forward_pairs.h), whose lanes walk
 // their own pixel's (pixel, face) pairs; smaller launches keep the latency designs above.  Its output differs from theirs in the
 // rounding sequence only (image within ~1e-6).  LASR_SR_PAIR_MIN_TILES at load time, lasr_sr_options.pair_min_tiles per call.
-// Measured on an MI355X (profiles/r06_pairs_ab.txt), mesh M2 at 256x256, forward + order kernels, one wave per tile -> pair walk:
-//   16 frames .188 -> .166 ms, 32: .293 -> .254, 64: .499 -> .463, 128: .971 -> .904, 256: 1.927 -> 1.758; 8 frames: .097 -> .15
-//   (four waves per tile win).  By DEFAULT the kernel is taken for three channels and at most 48 pixels per face only: where the
-//   faces are large against an 8x8 tile the one-wave kernel's lanes are already full (64 frames of M2 at 512x512, 108 pixels per
-//   face: 1.21 -> 1.23 ms; the nine-channel render of spot3 stage 0, 16 meshes of 1280 faces filling the frame: 104 -> 106 us).
-//   An explicit pair_min_tiles applies to every channel count and size.
+// Measured on an MI355X (profiles/r06_pairs_ab.txt), one wave per tile (+ order kernels) -> pair walk:
+//   mesh M2 at 256x256, three channels: 16 frames .188 -> .124 ms, 256: 1.927 -> 1.36; 8 frames: the four-waves-per-tile kernel wins
+//   nine channels: the render of spot3 stage 0 (16 meshes of 1280 faces filling the frame) 104 -> 89 us, camel stage 4 (4 meshes of
+//   2560 faces at 512x512) 150 -> 123 us -- every channel count and face size takes the kernel from the threshold up
 static const long long k_pair_min_tiles = env_blocks("LASR_SR_PAIR_MIN_TILES", 16384);
-static const bool k_pair_forced = getenv("LASR_SR_PAIR_MIN_TILES") != nullptr;
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -841,9 +838,8 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
     const long long tiles8o = (long long)N * t8o * t8o;
     const long long g_pair_min_tiles = opt && opt->pair_min_tiles >= 0 ? opt->pair_min_tiles : k_pair_min_tiles;
     // the pair-walk kernel: LASR's modes, default arithmetic, launches from pair_min_tiles up; its tiles are 16x16 pixels
-    const bool pair_any = (opt && opt->pair_min_tiles >= 0) || k_pair_forced;             // explicit threshold: no density rule
     const bool pairs = total > 0 && (nch > 3 || is_lasr_fast(A.m)) && !(flags & (LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) &&
-                       tiles8o >= g_pair_min_tiles && (pair_any || (nch == 3 && (long long)IS * IS <= 48ll * F));
+                       tiles8o >= g_pair_min_tiles;
     const int tile_shift = pairs ? 4 : 3;
     const int tso = (IS + (1 << tile_shift) - 1) >> tile_shift;              // tiles per side of the order table
     const long long tileso = (long long)N * tso * tso;

@@ -143,20 +143,21 @@ def test_the_device_side_choice_takes_either_kernel_and_the_bits_do_not_change(t
 
 
 def test_default_thresholds_pick_by_launch_size(cuda):
-    # the defaults are in force outside this file's fixture: a 1-frame and a 16-frame launch go through without error and agree
-    # with each other frame by frame (a frame rendered alone or in a batch gives the same bits -- 1280 faces at 256x256 are 51
-    # pixels per face: over the density the pair-walk kernel is taken for by default, so both launches keep the reference order);
-    # 16 frames of the 2420-face mesh (27 pixels per face) take the pair walk by default: same image to rounding
-    fv, ft, near, far = synth.raster_batch(8, 3, count=16)
-    kw = dict(synth.LASR_MODES, near=near, far=far)
-    batch = render(cuda, fv, ft, 256, kw)
-    one = render(cuda, fv[5:6], ft[5:6], 256, kw)
-    assert np.array_equal(batch[5:6], one)
-    fv, ft, near, far = synth.raster_batch(11, 3, count=16)
-    kw = dict(synth.LASR_MODES, near=near, far=far)
-    batch = render(cuda, fv, ft, 256, kw)
-    one = render(cuda, fv[5:6], ft[5:6], 256, kw)
-    assert np.abs(batch[5:6] - one).max() <= PAIR_TOL and not np.array_equal(batch[5:6], one)
+    # the defaults are in force outside this file's fixture: launches below the pair-walk threshold (16 frames of 256x256) keep the
+    # reference order -- a frame rendered alone or in a batch of eight gives the same bits -- and 16 frames take the pair walk
+    # whatever the face size (1280 faces = 51 pixels per face, 2420 faces = 27): same image to rounding
+    for nu, cnt in ((8, 8), (11, 8)):
+        fv, ft, near, far = synth.raster_batch(nu, 3, count=cnt)
+        kw = dict(synth.LASR_MODES, near=near, far=far)
+        batch = render(cuda, fv, ft, 256, kw)
+        one = render(cuda, fv[5:6], ft[5:6], 256, kw)
+        assert np.array_equal(batch[5:6], one)
+    for nu in (8, 11):
+        fv, ft, near, far = synth.raster_batch(nu, 3, count=16)
+        kw = dict(synth.LASR_MODES, near=near, far=far)
+        batch = render(cuda, fv, ft, 256, kw)
+        one = render(cuda, fv[5:6], ft[5:6], 256, kw)
+        assert np.abs(batch[5:6] - one).max() <= PAIR_TOL and not np.array_equal(batch[5:6], one)
 
 
 def test_the_pair_walk_handles_faces_that_are_not_tame(thresholds, oracle, cuda):

@@ -1,0 +1,7 @@
+# pair walk (default) vs the one-wave kernels (LASR_SR_PAIR_MIN_TILES huge) at sizes the density rule used to exclude: bash tools/prof/pairs512_ab.sh
+R=$GRAFT_REPO_ROOT; cd $R
+for rep in 1 2; do for v in default 1000000000000; do
+  if [ $v = default ]; then unset LASR_SR_PAIR_MIN_TILES; else export LASR_SR_PAIR_MIN_TILES=$v; fi
+  for args in "--image-size 512 --frames 64" "--image-size 512 --frames 16" "--image-size 512 --frames 4"; do
+    python bench.py $args --no-cpu-baseline --no-lbs --no-sweep --lasr-iters 0 --no-step-profile --steps 20 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('pair_min_tiles=$v', '$args', round(d['value']), round(d['ms_per_step'],4), {k: round(v,4) for k,v in d['roofline']['all_kernels_avg_ms'].items()})"
+  done; done; done
