@@ -56,6 +56,30 @@ int lasr_project_points_backward(const float* rest_ts, const float* ctl_ts, cons
                                  const float* grad_proj, float* grad_rest, float* grad_ctl, int M, int H, int K, void* hip_stream);
 
 /*
+ * The pose chain of LASR.forward in ONE launch each way (round 6; nnutils/mesh_net.py:204-217 intrinsics bookkeeping, :232 quaternion ->
+ * matrix, :259-283 bone fix-up with the rotation distance of :514-516, :285-288 + :302 joint / control-point projection): the
+ * phases of lasr_intrinsics_*, lasr_quat_to_rotmat_*, lasr_bone_fixup_pair_* and lasr_project_points_* run by one workgroup, with
+ * the `.repeat(1, H, 1, 1)` of trans / depth (:237-238) inside.  B image pairs, H hypotheses, K bones, M = 2B*H:
+ *   in   cams [2B, cam_stride] (column 0 = crop scale), pp [2B,2], scale [2B,H], depth [2B,K], ppoint [2B,2], quat4 [M*K,4] (x,y,z,w),
+ *        trans [2B*K,2], rest_ts / ctl_ts [H,K-1,3] (NULL when K == 1)
+ *   out  scale_out [2B,H], depth_out [2B,K], ppoint_out [2B,2], trans_rep [M*K,2], depth_rep [M*K], rmat [M*K,3,3], tmat [M*K,3],
+ *        pair_angle [M*K/2] (NULL: not wanted), proj [M, 2(K-1), 4] (K > 1)
+ * Backward: gradients of the outputs (any of grad_scale_out / grad_ppoint_out / grad_trans_rep / grad_depth_rep / grad_pair_angle /
+ * grad_proj may be NULL = zero) -> gradients of scale, depth, ppoint, quat4, trans, rest_ts, ctl_ts (overwritten); the
+ * projection treats transforms and intrinsics as constants like lasr_project_points_backward; scratch = M*K*3 floats.
+ */
+int lasr_pose_chain_forward(const float* cams, int cam_stride, const float* pp, const float* scale, const float* depth,
+                            const float* ppoint, const float* quat4, const float* trans, const float* rest_ts, const float* ctl_ts,
+                            float* scale_out, float* depth_out, float* ppoint_out, float* trans_rep, float* depth_rep, float* rmat,
+                            float* tmat, float* pair_angle, float* proj, int B, int H, int K, float half_size, void* hip_stream);
+int lasr_pose_chain_backward(const float* cams, int cam_stride, const float* quat4, const float* rest_ts, const float* ctl_ts,
+                             const float* rmat, const float* tmat, const float* scale_out, const float* grad_scale_out,
+                             const float* grad_ppoint_out, const float* grad_trans_rep, const float* grad_depth_rep,
+                             const float* grad_rmat, const float* grad_tmat, const float* grad_pair_angle, const float* grad_proj,
+                             float* grad_scale, float* grad_depth, float* grad_ppoint, float* grad_quat4, float* grad_trans,
+                             float* grad_rest, float* grad_ctl, float* scratch, int B, int H, int K, void* hip_stream);
+
+/*
  * Pinhole projection, nnutils/geom_utils.py:27-34 (pinhole_cam), with pp / fl already expanded per mesh:
  *   out.x = pp[n,0] + x * fl[n] / z ;  out.y = pp[n,1] + y * fl[n] / z ;  out.z = z ; out.w = w
  * verts/out [N,V,4], pp [N,2], fl [N].  Backward overwrites grad_verts [N,V,4], grad_pp [N,2], grad_fl [N].

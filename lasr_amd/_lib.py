@@ -29,6 +29,8 @@ SIGNATURES = {
     'lasr_lbs_backward': (_i, [_p] * 10 + [_i, _i, _i, _i, _p]),
     'lasr_project_points_forward': (_i, [_p] * 7 + [_i, _i, _i, _p]),
     'lasr_project_points_backward': (_i, [_p] * 8 + [_i, _i, _i, _p]),
+    'lasr_pose_chain_forward': (_i, [_p, _i] + [_p] * 17 + [_i, _i, _i, _f, _p]),
+    'lasr_pose_chain_backward': (_i, [_p, _i] + [_p] * 22 + [_i, _i, _i, _p]),
     'lasr_pinhole_forward': (_i, [_p, _p, _p, _p, _i, _i, _p]),
     'lasr_pinhole_backward': (_i, [_p] * 7 + [_i, _i, _p]),
     'lasr_loss_scratch_floats': (_sz, [_i, _i, _i]),

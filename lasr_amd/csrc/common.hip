@@ -26,7 +26,7 @@ const char* const kKernelNames[K_NUM_KERNELS] = {
     "face_gather_forward_kernel", "face_gather_backward_kernel", "nearest_point_kernel", "point_mesh_forward_kernel",
     "point_mesh_backward_kernel", "cosdist_forward_kernel", "cosdist_backward_kernel", "load_textures_kernel",
     "geodesic_forward_kernel", "geodesic_backward_kernel", "weighted_means_kernel", "intrinsics_kernel", "bone_fixup_kernel", "chamfer_kernel", "mean_shape_kernel", "obs_pair_kernel", "tail_kernel", "fill_planes_kernel", "gather_rows_kernel", "render_tables_forward_kernel", "render_tables_backward_kernel", "raster_inputs_kernel", "sr_order_kernel",
-    "render_tables_flow_kernel", "raster_faces_kernel", "mesh_reg_kernel", "render_tables_fold_kernel", "lbs_backward_fold_kernel", "project_points_kernel"};
+    "render_tables_flow_kernel", "raster_faces_kernel", "mesh_reg_kernel", "render_tables_fold_kernel", "lbs_backward_fold_kernel", "project_points_kernel", "pose_chain_kernel"};
 }  // namespace
 
 int lasr_launch_ok()

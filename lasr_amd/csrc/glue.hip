@@ -319,6 +319,212 @@ __global__ __launch_bounds__(256) void project_points_backward_kernel(const floa
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
 }
 
+// ---- the pose chain: intrinsics -> quaternion matrices -> bone fix-up -> joint / control-point projection, ONE launch each way ----
+// The four operators above (and fused.hip's quat kernels) in the order LASR.forward runs them (nnutils/mesh_net.py:204-217, :232,
+// :259-289, :302), as phases of one 256-thread workgroup separated by barriers: the tensors hold a few hundred floats, every
+// launch of the chain costs ~4.7 us of which ~0.3 us is work.  Each phase is the expression sequence of its stand-alone kernel,
+// so values and gradients are the ones the separate launches give (tests/test_step_fusions_gpu.py); the H-fold broadcast of
+// trans / depth (`.repeat(1, H, 1, 1)`) and its gradient (the sum over hypotheses, in hypothesis order) happen inside.
+//   quat4 [M*K,4] unit quaternions (x, y, z, w), trans [2B*K,2], depth [2B,K], scale [2B,H], ppoint [2B,2], M = 2B*H
+struct PoseChain {
+    const float* cams; const float* pp; const float* scale; const float* depth; const float* ppoint;
+    const float* quat4; const float* trans; const float* rest; const float* ctl;
+    float* scale_out; float* depth_out; float* ppoint_out; float* trans_rep; float* depth_rep;
+    float* Rmat; float* Tmat; float* pair_angle; float4* proj;
+    int cam_stride, B, H, K; float half;
+};
+
+__global__ __launch_bounds__(256) void pose_chain_forward_kernel(PoseChain A)
+{
+    const int B = A.B, H = A.H, K = A.K, n2 = 2 * B, M = n2 * H, MK = M * K;
+    // phase 1: intrinsics (intrinsics_forward_kernel)
+    for (int i = threadIdx.x; i < n2 * H; i += 256) A.scale_out[i] = A.cams[(i / H) * A.cam_stride] * A.scale[i];
+    for (int i = threadIdx.x; i < n2 * K; i += 256) {
+        const float d = A.depth[i];
+        A.depth_out[i] = (i % K == 0) ? A.cams[(i / K) * A.cam_stride] * d : d;
+    }
+    for (int i = threadIdx.x; i < n2 * 2; i += 256) {
+        const int r = i >> 1, c = i & 1;
+        if (r < B) { A.ppoint_out[i] = A.ppoint[i]; continue; }
+        const int r0 = r - B;
+        const float a0 = A.cams[r0 * A.cam_stride], a1 = A.cams[r * A.cam_stride];
+        const float ppb1 = a0 * A.pp[2 * r0 + c] / A.half, ppb2 = a1 * A.pp[2 * r + c] / A.half;
+        const float ppa1 = A.ppoint[2 * r0 + c] + ppb1 + 1.f;
+        A.ppoint_out[i] = ppa1 * (a1 / a0) - ppb2 - 1.f;
+    }
+    __syncthreads();
+    // phase 2: quaternion -> matrix (quat_forward_kernel), rotation distance of the pair and bone fix-up (bone_fixup_forward_kernel)
+    for (int i = threadIdx.x; i < MK; i += 256) {
+        float q[9];
+        quat_matrix(load_quat(A.quat4 + 4 * (size_t)i), q);
+        if (A.pair_angle && i < MK / 2) {
+            float o[9];
+            quat_matrix(load_quat(A.quat4 + 4 * ((size_t)i + MK / 2)), o);
+            const float c = geodesic_cos(q, o);
+            A.pair_angle[i] = fabsf(c) < 1.f ? acosf(c) : (c > 0.f ? 0.f : 3.14159265358979323846f);
+        }
+        const int k = i % K, m = i / K, h = m % H, img = m / H;
+        float* R = A.Rmat + 9 * (size_t)i;
+        const float tx0 = A.trans[2 * ((size_t)img * K + k)], ty0 = A.trans[2 * ((size_t)img * K + k) + 1], tz0 = A.depth_out[img * K + k];
+        A.trans_rep[2 * (size_t)i] = tx0; A.trans_rep[2 * (size_t)i + 1] = ty0; A.depth_rep[i] = tz0;
+        float tx = tx0, ty = ty0, tz = tz0;
+        if (k == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) R[3 * r + c] = q[3 * c + r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 9; j++) R[j] = q[j];
+            const float* c = A.rest + 3 * ((size_t)h * (K - 1) + (k - 1));
+            const float r0 = q[0] * c[0] + q[3] * c[1] + q[6] * c[2];
+            const float r1 = q[1] * c[0] + q[4] * c[1] + q[7] * c[2];
+            const float r2 = q[2] * c[0] + q[5] * c[1] + q[8] * c[2];
+            tx = -r0 + tx + c[0]; ty = -r1 + ty + c[1]; tz = -r2 + tz + c[2];
+        }
+        A.Tmat[3 * (size_t)i] = tx; A.Tmat[3 * (size_t)i + 1] = ty; A.Tmat[3 * (size_t)i + 2] = tz;
+    }
+    if (K < 2) return;
+    __syncthreads();
+    // phase 3: joints and control points into the image (project_points_forward_kernel; fl = scale_out, pp = ppoint_out)
+    const int nb = K - 1, Pn = 2 * nb;
+    for (int i = threadIdx.x; i < M * Pn; i += 256) {
+        const int m = i / Pn, j = i - m * Pn, h = m % H, b = j % nb;
+        const float* p = (j < nb ? A.rest : A.ctl) + ((size_t)h * nb + b) * 3;
+        const float* R = A.Rmat + ((size_t)m * K + b + 1) * 9;
+        const float* T = A.Tmat + ((size_t)m * K + b + 1) * 3;
+        const float* R0 = A.Rmat + (size_t)m * K * 9;
+        const float* T0 = A.Tmat + (size_t)m * K * 3;
+        float vs[3], c[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) vs[d] = (T[d] + p[2] * R[6 + d]) + (p[1] * R[3 + d] + p[0] * R[d]);
+#pragma unroll
+        for (int d = 0; d < 3; d++) c[d] = vs[0] * R0[d] + vs[1] * R0[3 + d] + vs[2] * R0[6 + d] + T0[d];
+        const int img = m / H;
+        const float f = A.scale_out[m];
+        A.proj[i] = make_float4(A.ppoint_out[2 * img] + c[0] * f / c[2], A.ppoint_out[2 * img + 1] + c[1] * f / c[2], c[2], 1.f);
+    }
+}
+
+struct PoseChainGrad {
+    const float* cams; const float* quat4; const float* rest; const float* ctl; const float* Rmat; const float* Tmat; const float* fl;
+    const float* g_scale_out; const float* g_ppoint_out; const float* g_trans_rep; const float* g_depth_rep;
+    const float* gR; const float* gT; const float* g_angle; const float4* g_proj;
+    float* g_scale; float* g_depth; float* g_ppoint; float* g_quat4; float* g_trans; float* g_rest; float* g_ctl;
+    float* scratch;                                   // [M*K, 3]: gradient of the repeated (trans_x, trans_y, depth) per (m, k)
+    int cam_stride, B, H, K;
+};
+
+__global__ __launch_bounds__(256) void pose_chain_backward_kernel(PoseChainGrad A)
+{
+    const int B = A.B, H = A.H, K = A.K, n2 = 2 * B, M = n2 * H, MK = M * K, nb = K - 1, Pn = 2 * nb;
+    // phase 1: projection (project_points_backward_kernel): gradient of the points, summed over the images in image order
+    if (K > 1) {
+        for (int i = threadIdx.x; i < H * Pn; i += 256) {
+            const int h = i / Pn, j = i - h * Pn, b = j % nb;
+            const float* p = (j < nb ? A.rest : A.ctl) + ((size_t)h * nb + b) * 3;
+            float acc[3] = {0.f, 0.f, 0.f};
+            if (A.g_proj)
+            for (int img = 0; img < n2; img++) {
+                const int m = img * H + h;
+                const float* R = A.Rmat + ((size_t)m * K + b + 1) * 9;
+                const float* T = A.Tmat + ((size_t)m * K + b + 1) * 3;
+                const float* R0 = A.Rmat + (size_t)m * K * 9;
+                const float* T0 = A.Tmat + (size_t)m * K * 3;
+                float vs[3], c[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) vs[d] = (T[d] + p[2] * R[6 + d]) + (p[1] * R[3 + d] + p[0] * R[d]);
+#pragma unroll
+                for (int d = 0; d < 3; d++) c[d] = vs[0] * R0[d] + vs[1] * R0[3 + d] + vs[2] * R0[6 + d] + T0[d];
+                const float4 g = A.g_proj[(size_t)m * Pn + j];
+                const float f = A.fl[m], iz = 1.f / c[2], xz = c[0] * iz, yz = c[1] * iz;
+                const float gc[3] = {g.x * f * iz, g.y * f * iz, g.z - (g.x * xz + g.y * yz) * f * iz};
+                float gv[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) gv[d] = gc[0] * R0[3 * d] + gc[1] * R0[3 * d + 1] + gc[2] * R0[3 * d + 2];
+#pragma unroll
+                for (int d = 0; d < 3; d++) acc[d] += gv[0] * R[3 * d] + gv[1] * R[3 * d + 1] + gv[2] * R[3 * d + 2];
+            }
+            float* o = (j < nb ? A.g_rest : A.g_ctl) + ((size_t)h * nb + b) * 3;
+            o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+        }
+        __syncthreads();
+    }
+    // phase 2: bone fix-up + rotation distance (bone_fixup_backward_kernel), then through the quaternion (quat_backward_kernel)
+    for (int i = threadIdx.x; i < MK; i += 256) {
+        const int k = i % K, h = (i / K) % H;
+        const float* g = A.gR + 9 * (size_t)i;
+        const float* t = A.gT + 3 * (size_t)i;
+        A.scratch[3 * (size_t)i] = t[0] + (A.g_trans_rep ? A.g_trans_rep[2 * (size_t)i] : 0.f);
+        A.scratch[3 * (size_t)i + 1] = t[1] + (A.g_trans_rep ? A.g_trans_rep[2 * (size_t)i + 1] : 0.f);
+        A.scratch[3 * (size_t)i + 2] = t[2] + (A.g_depth_rep ? A.g_depth_rep[i] : 0.f);
+        float v[9];
+        if (k == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) v[3 * c + r] = g[3 * r + c];
+        } else {
+            const float* c = A.rest + 3 * ((size_t)h * (K - 1) + (k - 1));
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int r = 0; r < 3; r++) v[3 * j + r] = g[3 * j + r] - c[j] * t[r];
+        }
+        const Quat qi = load_quat(A.quat4 + 4 * (size_t)i);
+        if (A.g_angle) {
+            const int half = MK / 2, first = i < half ? i : i - half;
+            float a[9], b[9];
+            quat_matrix(load_quat(A.quat4 + 4 * (size_t)first), a);
+            quat_matrix(load_quat(A.quat4 + 4 * ((size_t)first + half)), b);
+            const float cs = geodesic_cos(a, b);
+            const float gc = fabsf(cs) < 1.f ? -A.g_angle[first] / sqrtf(1.f - cs * cs) * 0.5f : 0.f;
+            const float* other = i < half ? b : a;
+#pragma unroll
+            for (int j = 0; j < 9; j++) v[j] = v[j] + gc * other[j];
+        }
+        float o[4];
+        quat_matrix_backward(qi, v, o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) A.g_quat4[4 * (size_t)i + j] = o[j];
+    }
+    if (K > 1) {
+        // rest_ts: one thread per (h, k-1, component) sums its images in order, then adds the projection's part (phase 1)
+        for (int i = threadIdx.x; i < H * nb * 3; i += 256) {
+            const int comp = i % 3, kb = (i / 3) % nb, h = i / (3 * nb);
+            float s = 0.f;
+            for (int im = 0; im < n2; im++) {
+                const size_t e = ((size_t)(im * H + h)) * K + (kb + 1);
+                float q[9];
+                quat_matrix(load_quat(A.quat4 + 4 * e), q);
+                const float* t = A.gT + 3 * e;
+                s += t[comp] - (q[3 * comp + 0] * t[0] + q[3 * comp + 1] * t[1] + q[3 * comp + 2] * t[2]);
+            }
+            A.g_rest[i] = s + A.g_rest[i];
+        }
+    }
+    __syncthreads();
+    // phase 3: the H-fold broadcast of trans / depth backwards (hypothesis order), then intrinsics (intrinsics_backward_kernel)
+    for (int i = threadIdx.x; i < n2 * K; i += 256) {
+        const int img = i / K, k = i - img * K;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int h = 0; h < H; h++) {
+            const float* t = A.scratch + 3 * ((size_t)(img * H + h) * K + k);
+            sx += t[0]; sy += t[1]; sz += t[2];
+        }
+        A.g_trans[2 * (size_t)i] = sx; A.g_trans[2 * (size_t)i + 1] = sy;
+        A.g_depth[i] = k == 0 ? A.cams[img * A.cam_stride] * sz : sz;
+    }
+    for (int i = threadIdx.x; i < n2 * H; i += 256)
+        A.g_scale[i] = A.g_scale_out ? A.cams[(i / H) * A.cam_stride] * A.g_scale_out[i] : 0.f;
+    for (int i = threadIdx.x; i < n2 * 2; i += 256) {
+        const int r = i >> 1, c = i & 1;
+        if (r >= B || !A.g_ppoint_out) { A.g_ppoint[i] = 0.f; continue; }
+        const float a0 = A.cams[r * A.cam_stride], a1 = A.cams[(r + B) * A.cam_stride];
+        A.g_ppoint[i] = A.g_ppoint_out[i] + A.g_ppoint_out[2 * (r + B) + c] * (a1 / a0);
+    }
+}
+
 // ---- symmetric Chamfer distance of two small point sets (pytorch3d.loss.chamfer_distance as used at nnutils/mesh_net.py:503) --
 // a [N,P,3], b [N,Q,3] -> out[n] = mean_i min_j |a_i - b_j|^2 + mean_j min_i |b_j - a_i|^2, nearest indices kept for the
 // backward.  One workgroup per batch item (the control-point sets hold <= 35 points; larger sets loop).
@@ -597,6 +803,45 @@ extern "C" int lasr_project_points_backward(const float* rest_ts, const float* c
     const int total = H * 2 * (K - 1);
     LASR_LAUNCH(K_PROJECT_POINTS, project_points_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, rest_ts, ctl_ts, Rmat, Tmat, fl,
                 (const float4*)grad_proj, grad_rest, grad_ctl, M, H, K);
+    return launch_ok();
+}
+
+extern "C" int lasr_pose_chain_forward(const float* cams, int cam_stride, const float* pp, const float* scale, const float* depth,
+                                       const float* ppoint, const float* quat4, const float* trans, const float* rest_ts,
+                                       const float* ctl_ts, float* scale_out, float* depth_out, float* ppoint_out, float* trans_rep,
+                                       float* depth_rep, float* rmat, float* tmat, float* pair_angle, float* proj, int B, int H, int K,
+                                       float half_size, void* hip_stream)
+{
+    if (B < 0 || H < 1 || K < 1 || cam_stride < 1 || !(half_size > 0.f)) return LASR_E_BADARG;
+    if (B == 0) return LASR_OK;
+    if (!cams || !pp || !scale || !depth || !ppoint || !quat4 || !trans || !scale_out || !depth_out || !ppoint_out || !trans_rep ||
+        !depth_rep || !rmat || !tmat || (K > 1 && (!rest_ts || !ctl_ts || !proj)))
+        return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    PoseChain A{cams, pp, scale, depth, ppoint, quat4, trans, rest_ts, ctl_ts, scale_out, depth_out, ppoint_out, trans_rep, depth_rep,
+                rmat, tmat, pair_angle, (float4*)proj, cam_stride, B, H, K, half_size};
+    LASR_LAUNCH(K_POSE_CHAIN, pose_chain_forward_kernel, dim3(1), dim3(256), 0, A);
+    return launch_ok();
+}
+
+extern "C" int lasr_pose_chain_backward(const float* cams, int cam_stride, const float* quat4, const float* rest_ts, const float* ctl_ts,
+                                        const float* rmat, const float* tmat, const float* scale_out, const float* grad_scale_out,
+                                        const float* grad_ppoint_out, const float* grad_trans_rep, const float* grad_depth_rep,
+                                        const float* grad_rmat, const float* grad_tmat, const float* grad_pair_angle,
+                                        const float* grad_proj, float* grad_scale, float* grad_depth, float* grad_ppoint,
+                                        float* grad_quat4, float* grad_trans, float* grad_rest, float* grad_ctl, float* scratch, int B,
+                                        int H, int K, void* hip_stream)
+{
+    if (B < 0 || H < 1 || K < 1 || cam_stride < 1) return LASR_E_BADARG;
+    if (B == 0) return LASR_OK;
+    if (!cams || !quat4 || !grad_rmat || !grad_tmat || !grad_scale || !grad_depth || !grad_ppoint || !grad_quat4 || !grad_trans ||
+        !scratch || (K > 1 && (!rest_ts || !ctl_ts || !rmat || !tmat || !scale_out || !grad_rest || !grad_ctl)))
+        return LASR_E_BADARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    PoseChainGrad A{cams, quat4, rest_ts, ctl_ts, rmat, tmat, scale_out, grad_scale_out, grad_ppoint_out, grad_trans_rep, grad_depth_rep,
+                    grad_rmat, grad_tmat, grad_pair_angle, (const float4*)grad_proj, grad_scale, grad_depth, grad_ppoint, grad_quat4,
+                    grad_trans, grad_rest, grad_ctl, scratch, cam_stride, B, H, K};
+    LASR_LAUNCH(K_POSE_CHAIN, pose_chain_backward_kernel, dim3(1), dim3(256), 0, A);
     return launch_ok();
 }
 

@@ -14,7 +14,7 @@ enum LasrKernelId {
     K_FLATTEN_FORWARD, K_FLATTEN_BACKWARD, K_FACE_GATHER_FORWARD, K_FACE_GATHER_BACKWARD,
     K_NEAREST_POINT, K_POINT_MESH_FORWARD, K_POINT_MESH_BACKWARD, K_COSDIST_FORWARD, K_COSDIST_BACKWARD,
     K_LOAD_TEXTURES, K_GEODESIC_FORWARD, K_GEODESIC_BACKWARD, K_WEIGHTED_MEANS, K_INTRINSICS, K_BONE_FIXUP, K_CHAMFER, K_MEAN_SHAPE, K_OBS_PAIR, K_TAIL, K_FILL_PLANES, K_GATHER_ROWS, K_RENDER_TABLES_FORWARD, K_RENDER_TABLES_BACKWARD, K_RASTER_INPUTS, K_SR_ORDER,
-    K_RENDER_TABLES_FLOW, K_RASTER_FACES, K_MESH_REG, K_RENDER_TABLES_FOLD, K_LBS_BACKWARD_FOLD, K_PROJECT_POINTS,
+    K_RENDER_TABLES_FLOW, K_RASTER_FACES, K_MESH_REG, K_RENDER_TABLES_FOLD, K_LBS_BACKWARD_FOLD, K_PROJECT_POINTS, K_POSE_CHAIN,
     K_NUM_KERNELS
 };
 

@@ -878,6 +878,78 @@ def project_points(rest_ts, ctl_ts, Rmat, Tmat, ppoint, scale, n_hypo, n_bones):
     return _ProjectPoints.apply(rest_ts, ctl_ts, Rmat, Tmat, ppoint, scale.reshape(-1), int(n_hypo), int(n_bones))
 
 
+class _PoseChain(Function):
+    @staticmethod
+    def forward(ctx, cams, pp, scale, depth, ppoint, quat4, trans, rest, ctl, H, K, half, pair):
+        _lib.need_cuda(cams, pp, scale, depth, ppoint, quat4, trans)
+        f = lambda t: None if t is None else t.contiguous().float()                                   # noqa: E731
+        cams, pp, scale, depth, ppoint, quat4, trans, rest, ctl = map(f, (cams, pp, scale, depth, ppoint, quat4, trans, rest, ctl))
+        n2 = scale.shape[0]
+        M, MK = n2 * H, n2 * H * K
+        if scale.numel() != M or depth.numel() != n2 * K or ppoint.numel() != 2 * n2 or quat4.numel() != 4 * MK or \
+                trans.numel() != 2 * n2 * K or n2 % 2 or (K > 1 and (rest is None or ctl is None or rest.numel() != 3 * H * (K - 1)
+                                                                    or ctl.numel() != rest.numel())):
+            raise ValueError('pose_chain: scale [2B,H], depth [2B,K], ppoint [2B,2], quat4 [2B*H*K,4], trans [2B*K,2], rest_ts / ctl_ts [H,K-1,3]')
+        dev = scale.device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)                     # noqa: E731
+        so, do, po = new(n2, H), new(n2, K), new(n2, 2)
+        trep, drep, rmat, tmat = new(MK, 2), new(MK, 1), new(MK, 3, 3), new(MK, 3)
+        angle = new(MK // 2) if pair else None
+        proj = new(M, 2 * (K - 1), 4) if K > 1 else None
+        ptr = lambda t: None if t is None else t.data_ptr()                                           # noqa: E731
+        guard, st = _lib.stream_of(scale)
+        with guard:
+            rc = _lib.lib().lasr_pose_chain_forward(cams.data_ptr(), cams.shape[1], pp.data_ptr(), scale.data_ptr(), depth.data_ptr(),
+                                                    ppoint.data_ptr(), quat4.data_ptr(), trans.data_ptr(), ptr(rest), ptr(ctl),
+                                                    so.data_ptr(), do.data_ptr(), po.data_ptr(), trep.data_ptr(), drep.data_ptr(),
+                                                    rmat.data_ptr(), tmat.data_ptr(), ptr(angle), ptr(proj), n2 // 2, H, K,
+                                                    float(half), st)
+        _lib.check(rc, 'lasr_pose_chain_forward')
+        ctx.save_for_backward(cams, quat4, rest, ctl, rmat, tmat, so)
+        ctx.dims = (n2 // 2, H, K)
+        ctx.in_shapes = (scale.shape, depth.shape, ppoint.shape, quat4.shape, trans.shape)
+        return so, po, rmat, tmat, trep, drep, angle, proj
+
+    @staticmethod
+    def backward(ctx, g_so, g_po, gR, gT, g_trep, g_drep, g_angle, g_proj):
+        cams, quat4, rest, ctl, rmat, tmat, so = ctx.saved_tensors
+        B, H, K = ctx.dims
+        n2, MK = 2 * B, 2 * B * H * K
+        dev = quat4.device
+        f = lambda t: None if t is None else t.contiguous().float()                                   # noqa: E731
+        g_so, g_po, g_trep, g_drep, g_angle, g_proj = map(f, (g_so, g_po, g_trep, g_drep, g_angle, g_proj))
+        gR = f(gR) if gR is not None else torch.zeros(MK, 3, 3, device=dev)
+        gT = f(gT) if gT is not None else torch.zeros(MK, 3, device=dev)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)                     # noqa: E731
+        gs, gd, gp, gq, gt = new(n2, H), new(n2, K), new(n2, 2), new(MK, 4), new(n2 * K, 2)
+        gr = torch.empty_like(rest) if rest is not None else None
+        gc = torch.empty_like(ctl) if ctl is not None else None
+        scratch = new(MK, 3)
+        ptr = lambda t: None if t is None else t.data_ptr()                                           # noqa: E731
+        guard, st = _lib.stream_of(quat4)
+        with guard:
+            rc = _lib.lib().lasr_pose_chain_backward(cams.data_ptr(), cams.shape[1], quat4.data_ptr(), ptr(rest), ptr(ctl), rmat.data_ptr(),
+                                                     tmat.data_ptr(), so.data_ptr(), ptr(g_so), ptr(g_po), ptr(g_trep), ptr(g_drep),
+                                                     gR.data_ptr(), gT.data_ptr(), ptr(g_angle), ptr(g_proj), gs.data_ptr(), gd.data_ptr(),
+                                                     gp.data_ptr(), gq.data_ptr(), gt.data_ptr(), ptr(gr), ptr(gc), scratch.data_ptr(),
+                                                     B, H, K, st)
+        _lib.check(rc, 'lasr_pose_chain_backward')
+        ss, ds, ps, qs, ts = ctx.in_shapes
+        return None, None, gs.view(ss), gd.view(ds), gp.view(ps), gq.view(qs), gt.view(ts), gr, gc, None, None, None, None
+
+
+def pose_chain(cams, pp, scale, depth, ppoint, quat4, trans, rest_ts, ctl_ts, n_hypo, n_bones, img_size, pair_angle=True):
+    """intrinsics -> quaternion matrices -> bone fix-up (+ the rotation distance of the frame pair) -> joint / control-point
+    projection, the chain of /root/reference/nnutils/mesh_net.py:204-217, :232, :259-289, :302, :514-516 in one launch each way
+    (`intrinsics`, `quat_to_rotmat`, `bone_fixup`, `project_points` of this module are its phases; same values and gradients).
+    scale [2B,H], depth [2B,K], ppoint [2B,2], quat4 [2B*H*K,4] unit quaternions (x, y, z, w), trans [2B*K,2] ->
+    (scale [2B,H], ppoint [2B,2], Rmat [M*K,3,3], Tmat [M*K,3], trans repeated over the hypotheses [M*K,2], depth likewise
+    [M*K,1], pair_angle [M*K/2] or None, proj [M, 2(K-1), 4] or None for K == 1)."""
+    K = int(n_bones)
+    return _PoseChain.apply(cams, pp, scale, depth, ppoint, quat4, trans, rest_ts if K > 1 else None, ctl_ts if K > 1 else None,
+                            int(n_hypo), K, img_size / 2., bool(pair_angle))
+
+
 class _Chamfer(Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -253,11 +253,13 @@ class QuatPredictor(_Linear):
         super().__init__(nz_feat, 4 * n_bones * n_hypo)
         self.nmesh, self.nhypo = n_bones, n_hypo
 
-    def forward(self, feat):
+    def forward(self, feat, raw=False):
         quat = self.pred_layer(feat).view(-1, self.nhypo, self.nmesh, 4)
         bias = torch.zeros_like(quat)
         bias[:, :, 1:, 3] = 10                       # part bones start near identity (net_blocks.py:353)
         quat = F.normalize((quat + bias).view(-1, 4))
+        if raw:                                      # the caller turns the quaternions into matrices itself (fused_ops.pose_chain)
+            return quat
         return quaternion_to_rotation_matrix(quat).reshape(-1, 9)
 
 
@@ -300,9 +302,9 @@ class CodePredictor(nn.Module):
         self.ppoint_predictor = PPointPredictor(nz_feat)
         self.nmesh, self.nhypo = n_bones, n_hypo
 
-    def forward(self, feat):
+    def forward(self, feat, raw_quat=False):
         scale = self.scale_predictor(feat)
-        quat = self.quat_predictor(feat)
+        quat = self.quat_predictor(feat, raw_quat)          # raw_quat: unit quaternions [2B*H*K,4] instead of matrices
         trans = self.trans_predictor(feat) / 10.
         depth = self.depth_predictor(feat).view(-1, 1, self.nmesh)
         depth = torch.cat([depth[:, :, :1], (depth[:, :, 1:] - self.offset) / 10.], 2).view(feat.shape[0], -1)
@@ -610,55 +612,68 @@ class LASR(MeshNet):
         for m in self.modules():                                                 # BN always in eval mode (:190-195)
             if isinstance(m, nn.modules.batchnorm._BatchNorm):                   # incl. SyncBatchNorm (class-name match in the reference)
                 m.eval()
-        scale, trans, quat, depth, ppoint = self.code_predictor(self.encoder(self.input_imgs))
-
-        # intrinsics bookkeeping (:204-217): crop scale into focal length / root depth, frame t' shares frame t's principal point
-        scale, depth, ppoint = fused_ops.intrinsics(self.cams, self.pp, scale, depth, ppoint, IS)
-        depth = depth.reshape(-1, 1)
-
-        quat = quat.view(-1, 9)
-        if opts.noise and self.epoch > 0 and 1 < self.iters < 100:               # pose / scale noise (:220-235)
-            decay = self.noise_decay                          # 0.2 * 1e-4 ** (iters / 100), device scalar (schedule_scalars)
-            noise = pose_noise_quat(quat.shape[0], decay, quat.device)
-            quat = quat.view(-1, 3, 3).matmul(quaternion_to_rotation_matrix(noise)).view(-1, 9)
-            scale = scale * (decay * torch.randn_like(scale) * opts.rscale).exp()
-        depth = depth.view(n2, 1, K, 1).repeat(1, H, 1, 1).view(-1, 1)
-        trans = trans.view(n2, 1, K, 2).repeat(1, H, 1, 1).view(-1, 2)
-
-        if opts.use_gtpose:                                                      # (:240-253)
-            quat_pred, scale_pred, trans_pred = quat.clone(), scale.clone(), trans.clone()
-            ppoint_pred, depth_pred = ppoint.clone(), depth.clone()
-            scale = 10 * self.cams[:, :1]
-            trans = self.cams[:, 1:3]
-            quat = quaternion_to_rotation_matrix(torch.cat((self.cams[:, 4:], self.cams[:, 3:4]), -1)).view(-1, 9)
-            depth = self.depth_gt[:]
-            halforisize = 0.5 * IS / self.cams[:, :1]
-            ppoint = (0.5 * self.oriimg_shape - self.pp[:]) / halforisize - 1
-
-        # ---- rigid + articulated transforms (:259-289): Rmat = predicted matrix transposed, Tmat = (trans, depth); bones
-        # k >= 1 rotate about their joint (T' = -R c + T + c with c = rest_ts) and are transposed back -- one kernel (row a3)
-        # (without ground-truth poses the camera term is the rotation distance between the two frames' matrices, :514-516: it rides on
-        # the fix-up's launches)
+        noise_now = opts.noise and self.epoch > 0 and 1 < self.iters < 100
+        # the pose chain in one launch each way (fused_ops.pose_chain) whenever nothing sits between its stages: no pose noise,
+        # no ground-truth poses
+        chain = self.input_imgs.is_cuda and not noise_now and not opts.use_gtpose
+        scale, trans, quat, depth, ppoint = self.code_predictor(self.encoder(self.input_imgs), raw_quat=chain)
         pair_angle = None
-        if opts.use_gtpose:
-            Rmat, Tmat = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K)
+        if chain:
+            scale, ppoint, Rmat, Tmat, trans, depth, pair_angle, proj = fused_ops.pose_chain(
+                self.cams, self.pp, scale, depth, ppoint, quat, trans, self.rest_ts, self.ctl_ts, H, K, IS)
+            skin = None
+            if K > 1:
+                skin_h = self._skinning(pred_v, n2)
+                skin = skin_h.repeat(n2, 1, 1, 1)
+                self.joints_proj, self.ctl_proj = proj.split([K - 1, K - 1], 1)
         else:
-            Rmat, Tmat, pair_angle = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K, pair_angle=True)
-        skin = None
-        if K > 1:
-            skin_h = self._skinning(pred_v, n2)
-            skin = skin_h.repeat(n2, 1, 1, 1)
-            # joints and control points through the same transforms and the projection, one launch each way (the reference: two
-            # obj_to_cam calls with an identity skin, :285-288, and pinhole_cam); only rest_ts / ctl_ts receive gradient
-            if Rmat.is_cuda:
-                proj = fused_ops.project_points(self.rest_ts, self.ctl_ts, Rmat, Tmat, ppoint, scale, H, K)
+            # intrinsics bookkeeping (:204-217): crop scale into focal length / root depth, frame t' shares frame t's principal point
+            scale, depth, ppoint = fused_ops.intrinsics(self.cams, self.pp, scale, depth, ppoint, IS)
+            depth = depth.reshape(-1, 1)
+
+            quat = quat.view(-1, 9)
+            if noise_now:                                                        # pose / scale noise (:220-235)
+                decay = self.noise_decay                          # 0.2 * 1e-4 ** (iters / 100), device scalar (schedule_scalars)
+                noise = pose_noise_quat(quat.shape[0], decay, quat.device)
+                quat = quat.view(-1, 3, 3).matmul(quaternion_to_rotation_matrix(noise)).view(-1, 9)
+                scale = scale * (decay * torch.randn_like(scale) * opts.rscale).exp()
+            depth = depth.view(n2, 1, K, 1).repeat(1, H, 1, 1).view(-1, 1)
+            trans = trans.view(n2, 1, K, 2).repeat(1, H, 1, 1).view(-1, 2)
+
+            if opts.use_gtpose:                                                      # (:240-253)
+                quat_pred, scale_pred, trans_pred = quat.clone(), scale.clone(), trans.clone()
+                ppoint_pred, depth_pred = ppoint.clone(), depth.clone()
+                scale = 10 * self.cams[:, :1]
+                trans = self.cams[:, 1:3]
+                quat = quaternion_to_rotation_matrix(torch.cat((self.cams[:, 4:], self.cams[:, 3:4]), -1)).view(-1, 9)
+                depth = self.depth_gt[:]
+                halforisize = 0.5 * IS / self.cams[:, :1]
+                ppoint = (0.5 * self.oriimg_shape - self.pp[:]) / halforisize - 1
+
+            # ---- rigid + articulated transforms (:259-289): Rmat = predicted matrix transposed, Tmat = (trans, depth); bones
+            # k >= 1 rotate about their joint (T' = -R c + T + c with c = rest_ts) and are transposed back -- one kernel (row a3)
+            # (without ground-truth poses the camera term is the rotation distance between the two frames' matrices, :514-516: it rides on
+            # the fix-up's launches)
+            pair_angle = None
+            if opts.use_gtpose:
+                Rmat, Tmat = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K)
             else:
-                eye = torch.eye(K - 1, device=Rmat.device)[None, :, :, None]
-                eye = torch.cat([eye, eye], 2)                                   # [1, K-1, 2(K-1), 1]
-                pts = torch.cat([self.rest_ts.view(H, K - 1, 3), self.ctl_ts.view(H, K - 1, 3)], 1).repeat(n2, 1, 1)
-                jc = obj_to_cam(pts, Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
-                proj = pinhole_cam(torch.cat([jc, torch.ones_like(jc[:, :, :1])], -1), ppoint.detach(), scale.detach())
-            self.joints_proj, self.ctl_proj = proj.split([K - 1, K - 1], 1)
+                Rmat, Tmat, pair_angle = fused_ops.bone_fixup(quat, trans, depth, self.rest_ts, H, K, pair_angle=True)
+            skin = None
+            if K > 1:
+                skin_h = self._skinning(pred_v, n2)
+                skin = skin_h.repeat(n2, 1, 1, 1)
+                # joints and control points through the same transforms and the projection, one launch each way (the reference: two
+                # obj_to_cam calls with an identity skin, :285-288, and pinhole_cam); only rest_ts / ctl_ts receive gradient
+                if Rmat.is_cuda:
+                    proj = fused_ops.project_points(self.rest_ts, self.ctl_ts, Rmat, Tmat, ppoint, scale, H, K)
+                else:
+                    eye = torch.eye(K - 1, device=Rmat.device)[None, :, :, None]
+                    eye = torch.cat([eye, eye], 2)                                   # [1, K-1, 2(K-1), 1]
+                    pts = torch.cat([self.rest_ts.view(H, K - 1, 3), self.ctl_ts.view(H, K - 1, 3)], 1).repeat(n2, 1, 1)
+                    jc = obj_to_cam(pts, Rmat.detach(), Tmat[:, None].detach(), K, H, eye)
+                    proj = pinhole_cam(torch.cat([jc, torch.ones_like(jc[:, :, :1])], -1), ppoint.detach(), scale.detach())
+                self.joints_proj, self.ctl_proj = proj.split([K - 1, K - 1], 1)
         # ---- 1) flow rendering (:298-335); deform_v (:291) is the same blend before the body transform: one launch for both
         verts_cam, self.deform_v = obj_to_cam_both(pred_v, Rmat, Tmat[:, None, :], K, H, skin)
         self.verts_cam = verts_cam.detach()                                      # per-frame shape in camera space (export)

@@ -333,17 +333,18 @@ def test_normal_consistency_of_the_mesh_evaluation_on_analytic_meshes(cuda):
     assert torch.allclose(nrm.abs(), torch.full_like(nrm, 3 ** -0.5), atol=1e-6)
     assert torch.allclose((p * nrm).sum(1), torch.full((4000,), 3 ** -0.5, device=cuda), atol=1e-5)      # outward, on the plane x.n = 1/sqrt(3)
     assert torch.allclose(p.abs().sum(1), torch.ones(4000, device=cuda), atol=1e-5)                     # |x| + |y| + |z| = 1
-    v, f, _ = synth.blobby_mesh(8)
+    v, f = synth.geodesic_sphere(8)                                              # 642 vertices, 1280 faces
     f = torch.from_numpy(np.asarray(f, np.int64)).to(cuda)
-    sphere = torch.nn.functional.normalize(torch.from_numpy(v).float().to(cuda), dim=1)
+    sphere = torch.nn.functional.normalize(torch.from_numpy(np.asarray(v)).float().to(cuda), dim=1)
     q, nq = ev.sample_points(sphere, f, 4000, gen, True)
     assert float((torch.nn.functional.normalize(q, dim=1) * nq).sum(1).abs().min()) > 0.97              # facet angle of 1280 faces
     # the metric: a mesh against itself (other samples), against its copy with every face flipped (abs_cosine: still ~1),
     # against another shape (lower); the octahedron against itself is 1 up to sampling at the edges
     same_cd, same_nc = ev.evaluate_pair((sphere, f), (sphere, f), with_normals=True)
     flip_cd, flip_nc = ev.evaluate_pair((sphere, f.flip(1)), (sphere, f), with_normals=True)
-    blob = torch.from_numpy(v).float().to(cuda)
-    other_cd, other_nc = ev.evaluate_pair((blob, f), (sphere, f), with_normals=True)
+    bv, bf, _ = synth.blobby_mesh(8)
+    blob, bf = torch.from_numpy(bv).float().to(cuda), torch.from_numpy(np.asarray(bf, np.int64)).to(cuda)
+    other_cd, other_nc = ev.evaluate_pair((blob, bf), (sphere, f), with_normals=True)
     assert same_nc > 0.97 and abs(flip_nc - same_nc) < 0.01 and other_nc < same_nc - 0.02 and other_cd > 5 * same_cd
     # closed form for the normal term: every sampled point of octant (+,+,+) matched to a point of the SAME face gives cos = 1
     x, nx = ev.sample_points(ov, of, 6000, gen, True)

@@ -63,20 +63,34 @@ def run_both(tmp_path, independent=True, trainer=None, **over):
         if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
             mod.eval()
     perm = {k: v.view(B, 2, -1).permute(1, 0, 2).reshape(v.shape) for k, v in batch.items()}
+    # (without ground-truth poses LASR.forward asks the predictor for unit quaternions and runs the pose chain -- intrinsics,
+    # quaternion matrices, bone fix-up, joint projection -- as one launch, fused_ops.pose_chain: the frozen leaf is then the
+    # quaternion, and the oracle gets its matrix through oracle/path_oracle.py's restatement of kornia's conversion)
+    chain = not opts.use_gtpose
+    from lasr_amd.nnutils.mesh_net import quaternion_to_rotation_matrix
     with torch.no_grad():
-        code = [c.detach().clone() for c in m.code_predictor(m.encoder(perm['input_imgs  ']))]
+        code = [c.detach().clone() for c in m.code_predictor(m.encoder(perm['input_imgs  ']), raw_quat=chain)]
         scale, trans, quat, depth, ppoint = code
-        quat = quat.view(-1, 3, 3)
-        ang = 0.15 * torch.randn(quat.shape[0], 3, generator=g).to(quat.device)
-        from lasr_amd.nnutils.mesh_net import quaternion_to_rotation_matrix
-        dq = torch.cat([ang, torch.ones_like(ang[:, :1])], 1)
-        quat = quat.matmul(quaternion_to_rotation_matrix(dq)).reshape(-1, 9)
+        if chain:
+            quat = torch.nn.functional.normalize(quat + 0.08 * torch.randn(quat.shape, generator=g).to(quat.device), dim=1)
+        else:
+            quat = quat.view(-1, 3, 3)
+            ang = 0.15 * torch.randn(quat.shape[0], 3, generator=g).to(quat.device)
+            dq = torch.cat([ang, torch.ones_like(ang[:, :1])], 1)
+            quat = quat.matmul(quaternion_to_rotation_matrix(dq)).reshape(-1, 9)
         trans = trans + 0.02 * torch.randn(trans.shape, generator=g).to(trans.device)
         depth = depth + 0.02 * torch.randn(depth.shape, generator=g).to(depth.device)
         ppoint = ppoint + 0.02 * torch.randn(ppoint.shape, generator=g).to(ppoint.device)
         scale = scale * (1 + 0.02 * torch.randn(scale.shape, generator=g).to(scale.device))
     code_gpu = [c.clone().requires_grad_(True) for c in (scale, trans, quat, depth, ppoint)]
-    m.code_predictor.forward = lambda feat: tuple(c * 1 for c in code_gpu)     # instance attribute shadows the method
+
+    def frozen_code(feat, raw_quat=False):
+        c = [x * 1 for x in code_gpu]
+        if chain and not raw_quat:
+            c[2] = quaternion_to_rotation_matrix(c[2]).reshape(-1, 9)
+        assert chain or not raw_quat
+        return tuple(c)
+    m.code_predictor.forward = frozen_code                                       # instance attribute shadows the method
 
     # record the geometry the product hands to its three render calls
     captured = {}
@@ -129,7 +143,11 @@ def run_both(tmp_path, independent=True, trainer=None, **over):
             continue
         P = {n: getattr(m, n).detach().cpu().clone().requires_grad_(True) for n in names}
         code_cpu = [c.detach().cpu().clone().requires_grad_(True) for c in code_gpu]
-        ref_loss, ref = lfo.lasr_forward(P, code_cpu, cpu_batch, dict(cfg, inject=inject))
+        code_in = list(code_cpu)
+        if chain:
+            from oracle import path_oracle
+            code_in[2] = path_oracle.quaternion_to_rotation_matrix(code_cpu[2]).reshape(-1, 9)
+        ref_loss, ref = lfo.lasr_forward(P, code_in, cpu_batch, dict(cfg, inject=inject))
         ref_loss.backward()
         runs.append((P, code_cpu, ref_loss, ref))
     return m, loss, code_gpu, captured, runs

@@ -378,7 +378,7 @@ def test_point_mesh_distance_matches_restatement(cuda, seed):
         c = [verts.clone().to(cuda).requires_grad_(True), pts.clone().to(cuda).requires_grad_(True)]
         (fused_ops.point_mesh_face_distance(c[0], fc, c[1]) * 1.7).backward()
         grads.append((c[0].grad, c[1].grad))
-    assert geometry._INC_CACHE[id(fc)][3] is not None
+    assert geometry._INC_CACHE[id(fc)][2] is not None
     assert all(torch.equal(gv, b[0].grad) and torch.equal(gp, b[1].grad) for gv, gp in grads)
 
 
