@@ -464,6 +464,14 @@ int lasr_render_tables_forward(const float* px, const float* masks, const float*
                                const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab, float* tex_tab, float* flow_rd,
                                unsigned char* bgmask, float* flow_map, unsigned char* vis_mask, float* rndpair, float* scratch,
                                int I, int H, int P, void* hip_stream);
+/* The same pass from the observed images themselves (round 6): imgs [I,3,P]; the object on black and on white (nnutils/mesh_net.py:364-366,
+ * lasr_obs_pair's values) is formed inside and written to obs_pair_out [2I,3,P] (black first) -- what the backward and the perceptual
+ * term take as img_obs / img_white.  One launch (lasr_obs_pair) and three input planes less than the call above; same tables. */
+int lasr_render_tables_forward_imgs(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                                    long long flow_obs_image_stride, const float* imgs, float* obs_pair_out, const float* pp,
+                                    const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab, float* tex_tab, float* flow_rd,
+                                    unsigned char* bgmask, float* flow_map, unsigned char* vis_mask, float* rndpair, float* scratch,
+                                    int I, int H, int P, void* hip_stream);
 int lasr_render_tables_backward(const float* px, const float* masks, const float* occ, const float* flow_obs,
                                 long long flow_obs_image_stride, const float* img_obs, const float* img_white, const float* pp,
                                 const float* fl, float l1tex_wt, const float* grad_mask_tab, const float* grad_flow_tab,

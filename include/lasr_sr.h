@@ -52,7 +52,8 @@ extern "C" {
  *      lasr_face_gather_backward_csr, lasr_bone_fixup_pair_*, lasr_step_regularisers_*, lasr_point_mesh_scratch_floats (+ a scratch argument of lasr_point_mesh_forward).
  *      (lasr_lbs_backward_scratch_floats grew about 4x with the 64-vertex chunks of the MFMA backward: re-query it, never cache it per (N, V, K).)
  *   4  round 6: lasr_sr_options.mixed_min_weight (fifth field) became pair_min_tiles -- the one-launch mix of two tile bodies is gone,
- *      launches from that many 8x8 tiles up take the pair-walk forward kernel.  New (no existing signature changes): lasr_pose_chain_*. */
+ *      launches from that many 8x8 tiles up take the pair-walk forward kernel.  New (no existing signature changes): lasr_pose_chain_*,
+ *      lasr_render_tables_forward_imgs. */
 #define LASR_ABI_VERSION 4
 int         lasr_abi_version(void);
 const char* lasr_strerror(int code);

@@ -93,6 +93,7 @@ SIGNATURES = {
     'lasr_obs_pair': (_i, [_p, _p, _p, _i, _i, _p]),
     'lasr_render_tables_scratch_floats': (_sz, [_i, _i, _i]),
     'lasr_render_tables_forward': (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f] + [_p] * 9 + [_i, _i, _i, _p]),
+    'lasr_render_tables_forward_imgs': (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f] + [_p] * 9 + [_i, _i, _i, _p]),
     'lasr_render_tables_backward': (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f] + [_p] * 8 + [_i, _i, _i, _p]),
     'lasr_raster_inputs_forward': (_i, [_p] * 9 + [_i, _i, _p]),
     'lasr_raster_inputs_backward': (_i, [_p] * 8 + [_i, _i, _p]),

@@ -65,8 +65,13 @@ struct PrArgs {
 };
 
 // ---- forward pass 1: everything that needs one look at the render ------------------------------------------------------------
+// FROM_IMGS: A.img_obs holds the observed images themselves; the object on black / on white (nnutils/mesh_net.py:364-366,
+// obs_pair_kernel's expressions) is formed here and written to obs_out [2I,3,P] by the blocks of hypothesis 0 -- the launch of
+// lasr_obs_pair and three of the pass' input planes are saved.
+template <bool FROM_IMGS>
 __global__ __launch_bounds__(256) void render_tables_forward_kernel(PrArgs A, float2* __restrict__ flow, unsigned char* __restrict__ bg,
-                                                                    float* __restrict__ rndpair, float* __restrict__ part)
+                                                                    float* __restrict__ rndpair, float* __restrict__ part,
+                                                                    float* __restrict__ obs_out)
 {
     __shared__ float red[4];
     const int ij = blockIdx.x, i = ij / A.H, ch = blockIdx.y, P = A.P, N = A.I * A.H;
@@ -94,11 +99,26 @@ __global__ __launch_bounds__(256) void render_tables_forward_kernel(PrArgs A, fl
         flow[(size_t)ij * P + p] = make_float2(u1 - u0, v1 - v0);
         bg[(size_t)ij * P + p] = b ? 1 : 0;
         const float o = oc[p];
+        float b0, b1, b2, w0, w1, w2;                                   // observed object on black | on white
+        if (FROM_IMGS) {
+            const float fg = m[p] > 0.f ? 1.f : 0.f;
+            b0 = io[p] * fg; b1 = io[P + p] * fg; b2 = io[2 * (size_t)P + p] * fg;
+            w0 = 1.f - fg + b0; w1 = 1.f - fg + b1; w2 = 1.f - fg + b2;
+            if (ij == i * A.H) {
+                float* ob = obs_out + (size_t)i * 3 * P + p;
+                float* ow = obs_out + ((size_t)A.I + i) * 3 * P + p;
+                ob[0] = b0; ob[P] = b1; ob[2 * (size_t)P] = b2;
+                ow[0] = w0; ow[P] = w1; ow[2 * (size_t)P] = w2;
+            }
+        } else if (o != 0.f) {
+            b0 = io[p]; b1 = io[P + p]; b2 = io[2 * (size_t)P + p];
+            w0 = iw[p]; w1 = iw[P + p]; w2 = iw[2 * (size_t)P + p];
+        }
         if (o != 0.f) {
             const float d = a - m[p];                                   // silhouette (== mask_loss_forward_kernel)
             s_mask += d * d; c_occ += 1.f;
-            const float e1 = fabsf(io[p] - r0 * a) + fabsf(io[P + p] - r1 * a) + fabsf(io[2 * (size_t)P + p] - r2 * a);
-            const float e2 = fabsf(iw[p] - r0) + fabsf(iw[P + p] - r1) + fabsf(iw[2 * (size_t)P + p] - r2);
+            const float e1 = fabsf(b0 - r0 * a) + fabsf(b1 - r1 * a) + fabsf(b2 - r2 * a);
+            const float e2 = fabsf(w0 - r0) + fabsf(w1 - r1) + fabsf(w2 - r2);
             s1 += e1 / 3.f; s2 += e2 / 3.f;                             // texture L1 (== tex_loss_forward_kernel)
             if (!b && m[p] > 0.f) { s_sig += pr_sigmoid(-o); c_sel += 1.f; }   // (== flow_loss_stats_kernel)
         }
@@ -687,11 +707,11 @@ static int pr_args(PrArgs& A, const float* px, const float* masks, const float* 
     return LASR_OK;
 }
 
-extern "C" int lasr_render_tables_forward(const float* px, const float* masks, const float* occ, const float* flow_obs,
-                                          long long flow_obs_image_stride, const float* img_obs, const float* img_white,
-                                          const float* pp, const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab,
-                                          float* tex_tab, float* flow_rd, unsigned char* bgmask, float* flow_map, unsigned char* vis_mask,
-                                          float* rndpair, float* scratch, int I, int H, int P, void* hip_stream)
+static int render_tables_forward_impl(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                                      long long flow_obs_image_stride, const float* img_obs, const float* img_white,
+                                      const float* pp, const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab,
+                                      float* tex_tab, float* flow_rd, unsigned char* bgmask, float* flow_map, unsigned char* vis_mask,
+                                      float* rndpair, float* scratch, int I, int H, int P, void* hip_stream, float* obs_pair_out)
 {
     PrArgs A;
     int rc = pr_args(A, px, masks, occ, flow_obs, flow_obs_image_stride, img_obs, img_white, pp, fl, I, H, P);
@@ -700,8 +720,12 @@ extern "C" int lasr_render_tables_forward(const float* px, const float* masks, c
     hipStream_t st = (hipStream_t)hip_stream;
     const PrScratch S = pr_scratch(scratch, I, H, P);
     const int N = I * H;
-    LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_forward_kernel, dim3(N, A.nch), dim3(256), 0, A, (float2*)flow_rd, bgmask,
-                rndpair, S.part);
+    if (obs_pair_out)
+        LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_forward_kernel<true>, dim3(N, A.nch), dim3(256), 0, A, (float2*)flow_rd, bgmask,
+                    rndpair, S.part, obs_pair_out);
+    else
+        LASR_LAUNCH(K_RENDER_TABLES_FORWARD, render_tables_forward_kernel<false>, dim3(N, A.nch), dim3(256), 0, A, (float2*)flow_rd, bgmask,
+                    rndpair, S.part, (float*)nullptr);
     if ((rc = launch_ok())) return rc;
     LASR_LAUNCH(K_RENDER_TABLES_FLOW, render_tables_flow_kernel, dim3(N, A.nch), dim3(256), 0, A, (const float2*)flow_rd, bgmask,
                 S.part, S.tot, S.img, mask_tab, tex_tab, 2.f * l1tex_wt, S.part2, flow_map, vis_mask);
@@ -709,6 +733,28 @@ extern "C" int lasr_render_tables_forward(const float* px, const float* masks, c
     LASR_LAUNCH(K_RENDER_TABLES_FOLD, render_tables_flow_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, S.part2, S.tot, flow_tab,
                 N, A.nch);
     return launch_ok();
+}
+
+extern "C" int lasr_render_tables_forward(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                                          long long flow_obs_image_stride, const float* img_obs, const float* img_white,
+                                          const float* pp, const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab,
+                                          float* tex_tab, float* flow_rd, unsigned char* bgmask, float* flow_map, unsigned char* vis_mask,
+                                          float* rndpair, float* scratch, int I, int H, int P, void* hip_stream)
+{
+    return render_tables_forward_impl(px, masks, occ, flow_obs, flow_obs_image_stride, img_obs, img_white, pp, fl, l1tex_wt, mask_tab,
+                                      flow_tab, tex_tab, flow_rd, bgmask, flow_map, vis_mask, rndpair, scratch, I, H, P, hip_stream, nullptr);
+}
+
+extern "C" int lasr_render_tables_forward_imgs(const float* px, const float* masks, const float* occ, const float* flow_obs,
+                                               long long flow_obs_image_stride, const float* imgs, float* obs_pair_out,
+                                               const float* pp, const float* fl, float l1tex_wt, float* mask_tab, float* flow_tab,
+                                               float* tex_tab, float* flow_rd, unsigned char* bgmask, float* flow_map,
+                                               unsigned char* vis_mask, float* rndpair, float* scratch, int I, int H, int P,
+                                               void* hip_stream)
+{
+    if (I > 0 && H > 0 && P > 0 && !obs_pair_out) return LASR_E_BADARG;
+    return render_tables_forward_impl(px, masks, occ, flow_obs, flow_obs_image_stride, imgs, imgs, pp, fl, l1tex_wt, mask_tab, flow_tab,
+                                      tex_tab, flow_rd, bgmask, flow_map, vis_mask, rndpair, scratch, I, H, P, hip_stream, obs_pair_out);
 }
 
 extern "C" int lasr_render_tables_backward(const float* px, const float* masks, const float* occ, const float* flow_obs,

@@ -100,15 +100,18 @@ class _RenderTables(Function):
     """lasr_render_tables_*: see render_tables()."""
 
     @staticmethod
-    def forward(ctx, px, masks, occ, flow_obs, obspair, pp, fl, wt, want_pair):
+    def forward(ctx, px, masks, occ, flow_obs, obspair, pp, fl, wt, want_pair, from_imgs=False):
         _lib.need_cuda(px, masks, occ, flow_obs, obspair, pp, fl)
         N, I = px.shape[0], masks.shape[0]
         H, P = N // max(I, 1), masks[0].numel()
-        if px.dtype != torch.float32 or px.shape[1] != 10 or N != I * H or obspair.shape[0] != 2 * I:
-            raise ValueError('px must be float32 [I*H,10,IS,IS], obspair [2I,3,IS,IS]')
+        if px.dtype != torch.float32 or px.shape[1] != 10 or N != I * H or obspair.shape[0] != (I if from_imgs else 2 * I):
+            raise ValueError('px must be float32 [I*H,10,IS,IS], obspair [2I,3,IS,IS] (or the images [I,3,IS,IS])')
         px = px.contiguous()
         masks, occ, flow_obs = masks.contiguous().float(), occ.contiguous().float(), flow_obs.contiguous().float()
-        obspair, pp, fl = obspair.contiguous().float(), pp.contiguous().float(), fl.contiguous().float()
+        obspair, pp, fl = obspair.detach().contiguous().float(), pp.contiguous().float(), fl.contiguous().float()
+        imgs = obspair if from_imgs else None
+        if from_imgs:                                      # the pair is formed by the pass itself (lasr_render_tables_forward_imgs)
+            obspair = torch.empty(2 * I, *imgs.shape[1:], dtype=torch.float32, device=px.device)
         dev, hw = px.device, px.shape[2:]
         h = _lib.lib()
         tabs = torch.empty(3, I, H, dtype=torch.float32, device=dev)
@@ -120,23 +123,30 @@ class _RenderTables(Function):
         scratch = torch.empty(h.lasr_render_tables_scratch_floats(I, H, P), dtype=torch.float32, device=dev)
         guard, st = _lib.stream_of(px)
         with guard:
-            rc = h.lasr_render_tables_forward(px.data_ptr(), masks.data_ptr(), occ.data_ptr(), flow_obs.data_ptr(), flow_obs[0].numel(),
-                                              obspair.data_ptr(), obspair[I:].data_ptr(), pp.data_ptr(), fl.data_ptr(), float(wt),
-                                              tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), flow.data_ptr(),
-                                              bg.data_ptr(), fmap.data_ptr(), vis.data_ptr(),
-                                              pair.data_ptr() if want_pair else None, scratch.data_ptr(), I, H, P, st)
+            tail = (pp.data_ptr(), fl.data_ptr(), float(wt), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), flow.data_ptr(),
+                    bg.data_ptr(), fmap.data_ptr(), vis.data_ptr(), pair.data_ptr() if want_pair else None, scratch.data_ptr(), I, H, P, st)
+            head = (px.data_ptr(), masks.data_ptr(), occ.data_ptr(), flow_obs.data_ptr(), flow_obs[0].numel())
+            if from_imgs:
+                rc = h.lasr_render_tables_forward_imgs(*head, imgs.data_ptr(), obspair.data_ptr(), *tail)
+            else:
+                rc = h.lasr_render_tables_forward(*head, obspair.data_ptr(), obspair[I:].data_ptr(), *tail)
         _lib.check(rc, 'lasr_render_tables_forward')
         ctx.save_for_backward(px, masks, occ, flow_obs, obspair, pp, fl, scratch)
         ctx.wt, ctx.geom = float(wt), (I, H, P)
+        ctx.from_imgs, ctx.want_pair = bool(from_imgs), bool(want_pair)
         bg, vis = bg.view(torch.bool), vis.view(torch.bool)
         ctx.mark_non_differentiable(flow, bg, fmap, vis)
         ctx.set_materialize_grads(False)
-        if want_pair:
-            return tabs[0], tabs[1], tabs[2], flow, bg, fmap, vis, pair
-        return tabs[0], tabs[1], tabs[2], flow, bg, fmap, vis
+        out = (tabs[0], tabs[1], tabs[2], flow, bg, fmap, vis) + ((pair,) if want_pair else ())
+        if from_imgs:
+            ctx.mark_non_differentiable(obspair)
+            out = out + (obspair,)
+        return out
 
     @staticmethod
-    def backward(ctx, g_mask, g_flow, g_tex, _gf=None, _gb=None, _gm=None, _gv=None, g_pair=None):
+    def backward(ctx, g_mask, g_flow, g_tex, _gf=None, _gb=None, _gm=None, _gv=None, g_pair=None, _g_obs=None):
+        if ctx.from_imgs and not ctx.want_pair:
+            g_pair = None                                  # (the eighth output is then the observed pair: data)
         px, masks, occ, flow_obs, obspair, pp, fl, scratch = ctx.saved_tensors
         I, H, P = ctx.geom
         dev = px.device
@@ -162,7 +172,7 @@ class _RenderTables(Function):
                 g_pair.data_ptr() if g_pair is not None else None, scratch.data_ptr(), gpx.data_ptr(), gpp.data_ptr(),
                 gfl.data_ptr(), I, H, P, st)
         _lib.check(rc, 'lasr_render_tables_backward')
-        return gpx, None, None, None, None, gpp, gfl, None, None
+        return gpx, None, None, None, None, gpp, gfl, None, None, None
 
 
 def render_tables(px, masks, occ, flow_obs, obspair, pp, fl, l1tex_wt=1.0, want_pair=False):
@@ -174,6 +184,12 @@ def render_tables(px, masks, occ, flow_obs, obspair, pp, fl, l1tex_wt=1.0, want_
     -> mask table [I,H], flow table [I,H], texture L1 table [I,H] (= 2 wt (mean1 + mean2)), flow_rd [N,IS,IS,2], bgmask,
        weighted flow error map, vis_mask [N,IS,IS] (+ rndpair [2N,3,IS,IS] = (render * alpha | render) when want_pair)."""
     return _RenderTables.apply(px, masks, occ, flow_obs, obspair, pp, fl, l1tex_wt, want_pair)
+
+
+def render_tables_imgs(px, masks, occ, flow_obs, imgs, pp, fl, l1tex_wt=1.0, want_pair=False):
+    """render_tables from the observed images [I,3,IS,IS] themselves: the object on black | on white (obs_pair's values) is formed
+    inside the pass and returned as the LAST element [2I,3,IS,IS] -- one launch and three input planes less."""
+    return _RenderTables.apply(px, masks, occ, flow_obs, imgs, pp, fl, l1tex_wt, want_pair, True)
 
 
 class _RasterInputs(Function):

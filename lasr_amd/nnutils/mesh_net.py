@@ -726,11 +726,12 @@ class LASR(MeshNet):
             px = r_tex.render_mesh(sr.Mesh(verts_pre, faces_rep, textures=attrs, texture_type='vertex'))
         self.texture_render, alpha = px[:, :3], px[:, 9]                         # views of the wide render
         self.mask_pred = alpha
-        obspair = fused_ops.obs_pair(self.imgs, self.masks)                     # observed object on black | on white (:364-366)
         # ---- reprojection + the three image-loss tables (+ the perceptual net's input pair) in one pass over the render and
         # one pass back (fused_ops.render_tables; mesh_net.py:87-104, :374-441)
         want_pair = self.ptex_loss is not None
-        rt = fused_ops.render_tables(px, self.masks, self.occ, self.flow, obspair, pp_all, sc_all, opts.l1tex_wt, want_pair)
+        # (the observed object on black | on white, :364-366, is formed by the same pass and comes back as its last output)
+        rt = fused_ops.render_tables_imgs(px, self.masks, self.occ, self.flow, self.imgs, pp_all, sc_all, opts.l1tex_wt, want_pair)
+        obspair = rt[-1]
         self.mask_loss_sub, self.flow_rd_loss_sub, tex_l1, self.flow_rd, self.bgmask, flow_map, vis = rt[:7]
         self.flow_rd_map, self.vis_mask = flow_map.view(n2, H, IS, IS), vis.view(n2, H, IS, IS)
         self.flow_fw, self.flow_bw = self.flow_rd[:BH], self.flow_rd[BH:]         # the reference's per-direction attributes (views)

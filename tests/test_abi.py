@@ -191,5 +191,6 @@ def test_round5_entry_points_validate_on_the_host():
     assert h.lasr_cosdist_multi_scratch_floats(n, 3, 2) == 0
     assert h.lasr_raster_faces_scratch_floats(2, 10, 16) > 0
     assert h.lasr_project_points_forward(n, n, n, n, n, n, n, 0, 1, 2, n) in (0, -1)
+    assert h.lasr_render_tables_forward_imgs(n, n, n, n, 0, n, n, n, n, 1.0, n, n, n, n, n, n, n, n, n, 0, 1, 4, n) in (0, -1)
     assert h.lasr_pose_chain_forward(n, 1, *([n] * 17), 0, 1, 2, 1.0, n) == 0 and h.lasr_pose_chain_forward(n, 1, *([n] * 17), 1, 1, 2, 1.0, n) == -1
     assert h.lasr_pose_chain_backward(n, 1, *([n] * 22), 0, 1, 2, n) == 0 and h.lasr_pose_chain_backward(n, 0, *([n] * 22), 1, 1, 2, n) == -1

@@ -107,6 +107,31 @@ def test_tables_are_bit_identical_to_the_separate_operators(cuda):
     assert torch.equal(out[7], torch.cat([rgb * alpha[:, None], rgb], 0))
 
 
+@pytest.mark.parametrize('want_pair', [False, True])
+def test_the_pass_from_the_images_forms_the_observed_pair_itself(cuda, want_pair):
+    # render_tables_imgs = obs_pair + render_tables in one launch less: every output, the pair it hands back and the gradients are
+    # the same bits (ragged size: chunks that do not divide the image)
+    I, H, IS = 2, 3, 52
+    px, masks, occ, flow_obs, imgs, pp, fl = [t.to(cuda) for t in make_case(I, H, IS, seed=5)]
+    res = []
+    for fused in (False, True):
+        lp, lpp, lfl = (t.clone().requires_grad_(True) for t in (px, pp, fl))
+        if fused:
+            out = fused_ops.render_tables_imgs(lp, masks, occ, flow_obs, imgs, lpp, lfl, 0.7, want_pair)
+            pair, out = out[-1], out[:-1]
+        else:
+            pair = fused_ops.obs_pair(imgs, masks)
+            out = fused_ops.render_tables(lp, masks, occ, flow_obs, pair, lpp, lfl, 0.7, want_pair)
+        tot = out[0].sum() * 1.3 + out[1].sum() * 0.4 + out[2].sum() * 2.1
+        if want_pair:
+            tot = tot + (out[7] * torch.linspace(-1, 1, out[7].numel(), device=cuda).view_as(out[7])).sum()
+        tot.backward()
+        res.append((out, pair, (lp.grad, lpp.grad, lfl.grad)))
+    (oa, pa, ga), (ob, pb, gb) = res
+    assert len(oa) == len(ob) == (8 if want_pair else 7) and torch.equal(pa, pb) and not pb.requires_grad
+    assert all(torch.equal(a, b) for a, b in zip(oa, ob)) and all(torch.equal(a, b) for a, b in zip(ga, gb))
+
+
 def test_an_image_without_flow_selection_gives_the_reference_nan_gradient(cuda):
     # mesh_net.py:408-412: the per-image weight normaliser is a mean over an empty selection -> NaN; the loss row is 0 but the
     # gradient is NaN, and the reference's trainer then drops the step (train_utils.py:289-290).  Kept on purpose.
