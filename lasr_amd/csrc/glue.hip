@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void project_points_backward_kernel(const floa
 // ---- the pose chain: intrinsics -> quaternion matrices -> bone fix-up -> joint / control-point projection, ONE launch each way ----
 // The four operators above (and fused.hip's quat kernels) in the order LASR.forward runs them (nnutils/mesh_net.py:204-217, :232,
 // :259-289, :302), as phases of one 256-thread workgroup separated by barriers: the tensors hold a few hundred floats, every
-// launch of the chain costs ~4.7 us of which ~0.3 us is work.  Each phase is the expression sequence of its stand-alone kernel,
+// launch of the chain costs ~4.7 us of which ~0.3 us is work (1024 threads: every phase is one pass at LASR's sizes).  Each phase is the expression sequence of its stand-alone kernel,
 // so values and gradients are the ones the separate launches give (tests/test_step_fusions_gpu.py); the H-fold broadcast of
 // trans / depth (`.repeat(1, H, 1, 1)`) and its gradient (the sum over hypotheses, in hypothesis order) happen inside.
 //   quat4 [M*K,4] unit quaternions (x, y, z, w), trans [2B*K,2], depth [2B,K], scale [2B,H], ppoint [2B,2], M = 2B*H
@@ -334,16 +334,16 @@ struct PoseChain {
     int cam_stride, B, H, K; float half;
 };
 
-__global__ __launch_bounds__(256) void pose_chain_forward_kernel(PoseChain A)
+__global__ __launch_bounds__(1024) void pose_chain_forward_kernel(PoseChain A)
 {
     const int B = A.B, H = A.H, K = A.K, n2 = 2 * B, M = n2 * H, MK = M * K;
     // phase 1: intrinsics (intrinsics_forward_kernel)
-    for (int i = threadIdx.x; i < n2 * H; i += 256) A.scale_out[i] = A.cams[(i / H) * A.cam_stride] * A.scale[i];
-    for (int i = threadIdx.x; i < n2 * K; i += 256) {
+    for (int i = threadIdx.x; i < n2 * H; i += 1024) A.scale_out[i] = A.cams[(i / H) * A.cam_stride] * A.scale[i];
+    for (int i = threadIdx.x; i < n2 * K; i += 1024) {
         const float d = A.depth[i];
         A.depth_out[i] = (i % K == 0) ? A.cams[(i / K) * A.cam_stride] * d : d;
     }
-    for (int i = threadIdx.x; i < n2 * 2; i += 256) {
+    for (int i = threadIdx.x; i < n2 * 2; i += 1024) {
         const int r = i >> 1, c = i & 1;
         if (r < B) { A.ppoint_out[i] = A.ppoint[i]; continue; }
         const int r0 = r - B;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void pose_chain_forward_kernel(PoseChain A)
     }
     __syncthreads();
     // phase 2: quaternion -> matrix (quat_forward_kernel), rotation distance of the pair and bone fix-up (bone_fixup_forward_kernel)
-    for (int i = threadIdx.x; i < MK; i += 256) {
+    for (int i = threadIdx.x; i < MK; i += 1024) {
         float q[9];
         quat_matrix(load_quat(A.quat4 + 4 * (size_t)i), q);
         if (A.pair_angle && i < MK / 2) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void pose_chain_forward_kernel(PoseChain A)
     __syncthreads();
     // phase 3: joints and control points into the image (project_points_forward_kernel; fl = scale_out, pp = ppoint_out)
     const int nb = K - 1, Pn = 2 * nb;
-    for (int i = threadIdx.x; i < M * Pn; i += 256) {
+    for (int i = threadIdx.x; i < M * Pn; i += 1024) {
         const int m = i / Pn, j = i - m * Pn, h = m % H, b = j % nb;
         const float* p = (j < nb ? A.rest : A.ctl) + ((size_t)h * nb + b) * 3;
         const float* R = A.Rmat + ((size_t)m * K + b + 1) * 9;
@@ -415,12 +415,19 @@ struct PoseChainGrad {
     int cam_stride, B, H, K;
 };
 
-__global__ __launch_bounds__(256) void pose_chain_backward_kernel(PoseChainGrad A)
+// (1024 threads: every phase is one pass at LASR's sizes -- a second pass is a second chain of load round trips, and the launch is
+// nothing but such chains; the per-(m, k) gradient of the repeated trans / depth stays in LDS when it fits, `lds_scratch`)
+constexpr int POSE_CHAIN_THREADS = 1024;
+constexpr int POSE_CHAIN_LDS_FLOATS = 12288;
+__global__ __launch_bounds__(POSE_CHAIN_THREADS) void pose_chain_backward_kernel(PoseChainGrad A, int lds_scratch)
 {
+    extern __shared__ float pose_lds[];
+    constexpr int NT = POSE_CHAIN_THREADS;
+    float* const scratch = lds_scratch ? pose_lds : A.scratch;
     const int B = A.B, H = A.H, K = A.K, n2 = 2 * B, M = n2 * H, MK = M * K, nb = K - 1, Pn = 2 * nb;
     // phase 1: projection (project_points_backward_kernel): gradient of the points, summed over the images in image order
     if (K > 1) {
-        for (int i = threadIdx.x; i < H * Pn; i += 256) {
+        for (int i = threadIdx.x; i < H * Pn; i += NT) {
             const int h = i / Pn, j = i - h * Pn, b = j % nb;
             const float* p = (j < nb ? A.rest : A.ctl) + ((size_t)h * nb + b) * 3;
             float acc[3] = {0.f, 0.f, 0.f};
@@ -451,13 +458,13 @@ __global__ __launch_bounds__(256) void pose_chain_backward_kernel(PoseChainGrad 
         __syncthreads();
     }
     // phase 2: bone fix-up + rotation distance (bone_fixup_backward_kernel), then through the quaternion (quat_backward_kernel)
-    for (int i = threadIdx.x; i < MK; i += 256) {
+    for (int i = threadIdx.x; i < MK; i += NT) {
         const int k = i % K, h = (i / K) % H;
         const float* g = A.gR + 9 * (size_t)i;
         const float* t = A.gT + 3 * (size_t)i;
-        A.scratch[3 * (size_t)i] = t[0] + (A.g_trans_rep ? A.g_trans_rep[2 * (size_t)i] : 0.f);
-        A.scratch[3 * (size_t)i + 1] = t[1] + (A.g_trans_rep ? A.g_trans_rep[2 * (size_t)i + 1] : 0.f);
-        A.scratch[3 * (size_t)i + 2] = t[2] + (A.g_depth_rep ? A.g_depth_rep[i] : 0.f);
+        scratch[3 * (size_t)i] = t[0] + (A.g_trans_rep ? A.g_trans_rep[2 * (size_t)i] : 0.f);
+        scratch[3 * (size_t)i + 1] = t[1] + (A.g_trans_rep ? A.g_trans_rep[2 * (size_t)i + 1] : 0.f);
+        scratch[3 * (size_t)i + 2] = t[2] + (A.g_depth_rep ? A.g_depth_rep[i] : 0.f);
         float v[9];
         if (k == 0) {
 #pragma unroll
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256) void pose_chain_backward_kernel(PoseChainGrad 
     }
     if (K > 1) {
         // rest_ts: one thread per (h, k-1, component) sums its images in order, then adds the projection's part (phase 1)
-        for (int i = threadIdx.x; i < H * nb * 3; i += 256) {
+        for (int i = threadIdx.x; i < H * nb * 3; i += NT) {
             const int comp = i % 3, kb = (i / 3) % nb, h = i / (3 * nb);
             float s = 0.f;
             for (int im = 0; im < n2; im++) {
@@ -505,19 +512,19 @@ __global__ __launch_bounds__(256) void pose_chain_backward_kernel(PoseChainGrad 
     }
     __syncthreads();
     // phase 3: the H-fold broadcast of trans / depth backwards (hypothesis order), then intrinsics (intrinsics_backward_kernel)
-    for (int i = threadIdx.x; i < n2 * K; i += 256) {
+    for (int i = threadIdx.x; i < n2 * K; i += NT) {
         const int img = i / K, k = i - img * K;
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int h = 0; h < H; h++) {
-            const float* t = A.scratch + 3 * ((size_t)(img * H + h) * K + k);
+            const float* t = scratch + 3 * ((size_t)(img * H + h) * K + k);
             sx += t[0]; sy += t[1]; sz += t[2];
         }
         A.g_trans[2 * (size_t)i] = sx; A.g_trans[2 * (size_t)i + 1] = sy;
         A.g_depth[i] = k == 0 ? A.cams[img * A.cam_stride] * sz : sz;
     }
-    for (int i = threadIdx.x; i < n2 * H; i += 256)
+    for (int i = threadIdx.x; i < n2 * H; i += NT)
         A.g_scale[i] = A.g_scale_out ? A.cams[(i / H) * A.cam_stride] * A.g_scale_out[i] : 0.f;
-    for (int i = threadIdx.x; i < n2 * 2; i += 256) {
+    for (int i = threadIdx.x; i < n2 * 2; i += NT) {
         const int r = i >> 1, c = i & 1;
         if (r >= B || !A.g_ppoint_out) { A.g_ppoint[i] = 0.f; continue; }
         const float a0 = A.cams[r * A.cam_stride], a1 = A.cams[(r + B) * A.cam_stride];
@@ -820,7 +827,7 @@ extern "C" int lasr_pose_chain_forward(const float* cams, int cam_stride, const 
     hipStream_t st = (hipStream_t)hip_stream;
     PoseChain A{cams, pp, scale, depth, ppoint, quat4, trans, rest_ts, ctl_ts, scale_out, depth_out, ppoint_out, trans_rep, depth_rep,
                 rmat, tmat, pair_angle, (float4*)proj, cam_stride, B, H, K, half_size};
-    LASR_LAUNCH(K_POSE_CHAIN, pose_chain_forward_kernel, dim3(1), dim3(256), 0, A);
+    LASR_LAUNCH(K_POSE_CHAIN, pose_chain_forward_kernel, dim3(1), dim3(1024), 0, A);
     return launch_ok();
 }
 
@@ -841,7 +848,9 @@ extern "C" int lasr_pose_chain_backward(const float* cams, int cam_stride, const
     PoseChainGrad A{cams, quat4, rest_ts, ctl_ts, rmat, tmat, scale_out, grad_scale_out, grad_ppoint_out, grad_trans_rep, grad_depth_rep,
                     grad_rmat, grad_tmat, grad_pair_angle, (const float4*)grad_proj, grad_scale, grad_depth, grad_ppoint, grad_quat4,
                     grad_trans, grad_rest, grad_ctl, scratch, cam_stride, B, H, K};
-    LASR_LAUNCH(K_POSE_CHAIN, pose_chain_backward_kernel, dim3(1), dim3(256), 0, A);
+    const size_t floats = (size_t)2 * B * H * K * 3;
+    const int in_lds = floats <= (size_t)POSE_CHAIN_LDS_FLOATS;
+    LASR_LAUNCH(K_POSE_CHAIN, pose_chain_backward_kernel, dim3(1), dim3(POSE_CHAIN_THREADS), in_lds ? floats * sizeof(float) : 0, A, in_lds);
     return launch_ok();
 }
 
