@@ -20,6 +20,12 @@ namespace lasr {
 // compaction they would idle through the heavy code.  The heavy code uses v_rcp/v_exp based math
 // (FM = true): the reference backward is itself only defined up to float-atomic ordering.
 constexpr bool BWD_FM = true;
+#ifndef LASR_BWD_LDSREC
+#define LASR_BWD_LDSREC 1      // LASR's modes: stage 2 reads the face's record and attributes from LDS (see the kernel)
+#endif
+#ifndef LASR_BWD_WPE8
+#define LASR_BWD_WPE8 0
+#endif
 #ifndef LASR_BWD_ONE
 #define LASR_BWD_ONE 1      // one edge projection per pixel for well-conditioned faces (sr_device.h: euclid_one)
 #endif
@@ -30,12 +36,25 @@ constexpr int BWD_THREADS = 64;   // one wave per workgroup (see backward_impl)
 // amdgpu_waves_per_eu(6 / 5), gives 78 / 88 VGPRs without a spill and a 28-50 % SLOWER kernel -- the schedule that fits re-derives
 // instead of keeping -- profiles/r05_backward_ab.txt.  Not requested.)
 template <bool LASR_FAST, int NCH>
-__global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
+__global__ __launch_bounds__(BWD_THREADS)
+#if LASR_BWD_WPE8
+__attribute__((amdgpu_waves_per_eu(LASR_FAST && NCH == 3 ? 8 : 1, LASR_FAST && NCH == 3 ? 8 : 8)))      // measurement build
+#endif
+void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
                                                           const float* __restrict__ aggrs,
                                                           const float* __restrict__ gcolors,
                                                           float* __restrict__ gfaces, float* __restrict__ gtex)
 {
     __shared__ unsigned int s_ring[BWD_THREADS / 64][QCAP];
+#if LASR_BWD_LDSREC
+    // LASR's modes: stage 2 reads the face's record and vertex attributes from LDS -- broadcast ds_reads whose results are VGPR
+    // operands -- instead of scalar registers: a VALU instruction with an SGPR operand issues in ~4 cycles, with VGPR operands in
+    // ~2.5 (profiles/r02_valu_issue.txt), and stage 2 has ~130 record operands per batch.  (Holding the record in VGPRs for the
+    // whole face costs 33 registers = half the resident waves: slower, profiles/experiments/README.md.)  Measured: backward
+    // 1.139 -> 1.092 ms at 256 frames, 65 VGPRs (the distance code only: with the vertex attributes and 1 / z from LDS as well the
+    // kernel needs 70 VGPRs and takes 1.105 ms).
+    __shared__ __attribute__((aligned(16))) float s_rec[BWD_THREADS / 64][REC];
+#endif
     constexpr bool FM = BWD_FM;
     const Modes m = LASR_FAST ? Modes{2, 1, 2, 1, 1} : A.m;
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
@@ -72,6 +91,15 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
     const cptr_t rec = as_const(A.recs + (size_t)gw * REC);
     const cptr_t tex = as_const(A.textures + (size_t)gw * A.T * NCH);
     const int flags = __float_as_int(rec[R_FLAGS]);
+#if LASR_BWD_LDSREC
+    typedef const float __attribute__((address_space(3)))* lptr_t;
+    if (LASR_FAST && (flags & 16)) {
+        float* dst = s_rec[threadIdx.x >> 6];
+        if (lane < REC) dst[lane] = A.recs[(size_t)gw * REC + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    const lptr_t lrec = (lptr_t)s_rec[threadIdx.x >> 6];
+#endif
 
     // exact pixel rectangle of the bbox test (columns x0..x1, rows r0..r1 from the top); empty when x0 > x1.  Read from the
     // record's first cache line (the flags sit there too) rather than from the separate rect array the forward's binning scans
@@ -191,7 +219,11 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
 #if LASR_BWD_ONE
         // (wave-uniform choice: the face's flags)
         if (LASR_FAST && (flags & 16)) {
+#if LASR_BWD_LDSREC
+            if (!fragment_one(lrec, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+#else
             if (!fragment_one(rec, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+#endif
         } else
 #endif
         if (!fragment<FM, cptr_t, (OPT_BWD_MATH && LASR_FAST)>(rec, m.dist, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
@@ -214,7 +246,8 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
         // surface sampling picks a texel from (int)(w * res): keep the exact division there
         if (vertex_tex) clip_normalise<FM, (OPT_BWD_MATH && LASR_FAST)>(w0, w1, w2); else clip_normalise<false>(w0, w1, w2);
         // (the record holds the correctly rounded 1 / z_k: no v_rcp per fragment)
-        const float q0 = w0 * rec[R_IZ + 0], q1 = w1 * rec[R_IZ + 1], q2 = w2 * rec[R_IZ + 2];
+        const float iz0r = rec[R_IZ + 0], iz1r = rec[R_IZ + 1], iz2r = rec[R_IZ + 2];
+        const float q0 = w0 * iz0r, q1 = w1 * iz1r, q2 = w2 * iz2r;
         const float zp = OPT_BWD_MATH && LASR_FAST ? __builtin_amdgcn_rcpf(q0 + q1 + q2) : depth_at<FM>(rec, w0, w1, w2);
         if (!depth_safe) {
             // K.cu:599: no gradient at all for a fragment the forward pass depth-culled.  The fast-math depth decides unless it
@@ -272,7 +305,7 @@ __global__ __launch_bounds__(BWD_THREADS) void sr_backward_kernel(RasterArgs A, 
             C += div_<FM>(Crgb, D);
             const float Cz = div_<FM>(div_<FM>(Crgb, A.gamma), A.near - A.far) * zp * zp;
             if (OPT_BWD_MATH && LASR_FAST) {
-                gz0 = Cz * q0 * rec[R_IZ + 0]; gz1 = Cz * q1 * rec[R_IZ + 1]; gz2 = Cz * q2 * rec[R_IZ + 2];       // q_k = w_k / z_k
+                gz0 = Cz * q0 * iz0r; gz1 = Cz * q1 * iz1r; gz2 = Cz * q2 * iz2r;       // q_k = w_k / z_k
             } else {
                 const float iz0 = __builtin_amdgcn_rcpf(rec[R_FACE + 2]), iz1 = __builtin_amdgcn_rcpf(rec[R_FACE + 5]), iz2 = __builtin_amdgcn_rcpf(rec[R_FACE + 8]);
                 gz0 = Cz * w0 * iz0 * iz0;

@@ -476,10 +476,33 @@ __device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
 // three projections (a region most batches skip).  Why: in the bench launch 15 % of the surviving pixels of a face are inside and
 // nearly every batch holds some -- the three-projection branch ran for every batch at ~10 live lanes.
 constexpr float NEAR_TIE = 0.985f;
+#ifndef LASR_BWD_FMA
+#define LASR_BWD_FMA 0
+#endif
+// edge_project<K, CLAMP = true, FM = true, IDEN = true> for the backward's single projection; with LASR_BWD_FMA its multiply-add
+// pairs may fuse (the translation unit's -ffp-contract=fast): a well-conditioned face's distance moves by ~1e-6 relative
+template <int K, typename RP>
+__device__ __forceinline__ void edge_project_one(RP rec, float w0, float w1, float w2, float& u0, float& u1, float& u2)
+{
+#if !LASR_BWD_FMA
+#pragma clang fp contract(off)
+#endif
+    constexpr int B = (K + 1) % 3;
+    const float num = w0 * rec[R_E + 3 * K + 0] + w1 * rec[R_E + 3 * K + 1] + w2 * rec[R_E + 3 * K + 2] - rec[R_E + 3 * K + B];
+    float ta = num * rec[R_IDEN + K];
+    float tb = 1 - ta;
+    ta = fminf(fmaxf(ta, 0.f), 1.f);
+    tb = fminf(fmaxf(tb, 0.f), 1.f);
+    float t[3];
+    t[K] = ta; t[B] = tb; t[(K + 2) % 3] = 0;
+    u0 = t[0] - w0; u1 = t[1] - w1; u2 = t[2] - w2;
+}
 template <typename RP>
 __device__ __forceinline__ void euclid_one(RP rec, float xp, float yp, float w0, float w1, float w2, Frag& fr)
 {
+#if !LASR_BWD_FMA
 #pragma clang fp contract(off)   // see edge_project
+#endif
     const float x0 = rec[R_FACE + 0], y0 = rec[R_FACE + 1], x1 = rec[R_FACE + 3], y1 = rec[R_FACE + 4], x2 = rec[R_FACE + 6], y2 = rec[R_FACE + 7];
     const bool inside = (bool)((int)(fminf(fminf(w0, w1), w2) > 0) & (int)(fmaxf(fmaxf(w0, w1), w2) < 1));
     const int flags = __float_as_int(rec[R_FLAGS]);
@@ -516,9 +539,9 @@ __device__ __forceinline__ void euclid_one(RP rec, float xp, float yp, float w0,
         e1 = inside ? i1 : e1;
         e2 = inside ? i2 : e2;
         const bool e0 = !(e1 | e2);
-        if (e0) edge_project<0, true, true, false, RP, true>(rec, w0, w1, w2, u0, u1, u2);
-        if (e1) edge_project<1, true, true, false, RP, true>(rec, w0, w1, w2, u0, u1, u2);
-        if (e2) edge_project<2, true, true, false, RP, true>(rec, w0, w1, w2, u0, u1, u2);
+        if (e0) edge_project_one<0>(rec, w0, w1, w2, u0, u1, u2);
+        if (e1) edge_project_one<1>(rec, w0, w1, w2, u0, u1, u2);
+        if (e2) edge_project_one<2>(rec, w0, w1, w2, u0, u1, u2);
         fr.dx = u0 * x0 + u1 * x1 + u2 * x2;
         fr.dy = u0 * y0 + u1 * y1 + u2 * y2;
     }
@@ -580,8 +603,14 @@ __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float si
 template <typename RP>
 __device__ __forceinline__ bool fragment_one(RP rec, float thr, float sigma, float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
 {
+#if LASR_BWD_FMA
+    w0 = rec[R_INV + 0] * xp + rec[R_INV + 1] * yp + rec[R_INV + 2];   // K.cu:24-29, contractable
+    w1 = rec[R_INV + 3] * xp + rec[R_INV + 4] * yp + rec[R_INV + 5];
+    w2 = rec[R_INV + 6] * xp + rec[R_INV + 7] * yp + rec[R_INV + 8];
+#else
 #pragma clang fp contract(off)   // see edge_project
     barycentric(rec, xp, yp, w0, w1, w2);
+#endif
     euclid_one(rec, xp, yp, w0, w1, w2, fr);
     fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
     if (fr.sign < 0 && fr.dis >= thr) return false;

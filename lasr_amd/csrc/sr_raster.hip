@@ -803,7 +803,7 @@ static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES",
 //   mesh M2 at 256x256, three channels: 16 frames .188 -> .124 ms, 256: 1.927 -> 1.36; 8 frames: the four-waves-per-tile kernel wins
 //   nine channels: the render of spot3 stage 0 (16 meshes of 1280 faces filling the frame) 104 -> 89 us, camel stage 4 (4 meshes of
 //   2560 faces at 512x512) 150 -> 123 us -- every channel count and face size takes the kernel from the threshold up
-static const long long k_pair_min_tiles = env_blocks("LASR_SR_PAIR_MIN_TILES", 16384);
+static const long long k_pair_min_tiles = env_blocks("LASR_SR_PAIR_MIN_TILES", 10240);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
