@@ -26,6 +26,9 @@ constexpr bool BWD_FM = true;
 #ifndef LASR_BWD_WPE8
 #define LASR_BWD_WPE8 0
 #endif
+#ifndef LASR_BWD_DIVREC
+#define LASR_BWD_DIVREC 1
+#endif
 #ifndef LASR_BWD_ONE
 #define LASR_BWD_ONE 1      // one edge projection per pixel for well-conditioned faces (sr_device.h: euclid_one)
 #endif
@@ -165,8 +168,15 @@ void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
 
     // lane -> (row, col) inside the bbox, advanced incrementally (one division per face)
     int r = 0, c = 0;
+#if LASR_BWD_DIVREC
+    // (the setup kernel left the divisions in the record: rec[15] = m | dr << 17 with lane / bw == (lane * m) >> 16, sr_device.h)
+    const int walk = __float_as_int(rec[15]);
+    const int dr = empty ? 0 : walk >> 17, dc = empty ? 0 : 64 - dr * bw;
+    if (!empty) { r = (lane * (walk & 0x1ffff)) >> 16; c = lane - r * bw; }
+#else
     const int dr = empty ? 0 : 64 / bw, dc = empty ? 0 : 64 - dr * bw;
     if (!empty) { r = lane / bw; c = lane - r * bw; }
+#endif
 
     int head = 0, tail = 0, base = 0;            // wave-uniform ring state
     while (true) {

@@ -256,7 +256,15 @@ __device__ __forceinline__ void build_record(const float* __restrict__ f, float*
 #pragma unroll
         for (int k = 0; k < 9; k++) ok = ok && fabsf(inv[k]) < 1e30f;          // false for NaN / inf as well
         if (ok) rec[R_FLAGS] = __int_as_float(__float_as_int(rec[R_FLAGS]) | 32);
-        rec[15] = 0.f; rec[31] = 0.f;                               // padding: defined bytes in the workspace
+        // rec[15]: the backward's lane -> (row, column) walk over the pixel rect, prepared here (one division per face instead of three
+        // in every backward wave): bits 0..16 m = 65536 / bw + 1 for bw < 64 (lane / bw == (lane * m) >> 16 for lane < 64; 0: one row
+        // holds the whole wave), bits 17..23 dr = 64 / bw
+        {
+            const int bw = px0 > px1 ? 1 : px1 - px0 + 1;
+            const int mdiv = bw < 64 ? 65536 / bw + 1 : 0, dr = 64 / bw;
+            rec[15] = __int_as_float(mdiv | (dr << 17));
+        }
+        rec[31] = 0.f;                                              // padding: defined bytes in the workspace
 #pragma unroll
         for (int k = 44; k < REC; k++) rec[k] = 0.f;
     }
