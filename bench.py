@@ -578,7 +578,7 @@ def loss_reduction_figures(step, I, H, P, feat_shapes):
 def in_scope_step_leg():
     """where the optimisation step's in-scope time goes at the sizes LASR launches.  For each configuration a
     child process runs a few graph-replayed iterations under `rocprofv3 --kernel-trace`; the trace's dispatch timestamps (what
-    profiles/r05_optimize_step_kernel_stats.txt is built from) give per-kernel us of one iteration.  In-library HIP events cannot
+    profiles/r06_optimize_step_kernel_stats.txt is built from) give per-kernel us of one iteration.  In-library HIP events cannot
     time kernels inside a graph replay, and around eager launches they add the launch gap to every few-us kernel."""
     import glob
     import shutil
@@ -737,7 +737,7 @@ def _latest_profile(suffix):
     d = json.load(open(files[-1]))
     name = os.path.basename(files[-1])
     if d.get('source_sha') != raster_source_hash():
-        msg = ('%s was measured on other raster sources (its source_sha %s, now %s): re-run tools/prof/r05_final.sh'
+        msg = ('%s was measured on other raster sources (its source_sha %s, now %s): re-run tools/prof/r06_final.sh'
                % (name, d.get('source_sha'), raster_source_hash()))
         print('bench.py: STALE COUNTER FILE -- ' + msg, file=sys.stderr, flush=True)
         return None, name, msg

@@ -19,9 +19,12 @@
 //   balance  the lanes are ranked by their pair count (six ballots) and lane of rank r is partnered with rank 63 - r: the lighter
 //            partner takes the upper half of the difference from the heavier one's outside mask and folds it into a private
 //            partial state;
-//   walk     every lane pops its own masks, inside pairs first (the three-projection branch of the distance code then runs in
-//            the first few iterations of a chunk only), gathers the entry's record from LDS with 16-byte reads and applies the
-//            pair with exactly the arithmetic of forward_face;
+//   walk     every lane pops its own masks, inside pairs first, gathers the entry's record from LDS with 16-byte reads and applies
+//            the pair with the arithmetic of forward_face.  Inside and outside pixels share ONE clamped edge projection: an inside
+//            pixel's nearest edge line follows from the three products w_k^2 hk2_k (sr_device.h: euclid_one); only where two
+//            lines are equidistant within 1.5 % -- the reference's own choice is then decided by its rounding -- the reference's
+//            three projections run (a region most iterations skip).  Before: in 43 % of the walk's iterations some lane was
+//            inside and the 90-instruction three-projection branch ran at 27 % live lanes (tools/pair_stats.py);
 //   merge    partial states (alpha product, running maximum, rescaled sums) are folded into their pixel's state.
 //
 // What changes against the one-wave kernel is the ORDER in which a pixel's fragments meet its state (inside fragments first,

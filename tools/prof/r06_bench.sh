@@ -1,6 +1,6 @@
-# the bench lines of the round, on a box that has not been profiled: bash tools/prof/r05_bench.sh <tag>   (one MI355X)
-# (run tools/prof/r05_final.sh first and copy its counter files into profiles/: the line quotes traffic / valu_frac from them)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; T=${1:-r05}
+# the bench lines of the round, on a box that has not been profiled: bash tools/prof/r06_bench.sh <tag>   (one MI355X)
+# (run tools/prof/r06_final.sh first and copy its counter files into profiles/: the line quotes traffic / valu_frac from them)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; T=${1:-r06}
 cd $R
 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
 python bench.py --image-size 512 --frames 64 --no-lbs --no-sweep --lasr-iters 0 > $O/${T}_bench_512.json 2>/dev/null

@@ -1,6 +1,6 @@
-# the measurement set of the round: bash tools/prof/r05_final.sh <tag>   (one MI355X; counters + step traces; the bench lines come
-# from tools/prof/r05_bench.sh on a FRESH box afterwards -- a box that has just run these passes clocks 6-8 % lower)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; T=${1:-r05}
+# the measurement set of the round: bash tools/prof/r06_final.sh <tag>   (one MI355X; counters + step traces; the bench lines come
+# from tools/prof/r06_bench.sh on a FRESH box afterwards -- a box that has just run these passes clocks 6-8 % lower)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; T=${1:-r06}
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-lbs --no-sweep --lasr-iters 0"
 # ---- one optimisation iteration, per kernel (the trace bench.py's in_scope_step block is built from) and in launch order

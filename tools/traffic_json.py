@@ -18,7 +18,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import raster_source_hash          # noqa: E402  (the sources the counters were measured on)
 
-READ_CLASS = {'sr_setup_kernel': 'vector', 'sr_forward_kernel': 'scalar', 'sr_backward_kernel': 'vector'}
+# (round 6: the pair-walk forward stages its records with vector loads -- sr_forward_pairs.h -- so its fetch is tallied at half too)
+READ_CLASS = {'sr_setup_kernel': 'vector', 'sr_forward_kernel': 'vector', 'sr_backward_kernel': 'vector'}
 
 txt, frames, note = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 cal = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
@@ -34,6 +35,8 @@ for line in open(txt):
     if not m or 'ILb1ELi3ELb1' in line:                       # skip the relaxed-math instantiation
         continue
     name, ctr, val = m.group(1), m.group(2), int(m.group(3))
+    if name.startswith('sr_forward_pairs'):                   # the forward kernel of launches from 10240 tiles up (ProfScope id sr_forward_kernel)
+        name = 'sr_forward_kernel'
     d = k.setdefault(name, {})
     d['fetch_kib' if ctr == 'FETCH_SIZE' else 'write_kib'] = val
 for name, d in k.items():

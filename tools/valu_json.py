@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import raster_source_hash          # noqa: E402  (the sources the counters were measured on)
 
 COST = {'fp32_vgpr': 2.5, 'fp32_sgpr_operand': 4.15, 'f64': 4.3, 'transcendental': 8.3, 'other': 4.1}   # cycles @ 2.4 GHz per wave64
-SGPR_SHARE = {'sr_forward_kernel': 0.28, 'sr_backward_kernel': 0.45}     # static share of fp32 mul/add/fma with an SGPR source (ISA)
+SGPR_SHARE = {'sr_forward_kernel': 0.05, 'sr_backward_kernel': 0.20}     # static share of fp32 mul/add/fma with an SGPR source (ISA, round 6:
+#   32 of 709 in sr_forward_pairs3_kernel -- records come from LDS -- and 106 of 519 in sr_backward_kernel<true, 3>; rounds 2-5: 0.28 / 0.45)
 SIMDS, GHZ = 1024, 2.4
 
 txt, frames = sys.argv[1], int(sys.argv[2])
@@ -21,7 +22,8 @@ for line in open(txt):
     m = re.match(r'\s*\S*(sr_\w+?_kernel)\S*\s+(SQ_\w+)\s+(\d+)', line)
     if not m or 'ILb1ELi3ELb1' in line or 'setup' in line:
         continue
-    k.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
+    name = 'sr_forward_kernel' if m.group(1).startswith('sr_forward_pairs') else m.group(1)
+    k.setdefault(name, {})[m.group(2)] = int(m.group(3))
 out = {'frames_per_launch': frames, 'source_sha': raster_source_hash(), 'cycles_per_wave_instruction': COST, 'simds': SIMDS, 'clock_ghz': GHZ, 'kernels': {}}
 for name, c in k.items():
     fp32 = c['SQ_INSTS_VALU_MUL_F32'] + c['SQ_INSTS_VALU_FMA_F32'] + c['SQ_INSTS_VALU_ADD_F32']
