@@ -147,6 +147,7 @@ void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
             ld[3 * k] = rec[R_INV + 3 * k] * h; ld[3 * k + 1] = rec[R_INV + 3 * k + 1] * h; ld[3 * k + 2] = rec[R_INV + 3 * k + 2] * h;
         }
     }
+    const float tie_scale = (flags & 16) ? near_tie_scale(rec[R_HK2], rec[R_HK2 + 1], rec[R_HK2 + 2]) : 0.f;     // (sr_device.h: near_tie)
     // K.cu:599: a fragment the forward pass depth-culled gets no gradient.  A well-conditioned face whose vertex depths lie
     // strictly inside (near, far) cannot be culled anywhere (its clipped barycentrics are >= 0 and sum to 1 within 1e-4, so the
     // interpolated depth stays within the vertex range up to rounding): one test per face instead of one per fragment
@@ -230,9 +231,9 @@ void sr_backward_kernel(RasterArgs A, const float* __restrict__ colors,
         // (wave-uniform choice: the face's flags)
         if (LASR_FAST && (flags & 16)) {
 #if LASR_BWD_LDSREC
-            if (!fragment_one(lrec, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+            if (!fragment_one(lrec, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, tie_scale)) continue;
 #else
-            if (!fragment_one(rec, A.thr, A.sigma, xp, yp, w0, w1, w2, fr)) continue;
+            if (!fragment_one(rec, A.thr, A.sigma, xp, yp, w0, w1, w2, fr, tie_scale)) continue;
 #endif
         } else
 #endif

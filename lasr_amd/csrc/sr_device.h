@@ -476,14 +476,32 @@ __device__ __forceinline__ bool euclid(RP rec, float xp, float yp,
 // the edge is clear.  K.cu:61-110 projects an inside pixel on all three edge LINES (no clamp) and keeps the nearest: that is the
 // line with the smallest perpendicular distance d_k = w_k h_k (h_k = height of vertex k over its opposite edge, hk2 = h_k^2 in
 // the record).  The three products q = w_k^2 hk2_k cost six multiplications; when the smallest is below the second smallest by
-// more than NEAR_TIE (the reference's own projections are only accurate to a fraction of a percent on small faces, so its
-// choice near an angle bisector is decided by its rounding), only that projection is evaluated -- by the same instructions on the
+// more than NEAR_TIE and by more than the face's rounding scale (near_tie below: the reference's own projections are only accurate
+// to a fraction of a percent on small faces, so its choice near an angle bisector is decided by its rounding), only that projection
+// is evaluated -- by the same instructions on the
 // same barycentrics as edge_project<k>, hence with the bits the three-projection form gives for that edge.  The clamp of the
 // outside branch is a no-op for an inside pixel (the foot of the perpendicular on the nearest line lies on the triangle's
 // boundary), so both kinds of pixel share the three exec-masked projections.  Inside pixels near a bisector take the reference's
 // three projections (a region most batches skip).  Why: in the bench launch 15 % of the surviving pixels of a face are inside and
 // nearly every batch holds some -- the three-projection branch ran for every batch at ~10 live lanes.
 constexpr float NEAR_TIE = 0.985f;
+// ... and an ABSOLUTE margin on the distances: the reference's projection p - foot = sum u_k v_k carries the rounding error of its
+// barycentrics (~2^-24 |inv| |coords| ~ 2e-7 / h_min each) times the vertex coordinates, ~6e-7 / h_min in the position
+// (h_min = the face's smallest height); which of two lines it finds nearer is its rounding's choice while
+// |d_mid - d_lo| < E = NEAR_TIE_ABS / h_min (four times that estimate).  As squared distances, without a root:
+// (q_mid - q_lo)^2 < 4 E^2 q_mid  (since q_mid - q_lo = (d_mid - d_lo)(d_mid + d_lo) <= 2 d_mid (d_mid - d_lo)).
+// near_tie_scale(hk2) = 4 E^2, per face.  Measured need: with the relative margin alone the image of LASR's own meshes (slivers at
+// the silhouette) moved by up to 5e-5 against the reference build (profiles/r06_whole_forward_parity.jsonl, first version).
+constexpr float NEAR_TIE_ABS = 2.4e-6f;
+__host__ __device__ __forceinline__ float near_tie_scale(float h2a, float h2b, float h2c)
+{
+    return 4.f * NEAR_TIE_ABS * NEAR_TIE_ABS / fminf(fminf(h2a, h2b), h2c);
+}
+__device__ __forceinline__ bool near_tie(float qlo, float qmid, float scale)
+{
+    const float gap = qmid - qlo;
+    return (bool)((int)!(qlo < NEAR_TIE * qmid) | (int)!(gap * gap > scale * qmid));
+}
 #ifndef LASR_BWD_FMA
 #define LASR_BWD_FMA 0
 #endif
@@ -506,7 +524,7 @@ __device__ __forceinline__ void edge_project_one(RP rec, float w0, float w1, flo
     u0 = t[0] - w0; u1 = t[1] - w1; u2 = t[2] - w2;
 }
 template <typename RP>
-__device__ __forceinline__ void euclid_one(RP rec, float xp, float yp, float w0, float w1, float w2, Frag& fr)
+__device__ __forceinline__ void euclid_one(RP rec, float xp, float yp, float w0, float w1, float w2, Frag& fr, float tie_scale)
 {
 #if !LASR_BWD_FMA
 #pragma clang fp contract(off)   // see edge_project
@@ -527,7 +545,7 @@ __device__ __forceinline__ void euclid_one(RP rec, float xp, float yp, float w0,
     // inside: edge k (from vertex k to k + 1, edge_project<k>) is the one opposite vertex (k + 2) % 3, at distance w_{k+2} h_{k+2}
     const float q0 = w2 * w2 * rec[R_HK2 + 2], q1 = w0 * w0 * rec[R_HK2 + 0], q2 = w1 * w1 * rec[R_HK2 + 1];   // edge 0, 1, 2
     const float qlo = fminf(fminf(q0, q1), q2), qmid = __builtin_amdgcn_fmed3f(q0, q1, q2);
-    const bool tie = (bool)((int)inside & (int)!(qlo < NEAR_TIE * qmid));
+    const bool tie = (bool)((int)inside & (int)near_tie(qlo, qmid, tie_scale));
     float u0, u1, u2;
     if (tie) {
         float best = 100000000.f, bx = 0, by = 0, b0 = 0, b1 = 0, b2 = 0;
@@ -609,7 +627,8 @@ __device__ __forceinline__ bool fragment_w(RP rec, int dist, float thr, float si
 
 // fragment<FM = true, .., BT = true> for a well-conditioned face in the euclidean mode, on euclid_one
 template <typename RP>
-__device__ __forceinline__ bool fragment_one(RP rec, float thr, float sigma, float xp, float yp, float& w0, float& w1, float& w2, Frag& fr)
+__device__ __forceinline__ bool fragment_one(RP rec, float thr, float sigma, float xp, float yp, float& w0, float& w1, float& w2, Frag& fr,
+                                             float tie_scale)
 {
 #if LASR_BWD_FMA
     w0 = rec[R_INV + 0] * xp + rec[R_INV + 1] * yp + rec[R_INV + 2];   // K.cu:24-29, contractable
@@ -619,7 +638,7 @@ __device__ __forceinline__ bool fragment_one(RP rec, float thr, float sigma, flo
 #pragma clang fp contract(off)   // see edge_project
     barycentric(rec, xp, yp, w0, w1, w2);
 #endif
-    euclid_one(rec, xp, yp, w0, w1, w2, fr);
+    euclid_one(rec, xp, yp, w0, w1, w2, fr, tie_scale);
     fr.dis = fr.dx * fr.dx + fr.dy * fr.dy;
     if (fr.sign < 0 && fr.dis >= thr) return false;
     fr.D = sigmoid_neg_<true>(div_<true>(-fr.sign * fr.dis, sigma));

@@ -22,7 +22,8 @@
 //   walk     every lane pops its own masks, inside pairs first, gathers the entry's record from LDS with 16-byte reads and applies
 //            the pair with the arithmetic of forward_face.  Inside and outside pixels share ONE clamped edge projection: an inside
 //            pixel's nearest edge line follows from the three products w_k^2 hk2_k (sr_device.h: euclid_one); only where two
-//            lines are equidistant within 1.5 % -- the reference's own choice is then decided by its rounding -- the reference's
+//            lines are equidistant within 1.5 % or within the face's rounding scale (sr_device.h: near_tie) -- the reference's own
+//            choice is then decided by its rounding -- the reference's
 //            three projections run (a region most iterations skip).  Before: in 43 % of the walk's iterations some lane was
 //            inside and the 90-instruction three-projection branch ran at 27 % live lanes (tools/pair_stats.py);
 //   merge    partial states (alpha product, running maximum, rescaled sums) are folded into their pixel's state.
@@ -50,7 +51,8 @@ typedef unsigned long long u64_t;
 //   q4  x0 y0 x1 y1  q5  x2 y2 z0 z1  q6  z2, 1/z0, 1/z1, 1/z2
 //   q7  obtuse corner c (flags bit0..2): x_c, y_c, x_o - x_c, y_o - y_c with o = (c + 2) % 3   (K.cu:113-125's override test)
 //   q8 + 2k, q9 + 2k   edge k: e[k][0..2], e[k][(k+1)%3]  |  den[k], 1/den[k], -, -
-//   q14 hq[0..2]: the squared height over edge k's line (hk2 of the vertex opposite edge k; 0 unless the face is well conditioned)
+//   q14 hq[0..2]: the squared height over edge k's line (hk2 of the vertex opposite edge k; 0 unless the face is well conditioned),
+//       hq[3]: the face's absolute near-tie scale (sr_device.h: near_tie_scale)
 //   60 ..  attributes [vertex][channel]
 constexpr int PR_INV = 0, PR_FLAGS = 9, PR_BB = 10, PR_ETBL = 11, PR_HK2 = 12, PR_BBE = 15, PR_XY = 16, PR_Z = 22, PR_IZ = 25, PR_OBT = 28, PR_EDGE = 32, PR_HQ = 56, PR_TEX = 60;
 
@@ -131,6 +133,7 @@ __device__ __forceinline__ void stage_quads(const float4* __restrict__ src, floa
             if (i >= R_HK2 && i < R_HK2 + 3) {                 // the far threshold; -inf (never far) unless the face is well conditioned
                 dst[pr_of(i)] = well ? -sqrtf(thr_far / w[j]) : -__builtin_huge_valf();
                 dst[PR_HQ + (i - R_HK2 + 1) % 3] = well ? w[j] : 0.f;     // vertex k lies opposite edge (k + 1) % 3
+                if (i == R_HK2) dst[PR_HQ + 3] = near_tie_scale(w[0], w[1], w[2]);        // (R_HK2 .. + 2 are words 0..2 of this source quad)
                 continue;
             }
             dst[pr_of(i)] = w[j];
@@ -234,7 +237,7 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
         const float4 hq = ld4(R + PR_HQ);
         const float g0 = w2 * w2 * hq.x, g1 = w0 * w0 * hq.y, g2 = w1 * w1 * hq.z;
         const float glo = fminf(fminf(g0, g1), g2), gmid = __builtin_amdgcn_fmed3f(g0, g1, g2);
-        tie = (bool)((int)is_in & (int)!(glo < NEAR_TIE * gmid));
+        tie = (bool)((int)is_in & (int)near_tie(glo, gmid, hq.w));
         k_in = g1 == glo ? 1 : g2 == glo ? 2 : 0;
     }
     if (tie) {
