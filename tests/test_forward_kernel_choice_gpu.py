@@ -316,3 +316,31 @@ def test_the_pair_walk_gives_the_same_bits_in_any_tile_order_and_run_after_run(c
     finally:
         srf.set_launch_thresholds()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
+
+
+@pytest.mark.parametrize('seed,nu,IS', [(0, 4, 64), (1, 8, 128), (2, 11, 256), (3, 16, 128)])
+def test_one_projection_agrees_with_three_on_slivers_and_edge_on_faces(cuda, seed, nu, IS):
+    # the pair walk evaluates ONE edge projection per pixel where the nearest edge line is clear (sr_device.h: near_tie -- a relative
+    # and an absolute margin scaled by the face's smallest height), the one-wave kernel the reference's three for every inside pixel:
+    # on objects squashed to a fraction of their width (edge-on faces at the silhouette, slivers inside) the images still agree to
+    # rounding.  With the relative margin alone LASR's own meshes differed by up to 5e-5 (tools/prof/tie_stress.py runs more cases).
+    rng = np.random.default_rng(seed)
+    fv, ft, near, far = synth.raster_batch(nu, 3, count=4)
+    fv = fv.copy()
+    for n in range(fv.shape[0]):
+        a = rng.uniform(0, np.pi)
+        d = np.array([np.cos(a), np.sin(a)], np.float32)
+        k = rng.uniform(0.05, 0.6)
+        xy = fv[n, :, :, :2]
+        c = xy.reshape(-1, 2).mean(0)
+        rel = xy - c
+        fv[n, :, :, :2] = c + rel - (1 - k) * (rel @ d)[..., None] * d
+    kw = dict(synth.LASR_MODES, near=near, far=far)
+    try:
+        srf.set_launch_thresholds(*VARIANTS['one wave per 8x8 tile'])
+        want = render(cuda, fv, ft, IS, kw)
+        srf.set_launch_thresholds(*PAIR_WALK)
+        got = render(cuda, fv, ft, IS, kw)
+    finally:
+        srf.set_launch_thresholds()
+    assert np.abs(got - want).max() <= PAIR_TOL, np.abs(got - want).max()
