@@ -455,7 +455,7 @@ STEP_CONFIGS = {
                           '512x512, 4 meshes per render'),
 }
 RASTER_KERNELS = ('sr_forward_kernel', 'sr_backward_kernel', 'sr_setup_kernel', 'sr_tile_weight_kernel', 'sr_order_kernel',
-                  'sr_forward_coop_kernel', 'sr_forward_pairs_kernel', 'sr_forward_pairs3_kernel', 'sr_forward_seg_kernel')
+                  'sr_forward_coop_kernel', 'sr_forward_pairs_kernel', 'sr_forward_pairs3_kernel', 'sr_forward_pairs_teams_kernel', 'sr_forward_seg_kernel')
 
 
 def step_worker(name):

@@ -168,6 +168,8 @@ int lasr_sr_backward_attr(const float* faces, const float* textures, const float
 #define LASR_SR_SEGMENTED     2   /* forward, LASR's modes, small launches: see below */
 #define LASR_SR_RECORDS_VALID 4
 #define LASR_SR_GRADS_OVERWRITE 8   /* backward, vertex textures: grad_faces / grad_textures need not be zeroed by the caller */
+#define LASR_SR_PAIR_ONE_TEAM  16  /* forward, pair-walk kernel: one team of four waves per 16x16 tile whatever the launch size (round 6) */
+#define LASR_SR_PAIR_TWO_TEAMS 32  /* forward, pair-walk kernel: two teams per tile (the default up to 8192 tiles); image within 1e-6 */
 int lasr_sr_forward_ex(const float* faces, const float* textures, float* faces_info, float* aggrs_info, float* soft_colors,
                        void* workspace, size_t workspace_bytes, int N, int F, int T, int channels, int IS, float near,
                        float far, const float* near_far_dev, float eps, float sigma_val, int func_id_dist, float dist_eps,

@@ -126,6 +126,7 @@ SIGNATURES = {
 ABI_VERSION = 4                                     # LASR_ABI_VERSION of include/lasr_sr.h (tests/test_abi.py compares them)
 # flags of the *_ex entry points (include/lasr_sr.h)
 SR_DEFAULT_FLAGS, SR_RELAXED_MATH, SR_SEGMENTED, SR_RECORDS_VALID, SR_GRADS_OVERWRITE = -1, 1, 2, 4, 8
+SR_PAIR_ONE_TEAM, SR_PAIR_TWO_TEAMS = 16, 32          # forward: teams of four waves per tile of the pair-walk kernel (default: by launch size)
 MEANS_MAX_TERMS, TAIL_MAX_GROUPS = 24, 16          # LASR_MEANS_MAX_TERMS / LASR_TAIL_MAX_GROUPS of include/lasr_ops.h
 
 

@@ -74,15 +74,19 @@ struct PairRecView {                                   // the staged record behi
 };
 
 // LDS: the chunk's staged records at an ODD number of quads per slot, the tile's list, the list builder's counts
-template <int NCH>
+// SPLIT teams of four waves share a tile (SPLIT = 2: launches whose time is the heaviest tile's chain of dependent phases, not the
+// chip's throughput): they build the list together, team t walks the chunks t, t + SPLIT, ... in its own staging buffer, and the
+// teams' partial states meet in `merge` at the end.
+template <int NCH, int SPLIT = 1>
 struct PairLds {
     static constexpr int Q0 = (PR_TEX + 3 * NCH + 3) / 4;
     static constexpr int RS = 4 * (Q0 | 1);
-    float rec[PW_CAP * RS];
+    float rec[SPLIT][PW_CAP * RS];
     unsigned short list[PW_LIST];
-    int wcnt[2][4];
+    int wcnt[2][4 * SPLIT];
     float sel[24];                    // edge k: (k == 0, k == 1, k == 2 | k + 1 == 0, k + 1 == 1, k + 1 == 2 mod 3) as 0 / 1, 8 floats apart
-    unsigned long long ball[2][16];   // the chunk's rect ballots: [0][x] entries whose rect holds column x, [1][y] row y (of the tile)
+    unsigned long long ball[SPLIT][2][16];   // the chunk's rect ballots: [0][x] entries whose rect holds column x, [1][y] row y (of the tile)
+    float merge[SPLIT > 1 ? (SPLIT - 1) * 256 * (3 + NCH) : 1];       // partial states of the teams >= 1, [team - 1][field][pixel lane]
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
@@ -338,10 +342,11 @@ __device__ __forceinline__ void pair_apply(const RasterArgs& A, const UniRecip& 
     }
 }
 
-template <int NCH>
-__device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors, PairLds<NCH>& L)
+template <int NCH, int SPLIT>
+__device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors, PairLds<NCH, SPLIT>& L)
 {
-    constexpr int RS = PairLds<NCH>::RS;
+    constexpr int RS = PairLds<NCH, SPLIT>::RS;
+    constexpr int NW = 4 * SPLIT;                       // waves per tile
 
     const Modes m = Modes{2, 1, 2, 1, 1};               // LASR's configuration: euclidean, softmax, prod, vertex, double-sided
     if (A.near_far_dev) { A.near = A.near_far_dev[0]; A.far = A.near_far_dev[1]; }
@@ -349,7 +354,8 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
     const int tiles_x = (IS + PW_TILE - 1) / PW_TILE;
     int bn, tx, ty;
     tile_of_block(blockIdx.x, gridDim.x, tiles_x, bn, tx, ty, A.order);      // this launch's own order when the host built one (16x16 tiles)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave_all = tid >> 6, lane = tid & 63;
+    const int team = SPLIT > 1 ? wave_all >> 2 : 0, wave = wave_all & 3;        // wave: within its team (the pixel rows it owns)
 #ifndef LASR_PW_ROWS
 #define LASR_PW_ROWS 1
 #endif
@@ -372,6 +378,11 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
     for (int k = 0; k < NCH; k++) {
         const float bg = A.use_bg ? A.bg[k] : (valid ? colors[((size_t)bn * (NCH + 1) + k) * P + pn] : 1.f);
         s.c[k] = bg * s.ssum;
+    }
+    if (SPLIT > 1 && team > 0) {                        // "no fragment yet": merged into team 0's state at the end (merge_partial)
+        s.ssum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; k++) s.c[k] = 0.f;
     }
 
     if (tid < 24) {
@@ -431,17 +442,17 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
             u64_t mm = gmask;
             int mine_g = -1, last_g = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < NW; k++) {
                 if (mm) {
                     const int bit = __builtin_ctzll(mm);
                     mm &= mm - 1;
-                    if (k == wave) mine_g = g_mask0 + bit;
+                    if (k == wave_all) mine_g = g_mask0 + bit;
                     last_g = g_mask0 + bit;
                 }
             }
             const int first_g = g_mask0 + __builtin_ctzll(gmask);
             if (base < 0) base = first_g * GROUP;
-            if (count + 256 > PW_LIST || (last_g + 1) * GROUP - base > 65536) break;  // walk what we have, then continue
+            if (count + 64 * NW > PW_LIST || (last_g + 1) * GROUP - base > 65536) break;  // walk what we have, then continue
             gmask = mm;
             const int f = mine_g * GROUP + lane;
             bool hit = false;
@@ -451,19 +462,26 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
                 if (hit) hit = reaches_block(recs + (size_t)f * REC, t_xlo, t_xhi, t_ylo, t_yhi, thr_cull);
             }
             const u64_t mask = wave_mask(hit);
-            if (lane == 0) L.wcnt[flip][wave] = __popcll(mask);
+            if (lane == 0) L.wcnt[flip][wave_all] = __popcll(mask);
             __syncthreads();
-            const int c0 = L.wcnt[flip][0], c1 = L.wcnt[flip][1], c2 = L.wcnt[flip][2], c3 = L.wcnt[flip][3];
-            const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+            int before = 0, step_total = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int ck = L.wcnt[flip][k];
+                before += k < wave_all ? ck : 0;
+                step_total += ck;
+            }
             if (hit) L.list[count + before + bits_below_lane(mask)] = (unsigned short)(f - base);
-            count += c0 + c1 + c2 + c3;
+            count += step_total;
             flip ^= 1;
         }
         if (base < 0) base = 0;
         __syncthreads();
 
-        for (int c0 = 0; c0 < count; c0 += PW_CAP) {
-            const int n = min(PW_CAP, count - c0);
+        float* const Lrec = L.rec[team];
+        for (int cb = 0; cb < count; cb += SPLIT * PW_CAP) {       // team t takes the chunks t, t + SPLIT, ...: same trip count, same barriers
+            const int c0 = cb + team * PW_CAP;
+            const int n = max(0, min(PW_CAP, count - c0));
             // ---- stage: lane = entry, every wave a quarter of the record's source quads (all loads of a chunk in flight at once)
             int cm = 0, rm = 0;                       // the entry's rect as a 16-bit column mask and row mask of the tile
             if (lane < n) {
@@ -477,7 +495,7 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
                 }
                 const float4* __restrict__ src = (const float4*)(recs + (size_t)fn * REC);
                 const float* __restrict__ ta = texs + (size_t)fn * texstride;
-                float* dst = L.rec + lane * RS;
+                float* dst = Lrec + lane * RS;
                 float tv[(3 * NCH + 3) / 4];
 #pragma unroll
                 for (int i = 0; i < (3 * NCH + 3) / 4; i++) tv[i] = wave + 4 * i < 3 * NCH ? ta[wave + 4 * i] : 0.f;
@@ -510,7 +528,7 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
                     if (lane == j) mine = Bc;
                     if (lane == 4 + j) mine = Br;
                 }
-                if (lane < 8) L.ball[lane >> 2][4 * wave + (lane & 3)] = mine;
+                if (lane < 8) L.ball[team][lane >> 2][4 * wave + (lane & 3)] = mine;
             }
             __syncthreads();
 
@@ -518,8 +536,8 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
             u64_t cand, tame_mask;
             {
                 bool tame_e = false;
-                if (lane < n) tame_e = (__float_as_int(L.rec[lane * RS + PR_FLAGS]) & ok_bit) != 0;
-                const u64_t cxv = L.ball[0][px - tX0], ryv = L.ball[1][py - tY0];
+                if (lane < n) tame_e = (__float_as_int(Lrec[lane * RS + PR_FLAGS]) & ok_bit) != 0;
+                const u64_t cxv = L.ball[team][0][px - tX0], ryv = L.ball[team][1][py - tY0];
                 cand = valid ? cxv & ryv : 0ull;
                 tame_mask = wave_mask(tame_e);
             }
@@ -537,7 +555,7 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
                 const int e = __builtin_ctzll(cand | (1ull << 63));
                 const u64_t rest = cand & (cand - 1), bit = cand ^ rest;
                 cand = rest;
-                const float* R = L.rec + e * RS;
+                const float* R = Lrec + e * RS;
                 const float4 q0 = ld4(R), q1 = ld4(R + 4);
                 const float inv8 = R[8];
                 const float4 q3 = ld4(R + PR_HK2);
@@ -635,7 +653,7 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
                 const bool has = cur != 0;
                 const int e = __builtin_ctzll(cur | (1ull << 63));
                 cur &= cur - 1;
-                pair_apply<NCH>(A, U, L.rec + e * RS, L.sel, (bool)((int)is_in & (int)has), has, cx, cy, s);
+                pair_apply<NCH>(A, U, Lrec + e * RS, L.sel, (bool)((int)is_in & (int)has), has, cx, cy, s);
                 advance();
             } while (wave_mask(cur != 0) != 0);
             // ---- merge the partial states into their pixels
@@ -654,11 +672,11 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
             // ---- the chunk's slow pairs (records that are not tame): wave-uniform entry, generic arithmetic
             for (int e = 0; wave_mask(ms != 0) != 0 && e < n; e++) {
                 if (wave_mask((ms >> e) & 1) == 0) continue;
-                const PairRecView R{L.rec + e * RS};
+                const PairRecView R{Lrec + e * RS};
                 if ((ms >> e) & 1) {
                     float w0, w1, w2;
                     barycentric(R, xp, yp, w0, w1, w2);
-                    forward_face<true, false, NCH>(A, m, R, L.rec + e * RS + PR_TEX, 0, 0, xp, yp, w0, w1, w2, s, U);
+                    forward_face<true, false, NCH>(A, m, R, Lrec + e * RS + PR_TEX, 0, 0, xp, yp, w0, w1, w2, s, U);
                 }
             }
             __syncthreads();                            // the slots are rewritten by the next chunk
@@ -666,6 +684,27 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
     }
     }   // tile meets at least one group
 
+    if (SPLIT > 1) {
+        // ---- the teams' partial states meet: team t >= 1 leaves its state in LDS, team 0 folds them in (team order) and finalises
+        const int pl = wave * 64 + lane;                    // the pixel's slot: same (wave, lane) -> pixel mapping in every team
+        if (team > 0) {
+            float* o = L.merge + (size_t)(team - 1) * (3 + NCH) * 256 + pl;
+            o[0] = s.a; o[256] = s.smax; o[512] = s.ssum;
+#pragma unroll
+            for (int k = 0; k < NCH; k++) o[(3 + k) * 256] = s.c[k];
+        }
+        __syncthreads();
+        if (team > 0) return;
+        const float inv_gamma = 1.f / A.gamma;
+#pragma unroll
+        for (int t = 1; t < SPLIT; t++) {
+            const float* o = L.merge + (size_t)(t - 1) * (3 + NCH) * 256 + pl;
+            float pc[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) pc[k] = o[(3 + k) * 256];
+            merge_partial<NCH>(s, o[0], o[256], o[512], pc, A.gamma, inv_gamma);
+        }
+    }
     if (!valid) return;
     // ---- finalise (K.cu:458-482)
     colors[((size_t)bn * (NCH + 1) + NCH) * P + pn] = (float)(1. - (double)s.a);
@@ -675,23 +714,29 @@ __device__ __forceinline__ void pairs_tile_body(RasterArgs A, float* __restrict_
     aggrs[((size_t)bn * 2 + 1) * P + pn] = s.smax;
 }
 
-// six / nine channels: the compiler's own register budget (87 / 104 VGPRs; the LDS slots allow six workgroups per CU there anyway)
+// six / nine channels: the compiler's own register budget (95 / 112 VGPRs)
 template <int NCH>
 __global__ __launch_bounds__(256) void sr_forward_pairs_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
 {
-    __shared__ __attribute__((aligned(16))) PairLds<NCH> L;
-    pairs_tile_body<NCH>(A, aggrs, colors, L);
+    __shared__ __attribute__((aligned(16))) PairLds<NCH, 1> L;
+    pairs_tile_body<NCH, 1>(A, aggrs, colors, L);
 }
-// three channels: registers for eight waves per SIMD (64 VGPRs; what that spills sits in the list builder, not in the walk --
-// measured 1.855 -> 1.80 ms at 256 frames, profiles/experiments/r06_pair_walk.md)
+// three channels: no occupancy request (87 VGPRs = 5 waves per SIMD; six / seven forced were slower, profiles/experiments/README.md)
 __global__ __launch_bounds__(256)
 #if LASR_PW_WAVES
 __attribute__((amdgpu_waves_per_eu(LASR_PW_WAVES, LASR_PW_WAVES)))
 #endif
 void sr_forward_pairs3_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
 {
-    __shared__ __attribute__((aligned(16))) PairLds<3> L;
-    pairs_tile_body<3>(A, aggrs, colors, L);
+    __shared__ __attribute__((aligned(16))) PairLds<3, 1> L;
+    pairs_tile_body<3, 1>(A, aggrs, colors, L);
+}
+// two / four teams of four waves per tile (512 / 1024 threads): launches bound by the heaviest tile's chain of phases, not by throughput
+template <int NCH, int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void sr_forward_pairs_teams_kernel(RasterArgs A, float* __restrict__ aggrs, float* __restrict__ colors)
+{
+    __shared__ __attribute__((aligned(16))) PairLds<NCH, SPLIT> L;
+    pairs_tile_body<NCH, SPLIT>(A, aggrs, colors, L);
 }
 
 }  // namespace lasr

@@ -799,11 +799,19 @@ static const long long k_order_max_tiles = env_blocks("LASR_SR_ORDER_MAX_TILES",
 // LASR's mode combination, launches of at least this many 8x8 tiles: the pair-walk kernel (sr_forward_pairs.h), whose lanes walk
 // their own pixel's (pixel, face) pairs; smaller launches keep the latency designs above.  Its output differs from theirs in the
 // rounding sequence only (image within ~1e-6).  LASR_SR_PAIR_MIN_TILES at load time, lasr_sr_options.pair_min_tiles per call.
-// Measured on an MI355X (profiles/r06_pairs_ab.txt), one wave per tile (+ order kernels) -> pair walk:
-//   mesh M2 at 256x256, three channels: 16 frames .188 -> .124 ms, 256: 1.927 -> 1.36; 8 frames: the four-waves-per-tile kernel wins
-//   nine channels: the render of spot3 stage 0 (16 meshes of 1280 faces filling the frame) 104 -> 89 us, camel stage 4 (4 meshes of
-//   2560 faces at 512x512) 150 -> 123 us -- every channel count and face size takes the kernel from the threshold up
-static const long long k_pair_min_tiles = env_blocks("LASR_SR_PAIR_MIN_TILES", 10240);
+// Measured on an MI355X (profiles/experiments/README.md, r06 sections), forward kernel ms, mesh M2 at 256x256, three channels:
+//   frames                      1      2      3      4      6      8      12     16     64     256
+//   cooperative 8x8 kernels    .051   .054   .085   .085   .093   .095   .107     -      -      -     (one wave per tile: .188 at 16, 1.93 at 256)
+//   pair walk, two teams       .068   .067   .069   .069   .079   .079   .103   .129   .459   1.86
+//   pair walk, one team        .104   .103     -    .105     -    .106   .107   .115   .322   1.32
+//   nine channels: the render of spot3 stage 0 (16 meshes of 1280 faces filling the frame) 104 -> 86 us (two teams: 132), camel stage 4
+//   (4 meshes of 2560 faces at 512x512) 150 -> 118 us -- every channel count and face size takes the kernel from the threshold up
+static const long long k_pair_min_tiles = env_blocks("LASR_SR_PAIR_MIN_TILES", 3072);
+// ... with TWO teams of four waves per 16x16 tile (sr_forward_pairs.h: SPLIT) up to this many 16x16 tiles: a launch that cannot fill
+// the chip takes as long as its heaviest tile's chain of dependent phases (list rounds, then stage -> classify -> walk per chunk of 64
+// entries: ~105 us on the bench object whatever the frame count), and two teams walk alternate chunks (~68 us); beyond, throughput
+// counts and one team's smaller footprint wins.  LASR_SR_PAIR_ONE_TEAM / LASR_SR_PAIR_TWO_TEAMS force either per call.
+static const long long k_pair_teams_max_tiles = env_blocks("LASR_SR_PAIR_TEAMS_MAX_TILES", 3072);
 
 static bool is_lasr_fast(const Modes& m) { return m.dist == 2 && m.rgb == 1 && m.alpha == 2 && m.tex == 1 && m.double_side; }
 
@@ -937,7 +945,15 @@ static int forward_impl(const float* faces, const float* textures, float* faces_
             if (plan == 5) {
                 const int t16 = (IS + PW_TILE - 1) / PW_TILE;
                 const dim3 grid16((unsigned)(N * t16 * t16));
-                if (nch == 9) hipLaunchKernelGGL((sr_forward_pairs_kernel<9>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
+                // two teams per tile while the launch cannot fill the chip with one (its time is then the heaviest tile's chain of
+                // phases); LASR_SR_PAIR_ONE_TEAM / LASR_SR_PAIR_TWO_TEAMS force either
+                const long long tiles16 = (long long)N * t16 * t16;
+                const bool teams2 = (flags & LASR_SR_PAIR_TWO_TEAMS) || (!(flags & LASR_SR_PAIR_ONE_TEAM) && tiles16 <= k_pair_teams_max_tiles);
+                if (teams2) {
+                    if (nch == 9) hipLaunchKernelGGL((sr_forward_pairs_teams_kernel<9, 2>), grid16, dim3(512), 0, st, A, aggrs_info, soft_colors);
+                    else if (nch == 6) hipLaunchKernelGGL((sr_forward_pairs_teams_kernel<6, 2>), grid16, dim3(512), 0, st, A, aggrs_info, soft_colors);
+                    else hipLaunchKernelGGL((sr_forward_pairs_teams_kernel<3, 2>), grid16, dim3(512), 0, st, A, aggrs_info, soft_colors);
+                } else if (nch == 9) hipLaunchKernelGGL((sr_forward_pairs_kernel<9>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else if (nch == 6) hipLaunchKernelGGL((sr_forward_pairs_kernel<6>), grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
                 else hipLaunchKernelGGL(sr_forward_pairs3_kernel, grid16, dim3(256), 0, st, A, aggrs_info, soft_colors);
             }
@@ -1102,7 +1118,7 @@ extern "C" int lasr_sr_forward_ex(const float* faces, const float* textures, flo
                                   int func_id_alpha, int texture_sample_type, int double_side, int flags, void* hip_stream)
 {
     if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
-    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) return LASR_E_BADARG;
+    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED | LASR_SR_PAIR_ONE_TEAM | LASR_SR_PAIR_TWO_TEAMS)) return LASR_E_BADARG;
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
     if (rc) return rc;
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
@@ -1119,7 +1135,7 @@ extern "C" int lasr_sr_forward_bg(const float* faces, const float* textures, flo
 {
     if (!background) return LASR_E_BADARG;
     if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
-    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) return LASR_E_BADARG;
+    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED | LASR_SR_PAIR_ONE_TEAM | LASR_SR_PAIR_TWO_TEAMS)) return LASR_E_BADARG;
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
     if (rc) return rc;
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,
@@ -1135,7 +1151,7 @@ extern "C" int lasr_sr_forward_opt(const float* faces, const float* textures, fl
                                    const lasr_sr_options* options, void* hip_stream)
 {
     if (flags == LASR_SR_DEFAULT_FLAGS) flags = default_flags();
-    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED)) return LASR_E_BADARG;
+    if (flags & ~(LASR_SR_RELAXED_MATH | LASR_SR_SEGMENTED | LASR_SR_PAIR_ONE_TEAM | LASR_SR_PAIR_TWO_TEAMS)) return LASR_E_BADARG;
     const int rc = check_nch(channels, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, double_side, T);
     if (rc) return rc;
     return forward_impl(faces, textures, faces_info, aggrs_info, soft_colors, workspace, workspace_bytes, N, F, T, IS, near,

@@ -1,6 +1,6 @@
 """The forward pass of LASR's mode combination picks one of four kernels by launch size (lasr_amd/csrc/sr_raster.hip
 forward_impl): eight or four waves sharing an 8x8 tile for launches that cannot fill the chip (sr_forward_coop.h), one wave per
-8x8 tile, and -- from 16 frames of 256x256 up -- the pair-walk kernel (sr_forward_pairs.h), whose lanes walk the (pixel, face)
+8x8 tile, and -- from 3 frames of 256x256 up -- the pair-walk kernel (sr_forward_pairs.h; two teams of four waves per tile up to 12 frames), whose lanes walk the (pixel, face)
 pairs of their own pixel.  The first three evaluate every pair with the same instruction sequence and visit the faces of a pixel
 in index order, so their outputs must be IDENTICAL bit for bit; the pair-walk kernel evaluates every pair with that same
 sequence but folds a pixel's fragments in another order (inside fragments first, a stolen run merged at the end of a chunk):
@@ -143,21 +143,43 @@ def test_the_device_side_choice_takes_either_kernel_and_the_bits_do_not_change(t
 
 
 def test_default_thresholds_pick_by_launch_size(cuda):
-    # the defaults are in force outside this file's fixture: launches below the pair-walk threshold (16 frames of 256x256) keep the
-    # reference order -- a frame rendered alone or in a batch of eight gives the same bits -- and 16 frames take the pair walk
-    # whatever the face size (1280 faces = 51 pixels per face, 2420 faces = 27): same image to rounding
-    for nu, cnt in ((8, 8), (11, 8)):
+    # the defaults are in force outside this file's fixture: launches below the pair-walk threshold (3 frames of 256x256) keep the
+    # reference order -- a frame rendered alone or in a batch of two gives the same bits; from there the pair walk takes over
+    # whatever the face size (1280 faces = 51 pixels per face, 2420 faces = 27), with two teams of four waves per tile up to 12
+    # frames and one beyond: same image to rounding
+    for nu in (8, 11):
+        fv, ft, near, far = synth.raster_batch(nu, 3, count=2)
+        kw = dict(synth.LASR_MODES, near=near, far=far)
+        batch = render(cuda, fv, ft, 256, kw)
+        one = render(cuda, fv[1:2], ft[1:2], 256, kw)
+        assert np.array_equal(batch[1:2], one)
+    for nu, cnt in ((8, 16), (11, 16), (8, 6), (11, 6)):
         fv, ft, near, far = synth.raster_batch(nu, 3, count=cnt)
         kw = dict(synth.LASR_MODES, near=near, far=far)
         batch = render(cuda, fv, ft, 256, kw)
         one = render(cuda, fv[5:6], ft[5:6], 256, kw)
-        assert np.array_equal(batch[5:6], one)
-    for nu in (8, 11):
-        fv, ft, near, far = synth.raster_batch(nu, 3, count=16)
-        kw = dict(synth.LASR_MODES, near=near, far=far)
-        batch = render(cuda, fv, ft, 256, kw)
-        one = render(cuda, fv[5:6], ft[5:6], 256, kw)
         assert np.abs(batch[5:6] - one).max() <= PAIR_TOL and not np.array_equal(batch[5:6], one)
+
+
+def test_one_and_two_teams_per_tile_agree(cuda):
+    # lasr_amd/csrc/sr_forward_pairs.h: SPLIT teams of four waves share a 16x16 tile, team t walks the chunks t, t + SPLIT, ... of the
+    # tile's list and the teams' partial states meet at the end -- forced either way by the per-call flags (three and nine channels)
+    from lasr_amd import _lib
+    fv, ft, near, far = synth.raster_batch(11, 3, count=5)
+    rng = np.random.default_rng(5)
+    tex9 = np.concatenate([ft] + [rng.uniform(-2, 2, ft.shape).astype(np.float32) for _ in range(2)], -1)
+    try:
+        srf.set_launch_thresholds(*PAIR_WALK)
+        for tex, kw in ((ft, dict(synth.LASR_MODES, near=near, far=far)),
+                        (tex9, dict(synth.LASR_MODES, near=near, far=far, background_color=[0.1 * k for k in range(9)]))):
+            srf.set_forward_flags(_lib.SR_PAIR_ONE_TEAM)
+            a = render(cuda, fv, tex, 160, kw)
+            srf.set_forward_flags(_lib.SR_PAIR_TWO_TEAMS)
+            b = render(cuda, fv, tex, 160, kw)
+            assert np.abs(a - b).max() <= PAIR_TOL and not np.array_equal(a, b)
+    finally:
+        srf.set_forward_flags(_lib.SR_DEFAULT_FLAGS)
+        srf.set_launch_thresholds()
 
 
 def test_the_pair_walk_handles_faces_that_are_not_tame(thresholds, oracle, cuda):
@@ -221,9 +243,9 @@ def test_the_tile_order_is_a_permutation_sorted_by_the_faces_that_touch_each_til
     fv[3] += np.array([0.45, -0.3, 0.], np.float32)            # one object off-centre: the fixed spiral would start in its empty middle
     F = fv.shape[1]
     try:
-        srf.set_launch_thresholds(-1, -1, -1, 0)
+        srf.set_launch_thresholds(-1, -1, -1, 0, BIG)           # (the 8x8-tile kernels: the pair walk orders 16x16 tiles)
         want = render(cuda, fv, ft, IS, dict(synth.LASR_MODES, near=near, far=far))
-        srf.set_launch_thresholds(-1, -1, -1, BIG)
+        srf.set_launch_thresholds(-1, -1, -1, BIG, BIG)
         got = render(cuda, fv, ft, IS, dict(synth.LASR_MODES, near=near, far=far))
     finally:
         srf.set_launch_thresholds()

@@ -45,6 +45,7 @@ def test_frames_of_a_batch_are_independent(full, cuda):
         # the 256-frame launch takes the pair-walk forward kernel (sr_forward_pairs.h); a lone frame would take the eight-wave
         # kernel, whose accumulation order per pixel differs (same image to ~5e-7): force the same kernel, then the bits must agree
         one.options = _lib.SrOptions(-1, -1, -1, -1, 0)
+        one.forward_flags = _lib.SR_PAIR_ONE_TEAM                # (a lone frame would also get two teams of waves per tile)
         assert torch.equal(one.fv[0], rs.fv[k])                  # same synthetic frame
         one.g.copy_(rs.g[k:k + 1])
         one.step()

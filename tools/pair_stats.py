@@ -17,6 +17,7 @@ print('F',f.shape[0],'thr',thr,'r px',r*IS/2)
 xs=(2*np.arange(IS)+1-IS)/IS
 tot=dict(cand=0,inside=0,near=0,real=0)
 stats=[]
+ALT=[]
 def tri_dist2(px,py,a,b,c):
     def seg(p0,p1):
         d=p1-p0; t=((px-p0[0])*d[0]+(py-p0[1])*d[1])/max(d@d,1e-30); t=np.clip(t,0,1)
@@ -78,6 +79,10 @@ for fr in frames:
                     kk=(ci+co)[w::4].reshape(-1); cand=cc[w::4].reshape(-1)
                     srt=np.sort(kk)[::-1]
                     bal=np.maximum.reduce([np.ceil((srt[i]+srt[63-i])/2) for i in range(32)])
+                    # alternatives: a heavy lane shared by TWO light ones (21 triples + 1 leftover), quads (rank r, 31-r, 32+r, 63-r)
+                    tri=max(max(np.ceil((srt[i]+srt[63-2*i]+srt[62-2*i])/3) for i in range(21)), srt[21])
+                    quad=max(np.ceil((srt[i]+srt[31-i]+srt[32+i]+srt[63-i])/4) for i in range(16))
+                    ALT.append((tri, quad, np.ceil(kk.sum()/64)))
                     row.append((kk.sum(),kk.max(),bal,cand.max(),cand.sum(),ci[w::4].max(),ci[w::4].sum()))
                 stats.append((len(ch),row))
 print(tot)
@@ -93,6 +98,7 @@ dense=sum(math.ceil(sum(r[0] for r in rows)/256)*4 for _,rows in st)
 densew=sum(math.ceil(r[0]/64) for _,rows in st for r in rows)
 print('frames',len(frames),'chunks',nchunks,'entries',sum(n for n,_ in st))
 print('pairs',pairs,'wave-iters: unbalanced',M,'balanced',Mb,'tile-synced',Mt,'dense per wave',densew,'dense per tile',dense)
+print('walk iterations with triples', sum(a[0] for a in ALT), 'quads', sum(a[1] for a in ALT), 'dense', sum(a[2] for a in ALT))
 print('classify iters (max cand per wave)',Cm,'cand sum/64',Cs/64)
 print('inside-mode iterations (max inside pairs per lane of a chunk-wave)',sum(r[5] for _,rows in st for r in rows),'inside pairs / 64',sum(r[6] for _,rows in st for r in rows)/64)
 import collections
