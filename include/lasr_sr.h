@@ -53,7 +53,7 @@ extern "C" {
  *      (lasr_lbs_backward_scratch_floats grew about 4x with the 64-vertex chunks of the MFMA backward: re-query it, never cache it per (N, V, K).)
  *   4  round 6: lasr_sr_options.mixed_min_weight (fifth field) became pair_min_tiles -- the one-launch mix of two tile bodies is gone,
  *      launches from that many 8x8 tiles up take the pair-walk forward kernel.  New (no existing signature changes): lasr_pose_chain_*,
- *      lasr_render_tables_forward_imgs. */
+ *      lasr_render_tables_forward_imgs; forward flag bits LASR_SR_PAIR_ONE_TEAM / LASR_SR_PAIR_TWO_TEAMS (formerly rejected). */
 #define LASR_ABI_VERSION 4
 int         lasr_abi_version(void);
 const char* lasr_strerror(int code);
