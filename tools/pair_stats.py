@@ -82,7 +82,17 @@ for fr in frames:
                     # alternatives: a heavy lane shared by TWO light ones (21 triples + 1 leftover), quads (rank r, 31-r, 32+r, 63-r)
                     tri=max(max(np.ceil((srt[i]+srt[63-2*i]+srt[62-2*i])/3) for i in range(21)), srt[21])
                     quad=max(np.ceil((srt[i]+srt[31-i]+srt[32+i]+srt[63-i])/4) for i in range(16))
-                    ALT.append((tri, quad, np.ceil(kk.sum()/64)))
+                    # the quad scheme with what the kernel can actually move: only OUTSIDE pairs change hands; flows A -> D, B -> C, A -> B
+                    ko=co[w::4].reshape(-1); order=np.argsort(-kk, kind='stable'); ks=kk[order]; os_=ko[order]
+                    cur_pairs=0; cur_quads=0
+                    for i in range(32):
+                        a,d=ks[i],ks[63-i]; mv=min((a-d)//2, os_[i]); cur_pairs=max(cur_pairs, a-mv, d+mv)
+                    for i in range(16):
+                        kA,kB,kC,kD=ks[i],ks[31-i],ks[32+i],ks[63-i]; pA,pB=os_[i],os_[31-i]
+                        t=-(-(kA+kB+kC+kD)//4)
+                        dD=min(max(0,t-kD),pA); y=min(max(0,t-kC),pB); x=min(max(0,t-kB+y),pA-dD)
+                        cur_quads=max(cur_quads, kA-dD-x, kD+dD, kB+x-y, kC+y)
+                    ALT.append((tri, quad, np.ceil(kk.sum()/64), cur_pairs, cur_quads))
                     row.append((kk.sum(),kk.max(),bal,cand.max(),cand.sum(),ci[w::4].max(),ci[w::4].sum()))
                 stats.append((len(ch),row))
 print(tot)
@@ -98,7 +108,7 @@ dense=sum(math.ceil(sum(r[0] for r in rows)/256)*4 for _,rows in st)
 densew=sum(math.ceil(r[0]/64) for _,rows in st for r in rows)
 print('frames',len(frames),'chunks',nchunks,'entries',sum(n for n,_ in st))
 print('pairs',pairs,'wave-iters: unbalanced',M,'balanced',Mb,'tile-synced',Mt,'dense per wave',densew,'dense per tile',dense)
-print('walk iterations with triples', sum(a[0] for a in ALT), 'quads', sum(a[1] for a in ALT), 'dense', sum(a[2] for a in ALT))
+print('walk iterations with triples', sum(a[0] for a in ALT), 'quads', sum(a[1] for a in ALT), 'dense', sum(a[2] for a in ALT), '| outside-only: pairs', sum(a[3] for a in ALT), 'quads', sum(a[4] for a in ALT))
 print('classify iters (max cand per wave)',Cm,'cand sum/64',Cs/64)
 print('inside-mode iterations (max inside pairs per lane of a chunk-wave)',sum(r[5] for _,rows in st for r in rows),'inside pairs / 64',sum(r[6] for _,rows in st for r in rows)/64)
 import collections
